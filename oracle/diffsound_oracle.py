@@ -1,0 +1,365 @@
+"""TEST INFRASTRUCTURE -- the parity oracle.  Not part of the product.
+
+A CPU restatement (plain torch-CPU / numpy, fp32 unless noted) of the reference's
+Diffsound generation path, written as pure functions over a flat state dict whose
+keys are the reference's own state-dict names.  Only tests/, __graft_entry__.smoke()
+and bench.py's `cpu_baseline` leg may import this file; the product path
+(text-to-sound-synthesis_amd/) never does and has no CPU fallback.
+
+Pinning: the reference has no tests, golden vectors or checkpoints (SURVEY.md §4,
+§8c), so this oracle is pinned against the reference *itself*: oracle/make_golden.py
+(run where /root/reference exists) executes the unmodified reference modules on
+seeded inputs and commits their outputs under tests/golden/; tests/test_oracle_golden.py
+checks every function below against those vectors.
+
+Every function cites the reference lines it restates (paths relative to
+/root/reference/Diffsound/).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LOG_ZERO = float(np.log(np.float32(1e-30)))  # -69.0776 = log(1e-30), diffusion_transformer.py:53,306
+
+
+# --------------------------------------------------------------------------- A11
+def make_schedule(num_timesteps=100, num_classes=257):
+    """Mask-and-uniform schedule buffers.
+    sound_synthesis/modeling/transformers/diffusion_transformer.py:122-151 (alpha_schedule,
+    att 0.99999->9e-6, ctt 9e-6->0.9, N = num_classes incl. [MASK]) and :193-231 (log
+    buffers built in float64, then cast to float32)."""
+    T, N = num_timesteps, num_classes
+    lin = np.arange(0, T) / (T - 1)
+    att = np.concatenate(([1.0], lin * (0.000009 - 0.99999) + 0.99999))
+    ctt = np.concatenate(([0.0], lin * (0.9 - 0.000009) + 0.000009))
+    at = att[1:] / att[:-1]
+    ct = 1.0 - (1.0 - ctt[1:]) / (1.0 - ctt[:-1])
+    bt = (1.0 - at - ct) / N
+    att = np.concatenate((att[1:], [1.0]))
+    ctt = np.concatenate((ctt[1:], [0.0]))
+    btt = (1.0 - att - ctt) / N
+
+    def lg(x):
+        return torch.log(torch.tensor(x.astype("float64")))
+
+    def l1m(la):  # log(1 - exp(a)), :25-26
+        return torch.log(1 - la.exp() + 1e-40)
+
+    log_ct, log_cct = lg(ct), lg(ctt)
+    return {
+        "log_at": lg(at).float(), "log_bt": lg(bt).float(), "log_ct": log_ct.float(),
+        "log_cumprod_at": lg(att).float(), "log_cumprod_bt": lg(btt).float(),
+        "log_cumprod_ct": log_cct.float(),
+        "log_1_min_ct": l1m(log_ct).float(), "log_1_min_cumprod_ct": l1m(log_cct).float(),
+    }
+
+
+# --------------------------------------------------------------------------- A8
+def content_embed(sd, tokens, pfx="transformer.transformer.content_emb.", hw=(5, 53)):
+    """Token embedding + (row + column) position embedding.
+    embeddings/dalle_mask_image_embedding.py:36-58: pos p uses height_emb[p // W] +
+    width_emb[p % W] (row-major positions over the column-major token sequence)."""
+    H, W = hw
+    e = sd[pfx + "emb.weight"][tokens.clamp(min=0)]
+    p = torch.arange(tokens.shape[1])
+    pos = sd[pfx + "height_emb.weight"][p // W] + sd[pfx + "width_emb.weight"][p % W]
+    return e + pos[None]
+
+
+# --------------------------------------------------------------------------- A7
+def _linear(sd, name, x):
+    return x @ sd[name + ".weight"].t() + sd[name + ".bias"]
+
+
+def _ada_ln(sd, name, x, t):
+    """transformer_utils.py:134-149: LN(x) (no affine, eps 1e-5) * (1+scale) + shift with
+    (scale, shift) = chunk(Linear(SiLU(Emb[t])))."""
+    e = sd[name + ".emb.weight"][t]
+    e = _linear(sd, name + ".linear", e * torch.sigmoid(e))[:, None, :]
+    d = x.shape[-1]
+    scale, shift = e[..., :d], e[..., d:]
+    return F.layer_norm(x, (d,), eps=1e-5) * (1 + scale) + shift
+
+
+def _mha(q, k, v, n_head):
+    """softmax(q k^T / sqrt(hd)) v per head; transformer_utils.py:43-58 / :91-109
+    (no mask, dropout p = 0)."""
+    B, Lq, C = q.shape
+    Lk = k.shape[1]
+    hd = C // n_head
+    qh = q.view(B, Lq, n_head, hd).transpose(1, 2)
+    kh = k.view(B, Lk, n_head, hd).transpose(1, 2)
+    vh = v.view(B, Lk, n_head, hd).transpose(1, 2)
+    att = torch.softmax((qh @ kh.transpose(-2, -1)) * (1.0 / math.sqrt(hd)), dim=-1)
+    return (att @ vh).transpose(1, 2).reshape(B, Lq, C)
+
+
+def transformer_block(sd, pfx, x, cond, t, n_head=16):
+    """transformer_utils.py:255-272 ('selfcross'): x += attn1(ln1(x,t)); x += attn2(ln1_1(x,t),
+    cond); x += mlp(ln2(x)); mlp = Linear, GELU2 (x*sigmoid(1.702x), :111-115), Linear."""
+    h = _ada_ln(sd, pfx + "ln1", x, t)
+    a = _mha(_linear(sd, pfx + "attn1.query", h), _linear(sd, pfx + "attn1.key", h),
+             _linear(sd, pfx + "attn1.value", h), n_head)
+    x = x + _linear(sd, pfx + "attn1.proj", a)
+    h = _ada_ln(sd, pfx + "ln1_1", x, t)
+    a = _mha(_linear(sd, pfx + "attn2.query", h), _linear(sd, pfx + "attn2.key", cond),
+             _linear(sd, pfx + "attn2.value", cond), n_head)
+    x = x + _linear(sd, pfx + "attn2.proj", a)
+    h = F.layer_norm(x, (x.shape[-1],), sd[pfx + "ln2.weight"], sd[pfx + "ln2.bias"], eps=1e-5)
+    h = _linear(sd, pfx + "mlp.0", h)
+    h = h * torch.sigmoid(1.702 * h)
+    return x + _linear(sd, pfx + "mlp.2", h)
+
+
+def transformer_forward(sd, tokens, cond_emb, t, pfx="transformer.transformer.", n_head=16,
+                        hw=(5, 53)):
+    """Text2ImageTransformer.forward, transformer_utils.py:421-443 -> logits [B, K, L]."""
+    x = content_embed(sd, tokens, pfx + "content_emb.", hw)
+    i = 0
+    while (pfx + "blocks.%d.ln2.weight" % i) in sd:
+        x = transformer_block(sd, pfx + "blocks.%d." % i, x, cond_emb, t, n_head)
+        i += 1
+    x = F.layer_norm(x, (x.shape[-1],), sd[pfx + "to_logits.0.weight"],
+                     sd[pfx + "to_logits.0.bias"], eps=1e-5)
+    return _linear(sd, pfx + "to_logits.1", x).transpose(1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------- A6 / A3
+def log_onehot(tokens, num_classes):
+    """index_to_log_onehot, diffusion_transformer.py:45-56: log(clamp(onehot, 1e-30))."""
+    oh = F.one_hot(tokens, num_classes).permute(0, 2, 1).float()
+    return torch.log(oh.clamp(min=1e-30))
+
+
+def initial_log_z(batch, num_classes=257, length=265):
+    """All-[MASK] start state, diffusion_transformer.py:633-636: log([0,...,0,1]) = -inf/0."""
+    z = torch.zeros(batch, num_classes, length)
+    z[:, -1, :] = 1.0
+    return torch.log(z)
+
+
+def predict_start(logits):
+    """diffusion_transformer.py:285-289: float64 log_softmax over classes, append a -70 row
+    for [MASK], clamp to [-70, 0].  `logits` is the transformer output [B, K, L]."""
+    lp = F.log_softmax(logits.double(), dim=1).float()
+    lp = torch.cat((lp, torch.full_like(lp[:, :1, :], -70.0)), dim=1)
+    return lp.clamp(-70.0, 0.0)
+
+
+def truncate_top_r(log_pred, r):
+    """Top-p ('r') truncation wrapper, models/dalle_spec.py:158-174.  Per column: rank the
+    classes by descending log-prob; a class survives iff the probability mass ranked
+    strictly before it is < r (rank 0 always survives); the rest become -70; no renorm."""
+    srt, idx = torch.sort(log_pred, dim=1, descending=True)
+    inc = torch.exp(srt).cumsum(dim=1)           # inclusive mass up to each rank
+    keep_sorted = torch.cat((torch.ones_like(inc[:, :1, :], dtype=torch.bool),
+                             (inc < r)[:, :-1, :]), dim=1)   # rank i looks at rank i-1's mass
+    keep = torch.zeros_like(keep_sorted).scatter(1, idx, keep_sorted)
+    return torch.where(keep, log_pred, torch.full_like(log_pred, -70.0))
+
+
+# --------------------------------------------------------------------------- A9
+def _lae(a, b):
+    """log(exp a + exp b), diffusion_transformer.py:28-30."""
+    m = torch.max(a, b)
+    return m + torch.log(torch.exp(a - m) + torch.exp(b - m))
+
+
+def _q_pred(sched, log_x, t, T):
+    """q(x_t | x_0) in log space, :253-267 (t wrapped mod T+1)."""
+    t = (t + (T + 1)) % (T + 1)
+    g = lambda n: sched[n][t].view(-1, 1, 1)
+    return torch.cat((_lae(log_x[:, :-1] + g("log_cumprod_at"), g("log_cumprod_bt")),
+                      _lae(log_x[:, -1:] + g("log_1_min_cumprod_ct"), g("log_cumprod_ct"))), dim=1)
+
+
+def _q_pred_one(sched, log_x, t):
+    """q(x_t | x_{t-1}) in log space, :241-251."""
+    g = lambda n: sched[n][t].view(-1, 1, 1)
+    return torch.cat((_lae(log_x[:, :-1] + g("log_at"), g("log_bt")),
+                      _lae(log_x[:, -1:] + g("log_1_min_ct"), g("log_ct"))), dim=1)
+
+
+def q_posterior(sched, log_x_start, log_x_t, t):
+    """log p_theta(x_{t-1} | x_t), diffusion_transformer.py:293-339, clamped to [-70, 0]."""
+    T = sched["log_at"].numel()
+    Kp1 = log_x_start.shape[1]
+    is_mask = (log_x_t.argmax(1) == Kp1 - 1).unsqueeze(1)           # [B,1,L]
+    lz = torch.full_like(log_x_t[:, :1, :], LOG_ZERO)
+
+    def fix(log_q, per_t):
+        # mask row -> log(1e-30); where x_t is [MASK]: classes -> per_t, mask row -> 0
+        log_q = torch.cat((log_q[:, :-1], lz), dim=1)
+        alt = torch.cat((per_t.view(-1, 1, 1).expand(-1, Kp1 - 1, 1),
+                         torch.zeros(log_q.shape[0], 1, 1)), dim=1)
+        return torch.where(is_mask, alt.expand_as(log_q), log_q)
+
+    log_qt = fix(_q_pred(sched, log_x_t, t, T), sched["log_cumprod_ct"][t])
+    log_q1 = fix(_q_pred_one(sched, log_x_t, t), sched["log_ct"][t])
+    q = log_x_start - log_qt
+    lse = torch.logsumexp(q, dim=1, keepdim=True)
+    q = q - lse
+    out = _q_pred(sched, q, t - 1, T) + log_q1 + lse
+    return out.clamp(-70.0, 0.0)
+
+
+# --------------------------------------------------------------------------- A10
+def gumbel_sample(log_prob, u):
+    """log_sample_categorical, :359-368, with the uniform noise `u` injected
+    (the reference draws torch.rand_like(logits)).  Returns token ids [B, L]."""
+    g = -torch.log(-torch.log(u + 1e-30) + 1e-30)
+    return (g + log_prob).argmax(dim=1)
+
+
+# --------------------------------------------------------------------------- A4 / A5
+def p_sample_step(sd, sched, log_z, cond_emb, t, u, trunc_r=0.85, n_head=16, detail=False):
+    """One reverse step, :342-357 with the truncation wrapper of dalle_spec.py:208-210
+    installed: argmax -> transformer -> log-softmax(f64) -> top-r -> posterior -> Gumbel."""
+    K = sd["transformer.transformer.to_logits.1.weight"].shape[0]
+    x_t = log_z.argmax(1)
+    logits = transformer_forward(sd, x_t, cond_emb, t, n_head=n_head)
+    log_pred = predict_start(logits)
+    trunc = truncate_top_r(log_pred, trunc_r) if trunc_r is not None else log_pred
+    post = q_posterior(sched, trunc, log_z, t)
+    tok = gumbel_sample(post, u)
+    new_log_z = log_onehot(tok, K + 1)
+    if detail:
+        return new_log_z, dict(x_t=x_t, logits=logits, log_pred=log_pred, trunc=trunc,
+                               post=post, tokens=tok)
+    return new_log_z
+
+
+def sample_loop(sd, cond_emb, noise_fn, num_timesteps=100, trunc_r=0.85, n_head=16,
+                record=None):
+    """DiffusionTransformer.sample with filter_ratio = 0, :633-641,654.
+    noise_fn(step_t, shape) supplies the uniform noise for step t."""
+    K = sd["transformer.transformer.to_logits.1.weight"].shape[0]
+    L = 265
+    B = cond_emb.shape[0]
+    sched = make_schedule(num_timesteps, K + 1)
+    log_z = initial_log_z(B, K + 1, L)
+    for step in range(num_timesteps - 1, -1, -1):
+        t = torch.full((B,), step, dtype=torch.long)
+        log_z = p_sample_step(sd, sched, log_z, cond_emb, t, noise_fn(step, log_z.shape),
+                              trunc_r, n_head)
+        if record is not None:
+            record.append(log_z.argmax(1).clone())
+    return log_z.argmax(1)
+
+
+# --------------------------------------------------------------------------- A12
+def codebook_gather(sd, tokens, hw=(5, 53), pfx="content_codec."):
+    """decode_to_img's first half, dalle_spec.py:80-89: ColumnMajor reverse permutation
+    (permuter.py:31-55: row-major cell (h,w) takes sequence item w*H + h) followed by the
+    codebook lookup (quantize.py:88-103) -> [B, C, H, W]."""
+    H, W = hw
+    hh = torch.arange(H).view(H, 1)
+    ww = torch.arange(W).view(1, W)
+    src = (ww * H + hh).reshape(-1)                                  # row-major -> seq index
+    z = sd[pfx + "quantize.embedding.weight"][tokens[:, src]]       # [B, H*W, C]
+    return z.view(tokens.shape[0], H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------- A13 / A14
+def _gn_swish(sd, name, x):
+    """Normalize = GroupNorm(32, C, eps 1e-6) (model.py:34-35) then swish (:29-31)."""
+    h = F.group_norm(x, 32, sd[name + ".weight"], sd[name + ".bias"], eps=1e-6)
+    return h * torch.sigmoid(h)
+
+
+def _conv2d(sd, name, x, pad):
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], padding=pad)
+
+
+def _res_block(sd, pfx, x):
+    """ResnetBlock.forward with temb=None, model.py:131-151."""
+    h = _conv2d(sd, pfx + "conv1", _gn_swish(sd, pfx + "norm1", x), 1)
+    h = _conv2d(sd, pfx + "conv2", _gn_swish(sd, pfx + "norm2", h), 1)
+    if (pfx + "nin_shortcut.weight") in sd:
+        x = _conv2d(sd, pfx + "nin_shortcut", x, 0)
+    return x + h
+
+
+def _attn_block(sd, pfx, x):
+    """AttnBlock.forward, model.py:202-226: single head over H*W positions, scale C^-0.5."""
+    B, C, H, W = x.shape
+    h = F.group_norm(x, 32, sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], eps=1e-6)
+    q = _conv2d(sd, pfx + "q", h, 0).reshape(B, C, H * W)
+    k = _conv2d(sd, pfx + "k", h, 0).reshape(B, C, H * W)
+    v = _conv2d(sd, pfx + "v", h, 0).reshape(B, C, H * W)
+    w = torch.softmax(torch.bmm(q.transpose(1, 2), k) * (int(C) ** (-0.5)), dim=2)  # [B, i, j]
+    o = torch.bmm(v, w.transpose(1, 2)).reshape(B, C, H, W)
+    return x + _conv2d(sd, pfx + "proj_out", o, 0)
+
+
+def vq_decode(sd, quant, pfx="content_codec.", num_resolutions=5, num_res_blocks=2,
+              taps=None):
+    """VQModel.decode (spec_codec/vqgan.py:62-65) = post_quant_conv + Decoder.forward
+    (specvqgan/modules/diffusionmodules/model.py:640-671).  `taps` (a dict) receives
+    intermediate activations for debugging the HIP path."""
+    d = pfx + "decoder."
+    h = _conv2d(sd, pfx + "post_quant_conv", quant, 0)
+    h = _conv2d(sd, d + "conv_in", h, 1)
+    h = _res_block(sd, d + "mid.block_1.", h)
+    h = _attn_block(sd, d + "mid.attn_1.", h)
+    h = _res_block(sd, d + "mid.block_2.", h)
+    if taps is not None:
+        taps["mid"] = h
+    for lvl in reversed(range(num_resolutions)):
+        for ib in range(num_res_blocks + 1):
+            h = _res_block(sd, d + "up.%d.block.%d." % (lvl, ib), h)
+            if (d + "up.%d.attn.%d.norm.weight" % (lvl, ib)) in sd:
+                h = _attn_block(sd, d + "up.%d.attn.%d." % (lvl, ib), h)
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")    # Upsample, model.py:48-52
+            h = _conv2d(sd, d + "up.%d.upsample.conv" % lvl, h, 1)
+        if taps is not None:
+            taps["up%d" % lvl] = h
+    h = _gn_swish(sd, d + "norm_out", h)
+    return _conv2d(sd, d + "conv_out", h, 1)
+
+
+def decode_tokens(sd, tokens, pfx="content_codec."):
+    """DALLE.decode_to_img, dalle_spec.py:80-91 -> mel-like image [B, 1, 80, 848]."""
+    return vq_decode(sd, codebook_gather(sd, tokens, pfx=pfx), pfx=pfx)
+
+
+# --------------------------------------------------------------------------- A15
+def _wn(sd, name):
+    """weight_norm fold: w = g * v / ||v||, norm over all dims but 0 (vocoder/modules.py:18-23;
+    for ConvTranspose1d dim 0 is the *input* channel)."""
+    v, g = sd[name + ".weight_v"], sd[name + ".weight_g"]
+    n = v.reshape(v.shape[0], -1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+    return g * v / n
+
+
+def melgan_generator(sd, mel, pfx="model.", ratios=(8, 8, 2, 2), n_res=3):
+    """Generator.forward, vocoder/modules.py:88-130.  mel [B, 80, T] in [0,1] ->
+    waveform [B, 1, 256*T]."""
+    lrelu = lambda x: F.leaky_relu(x, 0.2)
+    i = 1
+    x = F.conv1d(F.pad(mel, (3, 3), mode="reflect"), _wn(sd, pfx + "1"), sd[pfx + "1.bias"])
+    i = 2
+    for r in ratios:
+        # LeakyReLU at i, WNConvTranspose1d at i+1: k=2r, s=r, p=r//2+r%2, out_pad=r%2
+        x = F.conv_transpose1d(lrelu(x), _wn(sd, pfx + "%d" % (i + 1)), sd[pfx + "%d.bias" % (i + 1)],
+                               stride=r, padding=r // 2 + r % 2, output_padding=r % 2)
+        i += 2
+        for j in range(n_res):
+            b = pfx + "%d." % i
+            dil = 3 ** j
+            h = F.pad(lrelu(x), (dil, dil), mode="reflect")
+            h = F.conv1d(h, _wn(sd, b + "block.2"), sd[b + "block.2.bias"], dilation=dil)
+            h = F.conv1d(lrelu(h), _wn(sd, b + "block.4"), sd[b + "block.4.bias"])
+            x = F.conv1d(x, _wn(sd, b + "shortcut"), sd[b + "shortcut.bias"]) + h
+            i += 1
+    x = F.pad(lrelu(x), (3, 3), mode="reflect")
+    x = F.conv1d(x, _wn(sd, pfx + "%d" % (i + 2)), sd[pfx + "%d.bias" % (i + 2)])
+    return torch.tanh(x)
+
+
+def mel_to_unit(x):
+    """generate_samples_batch.py:181-182: spec = (x + 1) / 2 before saving / vocoding."""
+    return (x + 1.0) / 2.0

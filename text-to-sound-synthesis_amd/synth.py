@@ -1,0 +1,117 @@
+"""Seeded synthetic weights and inputs, keyed by state-dict name.
+
+The reference ships no checkpoints, so parity and bench runs use
+random weights with the reference's exact shapes.  Values depend only on
+(seed, state-dict key, shape) -- never on construction order -- so the same
+tensors can be poured into the reference modules (oracle/make_golden.py, run
+where /root/reference exists), into oracle/diffsound_oracle.py and into the HIP
+modules on the GPU box, without the reference being present there.
+
+Distributions follow the reference initialisers in spirit
+(transformer_utils.py:355-363 N(0,0.02); conv default ~U(+-1/sqrt(fan_in));
+quantize.py:24 U(+-1/K)), but biases and norm affines are made non-trivial so
+that every term of every kernel is exercised.
+"""
+import zlib
+
+import torch
+
+
+def _gen(seed, key):
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def synth_tensor(key, shape, seed=0, dtype=torch.float32):
+    """One deterministic tensor for a state-dict entry."""
+    g = _gen(seed, key)
+    shape = tuple(shape)
+    leaf = key.rsplit(".", 1)[-1]
+    nd = len(shape)
+    if key.endswith("quantize.embedding.weight"):
+        k = shape[0]
+        t = (torch.rand(shape, generator=g) * 2 - 1) / k
+    elif leaf == "bias":
+        t = torch.randn(shape, generator=g) * 0.02
+    elif leaf == "weight_g":
+        # filled in by synth_state_dict from the sibling weight_v
+        t = torch.randn(shape, generator=g)
+    elif nd == 1:  # norm scale
+        t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+    elif nd == 2:  # Linear / Embedding of the transformer
+        t = torch.randn(shape, generator=g) * 0.02
+    else:  # conv kernels: [out, in, k...] (or [in, out, k] transposed)
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        t = torch.randn(shape, generator=g) * (1.0 / (3.0 * fan_in) ** 0.5)
+        if leaf == "weight_v":
+            t = t * 3.0 ** 0.5
+    return t.to(dtype)
+
+
+def synth_state_dict(shapes, seed=0):
+    """shapes: {key: shape}.  Returns {key: tensor}; weight_g follows weight_v."""
+    out = {}
+    for k, shp in shapes.items():
+        out[k] = synth_tensor(k, shp, seed)
+    for k in list(out):
+        if k.endswith("weight_g"):
+            v = out.get(k[:-1] + "v")
+            if v is not None:
+                # torch weight_norm: norm over all dims except 0 (vocoder/modules.py:18-23)
+                nrm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(out[k].shape)
+                out[k] = nrm * (1.0 + 0.1 * out[k])
+    return out
+
+
+@torch.no_grad()
+def synth_init_(module, seed=0, prefix="", skip=()):
+    """Fill every parameter of `module` from its state-dict key (in place).
+
+    Floating-point buffers are left alone (schedules etc. are computed, not random)."""
+    shapes = {prefix + n: tuple(p.shape) for n, p in module.named_parameters()
+              if not any(n.startswith(s) for s in skip)}
+    sd = synth_state_dict(shapes, seed)
+    for n, p in module.named_parameters():
+        k = prefix + n
+        if k in sd:
+            p.copy_(sd[k].to(p.dtype))
+    return module
+
+
+def synth_tokens(batch, length=265, num_codes=256, mask_frac=0.3, seed=0, key="tokens"):
+    """Token grid with a controllable share of [MASK] (= num_codes)."""
+    g = _gen(seed, key)
+    tok = torch.randint(0, num_codes, (batch, length), generator=g)
+    m = torch.rand((batch, length), generator=g) < mask_frac
+    tok[m] = num_codes
+    return tok.long()
+
+
+def synth_cond_emb(batch, seq=77, dim=512, seed=0, key="cond_emb"):
+    """Stand-in for CLIPTextEmbedding output: rows L2-normalised
+    (clip_text_embedding.py:79-80)."""
+    g = _gen(seed, key)
+    x = torch.randn((batch, seq, dim), generator=g)
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def synth_uniform(shape, seed=0, key="u"):
+    g = _gen(seed, key)
+    return torch.rand(tuple(shape), generator=g)
+
+
+_WORDS = ("a dog barks while birds chirp in the distance rain falls on metal roof "
+          "engine idles then revs people talk and laugh water flows wind blows "
+          "door slams glass breaks music plays softly crowd cheers siren wails "
+          "keyboard typing footsteps on gravel thunder rumbles cat meows baby cries "
+          "bell rings train passes helicopter hovers waves crash fire crackles").split()
+
+
+def synth_captions(n, seed=7):
+    """Synthetic lowercase ASCII captions, 5-15 words."""
+    import random
+    r = random.Random(seed)
+    return [" ".join(r.choice(_WORDS) for _ in range(r.randint(5, 15))) for _ in range(n)]
