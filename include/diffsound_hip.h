@@ -1,0 +1,146 @@
+/* C ABI of libdiffsound_hip.so -- the MI355X (gfx950) kernels of the Diffsound generation path.
+ *
+ * The reference (yangdongchao/Text-to-sound-Synthesis) has no FFI / plugin boundary: its hot path
+ * is stock torch ops called from Python nn.Modules.  This header therefore
+ * defines the boundary a maintainer would bind instead of those op chains; each entry cites the
+ * reference lines it replaces (paths relative to Diffsound/).  INTEGRATION.md shows the ctypes
+ * binding and the module-level drop-ins.
+ *
+ * Conventions: every pointer is a DEVICE pointer to fp32 / int64 data unless stated otherwise;
+ * callers own all memory (outputs and workspaces included); calls are asynchronous on `stream`
+ * (a hipStream_t, passed as void*); the return value is 0 on success, -1 for a rejected argument,
+ * -2 for a failed launch, and ds_last_error_string() describes the last failure of the calling
+ * thread.  No function allocates, frees or synchronises.  Activations are channels-last.
+ */
+#ifndef DIFFSOUND_HIP_H
+#define DIFFSOUND_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ds_stream_t; /* hipStream_t */
+
+int ds_version(void);
+const char* ds_last_error_string(void);
+
+/* ---- gather-GEMM (fp32 MFMA): C = store(act(A(m,k) * W[n][k] + bias) + R) ----------------------
+ * replaces nn.Linear (sound_synthesis/modeling/transformers/transformer_utils.py:31-36,75-82,
+ * 248-253,345-348), Conv2d 1x1/3x3 (specvqgan/modules/diffusionmodules/model.py:92-226,570-671) and
+ * Conv1d / ConvTranspose1d (vocoder/modules.py:72-127). */
+enum { DS_LOAD_DENSE = 0, DS_LOAD_CONV2D = 1, DS_LOAD_CONV1D = 2, DS_LOAD_CONVT1D = 3 };
+enum { DS_PRO_NONE = 0, DS_PRO_AFFINE = 1, DS_PRO_AFFINE_SWISH = 2, DS_PRO_LRELU = 3 };
+enum { DS_ACT_NONE = 0, DS_ACT_GELU2 = 1, DS_ACT_TANH = 2 };
+enum { DS_STORE_ROW = 0, DS_STORE_BATCH_T = 1, DS_STORE_CONVT = 2 };
+
+typedef struct ds_gemm_desc {
+    const float* A;        /* activation base */
+    const float* W;        /* [groups][N][ldw], K contiguous */
+    const float* bias;     /* [N] or NULL */
+    const float* R;        /* residual [M][ldr] (row-major store only) or NULL; may alias C */
+    float* C;
+    int32_t M, N, K;       /* per group; K % 32 == 0 */
+    int32_t lda, ldw, ldc, ldr;
+    int32_t groups;        /* >= 1; A/W/C advance by the strides below per group */
+    int64_t a_gstride, w_gstride, c_gstride;
+    int32_t loader, pro, act, store;
+    const float* pro_scale; /* [samples][Cin] for DS_PRO_AFFINE* (GroupNorm folded to a*s + o) */
+    const float* pro_shift;
+    int32_t rows_per_sample; /* dense prologue / DS_STORE_BATCH_T: rows of one sample */
+    int32_t Cin;             /* channels per tap (conv loaders; dense prologue: = K) */
+    int32_t H, Wd;           /* conv2d: output H, W; conv1d / convT1d: Wd = output length / phase rows */
+    int32_t up;              /* conv2d: input is (H/2, W/2), nearest-upsampled on the fly */
+    int32_t taps, dil;       /* conv1d (reflect padding) */
+    int32_t ct_r, ct_p, ct_tin; /* convT1d polyphase: stride, padding, input length; groups = r */
+} ds_gemm_desc;
+
+int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream);
+void ds_gemm_force_tile(int cfg); /* test hook: 0..2 pins the block tile, -1 = auto */
+
+/* ---- row kernels of the denoiser -------------------------------------------------------------- */
+/* DalleMaskImageEmbedding.forward, sound_synthesis/modeling/embeddings/dalle_mask_image_embedding.py:36-58
+ * out[m] = emb[tokens[m]] + pos[m % L]   (pos = height_emb[p // W] + width_emb[p % W], precombined) */
+int ds_embed(const int64_t* tokens, const float* emb, const float* pos, float* out, int M, int L, int D,
+             ds_stream_t stream);
+/* AdaLayerNorm.forward, transformer_utils.py:145-149, with Linear(SiLU(Emb[t])) tabulated: table [T][2D] */
+int ds_adaln(const float* x, float* y, int M, int L, int D, const float* table, const int64_t* t,
+             ds_stream_t stream);
+/* nn.LayerNorm(D) eps 1e-5 with affine, transformer_utils.py:205,346 */
+int ds_layernorm(const float* x, float* y, int M, int D, const float* gamma, const float* beta,
+                 ds_stream_t stream);
+/* FullAttention / CrossAttention core, transformer_utils.py:43-58, 91-109 (head dim 64, Lk <= 288) */
+int ds_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                 int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
+
+/* ---- one reverse-diffusion step's per-column tail --------------------------------------------
+ * predict_start (diffusion_transformer.py:285-289) + top-r truncation (models/dalle_spec.py:158-174)
+ * + q_posterior (:293-339) + log_sample_categorical (:359-368).
+ * logits [B*L][K]; xt [B][L]; t [B]; u [B][K+1][L] uniforms; sched [8][T+1];
+ * dbg_* optional [B][K+1][L] dumps (NULL to skip); trunc_r < 0 disables truncation. */
+int ds_sample_tail(const float* logits, const int64_t* xt, const int64_t* t, const float* u, const float* sched,
+                   int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc, float* dbg_post, int B, int L,
+                   int K, int T, int initial, float trunc_r, ds_stream_t stream);
+
+/* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
+enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */
+    DS_LP_ADALN1 = 0,  /* [T][2D]  ln1 table   */
+    DS_LP_W_QKV,       /* [3D][D]  attn1 query|key|value */
+    DS_LP_B_QKV,       /* [3D] */
+    DS_LP_W_PROJ1, DS_LP_B_PROJ1,
+    DS_LP_ADALN2,      /* [T][2D]  ln1_1 table */
+    DS_LP_W_Q2, DS_LP_B_Q2,
+    DS_LP_W_KV2,       /* [2D][Dc] attn2 key|value */
+    DS_LP_B_KV2,
+    DS_LP_W_PROJ2, DS_LP_B_PROJ2,
+    DS_LP_LN2_G, DS_LP_LN2_B,
+    DS_LP_W_FC1, DS_LP_B_FC1, DS_LP_W_FC2, DS_LP_B_FC2,
+    DS_LP_COUNT
+};
+typedef struct ds_denoiser_desc {
+    int32_t n_layer, n_embd, n_head, seq_len, cond_len, cond_dim, n_codes, n_steps, mlp_mult;
+    const float* tok_emb;   /* [n_codes+1][D] */
+    const float* pos_emb;   /* [L][D] */
+    const float* lnf_g;     /* to_logits.0 */
+    const float* lnf_b;
+    const float* w_logits;  /* [n_codes][D] */
+    const float* b_logits;
+    const float* sched;     /* [8][n_steps+1] */
+} ds_denoiser_desc;
+typedef struct ds_denoiser ds_denoiser;
+
+int ds_denoiser_create(const ds_denoiser_desc* desc, const void* const* layer_ptrs, ds_denoiser** out);
+void ds_denoiser_destroy(ds_denoiser* h);
+int64_t ds_denoiser_workspace_bytes(const ds_denoiser* h, int B);
+int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B);
+/* cross-attention K/V depend only on the caption: computed once per batch (CrossAttention.key/value,
+ * transformer_utils.py:96,98).  cond [B][Lc][Dc] -> kv [n_layer][B*Lc][2D] */
+int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int B, float* kv, ds_stream_t stream);
+/* logits_layout 0: [B*L][K]; 1: [B][K][L] (the reference's output layout) */
+int ds_denoiser_forward(const ds_denoiser* h, const int64_t* tokens, const int64_t* t, const float* kv, int B,
+                        void* workspace, float* logits, int logits_layout, ds_stream_t stream);
+/* forward + ds_sample_tail: tokens_in -> tokens_out for timestep vector t */
+int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const float* kv,
+                     const float* u, int B, int initial, float trunc_r, void* workspace, int64_t* tokens_out,
+                     ds_stream_t stream);
+
+/* ---- SpecVQGAN decoder / MelGAN helpers ------------------------------------------------------- */
+/* ColumnMajor(reverse) + get_codebook_entry (permuter.py:31-55, quantize.py:88-103) -> [B][H][W][C] */
+int ds_codebook_gather(const int64_t* tokens, const float* codebook, float* out, int B, int H, int W, int C,
+                       int K, ds_stream_t stream);
+/* GroupNorm(groups, C, eps) statistics of x [B][P][C] folded into per-(b,c) scale/shift
+ * (model.py:34-35); work >= B*ceil(P/256)*2*C doubles */
+int ds_groupnorm_stats(const float* x, int B, int P, int C, int groups, const float* gamma, const float* beta,
+                       float eps, double* work, float* scale, float* shift, ds_stream_t stream);
+/* AttnBlock softmax (model.py:214-216): x[row][0..n) <- softmax(scale*x), x[row][n..ld) <- 0 */
+int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t stream);
+/* tap-sum for single-output-channel convs fed by a GEMM with N = taps */
+int ds_stencil9(const float* taps, int ldt, float bias, float* out, int B, int H, int W, ds_stream_t stream);
+int ds_stencil7_tanh(const float* taps, int ldt, float bias, float* out, int B, int N, ds_stream_t stream);
+/* mel [B][C][T] -> [B][T][Cpad], y = a*x + b (generate_samples_batch.py:181-182 uses a = b = 0.5) */
+int ds_mel_to_cl(const float* mel, float* out, int B, int C, int T, int Cpad, float a, float b,
+                 ds_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

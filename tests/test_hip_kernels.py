@@ -1,0 +1,295 @@
+"""Per-kernel parity: each C-ABI entry against the oracle / a float64 restatement, on seeded
+asymmetric inputs.  GPU only (-m gpu); everything is called through libdiffsound_hip.so."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import diffsound_oracle as O
+from text_to_sound_synthesis_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from text_to_sound_synthesis_amd import _lib
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    _lib.lib()
+    return _lib
+
+
+def rnd(shape, key, scale=1.0):
+    return (synth.synth_uniform(shape, key=key) * 2 - 1) * scale
+
+
+def relerr(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(530, 1024, 1024), (265, 3072, 1024), (100, 2048, 1024), (154, 2048, 512),
+                                   (300, 256, 1024), (64, 96, 32), (1, 32, 64), (333, 9, 128)])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+def test_gemm_dense(L, M, N, K, tile):
+    A, W, b, R = rnd((M, K), "gA"), rnd((N, K), "gW", 0.1), rnd((N,), "gb"), rnd((M, N), "gR")
+    ref = (A.double() @ W.double().t() + b.double() + R.double()).float()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    L.lib().ds_gemm_force_tile(tile)
+    try:
+        L.gemm(A.cuda(), W.cuda(), out, M, N, K, bias=b.cuda(), R=R.cuda())
+    finally:
+        L.lib().ds_gemm_force_tile(-1)
+    assert relerr(out.cpu(), ref) < 2e-6
+
+
+def test_gemm_gelu2_and_batch_transposed_store(L):
+    B, Lr, N, K = 3, 265, 256, 1024
+    M = B * Lr
+    A, W, b = rnd((M, K), "tA"), rnd((N, K), "tW", 0.05), rnd((N,), "tb")
+    y = A.double() @ W.double().t() + b.double()
+    out = torch.empty(M, N, device="cuda")
+    L.gemm(A.cuda(), W.cuda(), out, M, N, K, bias=b.cuda(), act=L.ACT_GELU2)
+    assert relerr(out.cpu(), (y * torch.sigmoid(1.702 * y)).float()) < 3e-6
+    outT = torch.empty(B, N, Lr, device="cuda")
+    L.gemm(A.cuda(), W.cuda(), outT, M, N, K, bias=b.cuda(), ldc=Lr, store=L.STORE_BATCH_T, rows_per_sample=Lr)
+    assert relerr(outT.cpu(), y.view(B, Lr, N).transpose(1, 2).float()) < 2e-6
+
+
+def test_gemm_inplace_residual(L):
+    M, N, K = 530, 1024, 4096
+    A, W, b, X = rnd((M, K), "rA"), rnd((N, K), "rW", 0.05), rnd((N,), "rb"), rnd((M, N), "rX")
+    x = X.cuda()
+    L.gemm(A.cuda(), W.cuda(), x, M, N, K, bias=b.cuda(), R=x)
+    assert relerr(x.cpu(), (A.double() @ W.double().t() + b.double() + X.double()).float()) < 3e-6
+
+
+def test_gemm_rejects_bad_arguments(L):
+    a = torch.zeros(64, 48, device="cuda")
+    with pytest.raises(L.DiffsoundHipError):
+        L.gemm(a, a, torch.zeros(64, 64, device="cuda"), 64, 64, 48)      # K % 32 != 0
+    with pytest.raises(L.DiffsoundHipError):
+        L.gemm(torch.zeros(64, 64), a, a, 64, 64, 64)                      # host tensor: no CPU path
+
+
+# --------------------------------------------------------------------------------- row kernels
+def test_embed(L, sd_dalle_l2):
+    tok = synth.synth_tokens(3, mask_frac=0.4, key="e.tok")
+    pfx = "transformer.transformer.content_emb."
+    ref = O.content_embed(sd_dalle_l2, tok)
+    p = torch.arange(265)
+    pos = (sd_dalle_l2[pfx + "height_emb.weight"][p // 53] + sd_dalle_l2[pfx + "width_emb.weight"][p % 53]).cuda()
+    out = torch.empty(3, 265, 1024, device="cuda")
+    L.check(L.lib().ds_embed(L.ptr(tok.cuda()), L.ptr(sd_dalle_l2[pfx + "emb.weight"].cuda()), L.ptr(pos),
+                             L.ptr(out), 3 * 265, 265, 1024, L.stream()))
+    assert torch.equal(out.cpu(), ref)   # one add per element: bit-exact
+
+
+def test_adaln_and_layernorm(L, sd_dalle_l2):
+    x = rnd((2, 265, 1024), "ln.x", 3.0) + 0.5
+    t = torch.tensor([3, 97])
+    name = "transformer.transformer.blocks.1.ln1_1"
+    ref = O._ada_ln(sd_dalle_l2, name, x, t)
+    e = sd_dalle_l2[name + ".emb.weight"]
+    tab = (F.silu(e) @ sd_dalle_l2[name + ".linear.weight"].t() + sd_dalle_l2[name + ".linear.bias"]).cuda()
+    out = torch.empty(2 * 265, 1024, device="cuda")
+    L.check(L.lib().ds_adaln(L.ptr(x.cuda()), L.ptr(out), 530, 265, 1024, L.ptr(tab.contiguous()),
+                             L.ptr(t.cuda()), L.stream()))
+    assert (out.cpu().view_as(ref) - ref).abs().max() < 2e-5
+    g, b = rnd((1024,), "ln.g") + 1.5, rnd((1024,), "ln.b")
+    ref = F.layer_norm(x, (1024,), g, b, eps=1e-5)
+    L.check(L.lib().ds_layernorm(L.ptr(x.cuda()), L.ptr(out), 530, 1024, L.ptr(g.cuda()), L.ptr(b.cuda()), L.stream()))
+    assert (out.cpu().view_as(ref) - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("Lk,B", [(265, 2), (77, 3), (32, 1), (288, 1)])
+def test_attention(L, Lk, B):
+    Lq, H, D = 265, 16, 1024
+    q, k, v = rnd((B, Lq, D), "at.q"), rnd((B, Lk, D), "at.k"), rnd((B, Lk, D), "at.v", 2.0)
+    # spike one key so the softmax is far from uniform for some rows
+    k[:, 5] *= 6.0
+    ref = O._mha(q, k, v, H)
+    out = torch.full((B * Lq, D), float("nan"), device="cuda")
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    L.check(L.lib().ds_attention(L.ptr(qc), D, L.ptr(kc), D, L.ptr(vc), D, L.ptr(out), D, B, H, Lq, Lk,
+                                 1.0 / math.sqrt(64), L.stream()))
+    assert (out.cpu().view_as(ref) - ref).abs().max() < 2e-5
+
+
+def test_attention_strided_qkv(L):
+    """Q/K/V read in place from the fused [M, 3D] projection buffer."""
+    B, Lq, H, D = 2, 265, 16, 1024
+    qkv = rnd((B, Lq, 3 * D), "at.qkv")
+    ref = O._mha(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], H)
+    g = qkv.cuda()
+    out = torch.empty(B * Lq, D, device="cuda")
+    L.check(L.lib().ds_attention(g.data_ptr(), 3 * D, g.data_ptr() + 4 * D, 3 * D, g.data_ptr() + 8 * D, 3 * D,
+                                 L.ptr(out), D, B, H, Lq, Lq, 0.125, L.stream()))
+    assert (out.cpu().view_as(ref) - ref).abs().max() < 2e-5
+
+
+# ------------------------------------------------------------------------------- sampler tail
+def _sched_table(T=100, K1=257):
+    s = O.make_schedule(T, K1)
+    tab = torch.zeros(8, T + 1)
+    for i, n in enumerate(("log_at", "log_bt", "log_ct", "log_1_min_ct")):
+        tab[i, :T] = s[n]
+    for i, n in enumerate(("log_cumprod_at", "log_cumprod_bt", "log_cumprod_ct", "log_1_min_cumprod_ct")):
+        tab[4 + i] = s[n]
+    return s, tab
+
+
+@pytest.mark.parametrize("K", [256, 512])
+@pytest.mark.parametrize("t,mask_frac", [(99, None), (60, 0.6), (1, 0.03), (0, 0.0)])
+def test_sample_tail(L, K, t, mask_frac):
+    B, Ln = 2, 265
+    sched, tab = _sched_table(100, K + 1)
+    logits = rnd((B, K, Ln), "st.logits%d" % t, 4.0)
+    if mask_frac is None:
+        log_z, xt = O.initial_log_z(B, K + 1, Ln), torch.full((B, Ln), K)
+    else:
+        xt = synth.synth_tokens(B, Ln, K, mask_frac, key="st.xt%d" % t)
+        log_z = O.log_onehot(xt, K + 1)
+    u = synth.synth_uniform((B, K + 1, Ln), key="st.u%d" % t)
+    tv = torch.tensor([t] * B)
+    lp = O.predict_start(logits)
+    tr = O.truncate_top_r(lp, 0.85)
+    post = O.q_posterior(sched, tr, log_z, tv)
+    tok = O.gumbel_sample(post, u)
+    rows = logits.permute(0, 2, 1).contiguous().view(B * Ln, K).cuda()
+    d = [torch.empty(B, K + 1, Ln, device="cuda") for _ in range(3)]
+    out = torch.empty(B, Ln, dtype=torch.long, device="cuda")
+    L.check(L.lib().ds_sample_tail(L.ptr(rows), L.ptr(xt.cuda()), L.ptr(tv.cuda()), L.ptr(u.cuda()), L.ptr(tab.cuda()),
+                                   L.ptr(out), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), B, Ln, K, 100,
+                                   int(mask_frac is None), 0.85, L.stream()))
+    assert (d[0].cpu() - lp).abs().max() < 1e-5
+    kept_h, kept_o = d[1].cpu() > -70, tr > -70
+    assert (kept_h != kept_o).sum().item() <= 1          # a cumsum within 1 ulp of r may flip one class
+    same = kept_h == kept_o
+    assert (d[1].cpu() - tr)[same].abs().max() < 1e-5
+    cols_same = same.all(1)
+    assert (d[2].cpu() - post).permute(0, 2, 1)[cols_same].abs().max() < 5e-5
+    assert (out.cpu() != tok)[cols_same].sum().item() == 0
+
+
+def test_sample_tail_without_truncation(L):
+    B, Ln, K = 1, 265, 256
+    sched, tab = _sched_table(100, K + 1)
+    logits = rnd((B, K, Ln), "nt.logits", 3.0)
+    xt = synth.synth_tokens(B, Ln, K, 0.5, key="nt.xt")
+    u = synth.synth_uniform((B, K + 1, Ln), key="nt.u")
+    tv = torch.tensor([42])
+    post = O.q_posterior(sched, O.predict_start(logits), O.log_onehot(xt, K + 1), tv)
+    rows = logits.permute(0, 2, 1).contiguous().view(B * Ln, K).cuda()
+    out = torch.empty(B, Ln, dtype=torch.long, device="cuda")
+    dp = torch.empty(B, K + 1, Ln, device="cuda")
+    L.check(L.lib().ds_sample_tail(L.ptr(rows), L.ptr(xt.cuda()), L.ptr(tv.cuda()), L.ptr(u.cuda()), L.ptr(tab.cuda()),
+                                   L.ptr(out), None, None, L.ptr(dp), B, Ln, K, 100, 0, -1.0, L.stream()))
+    assert (dp.cpu() - post).abs().max() < 5e-5
+    assert torch.equal(out.cpu(), O.gumbel_sample(post, u))
+
+
+# ------------------------------------------------------------------ decoder / vocoder building blocks
+def test_codebook_gather(L, sd_dalle_l2):
+    tok = synth.synth_tokens(2, mask_frac=0.0, key="cb.tok")
+    ref = O.codebook_gather(sd_dalle_l2, tok)                               # [B, C, H, W]
+    E = sd_dalle_l2["content_codec.quantize.embedding.weight"].cuda()
+    out = torch.empty(2, 5, 53, 256, device="cuda")
+    L.check(L.lib().ds_codebook_gather(L.ptr(tok.cuda()), L.ptr(E), L.ptr(out), 2, 5, 53, 256, 256, L.stream()))
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), ref)
+
+
+def test_groupnorm_stats(L):
+    B, P, C = 2, 1060, 128
+    x = rnd((B, P, C), "gn.x", 2.0) + 0.7
+    g, b = rnd((C,), "gn.g") + 1.2, rnd((C,), "gn.b")
+    ref = F.group_norm(x.permute(0, 2, 1).double(), 32, g.double(), b.double(), eps=1e-6).permute(0, 2, 1)
+    work = torch.empty(B * ((P + 255) // 256) * 2 * C, dtype=torch.float64, device="cuda")
+    sc, sh = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+    L.check(L.lib().ds_groupnorm_stats(L.ptr(x.cuda()), B, P, C, 32, L.ptr(g.cuda()), L.ptr(b.cuda()), 1e-6,
+                                       L.ptr(work), L.ptr(sc), L.ptr(sh), L.stream()))
+    got = x.double() * sc.cpu().double()[:, None] + sh.cpu().double()[:, None]
+    assert (got - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("up", [0, 1])
+@pytest.mark.parametrize("gn", [False, True])
+def test_conv2d_3x3(L, up, gn):
+    B, H, W, Cin, Cout = 2, 10, 106, 64, 96
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    x = rnd((B, hs, ws, Cin), "c2.x")
+    w, bias = rnd((Cout, Cin, 3, 3), "c2.w", 0.1), rnd((Cout,), "c2.b")
+    xin = x.permute(0, 3, 1, 2).double()
+    sc = sh = None
+    if gn:
+        sc, sh = rnd((B, Cin), "c2.s") + 1.5, rnd((B, Cin), "c2.o")
+        xin = xin * sc.double()[:, :, None, None] + sh.double()[:, :, None, None]
+        xin = xin * torch.sigmoid(xin)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1).float()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().cuda()
+    out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    L.gemm(x.cuda(), wp, out, B * H * W, Cout, 9 * Cin, bias=bias.cuda(), loader=L.LOAD_CONV2D,
+           pro=L.PRO_AFFINE_SWISH if gn else L.PRO_NONE, pro_scale=sc.cuda() if gn else None,
+           pro_shift=sh.cuda() if gn else None, Cin=Cin, H=H, Wd=W, up=up)
+    assert relerr(out.cpu(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("taps,dil", [(7, 1), (3, 1), (3, 3), (3, 9)])
+def test_conv1d_reflect(L, taps, dil):
+    B, T, Cin, Cout = 2, 212, 64, 96
+    x = rnd((B, T, Cin), "c1.x")
+    w, bias = rnd((Cout, Cin, taps), "c1.w", 0.1), rnd((Cout,), "c1.b")
+    pad = dil * (taps - 1) // 2
+    xin = F.leaky_relu(x.permute(0, 2, 1).double(), 0.2)
+    ref = F.conv1d(F.pad(xin, (pad, pad), mode="reflect"), w.double(), bias.double(), dilation=dil).permute(0, 2, 1).float()
+    wp = w.permute(0, 2, 1).reshape(Cout, -1).contiguous().cuda()
+    out = torch.empty(B, T, Cout, device="cuda")
+    L.gemm(x.cuda(), wp, out, B * T, Cout, taps * Cin, bias=bias.cuda(), loader=L.LOAD_CONV1D, pro=L.PRO_LRELU,
+           Cin=Cin, Wd=T, taps=taps, dil=dil)
+    assert relerr(out.cpu(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("r", [8, 2])
+def test_conv_transpose1d_polyphase(L, r):
+    B, T, Cin, Cout = 2, 53, 64, 32
+    x = rnd((B, T, Cin), "ct.x")
+    w, bias = rnd((Cin, Cout, 2 * r), "ct.w", 0.1), rnd((Cout,), "ct.b")
+    ref = F.conv_transpose1d(F.leaky_relu(x.permute(0, 2, 1).double(), 0.2), w.double(), bias.double(), stride=r,
+                             padding=r // 2).permute(0, 2, 1).float()
+    wph = w.permute(2, 1, 0).reshape(2, r, Cout, Cin).permute(1, 2, 0, 3).reshape(r, Cout, 2 * Cin).contiguous().cuda()
+    out = torch.full((B, T * r, Cout), float("nan"), device="cuda")
+    L.gemm(x.cuda(), wph, out, B * T, Cout, 2 * Cin, bias=bias.cuda(), ldc=Cout, loader=L.LOAD_CONVT1D,
+           pro=L.PRO_LRELU, store=L.STORE_CONVT, groups=r, w_gstride=Cout * 2 * Cin, Cin=Cin, Wd=T,
+           ct_r=r, ct_p=r // 2, ct_tin=T)
+    assert relerr(out.cpu(), ref) < 3e-6
+
+
+def test_softmax_rows_and_stencils(L):
+    x = rnd((530, 288), "sm.x", 30.0)
+    ref = torch.softmax(x[:, :265].double() * 0.044, dim=1).float()
+    g = x.cuda()
+    L.check(L.lib().ds_softmax_rows(L.ptr(g), 530, 265, 288, 0.044, L.stream()))
+    assert (g.cpu()[:, :265] - ref).abs().max() < 1e-6 and (g.cpu()[:, 265:] == 0).all()
+    # 3x3 zero-padded tap sum == conv with a 1-output-channel kernel
+    B, H, W = 2, 20, 33
+    taps = rnd((B, H, W, 16), "s9")
+    eye = torch.zeros(1, 9, 3, 3)
+    for k in range(9):
+        eye[0, k, k // 3, k % 3] = 1.0
+    ref = F.conv2d(taps[..., :9].permute(0, 3, 1, 2), eye, padding=1) + 0.25
+    out = torch.empty(B, 1, H, W, device="cuda")
+    L.check(L.lib().ds_stencil9(L.ptr(taps.cuda()), 16, 0.25, L.ptr(out), B, H, W, L.stream()))
+    assert (out.cpu() - ref).abs().max() < 1e-5
+    N = 500
+    t7 = rnd((B, N, 8), "s7")
+    eye7 = torch.zeros(1, 7, 7)
+    for k in range(7):
+        eye7[0, k, k] = 1.0
+    ref = torch.tanh(F.conv1d(F.pad(t7[..., :7].permute(0, 2, 1), (3, 3), mode="reflect"), eye7) - 0.1)
+    out = torch.empty(B, 1, N, device="cuda")
+    L.check(L.lib().ds_stencil7_tanh(L.ptr(t7.cuda()), 8, -0.1, L.ptr(out), B, N, L.stream()))
+    assert (out.cpu() - ref).abs().max() < 1e-5

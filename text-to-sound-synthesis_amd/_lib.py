@@ -1,0 +1,135 @@
+"""ctypes binding of libdiffsound_hip.so (include/diffsound_hip.h).
+
+There is no CPU fallback: if the shared object is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffsound_hip.so")
+
+# enums (diffsound_hip.h)
+LOAD_DENSE, LOAD_CONV2D, LOAD_CONV1D, LOAD_CONVT1D = 0, 1, 2, 3
+PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LRELU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU2, ACT_TANH = 0, 1, 2
+STORE_ROW, STORE_BATCH_T, STORE_CONVT = 0, 1, 2
+(LP_ADALN1, LP_W_QKV, LP_B_QKV, LP_W_PROJ1, LP_B_PROJ1, LP_ADALN2, LP_W_Q2, LP_B_Q2, LP_W_KV2, LP_B_KV2,
+ LP_W_PROJ2, LP_B_PROJ2, LP_LN2_G, LP_LN2_B, LP_W_FC1, LP_B_FC1, LP_W_FC2, LP_B_FC2, LP_COUNT) = range(19)
+
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", _vp), ("W", _vp), ("bias", _vp), ("R", _vp), ("C", _vp),
+                ("M", _i32), ("N", _i32), ("K", _i32),
+                ("lda", _i32), ("ldw", _i32), ("ldc", _i32), ("ldr", _i32),
+                ("groups", _i32),
+                ("a_gstride", _i64), ("w_gstride", _i64), ("c_gstride", _i64),
+                ("loader", _i32), ("pro", _i32), ("act", _i32), ("store", _i32),
+                ("pro_scale", _vp), ("pro_shift", _vp),
+                ("rows_per_sample", _i32), ("Cin", _i32), ("H", _i32), ("Wd", _i32), ("up", _i32),
+                ("taps", _i32), ("dil", _i32), ("ct_r", _i32), ("ct_p", _i32), ("ct_tin", _i32)]
+
+
+class DenoiserDesc(C.Structure):
+    _fields_ = [("n_layer", _i32), ("n_embd", _i32), ("n_head", _i32), ("seq_len", _i32),
+                ("cond_len", _i32), ("cond_dim", _i32), ("n_codes", _i32), ("n_steps", _i32),
+                ("mlp_mult", _i32),
+                ("tok_emb", _vp), ("pos_emb", _vp), ("lnf_g", _vp), ("lnf_b", _vp),
+                ("w_logits", _vp), ("b_logits", _vp), ("sched", _vp)]
+
+
+_PROTOS = {
+    "ds_version": (C.c_int, []),
+    "ds_last_error_string": (C.c_char_p, []),
+    "ds_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "ds_gemm_force_tile": (None, [C.c_int]),
+    "ds_embed": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_adaln": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "ds_layernorm": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "ds_attention": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_sample_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),
+    "ds_denoiser_destroy": (None, [_vp]),
+    "ds_denoiser_workspace_bytes": (_i64, [_vp, C.c_int]),
+    "ds_denoiser_kv_bytes": (_i64, [_vp, C.c_int]),
+    "ds_denoiser_cond_kv": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "ds_denoiser_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "ds_denoiser_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f, _vp, _vp, _vp]),
+    "ds_codebook_gather": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_groupnorm_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "ds_softmax_rows": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_stencil9": (C.c_int, [_vp, C.c_int, _f, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_stencil7_tanh": (C.c_int, [_vp, C.c_int, _f, _vp, C.c_int, C.c_int, _vp]),
+    "ds_mel_to_cl": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _vp]),
+}
+EXPORTED = tuple(_PROTOS)
+
+_lib = None
+
+
+def lib():
+    """The loaded shared object (loads on first use; raises if it was never built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdiffsound_hip.so is missing (%s). Build it with `python __graft_entry__.py` -- "
+                "there is no CPU or PyTorch fallback for the Diffsound HIP path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)   # AttributeError here == header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class DiffsoundHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise DiffsoundHipError("libdiffsound_hip: rc=%d: %s" % (rc, lib().ds_last_error_string().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses anything that is not fp32/int64/f64
+    contiguous device memory -- the kernels have no host path."""
+    if t is None:
+        return None
+    if isinstance(t, int):   # an already-computed device address (sub-matrix views)
+        return t
+    if not t.is_cuda:
+        raise DiffsoundHipError("tensor is not on a GPU: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise DiffsoundHipError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=None, ldr=None,
+         groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
+         act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
+         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0):
+    d = GemmDesc()
+    d.A, d.W, d.bias, d.R, d.C = ptr(A), ptr(W), ptr(bias), ptr(R), ptr(C_out)
+    d.M, d.N, d.K = M, N, K
+    d.lda = lda if lda is not None else K
+    d.ldw = ldw if ldw is not None else K
+    d.ldc = ldc if ldc is not None else N
+    d.ldr = ldr if ldr is not None else d.ldc
+    d.groups, d.a_gstride, d.w_gstride, d.c_gstride = groups, a_gstride, w_gstride, c_gstride
+    d.loader, d.pro, d.act, d.store = loader, pro, act, store
+    d.pro_scale, d.pro_shift = ptr(pro_scale), ptr(pro_shift)
+    d.rows_per_sample, d.Cin, d.H, d.Wd, d.up = rows_per_sample, Cin, H, Wd, up
+    d.taps, d.dil, d.ct_r, d.ct_p, d.ct_tin = taps, dil, ct_r, ct_p, ct_tin
+    check(lib().ds_gemm(C.byref(d), stream()))
+    return C_out

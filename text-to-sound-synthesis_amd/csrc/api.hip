@@ -1,0 +1,181 @@
+// C ABI glue: error strings, the public gather-GEMM entry, and the native denoiser driver that
+// enqueues the whole Text2ImageTransformer forward (transformer_utils.py:421-443) -- 19 blocks x 11
+// launches -- from C++ on one HIP stream (no Python in the per-layer loop).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ds_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int ds_version(void) { return 100; }
+extern "C" const char* ds_last_error_string(void) { return g_err; }
+
+static void fill(GemmParams& p, const ds_gemm_desc* d) {
+    p.A = d->A; p.W = d->W; p.bias = d->bias; p.R = d->R; p.C = d->C;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.ldc = d->ldc; p.ldr = d->ldr;
+    p.groups = d->groups > 0 ? d->groups : 1;
+    p.a_gstride = d->a_gstride; p.w_gstride = d->w_gstride; p.c_gstride = d->c_gstride;
+    p.pro = d->pro; p.act = d->act; p.store = d->store;
+    p.pro_scale = d->pro_scale; p.pro_shift = d->pro_shift;
+    p.rows_per_sample = d->rows_per_sample;
+    p.Cin = d->Cin; p.H = d->H; p.W_ = d->Wd; p.up = d->up; p.taps = d->taps; p.dil = d->dil;
+    p.ct_r = d->ct_r; p.ct_p = d->ct_p; p.ct_tin = d->ct_tin;
+}
+
+extern "C" int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream) {
+    DS_CHECK_ARG(d && d->A && d->W && d->C, "null pointer");
+    DS_CHECK_ARG(d->pro == DS_PRO_NONE || d->pro == DS_PRO_LRELU || (d->pro_scale && d->pro_shift && d->Cin > 0),
+                 "affine prologue needs pro_scale/pro_shift/Cin");
+    DS_CHECK_ARG(d->store != DS_STORE_BATCH_T || d->rows_per_sample > 0, "BATCH_T store needs rows_per_sample");
+    DS_CHECK_ARG(d->R == nullptr || d->store == DS_STORE_ROW, "residual only with row-major store");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    fill(p, d);
+    return ds_launch_gemm(p, (hipStream_t)stream, d->loader);
+}
+
+// ---- denoiser ---------------------------------------------------------------------------------------
+struct ds_denoiser {
+    ds_denoiser_desc d;
+    std::vector<const float*> lp;  // [n_layer][DS_LP_COUNT]
+    const float* P(int layer, int slot) const { return lp[(size_t)layer * DS_LP_COUNT + slot]; }
+};
+
+extern "C" int ds_denoiser_create(const ds_denoiser_desc* desc, const void* const* layer_ptrs, ds_denoiser** out) {
+    DS_CHECK_ARG(desc && layer_ptrs && out, "null pointer");
+    DS_CHECK_ARG(desc->n_embd == 1024 && desc->n_embd == desc->n_head * 64, "built for n_embd 1024, head dim 64");
+    DS_CHECK_ARG(desc->n_codes == 256 || desc->n_codes == 512, "codebook size must be 256 or 512");
+    DS_CHECK_ARG(desc->cond_dim % 32 == 0 && desc->cond_len <= 96 && desc->seq_len <= 288, "unsupported lengths");
+    DS_CHECK_ARG(desc->tok_emb && desc->pos_emb && desc->lnf_g && desc->lnf_b && desc->w_logits && desc->b_logits &&
+                     desc->sched,
+                 "null weight pointer");
+    for (int i = 0; i < desc->n_layer * DS_LP_COUNT; ++i) DS_CHECK_ARG(layer_ptrs[i], "null layer pointer");
+    ds_denoiser* h = new ds_denoiser;
+    h->d = *desc;
+    h->lp.resize((size_t)desc->n_layer * DS_LP_COUNT);
+    for (size_t i = 0; i < h->lp.size(); ++i) h->lp[i] = (const float*)layer_ptrs[i];
+    *out = h;
+    return 0;
+}
+
+extern "C" void ds_denoiser_destroy(ds_denoiser* h) { delete h; }
+
+// workspace carve (floats): x, hn, qkv, att, fc, logits
+struct Carve {
+    float *x, *hn, *qkv, *att, *fc, *logits;
+};
+static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c) {
+    const size_t M = (size_t)B * h->d.seq_len, D = h->d.n_embd;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        float* p = ws ? (float*)ws + off : nullptr;
+        off += (n + 63) & ~(size_t)63;
+        return p;
+    };
+    Carve t;
+    t.x = take(M * D);
+    t.hn = take(M * D);
+    t.qkv = take(M * 3 * D);
+    t.att = take(M * D);
+    t.fc = take(M * D * h->d.mlp_mult);
+    t.logits = take(M * h->d.n_codes);
+    if (c) *c = t;
+    return off * sizeof(float);
+}
+
+extern "C" int64_t ds_denoiser_workspace_bytes(const ds_denoiser* h, int B) {
+    return h && B > 0 ? (int64_t)carve(h, B, nullptr, nullptr) : -1;
+}
+extern "C" int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B) {
+    return h && B > 0 ? (int64_t)h->d.n_layer * B * h->d.cond_len * 2 * h->d.n_embd * (int64_t)sizeof(float) : -1;
+}
+
+static int dense(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc,
+                 int M, int N, int K, int act, hipStream_t s, int store = DS_STORE_ROW, int rps = 0) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.W = W; p.bias = bias; p.R = R; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = K; p.ldc = ldc; p.ldr = ldc;
+    p.groups = 1; p.act = act; p.store = store; p.rows_per_sample = rps;
+    return ds_launch_gemm(p, s, DS_LOAD_DENSE);
+}
+
+#define TRY(x)            \
+    do {                  \
+        int rc_ = (x);    \
+        if (rc_) return rc_; \
+    } while (0)
+
+extern "C" int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int B, float* kv, ds_stream_t stream) {
+    DS_CHECK_ARG(h && cond && kv && B > 0, "bad arguments");
+    const int D = h->d.n_embd, Mc = B * h->d.cond_len;
+    for (int l = 0; l < h->d.n_layer; ++l)
+        TRY(dense(cond, h->d.cond_dim, h->P(l, DS_LP_W_KV2), h->P(l, DS_LP_B_KV2), nullptr,
+                  kv + (size_t)l * Mc * 2 * D, 2 * D, Mc, 2 * D, h->d.cond_dim, DS_ACT_NONE, (hipStream_t)stream));
+    return 0;
+}
+
+static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64_t* t, const float* kv, int B,
+                        const Carve& w, float* logits, int layout, hipStream_t s) {
+    const ds_denoiser_desc& d = h->d;
+    const int D = d.n_embd, L = d.seq_len, M = B * L, Mc = B * d.cond_len;
+    const float scale = 0.125f;  // 1/sqrt(64), transformer_utils.py:48
+    TRY(ds_embed(tokens, d.tok_emb, d.pos_emb, w.x, M, L, D, s));
+    for (int l = 0; l < d.n_layer; ++l) {
+        // x += attn1(ln1(x, t))
+        TRY(ds_adaln(w.x, w.hn, M, L, D, h->P(l, DS_LP_ADALN1), t, s));
+        TRY(dense(w.hn, D, h->P(l, DS_LP_W_QKV), h->P(l, DS_LP_B_QKV), nullptr, w.qkv, 3 * D, M, 3 * D, D, DS_ACT_NONE, s));
+        TRY(ds_attention(w.qkv, 3 * D, w.qkv + D, 3 * D, w.qkv + 2 * D, 3 * D, w.att, D, B, d.n_head, L, L, scale, s));
+        TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ1), h->P(l, DS_LP_B_PROJ1), w.x, w.x, D, M, D, D, DS_ACT_NONE, s));
+        // x += attn2(ln1_1(x, t), cond)
+        TRY(ds_adaln(w.x, w.hn, M, L, D, h->P(l, DS_LP_ADALN2), t, s));
+        TRY(dense(w.hn, D, h->P(l, DS_LP_W_Q2), h->P(l, DS_LP_B_Q2), nullptr, w.qkv, D, M, D, D, DS_ACT_NONE, s));
+        const float* kvl = kv + (size_t)l * Mc * 2 * D;
+        TRY(ds_attention(w.qkv, D, kvl, 2 * D, kvl + D, 2 * D, w.att, D, B, d.n_head, L, d.cond_len, scale, s));
+        TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ2), h->P(l, DS_LP_B_PROJ2), w.x, w.x, D, M, D, D, DS_ACT_NONE, s));
+        // x += mlp(ln2(x))
+        TRY(ds_layernorm(w.x, w.hn, M, D, h->P(l, DS_LP_LN2_G), h->P(l, DS_LP_LN2_B), s));
+        TRY(dense(w.hn, D, h->P(l, DS_LP_W_FC1), h->P(l, DS_LP_B_FC1), nullptr, w.fc, D * d.mlp_mult, M, D * d.mlp_mult, D,
+                  DS_ACT_GELU2, s));
+        TRY(dense(w.fc, D * d.mlp_mult, h->P(l, DS_LP_W_FC2), h->P(l, DS_LP_B_FC2), w.x, w.x, D, M, D, D * d.mlp_mult,
+                  DS_ACT_NONE, s));
+    }
+    TRY(ds_layernorm(w.x, w.hn, M, D, d.lnf_g, d.lnf_b, s));
+    if (layout == 0)
+        TRY(dense(w.hn, D, d.w_logits, d.b_logits, nullptr, logits, d.n_codes, M, d.n_codes, D, DS_ACT_NONE, s));
+    else
+        TRY(dense(w.hn, D, d.w_logits, d.b_logits, nullptr, logits, L, M, d.n_codes, D, DS_ACT_NONE, s,
+                  DS_STORE_BATCH_T, L));
+    return 0;
+}
+
+extern "C" int ds_denoiser_forward(const ds_denoiser* h, const int64_t* tokens, const int64_t* t, const float* kv,
+                                   int B, void* workspace, float* logits, int logits_layout, ds_stream_t stream) {
+    DS_CHECK_ARG(h && tokens && t && kv && workspace && logits && B > 0, "bad arguments");
+    Carve w;
+    carve(h, B, workspace, &w);
+    return forward_impl(h, tokens, t, kv, B, w, logits, logits_layout, (hipStream_t)stream);
+}
+
+extern "C" int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const float* kv,
+                                const float* u, int B, int initial, float trunc_r, void* workspace,
+                                int64_t* tokens_out, ds_stream_t stream) {
+    DS_CHECK_ARG(h && tokens_in && t && kv && u && workspace && tokens_out && B > 0, "bad arguments");
+    Carve w;
+    carve(h, B, workspace, &w);
+    TRY(forward_impl(h, tokens_in, t, kv, B, w, w.logits, 0, (hipStream_t)stream));
+    return ds_sample_tail(w.logits, tokens_in, t, u, h->d.sched, tokens_out, nullptr, nullptr, nullptr, B,
+                          h->d.seq_len, h->d.n_codes, h->d.n_steps, initial, trunc_r, stream);
+}

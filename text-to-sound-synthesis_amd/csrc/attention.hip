@@ -1,0 +1,177 @@
+// Fused multi-head attention for the denoiser (head dim 64, fp32, exact-fp32 MFMA).
+// Replaces FullAttention.forward / CrossAttention.forward (transformer_utils.py:43-58, :91-109):
+//   att = softmax(q k^T / sqrt(64));  y = att v      -- no mask, dropout 0; the reference's
+//   att.mean(dim=1) (:54,:105) is dead on the sampling path and is not computed.
+//
+// One workgroup (3 waves) per (sample, head, group of 3 query tiles); a wave owns 32 query
+// rows.  All Lk <= 32*NKT keys of the head sit in LDS (rows padded to 68 floats: conflict-free
+// ds_read_b128), first K, then V in the same buffer.
+//   pass 1  S^T = K Q^T   (MFMA 32x32x2 f32, A = K rows from LDS, B = Q rows held in registers).
+//           Computing the TRANSPOSED scores makes lane&31 the query and spreads the keys over
+//           registers: the row softmax is in-lane (+ one cross-half shuffle), no LDS round trip.
+//   pass 2  O = P V       the P registers are already in MFMA A-operand layout
+//           (A[i = query = lane&31][k = key pair selected by lane>>5]); V rows are ds_read_b32.
+// The score tile never touches HBM (the reference materialises [B,16,265,265]).
+#include "common.h"
+
+#define ATT_LD 68
+#define ATT_WAVES 3
+
+template <int NKT>
+__global__ __launch_bounds__(ATT_WAVES * 64) void ds_attn_kernel(const float* __restrict__ Q, int ldq,
+                                                                 const float* __restrict__ Kp, int ldk,
+                                                                 const float* __restrict__ Vp, int ldv,
+                                                                 float* __restrict__ O, int ldo, int Lq, int Lk,
+                                                                 int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float kv[];  // [NKT*32][ATT_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int qgroups = gridDim.x / heads;  // blockIdx.x = grp * heads + head
+    (void)qgroups;
+    const int head = blockIdx.x % heads;
+    const int grp = blockIdx.x / heads;
+    const int b = blockIdx.y;
+    const int qt = grp * ATT_WAVES + wave;   // query tile of this wave
+    const int q0 = qt * 32;
+    const bool active = q0 < Lq;             // wave-uniform
+
+    const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
+    const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
+
+    // ---- stage K into LDS (zero rows beyond Lk) ----
+    for (int f = tid; f < NKT * 32 * 16; f += ATT_WAVES * 64) {
+        const int row = f >> 4, c4 = (f & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < Lk) v = *(const f32x4*)(kb + (size_t)row * ldk + c4);
+        *(f32x4*)(kv + row * ATT_LD + c4) = v;
+    }
+    // ---- Q fragment: lane (q = l31, half hh) keeps Q[q][8c + 4hh + j], c = 0..7, j = 0..3 ----
+    f32x4 qf[8];
+    {
+        int qr = q0 + l31;
+        if (qr >= Lq) qr = Lq - 1;
+        const float* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 64 + 4 * hh;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qf[c] = *(const f32x4*)(qp + 8 * c);
+    }
+    __syncthreads();
+
+    f32x16 s[NKT];
+    if (active) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            const float* kr = kv + (kt * 32 + l31) * ATT_LD + 4 * hh;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 kf = *(const f32x4*)(kr + 8 * c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], s[kt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // everyone is done reading K
+    // ---- stage V into the same buffer (overlaps with the softmax below) ----
+    for (int f = tid; f < NKT * 32 * 16; f += ATT_WAVES * 64) {
+        const int row = f >> 4, c4 = (f & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < Lk) v = *(const f32x4*)(vb + (size_t)row * ldv + c4);
+        *(f32x4*)(kv + row * ATT_LD + c4) = v;
+    }
+
+    // ---- softmax over keys: lane holds keys kt*32 + (r&3) + 8*(r>>2) + 4*hh of query l31 ----
+    if (active) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = key < Lk ? s[kt][r] * scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+    }
+    __syncthreads();  // V is in LDS
+
+    if (active) {
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float* vr = kv + key * ATT_LD + l31;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(s[kt][r], vr[0], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(s[kt][r], vr[32], o1, 0, 0, 0);
+            }
+        // O fragment: col = d = l31 (+32), row = query (r&3) + 8*(r>>2) + 4*hh
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (qr < Lq) {
+                float* op = O + ((size_t)b * Lq + qr) * ldo + head * 64 + l31;
+                op[0] = o0[r];
+                op[32] = o1[r];
+            }
+        }
+    }
+}
+
+// Q: [B*Lq][ldq] (head h at columns h*64..), K/V: [B*Lk][ldk/ldv], O: [B*Lq][ldo]
+extern "C" int ds_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                            int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(q && k && v && o, "null pointer");
+    DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "bad shape");
+    DS_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "leading dims must be multiples of 4");
+    const int qtiles = (Lq + 31) / 32;
+    const int groups = (qtiles + ATT_WAVES - 1) / ATT_WAVES;
+    dim3 grid(groups * heads, B), block(ATT_WAVES * 64);
+    static bool attr9 = false, attr3 = false;
+    if (Lk <= 96) {
+        const size_t lds = 3 * 32 * ATT_LD * sizeof(float);
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)ds_attn_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((ds_attn_kernel<3>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
+                           heads, scale);
+    } else {
+        DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
+        const size_t lds = 9 * 32 * ATT_LD * sizeof(float);
+        if (!attr9) {
+            hipError_t e = hipFuncSetAttribute((const void*)ds_attn_kernel<9>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                ds_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return -2;
+            }
+            attr9 = true;
+        }
+        hipLaunchKernelGGL((ds_attn_kernel<9>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
+                           heads, scale);
+    }
+    DS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,140 @@
+// Small HBM/latency-bound kernels around the contractions.
+#include "common.h"
+
+// ---- codebook lookup fused with the ColumnMajor inverse permutation ---------------------------
+// out[b][h][w][:] = E[tokens[b][w*H + h]][:]      (channels-last quant image)
+// replaces first_stage_permuter(reverse=True) + get_codebook_entry's one-hot matmul
+// (specvqgan/modules/transformer/permuter.py:31-55, vqvae/quantize.py:88-103).
+__global__ __launch_bounds__(256) void ds_codebook_gather_kernel(const int64_t* __restrict__ tok,
+                                                                 const float* __restrict__ E,
+                                                                 float* __restrict__ out, int B, int H, int W,
+                                                                 int C, int K) {
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= B * H * W) return;
+    const int lane = threadIdx.x & 63;
+    const int b = pix / (H * W), rem = pix - b * H * W;
+    const int h = rem / W, w = rem - h * W;
+    long long t = tok[(size_t)b * H * W + w * H + h];
+    if (t < 0) t = 0;
+    if (t >= K) t = K - 1;  // a leftover [MASK] cannot be decoded; the reference would raise
+    const float* e = E + (size_t)t * C;
+    float* o = out + (size_t)pix * C;
+    for (int c = lane * 4; c < C; c += 256) *(f32x4*)(o + c) = *(const f32x4*)(e + c);
+}
+
+// ---- row softmax with scale, in place, zero-filling the padded tail -----------------------------
+// x[row][0..n) <- softmax(scale * x[row][0..n)), x[row][n..ld) <- 0      (AttnBlock, model.py:214-216)
+__global__ __launch_bounds__(256) void ds_softmax_rows_kernel(float* __restrict__ x, int rows, int n, int ld,
+                                                              float scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* xr = x + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < n; c += 64) mx = fmaxf(mx, xr[c] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += expf(xr[c] * scale - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.f / s;
+    for (int c = lane; c < ld; c += 64) xr[c] = c < n ? expf(xr[c] * scale - mx) * inv : 0.f;
+}
+
+// ---- single-output-channel convs: the per-tap dot products come from the GEMM (N = taps), these
+//      kernels add the taps up with the conv's padding rule ---------------------------------------
+// 3x3, zero padding 1 (Decoder.conv_out, model.py:633-637):  out[b][y][x] = bias + sum_tap T[b][y+ky-1][x+kx-1][tap]
+__global__ __launch_bounds__(256) void ds_stencil9_kernel(const float* __restrict__ T, int ldt, float bias,
+                                                          float* __restrict__ out, int B, int H, int W) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H * W) return;
+    const int b = i / (H * W), rem = i - b * H * W;
+    const int y = rem / W, x = rem - y * W;
+    float acc = bias;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sy = y + ky - 1, sx = x + kx - 1;
+            if (sy >= 0 && sy < H && sx >= 0 && sx < W) acc += T[((size_t)(b * H + sy) * W + sx) * ldt + ky * 3 + kx];
+        }
+    out[i] = acc;
+}
+
+// k = 7, ReflectionPad1d(3), tanh (Generator tail, vocoder/modules.py:119-124)
+__global__ __launch_bounds__(256) void ds_stencil7_tanh_kernel(const float* __restrict__ T, int ldt, float bias,
+                                                               float* __restrict__ out, int B, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, t = i - b * N;
+    float acc = bias;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int s = t + k - 3;
+        if (s < 0) s = -s;
+        if (s >= N) s = 2 * (N - 1) - s;
+        acc += T[((size_t)b * N + s) * ldt + k];
+    }
+    out[i] = tanhf(acc);
+}
+
+// ---- mel [B][C][T] -> channels-last [B][T][Cpad] with y = a*x + b, zero channel padding ----------
+__global__ __launch_bounds__(256) void ds_mel_to_cl_kernel(const float* __restrict__ mel, float* __restrict__ out,
+                                                           int B, int C, int T, int Cpad, float a, float bb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // over B*T*Cpad, channel fastest
+    if (i >= B * T * Cpad) return;
+    const int c = i % Cpad, bt = i / Cpad;
+    const int b = bt / T, t = bt - b * T;
+    out[i] = c < C ? a * mel[((size_t)b * C + c) * T + t] + bb : 0.f;
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------
+extern "C" int ds_codebook_gather(const int64_t* tokens, const float* codebook, float* out, int B, int H, int W,
+                                  int C, int K, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(tokens && codebook && out, "null pointer");
+    DS_CHECK_ARG(C % 4 == 0, "C must be a multiple of 4");
+    hipLaunchKernelGGL(ds_codebook_gather_kernel, dim3((B * H * W + 3) / 4), dim3(256), 0, stream, tokens, codebook,
+                       out, B, H, W, C, K);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x && rows > 0 && n > 0 && ld >= n, "bad arguments");
+    hipLaunchKernelGGL(ds_softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, rows, n, ld, scale);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_stencil9(const float* taps, int ldt, float bias, float* out, int B, int H, int W,
+                           ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(taps && out && ldt >= 9, "bad arguments");
+    hipLaunchKernelGGL(ds_stencil9_kernel, dim3((B * H * W + 255) / 256), dim3(256), 0, stream, taps, ldt, bias, out,
+                       B, H, W);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_stencil7_tanh(const float* taps, int ldt, float bias, float* out, int B, int N,
+                                ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(taps && out && ldt >= 7, "bad arguments");
+    hipLaunchKernelGGL(ds_stencil7_tanh_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, taps, ldt, bias, out,
+                       B, N);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_mel_to_cl(const float* mel, float* out, int B, int C, int T, int Cpad, float a, float b,
+                            ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(mel && out && Cpad >= C, "bad arguments");
+    hipLaunchKernelGGL(ds_mel_to_cl_kernel, dim3((B * T * Cpad + 255) / 256), dim3(256), 0, stream, mel, out, B, C, T,
+                       Cpad, a, b);
+    DS_CHECK_LAUNCH();
+    return 0;
+}

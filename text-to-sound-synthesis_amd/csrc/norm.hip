@@ -1,0 +1,206 @@
+// Row-wise kernels of the denoiser (HBM-bound; one wavefront per 1024-wide row, float4 loads):
+//   ds_embed       token + position embedding            (dalle_mask_image_embedding.py:36-58)
+//   ds_layernorm   LayerNorm(eps 1e-5) with either the AdaLN modulation  y = xn*(1+scale[t])+shift[t]
+//                  (transformer_utils.py:134-149, scale/shift tabulated per timestep at load time)
+//                  or the ordinary affine  y = xn*gamma + beta  (ln2 / to_logits.0).
+// and GroupNorm(32, C, eps 1e-6) statistics for the SpecVQGAN decoder
+// (specvqgan/modules/diffusionmodules/model.py:34-35), emitted as the per-(sample, channel)
+// affine  a' = a*scale + shift  that the conv loaders apply on the fly (gemm_f32.hip).
+#include "common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// x[m][:] = emb[tok[m]][:] + pos[m % L][:]          D = 1024
+__global__ __launch_bounds__(256) void ds_embed_kernel(const int64_t* __restrict__ tok,
+                                                       const float* __restrict__ emb,
+                                                       const float* __restrict__ pos,
+                                                       float* __restrict__ out, int M, int L, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    long long t = tok[row];
+    if (t < 0) t = 0;  // index[index < 0] = 0, dalle_mask_image_embedding.py:41
+    const float* e = emb + (size_t)t * D;
+    const float* p = pos + (size_t)(row % L) * D;
+    float* o = out + (size_t)row * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 a = *(const f32x4*)(e + c), b = *(const f32x4*)(p + c);
+        *(f32x4*)(o + c) = a + b;
+    }
+}
+
+// mode 0: AdaLN   y = xn * (1 + tab[t[b]][c]) + tab[t[b]][D + c],  b = row / L
+// mode 1: affine  y = xn * gamma[c] + beta[c]
+template <int D>
+__global__ __launch_bounds__(256) void ds_layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int M, int L, int mode,
+                                                           const float* __restrict__ tab,  // [T][2D]
+                                                           const int64_t* __restrict__ t,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int NV = D / 256;
+    f32x4 v[NV];
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        v[j] = *(const f32x4*)(xr + (j * 64 + lane) * 4);
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = wave_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = v[j][k] - mean;
+            q += d * d;
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) * (1.f / D) + eps);  // biased variance, as torch
+    const float *sc, *sh;
+    if (mode == 0) {
+        const long long tt = t[row / L];
+        sc = tab + (size_t)tt * 2 * D;
+        sh = sc + D;
+    } else {
+        sc = gamma;
+        sh = beta;
+    }
+    float* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        const f32x4 a = *(const f32x4*)(sc + c), b = *(const f32x4*)(sh + c);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xn = (v[j][k] - mean) * rstd;
+            o[k] = mode == 0 ? xn * (1.f + a[k]) + b[k] : xn * a[k] + b[k];
+        }
+        *(f32x4*)(yr + c) = o;
+    }
+}
+
+// ---- GroupNorm statistics over a channels-last tensor x[B][P][C] (P = H*W pixels) -----------
+// pass 1: grid (chunks, B): each block reduces PCHUNK pixels into per-channel double partials
+// pass 2: grid (B): combine chunks -> per-group mean/rstd -> scale/shift per channel.
+#define GN_PCHUNK 256
+__global__ __launch_bounds__(256) void ds_gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                            int P, int C) {
+    // part[b][chunk][2][C]
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int p0 = chunk * GN_PCHUNK;
+    const int p1 = min(P, p0 + GN_PCHUNK);
+    const float* xb = x + ((size_t)b * P) * C;
+    // thread owns channel set {c = tid + 256*j}; loop pixels (coalesced across threads)
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s = 0.0, q = 0.0;
+        for (int p = p0; p < p1; ++p) {
+            const double v = (double)xb[(size_t)p * C + c];
+            s += v;
+            q += v * v;
+        }
+        double* o = part + (((size_t)b * nchunk + chunk) * 2) * C;
+        o[c] = s;
+        o[C + c] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void ds_gn_finish_kernel(const double* __restrict__ part, int nchunk, int P, int C,
+                                                           int groups, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double gs[64], gq[64];  // groups <= 64
+    const int b = blockIdx.x;
+    const int cpg = C / groups;
+    if (threadIdx.x < 64) { gs[threadIdx.x] = 0.0; gq[threadIdx.x] = 0.0; }
+    __syncthreads();
+    // one wave per group (strided), lanes over (chunk, channel-in-group)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int g = wave; g < groups; g += 4) {
+        double s = 0.0, q = 0.0;
+        for (int i = lane; i < nchunk * cpg; i += 64) {
+            const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
+            const double* o = part + (((size_t)b * nchunk + ch) * 2) * C;
+            s += o[c];
+            q += o[C + c];
+        }
+        s = wave_sum_d(s);
+        q = wave_sum_d(q);
+        if (lane == 0) { gs[g] = s; gq[g] = q; }
+    }
+    __syncthreads();
+    const double n = (double)P * cpg;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        const double mean = gs[g] / n;
+        double var = gq[g] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double ga = gamma[c], be = beta[c];
+        scale[(size_t)b * C + c] = (float)(rstd * ga);
+        shift[(size_t)b * C + c] = (float)(be - mean * rstd * ga);
+    }
+}
+
+// ---- C ABI entry points ---------------------------------------------------------------------
+extern "C" int ds_embed(const int64_t* tokens, const float* emb, const float* pos, float* out, int M, int L,
+                        int D, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(tokens && emb && pos && out, "null pointer");
+    DS_CHECK_ARG(M > 0 && L > 0 && D % 4 == 0, "bad shape");
+    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_adaln(const float* x, float* y, int M, int L, int D, const float* table, const int64_t* t,
+                        ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x && y && table && t, "null pointer");
+    DS_CHECK_ARG(D == 1024, "only D = 1024 is built");
+    hipLaunchKernelGGL((ds_layernorm_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, stream, x, y, M, L, 0, table,
+                       t, (const float*)nullptr, (const float*)nullptr, 1e-5f);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_layernorm(const float* x, float* y, int M, int D, const float* gamma, const float* beta,
+                            ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x && y && gamma && beta, "null pointer");
+    DS_CHECK_ARG(D == 1024, "only D = 1024 is built");
+    hipLaunchKernelGGL((ds_layernorm_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, stream, x, y, M, 1, 1,
+                       (const float*)nullptr, (const int64_t*)nullptr, gamma, beta, 1e-5f);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// x: [B][P][C] channels-last.  work: >= B * ceil(P/256) * 2 * C doubles.  scale/shift: [B][C].
+extern "C" int ds_groupnorm_stats(const float* x, int B, int P, int C, int groups, const float* gamma,
+                                  const float* beta, float eps, double* work, float* scale, float* shift,
+                                  ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x && gamma && beta && work && scale && shift, "null pointer");
+    DS_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0, "bad group count");
+    const int nchunk = (P + GN_PCHUNK - 1) / GN_PCHUNK;
+    hipLaunchKernelGGL(ds_gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, stream, x, work, P, C);
+    DS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ds_gn_finish_kernel, dim3(B), dim3(256), 0, stream, work, nchunk, P, C, groups, gamma, beta,
+                       eps, scale, shift);
+    DS_CHECK_LAUNCH();
+    return 0;
+}

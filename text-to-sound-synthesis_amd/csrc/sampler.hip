@@ -1,0 +1,225 @@
+// The per-column tail of one reverse-diffusion step, fused into one kernel (one wavefront per
+// grid position (b, pos); K codes = NPL*64 so each lane owns NPL classes; [MASK] is class K):
+//
+//   predict_start      diffusion_transformer.py:285-289   log_softmax in float64 -> f32, -70 row, clamp
+//   top-r truncation   models/dalle_spec.py:158-174       keep class iff mass ranked before it < r
+//   q_posterior        diffusion_transformer.py:293-339   (+ q_pred :253-267, q_pred_one_timestep
+//                                                          :241-251, log_add_exp :28-30)
+//   log_sample_categorical  :359-368                      Gumbel-argmax with the caller's uniforms
+//
+// State between steps is the token index, not the reference's 272 KB/sample log-one-hot: the
+// log-one-hot is only ever consumed through argmax / q_pred / q_pred_one_timestep, which need
+// {0 at x_t, log(1e-30) elsewhere}; the all-[MASK] start state is {0, -inf} (:633-636) and is
+// flagged by `initial`.
+//
+// The reference sorts each column (2 sorts + cumsum + gather); here the "mass ranked before me"
+// is an O(K^2/64) compare-and-add per lane against an LDS copy of the column -- 66k flops per
+// column, nothing next to the 155 GFLOP transformer step, and no sort network.
+// Noise is read in the reference's own [B, K+1, L] layout so that torch.rand_like on the same
+// shape reproduces the reference's RNG stream.
+#include "common.h"
+
+#define LOG_ZERO_F (-69.07755278982137f)  // logf(1e-30f)
+
+__device__ __forceinline__ float lae(float a, float b) {  // log(exp a + exp b)
+    const float m = fmaxf(a, b);
+    return m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float wmaxf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wsumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wsumd(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct SampleParams {
+    const float* logits;      // [B*L][K]  (row-major, class contiguous)
+    const int64_t* xt;        // [B][L] current tokens
+    const int64_t* t;         // [B]
+    const float* u;           // [B][K+1][L] uniforms in [0,1)
+    const float* sched;       // 8 rows of (T+1) floats: log_at, log_bt, log_ct, log_1_min_ct,
+                              //   log_cumprod_at, log_cumprod_bt, log_cumprod_ct, log_1_min_cumprod_ct
+    int64_t* out_tokens;      // [B][L]
+    float* dbg_log_pred;      // optional [B][K+1][L]
+    float* dbg_trunc;         // optional
+    float* dbg_post;          // optional
+    int B, L, T;
+    int initial;              // 1: x_t is the all-[MASK] start state (log one-hot = 0 / -inf)
+    float trunc_r;            // < 0: no truncation
+};
+
+template <int NPL>
+__global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams p) {
+    constexpr int K = NPL * 64;
+    __shared__ float s_lp[4][K];
+    __shared__ float s_pr[4][K];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int col = blockIdx.x * 4 + w;
+    const bool live = col < p.B * p.L;  // a dead wave shadows the last column and writes nothing
+    if (!live) col = p.B * p.L - 1;
+    const int b = col / p.L, pos = col - b * p.L;
+
+    // ---- predict_start: float64 log-softmax over the K real classes ----
+    float v[NPL];
+    const float* lg = p.logits + (size_t)col * K;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) v[j] = lg[j * 64 + lane];
+    float mx = v[0];
+#pragma unroll
+    for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, v[j]);
+    mx = wmaxf(mx);
+    double se = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) se += exp((double)v[j] - (double)mx);
+    se = wsumd(se);
+    const double lse64 = log(se);
+    float lp[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        float x = (float)(((double)v[j] - (double)mx) - lse64);
+        lp[j] = fminf(fmaxf(x, -70.f), 0.f);
+    }
+    const size_t dbg_base = (size_t)b * (K + 1) * p.L + pos;
+    if (p.dbg_log_pred && live) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) p.dbg_log_pred[dbg_base + (size_t)(j * 64 + lane) * p.L] = lp[j];
+        if (lane == 0) p.dbg_log_pred[dbg_base + (size_t)K * p.L] = -70.f;
+    }
+
+    // ---- top-r truncation ----
+    float tr[NPL];
+    if (p.trunc_r >= 0.f) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            s_lp[w][j * 64 + lane] = lp[j];
+            s_pr[w][j * 64 + lane] = expf(lp[j]);
+        }
+        __syncthreads();
+        float before[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) before[j] = 0.f;
+        for (int c = 0; c < K; ++c) {
+            const float ol = s_lp[w][c], op = s_pr[w][c];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int me = j * 64 + lane;
+                const bool ahead = ol > lp[j] || (ol == lp[j] && c < me);
+                before[j] += ahead ? op : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) tr[j] = before[j] < p.trunc_r ? lp[j] : -70.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) tr[j] = lp[j];
+    }
+    if (p.dbg_trunc && live) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) p.dbg_trunc[dbg_base + (size_t)(j * 64 + lane) * p.L] = tr[j];
+        if (lane == 0) p.dbg_trunc[dbg_base + (size_t)K * p.L] = -70.f;
+    }
+
+    // ---- q_posterior ----
+    const int T1 = p.T + 1;
+    const int t = (int)p.t[b];
+    const int tm1 = (t - 1 + T1) % T1;
+    const float* S = p.sched;
+    const float lat = S[0 * T1 + t], lbt = S[1 * T1 + t], lct = S[2 * T1 + t];
+    const float lcat = S[4 * T1 + t], lcbt = S[5 * T1 + t], lcct = S[6 * T1 + t];
+    const float lcat1 = S[4 * T1 + tm1], lcbt1 = S[5 * T1 + tm1], lcct1 = S[6 * T1 + tm1], l1mcct1 = S[7 * T1 + tm1];
+    const int xt = (int)p.xt[col];
+    const bool is_mask = xt == K;
+    const float off = p.initial ? -INFINITY : LOG_ZERO_F;  // log one-hot value away from x_t
+    // log q(x_t | x_0 = c) and log q(x_t | x_{t-1} = c) take two values per column: c == x_t or not
+    const float qt_hit = is_mask ? lcct : lae(0.f + lcat, lcbt);
+    const float qt_off = is_mask ? lcct : lae(off + lcat, lcbt);
+    const float q1_hit = is_mask ? lct : lae(0.f + lat, lbt);
+    const float q1_off = is_mask ? lct : lae(off + lat, lbt);
+    const float qt_m = is_mask ? 0.f : LOG_ZERO_F;  // [MASK] row
+    const float q1_m = qt_m;
+
+    float q[NPL];
+    float qmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int c = j * 64 + lane;
+        q[j] = tr[j] - (c == xt ? qt_hit : qt_off);
+        qmax = fmaxf(qmax, q[j]);
+    }
+    const float q_m = -70.f - qt_m;
+    qmax = fmaxf(wmaxf(qmax), q_m);
+    float es = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) es += expf(q[j] - qmax);
+    es = wsumf(es) + expf(q_m - qmax);
+    const float lse = logf(es) + qmax;  // torch.logsumexp
+
+    float post[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int c = j * 64 + lane;
+        const float ev = lae((q[j] - lse) + lcat1, lcbt1);
+        const float o = ev + (c == xt ? q1_hit : q1_off) + lse;
+        post[j] = fminf(fmaxf(o, -70.f), 0.f);
+    }
+    float post_m;
+    {
+        const float ev = lae((q_m - lse) + l1mcct1, lcct1);
+        post_m = fminf(fmaxf(ev + q1_m + lse, -70.f), 0.f);
+    }
+    if (p.dbg_post && live) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) p.dbg_post[dbg_base + (size_t)(j * 64 + lane) * p.L] = post[j];
+        if (lane == 0) p.dbg_post[dbg_base + (size_t)K * p.L] = post_m;
+    }
+
+    // ---- Gumbel-argmax (first index wins ties, as torch.argmax) ----
+    const float* up = p.u + dbg_base;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int c = j * 64 + lane;
+        const float uu = up[(size_t)c * p.L];
+        const float gsc = -logf(-logf(uu + 1e-30f) + 1e-30f) + post[j];
+        if (gsc > best) { best = gsc; bidx = c; }  // ascending c within a lane keeps the first max
+    }
+    if (lane == 0) {
+        const float uu = up[(size_t)K * p.L];
+        const float gsc = -logf(-logf(uu + 1e-30f) + 1e-30f) + post_m;
+        if (gsc > best) { best = gsc; bidx = K; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (lane == 0 && live) p.out_tokens[col] = bidx;
+}
+
+extern "C" int ds_sample_tail(const float* logits, const int64_t* xt, const int64_t* t, const float* u,
+                              const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc,
+                              float* dbg_post, int B, int L, int K, int T, int initial, float trunc_r,
+                              ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(logits && xt && t && u && sched && out_tokens, "null pointer");
+    DS_CHECK_ARG(K == 256 || K == 512, "codebook size must be 256 or 512");
+    SampleParams p{logits, xt, t, u, sched, out_tokens, dbg_log_pred, dbg_trunc, dbg_post, B, L, T, initial, trunc_r};
+    const int cols = B * L;
+    if (K == 256)
+        hipLaunchKernelGGL((ds_sample_tail_kernel<4>), dim3((cols + 3) / 4), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((ds_sample_tail_kernel<8>), dim3((cols + 3) / 4), dim3(256), 0, stream, p);
+    DS_CHECK_LAUNCH();
+    return 0;
+}

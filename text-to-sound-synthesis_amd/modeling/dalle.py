@@ -1,0 +1,87 @@
+"""Drop-in for sound_synthesis/modeling/models/dalle_spec.py:DALLE (generation side).
+
+generate_content() keeps the reference's keyword signature and `sample_type` mini-language
+(:179-247): "top{r}r" installs top-r truncation -- natively, as a kernel argument, instead of the
+reference's monkey-patched predict_start wrapper (:208-210).  Text tokenisation + the CLIP text
+encoder are the next scope row; until then the caption conditioning enters as
+`condition_embed_token` f32[B, 77, 512] (what CLIPTextEmbedding.forward returns), either in `batch`
+or as `condition=`.
+"""
+import torch
+from torch import nn
+
+from ..config import instantiate_from_config
+
+
+class DALLE(nn.Module):
+    def __init__(self, *, content_info={"key": "image"}, condition_info={"key": "text"}, content_codec_config,
+                 condition_codec_config, first_stage_permuter_config, diffusion_config):
+        super().__init__()
+        self.content_info = content_info
+        self.condition_info = condition_info
+        self.content_codec = instantiate_from_config(content_codec_config)
+        self.condition_codec = instantiate_from_config(condition_codec_config)  # Tokenize: section 8f-1
+        self.transformer = instantiate_from_config(diffusion_config)
+        self.first_stage_permuter = instantiate_from_config(first_stage_permuter_config)
+        self.truncation_forward = False
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    def get_ema_model(self):
+        return self.transformer
+
+    @torch.no_grad()
+    def decode_to_img(self, index, zshape, stage="first"):
+        """tokens (sequence order) -> mel image [B, 1, 80, 848] (:80-91)."""
+        assert stage == "first"
+        return self.content_codec.decode_tokens(index, zshape[2], zshape[3])
+
+    @torch.no_grad()
+    def prepare_condition(self, batch, condition=None):
+        cond = {}
+        src = batch if condition is None else condition
+        if torch.is_tensor(src):
+            src = {"condition_embed_token": src}
+        emb = src.get("condition_embed_token", src.get("embed_token"))
+        if emb is not None:
+            cond["condition_embed_token"] = emb.to(self.device)
+            cond["condition_token"] = None
+        elif self.condition_codec is not None:
+            for k, v in self.condition_codec.get_tokens(src[self.condition_info["key"]]).items():
+                cond["condition_" + k] = v.to(self.device) if torch.is_tensor(v) else v
+        else:
+            raise NotImplementedError(
+                "text -> CLIP embedding is the next scope row (SURVEY.md section 8f-1); pass "
+                "batch={'condition_embed_token': f32[B,77,512]}")
+        return cond
+
+    @torch.no_grad()
+    def generate_content(self, *, batch, condition=None, filter_ratio=0.5, temperature=1.0, content_ratio=0.0,
+                         replicate=1, return_att_weight=False, sample_type="top0.85r"):
+        self.eval()
+        condition = self.prepare_condition(batch=batch, condition=condition)
+        if replicate != 1:
+            for k in condition:
+                if condition[k] is not None:
+                    condition[k] = torch.cat([condition[k] for _ in range(replicate)], dim=0)
+        parts = sample_type.split(",")
+        if parts[0][:3] == "top":
+            if parts[0][-1] != "r":
+                raise NotImplementedError("top-k ('p') truncation: SURVEY.md section 8f-4")
+            self.transformer.truncation_r = float(parts[0][3:-1])
+            self.truncation_forward = True   # sticky, like the reference's wrapper (:208-210)
+        if len(parts) > 1:
+            raise NotImplementedError("'fast'/'q' samplers: SURVEY.md section 8f-4")
+        trans_out = self.transformer.sample(condition_token=condition.get("condition_token"),
+                                            condition_mask=condition.get("condition_mask"),
+                                            condition_embed=condition.get("condition_embed_token"),
+                                            content_token=None, filter_ratio=filter_ratio, temperature=temperature,
+                                            return_att_weight=return_att_weight, return_logits=False,
+                                            print_log=False, sample_type=sample_type)
+        tokens = trans_out["content_token"]
+        zshape = (tokens.shape[0], 256, 5, 53)   # hard-coded in the reference too (:236)
+        content = self.decode_to_img(tokens, zshape)
+        self.train()
+        return {"content": content, "content_token": tokens}

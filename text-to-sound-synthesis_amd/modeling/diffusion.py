@@ -1,0 +1,187 @@
+"""Drop-in for sound_synthesis/modeling/transformers/diffusion_transformer.py:DiffusionTransformer
+(sampling side), HIP-backed.
+
+State-dict keys (log_at ... Lt_count, transformer.*), constructor keywords and the
+sample()/p_sample()/predict_start() signatures follow the reference (:153-234, :269-291, :342-357,
+:587-659).  The reverse loop carries token indices; one step = ds_denoiser_step (19-block denoiser +
+the fused predict_start / top-r truncation / q_posterior / Gumbel-argmax tail).  The uniform noise is
+drawn with torch.rand on the reference's [B, K+1, L] shape so that the same seed consumes the same
+Philox stream as the reference's torch.rand_like(logits) (:360).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+from ..config import instantiate_from_config
+
+
+def alpha_schedule(time_step, N=100, att_1=0.99999, att_T=0.000009, ctt_1=0.000009, ctt_T=0.9):
+    """Mask-and-uniform schedule (:122-151); float64 numpy, as the reference."""
+    lin = np.arange(0, time_step) / (time_step - 1)
+    att = np.concatenate(([1], lin * (att_T - att_1) + att_1))
+    ctt = np.concatenate(([0], lin * (ctt_T - ctt_1) + ctt_1))
+    at = att[1:] / att[:-1]
+    ct = 1 - (1 - ctt[1:]) / (1 - ctt[:-1])
+    bt = (1 - at - ct) / N
+    att = np.concatenate((att[1:], [1]))
+    ctt = np.concatenate((ctt[1:], [0]))
+    btt = (1 - att - ctt) / N
+    return at, bt, ct, att, btt, ctt
+
+
+def _log_1_min_a(a):
+    return torch.log(1 - a.exp() + 1e-40)
+
+
+class DiffusionTransformer(nn.Module):
+    def __init__(self, *, content_emb_config=None, condition_emb_config=None, transformer_config=None,
+                 diffusion_step=100, alpha_init_type="cos", auxiliary_loss_weight=0,
+                 adaptive_auxiliary_loss=False, mask_weight=[1, 1]):
+        super().__init__()
+        self.condition_emb = instantiate_from_config(condition_emb_config)  # CLIP text: SURVEY 8(f)-1
+        transformer_config = dict(transformer_config)
+        transformer_config["params"] = dict(transformer_config["params"])
+        transformer_config["params"]["diffusion_step"] = diffusion_step
+        transformer_config["params"]["content_emb_config"] = content_emb_config
+        self.transformer = instantiate_from_config(transformer_config)
+        self.content_seq_len = transformer_config["params"]["content_seq_len"]
+        self.num_classes = self.transformer.content_emb.num_embed  # K + 1
+        self.shape = self.content_seq_len
+        self.num_timesteps = diffusion_step
+        self.parametrization = "x0"
+        self.loss_type = "vb_stochastic"
+        self.auxiliary_loss_weight = auxiliary_loss_weight
+        self.adaptive_auxiliary_loss = adaptive_auxiliary_loss
+        self.mask_weight = mask_weight
+        self.truncation_r = None  # set by DALLE.generate_content from sample_type "top{r}r"
+        assert alpha_init_type == "alpha1", "Diffsound uses alpha_init_type='alpha1'"
+        at, bt, ct, att, btt, ctt = alpha_schedule(self.num_timesteps, N=self.num_classes)
+        f64 = lambda x: torch.tensor(x.astype("float64"))
+        log_at, log_bt, log_ct = torch.log(f64(at)), torch.log(f64(bt)), torch.log(f64(ct))
+        log_cat, log_cbt, log_cct = torch.log(f64(att)), torch.log(f64(btt)), torch.log(f64(ctt))
+        for name, v in (("log_at", log_at), ("log_bt", log_bt), ("log_ct", log_ct),
+                        ("log_cumprod_at", log_cat), ("log_cumprod_bt", log_cbt), ("log_cumprod_ct", log_cct),
+                        ("log_1_min_ct", _log_1_min_a(log_ct)),
+                        ("log_1_min_cumprod_ct", _log_1_min_a(log_cct))):
+            self.register_buffer(name, v.float())
+        self.register_buffer("Lt_history", torch.zeros(self.num_timesteps))
+        self.register_buffer("Lt_count", torch.zeros(self.num_timesteps))
+        self._sched = None
+
+    @property
+    def device(self):
+        return self.log_at.device
+
+    def _schedule_table(self):
+        """[8][T+1] table consumed by ds_sample_tail (rows: log_at, log_bt, log_ct, log_1_min_ct,
+        log_cumprod_at, log_cumprod_bt, log_cumprod_ct, log_1_min_cumprod_ct)."""
+        if self._sched is None or self._sched.device != self.log_at.device:
+            T = self.num_timesteps
+            tab = torch.zeros(8, T + 1, device=self.log_at.device, dtype=torch.float32)
+            for i, n in enumerate(("log_at", "log_bt", "log_ct", "log_1_min_ct")):
+                tab[i, :T] = getattr(self, n)
+            for i, n in enumerate(("log_cumprod_at", "log_cumprod_bt", "log_cumprod_ct", "log_1_min_cumprod_ct")):
+                tab[4 + i] = getattr(self, n)
+            self._sched = tab
+        return self._sched
+
+    # ---- pieces with the reference's signatures (log-one-hot in / out) ------------------------------
+    @torch.no_grad()
+    def _tail(self, logits_rows, x_t, t, u, initial, want):
+        """Run ds_sample_tail on row-major logits; `want` selects debug dumps."""
+        B, L, K = x_t.shape[0], self.content_seq_len, self.num_classes - 1
+        dev = logits_rows.device
+        dump = {k: torch.empty(B, K + 1, L, device=dev) for k in want}
+        out = torch.empty(B, L, device=dev, dtype=torch.long)
+        r = -1.0 if self.truncation_r is None else float(self.truncation_r)
+        _lib.check(_lib.lib().ds_sample_tail(
+            _lib.ptr(logits_rows), _lib.ptr(x_t), _lib.ptr(t), _lib.ptr(u), _lib.ptr(self._schedule_table()),
+            _lib.ptr(out), _lib.ptr(dump.get("log_pred")), _lib.ptr(dump.get("trunc")), _lib.ptr(dump.get("post")),
+            B, L, K, self.num_timesteps, int(initial), r, _lib.stream()))
+        return out, dump
+
+    @staticmethod
+    def _is_initial(log_x):
+        return bool(torch.isinf(log_x[:, :-1]).all().item())
+
+    @torch.no_grad()
+    def step_detail(self, x_t, cond_emb, t, u, initial):
+        """Teacher-forced single step on token indices: returns (tokens, {log_pred, trunc, post})."""
+        tr = self.transformer
+        p = tr.packed(self._schedule_table())
+        B = x_t.shape[0]
+        x_t, t, u = x_t.contiguous(), t.to(x_t.device).contiguous(), u.contiguous()
+        kv = tr.condition_kv(cond_emb, self._schedule_table())
+        logits = torch.empty(B * self.content_seq_len, self.num_classes - 1, device=x_t.device)
+        _lib.check(_lib.lib().ds_denoiser_forward(p["handle"], _lib.ptr(x_t), _lib.ptr(t), _lib.ptr(kv), B,
+                                                  _lib.ptr(tr.workspace(B, self._schedule_table())),
+                                                  _lib.ptr(logits), 0, _lib.stream()))
+        return self._tail(logits, x_t, t, u, initial, ("log_pred", "trunc", "post"))
+
+    @torch.no_grad()
+    def predict_start(self, log_x_t, cond_emb, t):
+        """p(x0 | xt) as clamped log-probs [B, K+1, L] (:269-291); with truncation_r set this is the
+        reference's truncation-wrapped predict_start (dalle_spec.py:158-174)."""
+        x_t = log_x_t.argmax(1)
+        u = torch.full((x_t.shape[0], self.num_classes, self.content_seq_len), 0.5, device=x_t.device)
+        _, d = self.step_detail(x_t, cond_emb, t, u, self._is_initial(log_x_t))
+        return d["trunc"] if self.truncation_r is not None else d["log_pred"]
+
+    @torch.no_grad()
+    def p_sample(self, log_x, cond_emb, t):
+        """One reverse step on the reference's log-one-hot state (:353-357)."""
+        x_t = log_x.argmax(1)
+        u = torch.rand((x_t.shape[0], self.num_classes, self.content_seq_len), device=x_t.device)
+        tok = self.p_sample_tokens(x_t, self.transformer.condition_kv(cond_emb, self._schedule_table()), t, u,
+                                   self._is_initial(log_x))
+        oh = torch.nn.functional.one_hot(tok, self.num_classes).permute(0, 2, 1).float()
+        return torch.log(oh.clamp(min=1e-30))
+
+    @torch.no_grad()
+    def p_sample_tokens(self, x_t, kv, t, u, initial, out=None):
+        """x_t i64[B,L] -> x_{t-1} i64[B,L]; kv from transformer.condition_kv()."""
+        tr = self.transformer
+        sched = self._schedule_table()
+        p = tr.packed(sched)
+        B = x_t.shape[0]
+        if out is None:
+            out = torch.empty_like(x_t)
+        r = -1.0 if self.truncation_r is None else float(self.truncation_r)
+        _lib.check(_lib.lib().ds_denoiser_step(p["handle"], _lib.ptr(x_t), _lib.ptr(t), _lib.ptr(kv), _lib.ptr(u), B,
+                                               int(initial), r, _lib.ptr(tr.workspace(B, sched)), _lib.ptr(out),
+                                               _lib.stream()))
+        return out
+
+    @torch.no_grad()
+    def sample(self, condition_token, condition_mask, condition_embed, content_token=None, filter_ratio=0.5,
+               temperature=1.0, return_att_weight=False, return_logits=False, content_logits=None,
+               print_log=True, noise_fn=None, **kwargs):
+        """Reverse diffusion from the all-[MASK] state (:587-659, filter_ratio == 0 branch).
+
+        noise_fn(step, shape) may supply the uniforms (tests inject the oracle's noise)."""
+        device = self.device
+        if self.condition_emb is not None:
+            cond_emb = self.condition_emb(condition_token).float()
+        else:
+            if condition_embed is None:
+                raise ValueError("no condition_emb module is attached: pass condition_embed [B, 77, 512]")
+            cond_emb = condition_embed.float()
+        if int(self.num_timesteps * filter_ratio) != 0:
+            raise NotImplementedError("filter_ratio > 0 needs the VQ encoder path (SURVEY.md section 8f-2)")
+        B = cond_emb.shape[0]
+        K1, L, T = self.num_classes, self.content_seq_len, self.num_timesteps
+        cond_emb = cond_emb.to(device)
+        kv = self.transformer.condition_kv(cond_emb, self._schedule_table())
+        x = torch.full((B, L), K1 - 1, device=device, dtype=torch.long)  # all [MASK]
+        nxt = torch.empty_like(x)
+        for step in range(T - 1, -1, -1):
+            t = torch.full((B,), step, device=device, dtype=torch.long)
+            u = noise_fn(step, (B, K1, L)).to(device) if noise_fn is not None else \
+                torch.rand((B, K1, L), device=device)
+            self.p_sample_tokens(x, kv, t, u.contiguous(), initial=(step == T - 1), out=nxt)
+            x, nxt = nxt, x
+        out = {"content_token": x}
+        if return_logits:
+            out["logits"] = torch.nn.functional.one_hot(x, K1).permute(0, 2, 1).float()
+        return out

@@ -1,0 +1,244 @@
+"""Drop-in for the reference denoiser, HIP-backed.
+
+Mirrors sound_synthesis/modeling/transformers/transformer_utils.py (Text2ImageTransformer :289-443,
+Block :168-272, FullAttention :20-58, CrossAttention :60-109, AdaLayerNorm :134-149) and
+sound_synthesis/modeling/embeddings/dalle_mask_image_embedding.py:5-58 in constructor arguments,
+attribute names and state-dict keys, so reference checkpoints load unchanged.  The nn.Linear /
+nn.Embedding / nn.LayerNorm members are *parameter containers*: their torch forward is never
+called.  `Text2ImageTransformer.forward` packs the weights once (QKV concatenation, AdaLN tables,
+cross-attention K/V weights) and runs the whole stack through ds_denoiser_forward.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _lib
+from ..config import instantiate_from_config
+
+
+class DalleMaskImageEmbedding(nn.Module):
+    def __init__(self, num_embed=8192, spatial_size=[32, 32], embed_dim=3968, trainable=True,
+                 pos_emb_type="embedding"):
+        super().__init__()
+        if isinstance(spatial_size, int):
+            spatial_size = [spatial_size, spatial_size]
+        assert pos_emb_type == "embedding", "only pos_emb_type='embedding' is on the Diffsound path"
+        self.spatial_size = list(spatial_size)
+        self.num_embed = num_embed + 1  # + [MASK]
+        self.embed_dim = embed_dim
+        self.trainable = trainable
+        self.pos_emb_type = pos_emb_type
+        self.emb = nn.Embedding(self.num_embed, embed_dim)
+        self.height_emb = nn.Embedding(self.spatial_size[0], embed_dim)
+        self.width_emb = nn.Embedding(self.spatial_size[1], embed_dim)
+
+    def position_table(self):
+        """[L, D]: position p gets height_emb[p // W] + width_emb[p % W] (:50-56)."""
+        H, W = self.spatial_size
+        p = torch.arange(H * W, device=self.emb.weight.device)
+        return (self.height_emb.weight[p // W] + self.width_emb.weight[p % W]).contiguous()
+
+    @torch.no_grad()
+    def forward(self, index, **kwargs):
+        assert index.dim() == 2
+        B, L = index.shape
+        index = index.contiguous()
+        out = torch.empty(B, L, self.embed_dim, device=index.device, dtype=torch.float32)
+        pos = self.position_table()
+        _lib.check(_lib.lib().ds_embed(_lib.ptr(index), _lib.ptr(self.emb.weight), _lib.ptr(pos),
+                                       _lib.ptr(out), B * L, L, self.embed_dim, _lib.stream()))
+        return out
+
+
+class GELU2(nn.Module):
+    """x * sigmoid(1.702 x) (:111-115); fused into the FC1 GEMM epilogue."""
+
+
+class AdaLayerNorm(nn.Module):
+    def __init__(self, n_embd, diffusion_step, emb_type="adalayernorm"):
+        super().__init__()
+        assert "abs" not in emb_type, "sinusoidal timestep embedding is not used by Diffsound"
+        self.emb = nn.Embedding(diffusion_step, n_embd)
+        self.linear = nn.Linear(n_embd, n_embd * 2)
+
+    @torch.no_grad()
+    def table(self):
+        """[T, 2D] = Linear(SiLU(Emb)) for every timestep -- it depends on t only (:145-147)."""
+        T, D = self.emb.weight.shape
+        a = torch.nn.functional.silu(self.emb.weight).contiguous()
+        out = torch.empty(T, 2 * D, device=a.device, dtype=torch.float32)
+        return _lib.gemm(a, self.linear.weight, out, T, 2 * D, D, bias=self.linear.bias)
+
+
+class FullAttention(nn.Module):
+    def __init__(self, n_embd, n_head, seq_len=None, attn_pdrop=0.1, resid_pdrop=0.1, causal=True):
+        super().__init__()
+        assert n_embd % n_head == 0
+        self.key = nn.Linear(n_embd, n_embd)
+        self.query = nn.Linear(n_embd, n_embd)
+        self.value = nn.Linear(n_embd, n_embd)
+        self.proj = nn.Linear(n_embd, n_embd)
+        self.n_head = n_head
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, condition_seq_len, n_embd, condition_embd, n_head, seq_len=None, attn_pdrop=0.1,
+                 resid_pdrop=0.1, causal=True):
+        super().__init__()
+        self.key = nn.Linear(condition_embd, n_embd)
+        self.query = nn.Linear(n_embd, n_embd)
+        self.value = nn.Linear(condition_embd, n_embd)
+        self.proj = nn.Linear(n_embd, n_embd)
+        self.n_head = n_head
+        # dead buffer in the reference (:86-89), kept for state-dict compatibility
+        self.register_buffer("mask", torch.tril(torch.ones(seq_len, seq_len)).view(1, 1, seq_len, seq_len))
+
+
+class Block(nn.Module):
+    def __init__(self, n_embd=1024, n_head=16, seq_len=265, mlp_hidden_times=4, condition_seq_len=77,
+                 condition_dim=512, diffusion_step=100, timestep_type="adalayernorm"):
+        super().__init__()
+        self.ln1 = AdaLayerNorm(n_embd, diffusion_step, timestep_type)
+        self.ln2 = nn.LayerNorm(n_embd)
+        self.attn1 = FullAttention(n_embd, n_head, seq_len)
+        self.attn2 = CrossAttention(condition_seq_len, n_embd, condition_dim, n_head, seq_len)
+        self.ln1_1 = AdaLayerNorm(n_embd, diffusion_step, timestep_type)
+        self.mlp = nn.Sequential(nn.Linear(n_embd, mlp_hidden_times * n_embd), GELU2(),
+                                 nn.Linear(mlp_hidden_times * n_embd, n_embd), nn.Dropout(0.0))
+
+
+class Text2ImageTransformer(nn.Module):
+    def __init__(self, condition_seq_len=77, n_layer=14, n_embd=1024, n_head=16, content_seq_len=1024,
+                 attn_pdrop=0, resid_pdrop=0, mlp_hidden_times=4, block_activate=None, attn_type="selfcross",
+                 content_spatial_size=[32, 32], condition_dim=512, diffusion_step=1000,
+                 timestep_type="adalayernorm", content_emb_config=None, mlp_type="fc", checkpoint=False):
+        super().__init__()
+        assert attn_type == "selfcross" and mlp_type == "fc" and block_activate == "GELU2", \
+            "the HIP path implements the Diffsound configuration (selfcross / fc / GELU2)"
+        assert attn_pdrop == 0 and resid_pdrop == 0
+        self.content_emb = instantiate_from_config(content_emb_config)
+        self.blocks = nn.Sequential(*[Block(n_embd, n_head, content_seq_len, mlp_hidden_times, condition_seq_len,
+                                            condition_dim, diffusion_step, timestep_type) for _ in range(n_layer)])
+        out_cls = self.content_emb.num_embed - 1
+        self.to_logits = nn.Sequential(nn.LayerNorm(n_embd), nn.Linear(n_embd, out_cls))
+        self.condition_seq_len = condition_seq_len
+        self.content_seq_len = content_seq_len
+        self.n_layer, self.n_embd, self.n_head = n_layer, n_embd, n_head
+        self.condition_dim, self.diffusion_step, self.mlp_hidden_times = condition_dim, diffusion_step, mlp_hidden_times
+        self.num_codes = out_cls
+        self.apply(self._init_weights)
+        self._packed = None
+        self._register_load_state_dict_pre_hook(lambda *a, **k: self.invalidate())
+
+    def _init_weights(self, module):  # :355-363
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+            if isinstance(module, nn.Linear) and module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    # ---- weight packing + native handle -------------------------------------------------------------
+    def invalidate(self):
+        p = self._packed
+        self._packed = None
+        if p is not None and p.get("handle"):
+            _lib.lib().ds_denoiser_destroy(p["handle"])
+
+    def __del__(self):
+        try:
+            self.invalidate()
+        except Exception:
+            pass
+
+    def _apply(self, fn, *a, **k):  # .to()/.cuda() move the weights: repack lazily
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def packed(self, sched=None):
+        """Device-side packed weights + ds_denoiser handle (built once, on first use)."""
+        if self._packed is not None and (sched is None or self._packed["sched_src"] is sched):
+            return self._packed
+        self.invalidate()
+        dev = self.to_logits[1].weight.device
+        if dev.type != "cuda":
+            _lib.ptr(self.to_logits[1].weight)  # raises: no CPU path
+        keep = []  # owns every packed tensor the handle points into
+
+        def own(t):
+            t = t.detach().to(torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        ptrs = (C.c_void_p * (self.n_layer * _lib.LP_COUNT))()
+        for l, blk in enumerate(self.blocks):
+            a1, a2 = blk.attn1, blk.attn2
+            slot = {
+                _lib.LP_ADALN1: own(blk.ln1.table()),
+                _lib.LP_W_QKV: own(torch.cat((a1.query.weight, a1.key.weight, a1.value.weight), 0)),
+                _lib.LP_B_QKV: own(torch.cat((a1.query.bias, a1.key.bias, a1.value.bias), 0)),
+                _lib.LP_W_PROJ1: own(a1.proj.weight), _lib.LP_B_PROJ1: own(a1.proj.bias),
+                _lib.LP_ADALN2: own(blk.ln1_1.table()),
+                _lib.LP_W_Q2: own(a2.query.weight), _lib.LP_B_Q2: own(a2.query.bias),
+                _lib.LP_W_KV2: own(torch.cat((a2.key.weight, a2.value.weight), 0)),
+                _lib.LP_B_KV2: own(torch.cat((a2.key.bias, a2.value.bias), 0)),
+                _lib.LP_W_PROJ2: own(a2.proj.weight), _lib.LP_B_PROJ2: own(a2.proj.bias),
+                _lib.LP_LN2_G: own(blk.ln2.weight), _lib.LP_LN2_B: own(blk.ln2.bias),
+                _lib.LP_W_FC1: own(blk.mlp[0].weight), _lib.LP_B_FC1: own(blk.mlp[0].bias),
+                _lib.LP_W_FC2: own(blk.mlp[2].weight), _lib.LP_B_FC2: own(blk.mlp[2].bias),
+            }
+            for s, t in slot.items():
+                ptrs[l * _lib.LP_COUNT + s] = t.data_ptr()
+        T = self.diffusion_step
+        if sched is None:  # forward() alone does not need the diffusion schedule
+            sched_t = torch.zeros(8, T + 1, device=dev)
+        else:
+            sched_t = sched.to(dev)
+        d = _lib.DenoiserDesc()
+        d.n_layer, d.n_embd, d.n_head, d.seq_len = self.n_layer, self.n_embd, self.n_head, self.content_seq_len
+        d.cond_len, d.cond_dim, d.n_codes, d.n_steps = self.condition_seq_len, self.condition_dim, self.num_codes, T
+        d.mlp_mult = self.mlp_hidden_times
+        d.tok_emb = own(self.content_emb.emb.weight).data_ptr()
+        d.pos_emb = own(self.content_emb.position_table()).data_ptr()
+        d.lnf_g = own(self.to_logits[0].weight).data_ptr()
+        d.lnf_b = own(self.to_logits[0].bias).data_ptr()
+        d.w_logits = own(self.to_logits[1].weight).data_ptr()
+        d.b_logits = own(self.to_logits[1].bias).data_ptr()
+        d.sched = own(sched_t).data_ptr()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ds_denoiser_create(C.byref(d), ptrs, C.byref(h)))
+        self._packed = {"handle": h, "keep": keep, "sched_src": sched, "ws": {}, "device": dev}
+        return self._packed
+
+    def workspace(self, B, sched=None):
+        p = self.packed(sched)
+        if B not in p["ws"]:
+            n = _lib.lib().ds_denoiser_workspace_bytes(p["handle"], B)
+            p["ws"][B] = torch.empty(n // 4, device=p["device"], dtype=torch.float32)
+        return p["ws"][B]
+
+    @torch.no_grad()
+    def condition_kv(self, cond_emb, sched=None):
+        """Cross-attention K/V for all layers; caption-only, so computed once per batch."""
+        p = self.packed(sched)
+        B = cond_emb.shape[0]
+        cond_emb = cond_emb.to(torch.float32).contiguous()
+        kv = torch.empty(_lib.lib().ds_denoiser_kv_bytes(p["handle"], B) // 4, device=p["device"],
+                         dtype=torch.float32)
+        _lib.check(_lib.lib().ds_denoiser_cond_kv(p["handle"], _lib.ptr(cond_emb), B, _lib.ptr(kv), _lib.stream()))
+        return kv
+
+    @torch.no_grad()
+    def forward(self, input, cond_emb, t):
+        """input i64[B,L], cond_emb f32[B,Lc,Dc], t i64[B] -> logits f32[B,K,L] (:421-443)."""
+        p = self.packed(self._packed["sched_src"] if self._packed else None)
+        B = input.shape[0]
+        kv = self.condition_kv(cond_emb, p["sched_src"])
+        out = torch.empty(B, self.num_codes, self.content_seq_len, device=p["device"], dtype=torch.float32)
+        _lib.check(_lib.lib().ds_denoiser_forward(
+            p["handle"], _lib.ptr(input.contiguous()), _lib.ptr(t.to(p["device"]).contiguous()), _lib.ptr(kv), B,
+            _lib.ptr(self.workspace(B, p["sched_src"])), _lib.ptr(out), 1, _lib.stream()))
+        return out

@@ -1,0 +1,155 @@
+"""Drop-in for the MelGAN generator (Diffsound/vocoder/modules.py:Generator :88-130), HIP-backed.
+
+Same constructor, `model.N.*` state-dict keys (weight_g / weight_v / bias, as left by
+torch.nn.utils.weight_norm, :18-23) and forward signature: mel f32[B, 80, T] in [0,1] ->
+waveform f32[B, 1, 256*T].  Weight norm is folded once at pack time (the reference recomputes it on
+every call); activations are channels-last [B, T, C]; every layer is the gather-GEMM:
+  Conv1d k7 / dilated k3 (ReflectionPad1d)  -> conv1d loader, LeakyReLU(0.2) applied while staging A
+  ConvTranspose1d(k=2r, s=r)                -> r polyphase GEMMs with K = 2*Cin (no zero-stuffing)
+  ResnetBlock                               -> 3 GEMMs, shortcut added through the residual epilogue
+  final Conv1d(32->1, k7) + tanh            -> N=7 tap GEMM + reflect stencil
+The whole batch goes through at once (the reference vocodes sample by sample,
+evaluation/generate_samples_batch.py:183-187).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+
+
+class _WN(nn.Module):
+    """Parameter container with the names torch's weight_norm leaves behind."""
+
+    def __init__(self, shape_v, n_bias):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(n_bias))
+        self.weight_g = nn.Parameter(torch.ones(shape_v[0], *([1] * (len(shape_v) - 1))))
+        self.weight_v = nn.Parameter(torch.randn(*shape_v) * 0.02)
+
+    def folded(self):
+        """w = g * v / ||v||, norm over all dims but 0 (dim 0 = Cin for ConvTranspose1d)."""
+        v = self.weight_v.detach().float()
+        n = v.reshape(v.shape[0], -1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+        return self.weight_g.detach().float() * v / n
+
+
+def WNConv1d(cin, cout, k):
+    return _WN((cout, cin, k), cout)
+
+
+def WNConvTranspose1d(cin, cout, k):
+    return _WN((cin, cout, k), cout)
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, dim, dilation=1):
+        super().__init__()
+        self.dilation = dilation
+        # indices 2 and 4 hold the convs (0: LeakyReLU, 1: ReflectionPad1d, 3: LeakyReLU), :75-81
+        self.block = nn.Sequential(nn.Identity(), nn.Identity(), WNConv1d(dim, dim, 3), nn.Identity(),
+                                   WNConv1d(dim, dim, 1))
+        self.shortcut = WNConv1d(dim, dim, 1)
+
+
+class Generator(nn.Module):
+    def __init__(self, input_size, ngf, n_residual_layers):
+        super().__init__()
+        ratios = [8, 8, 2, 2]
+        self.ratios = ratios
+        self.hop_length = int(np.prod(ratios))
+        self.input_size = input_size
+        mult = int(2 ** len(ratios))
+        model = [nn.Identity(), WNConv1d(input_size, mult * ngf, 7)]
+        for r in ratios:
+            assert r % 2 == 0
+            model += [nn.Identity(), WNConvTranspose1d(mult * ngf, mult * ngf // 2, r * 2)]
+            for j in range(n_residual_layers):
+                model += [ResnetBlock(mult * ngf // 2, dilation=3 ** j)]
+            mult //= 2
+        model += [nn.Identity(), nn.Identity(), WNConv1d(ngf, 1, 7), nn.Identity()]
+        self.model = nn.Sequential(*model)
+        self.n_residual_layers = n_residual_layers
+        self._pk = None
+        self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
+
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def _packed(self):
+        if self._pk is not None:
+            return self._pk
+        c1 = lambda m: (m.folded().permute(0, 2, 1).reshape(m.weight_v.shape[0], -1).contiguous(),
+                        m.bias.detach().float().contiguous())   # [Cout][k][Cin]
+        layers = list(self.model)
+        first = layers[1]
+        w = first.folded()                                       # [512, 80, 7]
+        cpad = (w.shape[1] + 31) // 32 * 32
+        wp = torch.zeros(w.shape[0], 7, cpad, device=w.device)
+        wp[:, :, :w.shape[1]] = w.permute(0, 2, 1)
+        pk = {"first": (wp.reshape(w.shape[0], -1).contiguous(), first.bias.detach().float().contiguous()),
+              "cpad": cpad, "stages": []}
+        i = 2
+        for r in self.ratios:
+            ct = layers[i + 1]
+            w = ct.folded()                                      # [Cin, Cout, 2r]
+            cin, cout, k = w.shape
+            # phase p uses taps j = p (on x[s0]) and j = p + r (on x[s0-1]):  [r][Cout][2][Cin]
+            wph = w.permute(2, 1, 0).reshape(2, r, cout, cin).permute(1, 2, 0, 3).reshape(r, cout, 2 * cin)
+            st = {"r": r, "cin": cin, "cout": cout, "ct": (wph.contiguous(), ct.bias.detach().float().contiguous()),
+                  "res": []}
+            i += 2
+            for _ in range(self.n_residual_layers):
+                rb = layers[i]
+                st["res"].append({"dil": rb.dilation, "c3": c1(rb.block[2]), "c1": c1(rb.block[4]),
+                                  "sc": c1(rb.shortcut)})
+                i += 1
+            pk["stages"].append(st)
+        last = layers[i + 2]
+        wl = last.folded()                                       # [1, 32, 7] -> [7 taps][32]
+        pk["last"] = (wl[0].permute(1, 0).contiguous(), float(last.bias.item()))
+        self._pk = pk
+        return pk
+
+    @torch.no_grad()
+    def forward(self, x, scale=1.0, shift=0.0):
+        """x f32[B, 80, T] -> f32[B, 1, 256 T].  (scale, shift) lets the caller fold the
+        (mel + 1) / 2 of generate_samples_batch.py:182 into the layout change."""
+        pk = self._packed()
+        B, Cm, T = x.shape
+        dev = x.device
+        x = x.contiguous().float()
+        cpad = pk["cpad"]
+        h = torch.empty(B, T, cpad, device=dev)
+        _lib.check(_lib.lib().ds_mel_to_cl(_lib.ptr(x), _lib.ptr(h), B, Cm, T, cpad, float(scale), float(shift),
+                                           _lib.stream()))
+        w, b = pk["first"]
+        c = w.shape[0]
+        y = torch.empty(B, T, c, device=dev)
+        _lib.gemm(h, w, y, B * T, c, 7 * cpad, bias=b, loader=_lib.LOAD_CONV1D, Cin=cpad, Wd=T, taps=7, dil=1)
+        h = y
+        for st in pk["stages"]:
+            r, cin, cout = st["r"], st["cin"], st["cout"]
+            w, b = st["ct"]
+            y = torch.empty(B, T * r, cout, device=dev)
+            _lib.gemm(h, w, y, B * T, cout, 2 * cin, bias=b, ldc=cout, loader=_lib.LOAD_CONVT1D, pro=_lib.PRO_LRELU,
+                      store=_lib.STORE_CONVT, groups=r, w_gstride=cout * 2 * cin, Cin=cin, Wd=T,
+                      ct_r=r, ct_p=r // 2 + r % 2, ct_tin=T)
+            h, T = y, T * r
+            for rb in st["res"]:
+                M = B * T
+                h1 = torch.empty(B, T, cout, device=dev)
+                _lib.gemm(h, rb["c3"][0], h1, M, cout, 3 * cout, bias=rb["c3"][1], loader=_lib.LOAD_CONV1D,
+                          pro=_lib.PRO_LRELU, Cin=cout, Wd=T, taps=3, dil=rb["dil"])
+                sc = torch.empty(B, T, cout, device=dev)
+                _lib.gemm(h, rb["sc"][0], sc, M, cout, cout, bias=rb["sc"][1])
+                _lib.gemm(h1, rb["c1"][0], sc, M, cout, cout, bias=rb["c1"][1], R=sc, pro=_lib.PRO_LRELU)
+                h = sc
+        wl, bl = pk["last"]
+        taps = torch.empty(B * T, 8, device=dev)
+        _lib.gemm(h, wl, taps, B * T, 7, wl.shape[1], ldc=8, pro=_lib.PRO_LRELU)
+        out = torch.empty(B, 1, T, device=dev)
+        _lib.check(_lib.lib().ds_stencil7_tanh(_lib.ptr(taps), 8, bl, _lib.ptr(out), B, T, _lib.stream()))
+        return out

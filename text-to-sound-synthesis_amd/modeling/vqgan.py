@@ -1,0 +1,307 @@
+"""Drop-in for the SpecVQGAN decode side, HIP-backed.
+
+Mirrors sound_synthesis/modeling/codecs/spec_codec/vqgan.py:VQModel (decode :62-65),
+specvqgan/modules/diffusionmodules/model.py (Decoder :570-671, ResnetBlock :92-151, AttnBlock
+:174-226, Upsample :37-52), specvqgan/modules/vqvae/quantize.py:VectorQuantizer.get_codebook_entry
+(:88-103) and specvqgan/modules/transformer/permuter.py:ColumnMajor (:21-55) in attribute names and
+state-dict keys.  nn.Conv2d / nn.GroupNorm members are parameter containers only.
+
+Device layout: activations are channels-last [B, H, W, C] fp32.  Every conv is the gather-GEMM
+(implicit GEMM, fp32 MFMA); GroupNorm is a statistics pass whose (scale, shift) the next conv applies
+while staging its A tile together with swish; nearest-2x upsampling is index math inside the conv
+loader; the 512-channel spatial attention runs as two batched GEMMs around a row softmax.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+from ..config import instantiate_from_config
+
+
+def Normalize(c):
+    return nn.GroupNorm(num_groups=32, num_channels=c, eps=1e-6, affine=True)
+
+
+class Upsample(nn.Module):
+    def __init__(self, c, with_conv=True):
+        super().__init__()
+        self.with_conv = with_conv
+        if with_conv:
+            self.conv = nn.Conv2d(c, c, 3, 1, 1)
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        assert not conv_shortcut and temb_channels == 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
+
+
+class AttnBlock(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.in_channels = c
+        self.norm = Normalize(c)
+        self.q = nn.Conv2d(c, c, 1)
+        self.k = nn.Conv2d(c, c, 1)
+        self.v = nn.Conv2d(c, c, 1)
+        self.proj_out = nn.Conv2d(c, c, 1)
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, **ignore):
+        super().__init__()
+        assert out_ch == 1 and resamp_with_conv and not give_pre_end
+        self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
+        self.resolution = resolution
+        block_in = ch * ch_mult[-1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.conv_in = nn.Conv2d(z_channels, block_in, 3, 1, 1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            up = nn.Module()
+            up.block, up.attn = block, attn
+            if i_level != 0:
+                up.upsample = Upsample(block_in, True)
+                curr_res *= 2
+            self.up.insert(0, up)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
+
+
+class VectorQuantizer(nn.Module):
+    def __init__(self, n_e, e_dim, beta=0.25):
+        super().__init__()
+        self.n_e, self.e_dim, self.beta = n_e, e_dim, beta
+        self.embedding = nn.Embedding(n_e, e_dim)
+        self.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)
+
+    @torch.no_grad()
+    def get_codebook_entry(self, indices, shape):
+        """indices i64[B*H*W] in ROW-major cell order, shape (B, H, W, C) -> [B, C, H, W] (:88-103)."""
+        B, H, W, Cc = shape
+        # ds_codebook_gather reads the sequence in column-major order; present row-major cells that way
+        seq = indices.view(B, H, W).transpose(1, 2).reshape(B, H * W).contiguous()
+        out = torch.empty(B, H, W, Cc, device=indices.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ds_codebook_gather(_lib.ptr(seq), _lib.ptr(self.embedding.weight), _lib.ptr(out),
+                                                 B, H, W, Cc, self.n_e, _lib.stream()))
+        return out.permute(0, 3, 1, 2).contiguous()
+
+
+class ColumnMajor(nn.Module):
+    """Token order of spectrogram grids: sequence index w*H + h (permuter.py:21-55)."""
+
+    def __init__(self, H, W):
+        super().__init__()
+        self.H, self.W = H, W
+        idx = torch.tensor(np.arange(H * W).reshape(H, W).T.ravel())
+        self.register_buffer("forward_shuffle_idx", idx)
+        self.register_buffer("backward_shuffle_idx", torch.argsort(idx))
+
+    def forward(self, x, reverse=False):
+        return x[:, self.backward_shuffle_idx if reverse else self.forward_shuffle_idx]
+
+
+def _pack_conv3(conv):
+    w = conv.weight.detach().float()
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), conv.bias.detach().float().contiguous()
+
+
+def _pack_conv1(conv):
+    w = conv.weight.detach().float()
+    return w.reshape(w.shape[0], w.shape[1]).contiguous(), conv.bias.detach().float().contiguous()
+
+
+class VQModel(nn.Module):
+    def __init__(self, ddconfig, lossconfig=None, n_embed=256, embed_dim=256, ckpt_path=None, ignore_keys=[],
+                 image_key="image", colorize_nlabels=None, monitor=None):
+        super().__init__()
+        self.image_key = image_key
+        self.decoder = Decoder(**ddconfig)
+        self.quantize = VectorQuantizer(n_embed, embed_dim, beta=0.25)
+        self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        self.ddconfig = dict(ddconfig)
+        self._pk = None
+        self.decode_chunk = 16  # samples decoded at once (bounds the full-resolution workspace)
+        self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
+        self.load_state_dict(sd, strict=False)  # encoder / loss keys are not on this path
+
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    # ---- packing -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _packed(self):
+        if self._pk is not None:
+            return self._pk
+        d = self.decoder
+        pk = {"pq": _pack_conv1(self.post_quant_conv), "conv_in": _pack_conv3(d.conv_in)}
+
+        def res(b):
+            r = {"n1": (b.norm1.weight.detach().float().contiguous(), b.norm1.bias.detach().float().contiguous()),
+                 "c1": _pack_conv3(b.conv1),
+                 "n2": (b.norm2.weight.detach().float().contiguous(), b.norm2.bias.detach().float().contiguous()),
+                 "c2": _pack_conv3(b.conv2), "cin": b.in_channels, "cout": b.out_channels}
+            if b.in_channels != b.out_channels:
+                r["nin"] = _pack_conv1(b.nin_shortcut)
+            return r
+
+        def att(a):
+            qw, qb = _pack_conv1(a.q)
+            kw, kb = _pack_conv1(a.k)
+            return {"n": (a.norm.weight.detach().float().contiguous(), a.norm.bias.detach().float().contiguous()),
+                    "qk": (torch.cat((qw, kw), 0).contiguous(), torch.cat((qb, kb), 0).contiguous()),
+                    "v": _pack_conv1(a.v), "proj": _pack_conv1(a.proj_out), "c": a.in_channels}
+
+        pk["mid"] = (res(d.mid.block_1), att(d.mid.attn_1), res(d.mid.block_2))
+        pk["up"] = []
+        for lvl in range(d.num_resolutions):
+            u = d.up[lvl]
+            pk["up"].append({"block": [res(b) for b in u.block], "attn": [att(a) for a in u.attn],
+                             "upsample": _pack_conv3(u.upsample.conv) if lvl != 0 else None})
+        pk["norm_out"] = (d.norm_out.weight.detach().float().contiguous(), d.norm_out.bias.detach().float().contiguous())
+        w = d.conv_out.weight.detach().float()  # [1, C, 3, 3] -> [9 taps][C]
+        pk["conv_out"] = (w[0].permute(1, 2, 0).reshape(9, -1).contiguous(), float(d.conv_out.bias.item()))
+        self._pk = pk
+        return pk
+
+    # ---- HIP op helpers (channels-last) ------------------------------------------------------------------
+    @staticmethod
+    def _gn(x, B, P, Cc, gamma_beta):
+        dev = x.device
+        work = torch.empty(B * ((P + 255) // 256) * 2 * Cc, device=dev, dtype=torch.float64)
+        sc = torch.empty(B, Cc, device=dev)
+        sh = torch.empty(B, Cc, device=dev)
+        _lib.check(_lib.lib().ds_groupnorm_stats(_lib.ptr(x), B, P, Cc, 32, _lib.ptr(gamma_beta[0]),
+                                                 _lib.ptr(gamma_beta[1]), 1e-6, _lib.ptr(work), _lib.ptr(sc),
+                                                 _lib.ptr(sh), _lib.stream()))
+        return sc, sh
+
+    @staticmethod
+    def _conv3(x, B, H, W, Cin, wb, gn=None, R=None, up=0):
+        """3x3 conv, output H x W (input H/2 x W/2 if up).  gn = (scale, shift) -> GroupNorm+swish prologue."""
+        w, b = wb
+        Cout = w.shape[0]
+        out = torch.empty(B, H, W, Cout, device=x.device)
+        _lib.gemm(x, w, out, B * H * W, Cout, 9 * Cin, bias=b, R=R, loader=_lib.LOAD_CONV2D,
+                  pro=_lib.PRO_AFFINE_SWISH if gn is not None else _lib.PRO_NONE,
+                  pro_scale=gn[0] if gn is not None else None, pro_shift=gn[1] if gn is not None else None,
+                  Cin=Cin, H=H, Wd=W, up=up)
+        return out
+
+    @staticmethod
+    def _conv1(x, M, Cin, wb, R=None, gn=None, rows_per_sample=0):
+        w, b = wb
+        Cout = w.shape[0]
+        out = torch.empty(M, Cout, device=x.device)
+        _lib.gemm(x, w, out, M, Cout, Cin, bias=b, R=R,
+                  pro=_lib.PRO_AFFINE if gn is not None else _lib.PRO_NONE,
+                  pro_scale=gn[0] if gn is not None else None, pro_shift=gn[1] if gn is not None else None,
+                  Cin=Cin, rows_per_sample=rows_per_sample)
+        return out
+
+    def _res(self, x, B, H, W, r):
+        P = H * W
+        h = self._conv3(x, B, H, W, r["cin"], r["c1"], gn=self._gn(x, B, P, r["cin"], r["n1"]))
+        short = x if "nin" not in r else self._conv1(x, B * P, r["cin"], r["nin"])
+        return self._conv3(h, B, H, W, r["cout"], r["c2"], gn=self._gn(h, B, P, r["cout"], r["n2"]), R=short)
+
+    def _attn(self, x, B, H, W, a):
+        Cc, P = a["c"], H * W
+        Pp = (P + 31) // 32 * 32  # key axis padded to the GEMM's K granularity
+        dev = x.device
+        gn = self._gn(x, B, P, Cc, a["n"])
+        qk = self._conv1(x, B * P, Cc, a["qk"], gn=gn, rows_per_sample=P)          # [B*P][2C]
+        vT = torch.zeros(B, Cc, Pp, device=dev)                                     # [B][C][Pp]
+        _lib.gemm(x, a["v"][0], vT, B * P, Cc, Cc, bias=a["v"][1], ldc=Pp, store=_lib.STORE_BATCH_T,
+                  pro=_lib.PRO_AFFINE, pro_scale=gn[0], pro_shift=gn[1], Cin=Cc, rows_per_sample=P)
+        S = torch.empty(B, P, Pp, device=dev)
+        _lib.gemm(qk, qk.data_ptr() + 4 * Cc, S, P, P, Cc, lda=2 * Cc, ldw=2 * Cc, ldc=Pp, groups=B,
+                  a_gstride=P * 2 * Cc, w_gstride=P * 2 * Cc, c_gstride=P * Pp)
+        _lib.check(_lib.lib().ds_softmax_rows(_lib.ptr(S), B * P, P, Pp, float(int(Cc) ** (-0.5)), _lib.stream()))
+        O = torch.empty(B * P, Cc, device=dev)
+        _lib.gemm(S, vT, O, P, Cc, Pp, lda=Pp, ldw=Pp, ldc=Cc, groups=B,
+                  a_gstride=P * Pp, w_gstride=Cc * Pp, c_gstride=P * Cc)
+        return self._conv1(O, B * P, Cc, a["proj"], R=x).view(B, H, W, Cc)
+
+    @torch.no_grad()
+    def _decode_cl(self, q, B, H, W):
+        """q: channels-last quant [B, H, W, C] -> mel [B, 1, 16H, 16W]."""
+        pk, d = self._packed(), self.decoder
+        Cz = q.shape[-1]
+        h = self._conv1(q, B * H * W, Cz, pk["pq"]).view(B, H, W, -1)
+        h = self._conv3(h, B, H, W, h.shape[-1], pk["conv_in"])
+        r1, a1, r2 = pk["mid"]
+        h = self._res(h, B, H, W, r1)
+        h = self._attn(h, B, H, W, a1)
+        h = self._res(h, B, H, W, r2)
+        for lvl in reversed(range(d.num_resolutions)):
+            u = pk["up"][lvl]
+            for i, r in enumerate(u["block"]):
+                h = self._res(h, B, H, W, r)
+                if u["attn"]:
+                    h = self._attn(h, B, H, W, u["attn"][i])
+            if lvl != 0:
+                H, W = 2 * H, 2 * W
+                h = self._conv3(h, B, H, W, h.shape[-1], u["upsample"], up=1)
+        Cc = h.shape[-1]
+        gn = self._gn(h, B, H * W, Cc, pk["norm_out"])
+        taps = torch.empty(B * H * W, 16, device=h.device)
+        _lib.gemm(h, pk["conv_out"][0], taps, B * H * W, 9, Cc, ldc=16, pro=_lib.PRO_AFFINE_SWISH,
+                  pro_scale=gn[0], pro_shift=gn[1], Cin=Cc, rows_per_sample=H * W)
+        out = torch.empty(B, 1, H, W, device=h.device)
+        _lib.check(_lib.lib().ds_stencil9(_lib.ptr(taps), 16, pk["conv_out"][1], _lib.ptr(out), B, H, W, _lib.stream()))
+        return out
+
+    # ---- reference-facing API -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode(self, quant):
+        """quant f32[B, 256, 5, 53] -> f32[B, 1, 80, 848] (spec_codec/vqgan.py:62-65)."""
+        B, Cz, H, W = quant.shape
+        outs = []
+        for s in range(0, B, self.decode_chunk):
+            q = quant[s:s + self.decode_chunk].permute(0, 2, 3, 1).contiguous().float()
+            outs.append(self._decode_cl(q, q.shape[0], H, W))
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+
+    @torch.no_grad()
+    def decode_tokens(self, tokens, H=5, W=53):
+        """tokens i64[B, H*W] in sequence (column-major) order -> mel; fuses DALLE.decode_to_img's
+        permuter + codebook lookup (dalle_spec.py:80-91) with decode()."""
+        E = self.quantize.embedding.weight
+        outs = []
+        for s in range(0, tokens.shape[0], self.decode_chunk):
+            tk = tokens[s:s + self.decode_chunk].contiguous()
+            b = tk.shape[0]
+            q = torch.empty(b, H, W, E.shape[1], device=tk.device)
+            _lib.check(_lib.lib().ds_codebook_gather(_lib.ptr(tk), _lib.ptr(E), _lib.ptr(q), b, H, W, E.shape[1],
+                                                     E.shape[0], _lib.stream()))
+            outs.append(self._decode_cl(q, b, H, W))
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]

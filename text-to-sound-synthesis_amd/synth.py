@@ -4,7 +4,7 @@ The reference ships no checkpoints, so parity and bench runs us
 random weights with the reference's exact shapes.  Values depend only on
 (seed, state-dict key, shape) -- never on construction order -- so the same
 tensors can be poured into the reference modules (oracle/make_golden.py, run
-where /root/reference exists), into oracle/diffsound_oracle.py and into the HIP
+in the build container), into the CPU oracle and into the HIP
 modules on the GPU box, without the reference being present there.
 
 Distributions follow the reference initialisers in spirit
