@@ -1,0 +1,211 @@
+"""Benchmark of the Diffsound generation path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch: B captions per GPU go through the 100-step
+p_sample loop (19-layer denoiser + fused sampler tail), SpecVQGAN decode and the MelGAN vocoder,
+ending with f32[B, 1, 217088] waveforms in HBM.  Workload = BASELINE.json configs[2] (full pipeline,
+batch 64 per GPU, K=256 codebook) with the CLIP text stage replaced by synthetic caption embeddings
+(unit-norm rows f32[B,77,512]; the CLIP text encoder is scope row 8f-1, not built yet).  Weights are
+seeded random-init tensors of the reference's exact shapes (no checkpoints exist offline).
+Multi-GPU: captions shard across ranks (weak scaling, fixed B per GPU); rank 0 scatters the caption
+embeddings and gathers the waveforms over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).  `roofline` is measured live:
+HIP events around every denoiser GEMM launch in a separate profiled batch (ds_profile_*), algorithmic
+flops 2*M*N*K per launch.  `cpu_baseline` times the CPU oracle (a port of the reference path) on a
+bounded sample on this box's host cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GFLOP_PER_SAMPLE_STEP = 155.02  # SURVEY.md section 8d, hoisted formulation
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="captions per GPU per step")
+    ap.add_argument("--diffusion-steps", type=int, default=100)
+    ap.add_argument("--n-layer", type=int, default=19)
+    ap.add_argument("--codes", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_layer, codes, T):
+    """CPU oracle (port of the reference path), B=1: a few denoiser steps + one decode + one vocode,
+    extrapolated to T steps.  Bounded to roughly 10-30 s."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import diffsound_oracle as O
+    from text_to_sound_synthesis_amd import synth
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.vocoder import Generator
+    torch.set_grad_enabled(False)
+    m = build_model(default_config(n_layer=n_layer, diffusion_step=T, n_embed=codes))
+    synth.synth_init_(m, seed=0)
+    sd = m.state_dict()
+    g = Generator(80, 32, 3)
+    synth.synth_init_(g, seed=0)
+    gsd = g.state_dict()
+    cond = synth.synth_cond_emb(1, key="cpu.cond")
+    sched = O.make_schedule(T, codes + 1)
+    log_z = O.initial_log_z(1, codes + 1)
+    nsteps = 3
+    u = synth.synth_uniform((1, codes + 1, 265), key="cpu.u")
+    log_z = O.p_sample_step(sd, sched, log_z, cond, torch.tensor([T - 1]), u)   # warm-up
+    t0 = time.perf_counter()
+    for i in range(nsteps):
+        log_z = O.p_sample_step(sd, sched, log_z, cond, torch.tensor([T - 2 - i]), u)
+    t_step = (time.perf_counter() - t0) / nsteps
+    tok = synth.synth_tokens(1, 265, codes, 0.0, key="cpu.codes")
+    t0 = time.perf_counter()
+    mel = O.decode_tokens(sd, tok)
+    t_dec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.melgan_generator(gsd, O.mel_to_unit(mel[:, 0]))
+    t_voc = time.perf_counter() - t0
+    total = T * t_step + t_dec + t_voc
+    return {"value": 1.0 / total, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "B=1 fp32 torch-CPU oracle: %d of %d denoiser steps (%.3f s each) + 1 decode (%.2f s) + "
+                      "1 vocode (%.2f s), extrapolated to %d steps" % (nsteps, T, t_step, t_dec, t_voc, T)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    torch.set_grad_enabled(False)
+
+    from text_to_sound_synthesis_amd import _lib, shard, synth
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.vocoder import Generator
+
+    T, B = args.diffusion_steps, args.batch
+    model = build_model(default_config(n_layer=args.n_layer, diffusion_step=T, n_embed=args.codes))
+    synth.synth_init_(model, seed=0)
+    model = model.to(dev).eval()
+    voc = synth.synth_init_(Generator(80, 32, 3), seed=0).to(dev).eval()
+    dt = model.transformer
+    dt.truncation_r = 0.85
+    n_total = B * world
+    # rank 0 owns the captions' conditioning (stand-in for CLIP output), everyone gets a slice
+    cond_all = synth.synth_cond_emb(n_total, key="bench.cond") if rank == 0 else None
+    torch.manual_seed(1234 + rank)
+    stage = {"scatter": 0.0, "kv": 0.0, "sample": 0.0, "decode": 0.0, "vocode": 0.0, "gather": 0.0}
+
+    def one_step(timed_stages=False):
+        def mark():
+            if timed_stages:
+                torch.cuda.synchronize()
+            return time.perf_counter()
+        t0 = mark()
+        cond = shard.scatter_conditions(cond_all, n_total, (77, 512), dev)
+        t1 = mark()
+        out = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0)
+        t2 = mark()
+        mel = model.decode_to_img(out["content_token"], (B, 256, 5, 53))
+        t3 = mark()
+        wave = voc(mel[:, 0], scale=0.5, shift=0.5)
+        t4 = mark()
+        allw = shard.gather_outputs(wave, n_total)
+        t5 = mark()
+        if timed_stages:
+            for k, v in zip(("scatter", "sample", "decode", "vocode", "gather"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                stage[k] += v
+        return allw if allw is not None else wave
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w = one_step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    assert torch.isfinite(w).all() and w.shape[-1] == 217088
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # one profiled batch of a few denoiser steps: HIP events around every GEMM launch
+        L = _lib.lib()
+        cond = synth.synth_cond_emb(B, key="bench.cond").to(dev)
+        kv = dt.transformer.condition_kv(cond, dt._schedule_table())
+        x = torch.full((B, 265), args.codes, device=dev, dtype=torch.long)
+        u = torch.rand((B, args.codes + 1, 265), device=dev)
+        torch.cuda.synchronize()
+        L.ds_profile_enable(1)
+        for i in range(3):
+            t = torch.full((B,), T - 1 - i, device=dev, dtype=torch.long)
+            x = dt.p_sample_tokens(x, kv, t, u, initial=(i == 0))
+        L.ds_profile_enable(0)
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        L.ds_profile_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        ach = fl.value / (ms.value * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "ds_gemm_kernel<dense> (fp32 MFMA 32x32x2)", "launches": int(n.value),
+                "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
+                "avg_launch_gflop": round(fl.value / max(1, n.value) / 1e9, 3)}
+    if args.stage_times and rank == 0:
+        one_step(timed_stages=True)
+        print("stage seconds (1 step, B=%d): %s" % (B, {k: round(v, 3) for k, v in stage.items()}), file=sys.stderr)
+
+    if rank == 0:
+        clips = n_total * args.steps
+        value = clips / elapsed
+        line = {
+            "metric": "10s clips/sec whole-node, 100-step Diffsound sample + VQ decode + vocoder",
+            "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic caption embeddings (unit-norm f32[B,77,512]) + seeded random-init weights of the "
+                    "reference's shapes",
+            "config": {"workload": "BASELINE configs[2]: full pipeline, batch %d per GPU, %d diffusion steps, "
+                                   "codebook %d, 19-layer denoiser -> SpecVQGAN decode -> MelGAN 22 kHz; CLIP text "
+                                   "stage replaced by synthetic embeddings" % (B, T, args.codes),
+                       "global_batch": n_total, "n_layer": args.n_layer, "parallelism": "caption-sharded x%d" % world,
+                       "denoiser_tflops_effective": round(value * GFLOP_PER_SAMPLE_STEP * T / 1e3, 2)},
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.n_layer, args.codes, T)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,10 @@ int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64
                      const float* u, int B, int initial, float trunc_r, void* workspace, int64_t* tokens_out,
                      ds_stream_t stream);
 
+/* per-launch HIP-event timing of the denoiser's GEMM launches (measurement only, bench.py) */
+int ds_profile_enable(int on);
+int ds_profile_collect(double* total_ms, double* total_flops, int64_t* launches);
+
 /* ---- SpecVQGAN decoder / MelGAN helpers ------------------------------------------------------- */
 /* ColumnMajor(reverse) + get_codebook_entry (permuter.py:31-55, quantize.py:88-103) -> [B][H][W][C] */
 int ds_codebook_gather(const int64_t* tokens, const float* codebook, float* out, int B, int H, int W, int C,

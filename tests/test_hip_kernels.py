@@ -82,8 +82,8 @@ def test_embed(L, sd_dalle_l2):
     p = torch.arange(265)
     pos = (sd_dalle_l2[pfx + "height_emb.weight"][p // 53] + sd_dalle_l2[pfx + "width_emb.weight"][p % 53]).cuda()
     out = torch.empty(3, 265, 1024, device="cuda")
-    L.check(L.lib().ds_embed(L.ptr(tok.cuda()), L.ptr(sd_dalle_l2[pfx + "emb.weight"].cuda()), L.ptr(pos),
-                             L.ptr(out), 3 * 265, 265, 1024, L.stream()))
+    tk, ew = tok.cuda(), sd_dalle_l2[pfx + "emb.weight"].cuda()   # keep device copies alive across the launch
+    L.check(L.lib().ds_embed(L.ptr(tk), L.ptr(ew), L.ptr(pos), L.ptr(out), 3 * 265, 265, 1024, L.stream()))
     assert torch.equal(out.cpu(), ref)   # one add per element: bit-exact
 
 
@@ -93,14 +93,15 @@ def test_adaln_and_layernorm(L, sd_dalle_l2):
     name = "transformer.transformer.blocks.1.ln1_1"
     ref = O._ada_ln(sd_dalle_l2, name, x, t)
     e = sd_dalle_l2[name + ".emb.weight"]
-    tab = (F.silu(e) @ sd_dalle_l2[name + ".linear.weight"].t() + sd_dalle_l2[name + ".linear.bias"]).cuda()
+    tab = (F.silu(e) @ sd_dalle_l2[name + ".linear.weight"].t() + sd_dalle_l2[name + ".linear.bias"]).cuda().contiguous()
     out = torch.empty(2 * 265, 1024, device="cuda")
-    L.check(L.lib().ds_adaln(L.ptr(x.cuda()), L.ptr(out), 530, 265, 1024, L.ptr(tab.contiguous()),
-                             L.ptr(t.cuda()), L.stream()))
+    xc, tc = x.cuda(), t.cuda()
+    L.check(L.lib().ds_adaln(L.ptr(xc), L.ptr(out), 530, 265, 1024, L.ptr(tab), L.ptr(tc), L.stream()))
     assert (out.cpu().view_as(ref) - ref).abs().max() < 2e-5
     g, b = rnd((1024,), "ln.g") + 1.5, rnd((1024,), "ln.b")
     ref = F.layer_norm(x, (1024,), g, b, eps=1e-5)
-    L.check(L.lib().ds_layernorm(L.ptr(x.cuda()), L.ptr(out), 530, 1024, L.ptr(g.cuda()), L.ptr(b.cuda()), L.stream()))
+    gc, bc = g.cuda(), b.cuda()
+    L.check(L.lib().ds_layernorm(L.ptr(xc), L.ptr(out), 530, 1024, L.ptr(gc), L.ptr(bc), L.stream()))
     assert (out.cpu().view_as(ref) - ref).abs().max() < 2e-5
 
 
@@ -161,7 +162,8 @@ def test_sample_tail(L, K, t, mask_frac):
     rows = logits.permute(0, 2, 1).contiguous().view(B * Ln, K).cuda()
     d = [torch.empty(B, K + 1, Ln, device="cuda") for _ in range(3)]
     out = torch.empty(B, Ln, dtype=torch.long, device="cuda")
-    L.check(L.lib().ds_sample_tail(L.ptr(rows), L.ptr(xt.cuda()), L.ptr(tv.cuda()), L.ptr(u.cuda()), L.ptr(tab.cuda()),
+    xc, tc, uc, tabc = xt.cuda(), tv.cuda(), u.cuda(), tab.cuda()
+    L.check(L.lib().ds_sample_tail(L.ptr(rows), L.ptr(xc), L.ptr(tc), L.ptr(uc), L.ptr(tabc),
                                    L.ptr(out), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), B, Ln, K, 100,
                                    int(mask_frac is None), 0.85, L.stream()))
     assert (d[0].cpu() - lp).abs().max() < 1e-5
@@ -185,7 +187,8 @@ def test_sample_tail_without_truncation(L):
     rows = logits.permute(0, 2, 1).contiguous().view(B * Ln, K).cuda()
     out = torch.empty(B, Ln, dtype=torch.long, device="cuda")
     dp = torch.empty(B, K + 1, Ln, device="cuda")
-    L.check(L.lib().ds_sample_tail(L.ptr(rows), L.ptr(xt.cuda()), L.ptr(tv.cuda()), L.ptr(u.cuda()), L.ptr(tab.cuda()),
+    xc, tc, uc, tabc = xt.cuda(), tv.cuda(), u.cuda(), tab.cuda()
+    L.check(L.lib().ds_sample_tail(L.ptr(rows), L.ptr(xc), L.ptr(tc), L.ptr(uc), L.ptr(tabc),
                                    L.ptr(out), None, None, L.ptr(dp), B, Ln, K, 100, 0, -1.0, L.stream()))
     assert (dp.cpu() - post).abs().max() < 5e-5
     assert torch.equal(out.cpu(), O.gumbel_sample(post, u))
@@ -197,7 +200,8 @@ def test_codebook_gather(L, sd_dalle_l2):
     ref = O.codebook_gather(sd_dalle_l2, tok)                               # [B, C, H, W]
     E = sd_dalle_l2["content_codec.quantize.embedding.weight"].cuda()
     out = torch.empty(2, 5, 53, 256, device="cuda")
-    L.check(L.lib().ds_codebook_gather(L.ptr(tok.cuda()), L.ptr(E), L.ptr(out), 2, 5, 53, 256, 256, L.stream()))
+    tk = tok.cuda()
+    L.check(L.lib().ds_codebook_gather(L.ptr(tk), L.ptr(E), L.ptr(out), 2, 5, 53, 256, 256, L.stream()))
     assert torch.equal(out.cpu().permute(0, 3, 1, 2), ref)
 
 
@@ -208,7 +212,8 @@ def test_groupnorm_stats(L):
     ref = F.group_norm(x.permute(0, 2, 1).double(), 32, g.double(), b.double(), eps=1e-6).permute(0, 2, 1)
     work = torch.empty(B * ((P + 255) // 256) * 2 * C, dtype=torch.float64, device="cuda")
     sc, sh = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
-    L.check(L.lib().ds_groupnorm_stats(L.ptr(x.cuda()), B, P, C, 32, L.ptr(g.cuda()), L.ptr(b.cuda()), 1e-6,
+    xc, gc, bc = x.cuda(), g.cuda(), b.cuda()
+    L.check(L.lib().ds_groupnorm_stats(L.ptr(xc), B, P, C, 32, L.ptr(gc), L.ptr(bc), 1e-6,
                                        L.ptr(work), L.ptr(sc), L.ptr(sh), L.stream()))
     got = x.double() * sc.cpu().double()[:, None] + sh.cpu().double()[:, None]
     assert (got - ref).abs().max() < 1e-5
@@ -282,7 +287,8 @@ def test_softmax_rows_and_stencils(L):
         eye[0, k, k // 3, k % 3] = 1.0
     ref = F.conv2d(taps[..., :9].permute(0, 3, 1, 2), eye, padding=1) + 0.25
     out = torch.empty(B, 1, H, W, device="cuda")
-    L.check(L.lib().ds_stencil9(L.ptr(taps.cuda()), 16, 0.25, L.ptr(out), B, H, W, L.stream()))
+    tc = taps.cuda()
+    L.check(L.lib().ds_stencil9(L.ptr(tc), 16, 0.25, L.ptr(out), B, H, W, L.stream()))
     assert (out.cpu() - ref).abs().max() < 1e-5
     N = 500
     t7 = rnd((B, N, 8), "s7")
@@ -291,5 +297,6 @@ def test_softmax_rows_and_stencils(L):
         eye7[0, k, k] = 1.0
     ref = torch.tanh(F.conv1d(F.pad(t7[..., :7].permute(0, 2, 1), (3, 3), mode="reflect"), eye7) - 0.1)
     out = torch.empty(B, 1, N, device="cuda")
-    L.check(L.lib().ds_stencil7_tanh(L.ptr(t7.cuda()), 8, -0.1, L.ptr(out), B, N, L.stream()))
+    t7c = t7.cuda()
+    L.check(L.lib().ds_stencil7_tanh(L.ptr(t7c), 8, -0.1, L.ptr(out), B, N, L.stream()))
     assert (out.cpu() - ref).abs().max() < 1e-5

@@ -102,6 +102,32 @@ extern "C" int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B) {
     return h && B > 0 ? (int64_t)h->d.n_layer * B * h->d.cond_len * 2 * h->d.n_embd * (int64_t)sizeof(float) : -1;
 }
 
+// ---- optional per-launch timing of the denoiser's GEMMs (bench.py's roofline leg) ---------------
+struct ProfRec { hipEvent_t a, b; double flops; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+
+extern "C" int ds_profile_enable(int on) {
+    g_prof = on != 0;
+    return 0;
+}
+// Waits for the recorded launches; returns their summed duration (ms), algorithmic flops (2MNK) and count.
+extern "C" int ds_profile_collect(double* total_ms, double* total_flops, int64_t* launches) {
+    double ms = 0.0, fl = 0.0;
+    for (auto& r : g_recs) {
+        float e = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&e, r.a, r.b) == hipSuccess) ms += e;
+        fl += r.flops;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = (int64_t)g_recs.size();
+    g_recs.clear();
+    return 0;
+}
+
 static int dense(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc,
                  int M, int N, int K, int act, hipStream_t s, int store = DS_STORE_ROW, int rps = 0) {
     GemmParams p;
@@ -109,7 +135,18 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
     p.A = A; p.W = W; p.bias = bias; p.R = R; p.C = C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = K; p.ldc = ldc; p.ldr = ldc;
     p.groups = 1; p.act = act; p.store = store; p.rows_per_sample = rps;
-    return ds_launch_gemm(p, s, DS_LOAD_DENSE);
+    if (!g_prof) return ds_launch_gemm(p, s, DS_LOAD_DENSE);
+    ProfRec r;
+    r.flops = 2.0 * M * N * K;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+        ds_set_error("profile: hipEventCreate failed");
+        return -2;
+    }
+    (void)hipEventRecord(r.a, s);
+    const int rc = ds_launch_gemm(p, s, DS_LOAD_DENSE);
+    (void)hipEventRecord(r.b, s);
+    g_recs.push_back(r);
+    return rc;
 }
 
 #define TRY(x)            \

@@ -238,7 +238,9 @@ class Text2ImageTransformer(nn.Module):
         B = input.shape[0]
         kv = self.condition_kv(cond_emb, p["sched_src"])
         out = torch.empty(B, self.num_codes, self.content_seq_len, device=p["device"], dtype=torch.float32)
+        # device copies must outlive the launch call: keep them in locals, never as call temporaries
+        tok, tt = input.contiguous(), t.to(p["device"]).contiguous()
         _lib.check(_lib.lib().ds_denoiser_forward(
-            p["handle"], _lib.ptr(input.contiguous()), _lib.ptr(t.to(p["device"]).contiguous()), _lib.ptr(kv), B,
+            p["handle"], _lib.ptr(tok), _lib.ptr(tt), _lib.ptr(kv), B,
             _lib.ptr(self.workspace(B, p["sched_src"])), _lib.ptr(out), 1, _lib.stream()))
         return out
