@@ -125,7 +125,8 @@ int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64
 
 /* per-launch HIP-event timing of the denoiser's GEMM launches (measurement only, bench.py) */
 int ds_profile_enable(int on);
-int ds_profile_collect(double* total_ms, double* total_flops, int64_t* launches);
+/* arrays of 3, indexed by block-tile config (0: 128x128, 1: 128x64, 2: 64x64) */
+int ds_profile_collect(double* ms, double* flops, int64_t* launches);
 
 /* ---- SpecVQGAN decoder / MelGAN helpers ------------------------------------------------------- */
 /* ColumnMajor(reverse) + get_codebook_entry (permuter.py:31-55, quantize.py:88-103) -> [B][H][W][C] */

@@ -103,7 +103,8 @@ extern "C" int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B) {
 }
 
 // ---- optional per-launch timing of the denoiser's GEMMs (bench.py's roofline leg) ---------------
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int tile; };
+extern int g_last_tile;  // gemm_f32.hip
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 
@@ -111,19 +112,19 @@ extern "C" int ds_profile_enable(int on) {
     g_prof = on != 0;
     return 0;
 }
-// Waits for the recorded launches; returns their summed duration (ms), algorithmic flops (2MNK) and count.
-extern "C" int ds_profile_collect(double* total_ms, double* total_flops, int64_t* launches) {
-    double ms = 0.0, fl = 0.0;
+// Waits for the recorded launches; per block-tile config c (0: 128x128, 1: 128x64, 2: 64x64 -- each is
+// its own kernel symbol) returns summed duration ms[c], algorithmic flops[c] (2MNK) and launches[c].
+extern "C" int ds_profile_collect(double* ms, double* flops, int64_t* launches) {
+    DS_CHECK_ARG(ms && flops && launches, "null pointer");
+    for (int c = 0; c < 3; ++c) { ms[c] = 0.0; flops[c] = 0.0; launches[c] = 0; }
     for (auto& r : g_recs) {
         float e = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&e, r.a, r.b) == hipSuccess) ms += e;
-        fl += r.flops;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&e, r.a, r.b) == hipSuccess) ms[r.tile] += e;
+        flops[r.tile] += r.flops;
+        launches[r.tile] += 1;
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
-    if (total_ms) *total_ms = ms;
-    if (total_flops) *total_flops = fl;
-    if (launches) *launches = (int64_t)g_recs.size();
     g_recs.clear();
     return 0;
 }
@@ -145,6 +146,7 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
     (void)hipEventRecord(r.a, s);
     const int rc = ds_launch_gemm(p, s, DS_LOAD_DENSE);
     (void)hipEventRecord(r.b, s);
+    r.tile = g_last_tile;
     g_recs.push_back(r);
     return rc;
 }

@@ -16,31 +16,35 @@
 // bank-conflict free (16 consecutive rows start at distinct multiples of 4 banks).  One
 // ds_read_b128 per fragment feeds 4 MFMAs: lane half h supplies k = 8c+4h+j for MFMA j, which
 // both operands agree on, so the contraction index set is covered exactly once.
-// Register-staged double buffering: global loads for tile t+1 are issued before the MFMAs of
-// tile t and written to the other LDS buffer afterwards; one barrier per k-tile.
+// Register-staged double buffering: the raw global loads of tile t+1 are all issued (no
+// dependent branch between them) before the MFMAs of tile t; the prologue transform and the LDS
+// write happen after the MFMAs, so HBM/L2 latency hides under 64-cycle MFMAs; one barrier per
+// k-tile.  Loader and prologue are template parameters: the hot dense/no-prologue instance has a
+// branch-free staging path.
 #include "common.h"
 
 #define BK 32
 #define LDT 36  // padded LDS row (floats)
 
+template <int PRO>
 __device__ __forceinline__ f32x4 ds_pro(const GemmParams& p, f32x4 v, int sample, int ch) {
-    if (p.pro == DS_PRO_LRELU) {
+    if constexpr (PRO == DS_PRO_LRELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.2f * v[j];
-    } else if (p.pro != DS_PRO_NONE) {
+    } else if constexpr (PRO != DS_PRO_NONE) {
         const f32x4 s = *(const f32x4*)(p.pro_scale + (size_t)sample * p.Cin + ch);
         const f32x4 o = *(const f32x4*)(p.pro_shift + (size_t)sample * p.Cin + ch);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float y = v[j] * s[j] + o[j];
-            if (p.pro == DS_PRO_AFFINE_SWISH) y = y / (1.f + expf(-y));
+            if constexpr (PRO == DS_PRO_AFFINE_SWISH) y = y / (1.f + expf(-y));
             v[j] = y;
         }
     }
     return v;
 }
 
-template <int BM, int BN, int LOADER>
+template <int BM, int BN, int LOADER, int PRO>
 __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 fragments per wave (2x2 wave grid)
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
         if (m >= p.M) m = p.M - 1;
         if constexpr (LOADER == DS_LOAD_DENSE) {
             a_base[i] = Ag + (size_t)m * p.lda + kq;
-            a_b[i] = p.rows_per_sample > 0 ? m / p.rows_per_sample : 0;
+            a_b[i] = (PRO == DS_PRO_AFFINE || PRO == DS_PRO_AFFINE_SWISH) ? m / p.rows_per_sample : 0;
             a_y[i] = a_x[i] = 0;
         } else if constexpr (LOADER == DS_LOAD_CONV2D) {
             const int hw = p.H * p.W_;
@@ -110,43 +114,50 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
         w_base[i] = Wg + (size_t)n * p.ldw + kq;
     }
 
-    auto load_a = [&](int i, int k0) -> f32x4 {
-        f32x4 v;
+    // Raw load of one staging slot: address math + one global_load_dwordx4, no dependent branch
+    // on the loaded value.  Out-of-image taps read a valid dummy address and are zeroed in
+    // stage_finish (zero padding lives in the activated domain).
+    unsigned okmask = 0;  // bit i: slot i of the tile being staged is inside the image
+    auto stage_load = [&](int i, int k0) -> f32x4 {
         if constexpr (LOADER == DS_LOAD_DENSE) {
-            v = *(const f32x4*)(a_base[i] + k0);
-            if (p.pro != DS_PRO_NONE) v = ds_pro(p, v, a_b[i], k0 + kq);
+            return *(const f32x4*)(a_base[i] + k0);
         } else if constexpr (LOADER == DS_LOAD_CONV2D) {
             const int tap = k0 / p.Cin;
             const int c0 = k0 - tap * p.Cin + kq;
             const int ky = tap / 3, kx = tap - ky * 3;
             int sy = a_y[i] + ky - 1, sx = a_x[i] + kx - 1;
             const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W_;
+            sy = ok ? sy : a_y[i];
+            sx = ok ? sx : a_x[i];
             int hs = p.H, ws = p.W_;
             if (p.up) { sy >>= 1; sx >>= 1; hs >>= 1; ws >>= 1; }
-            if (ok) {
-                v = *(const f32x4*)(a_base[i] + ((size_t)(a_b[i] * hs + sy) * ws + sx) * p.Cin + c0);
-                if (p.pro != DS_PRO_NONE) v = ds_pro(p, v, a_b[i], c0);
-            } else {
-                v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding lives in the activated domain
-            }
+            okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
+            return *(const f32x4*)(a_base[i] + ((size_t)(a_b[i] * hs + sy) * ws + sx) * p.Cin + c0);
         } else if constexpr (LOADER == DS_LOAD_CONV1D) {
             const int tap = k0 / p.Cin;
             const int c0 = k0 - tap * p.Cin + kq;
             int ts = a_x[i] + (tap - (p.taps - 1) / 2) * p.dil;  // ReflectionPad1d
             if (ts < 0) ts = -ts;
             if (ts >= p.W_) ts = 2 * (p.W_ - 1) - ts;
-            v = *(const f32x4*)(a_base[i] + (size_t)ts * p.Cin + c0);
-            if (p.pro != DS_PRO_NONE) v = ds_pro(p, v, a_b[i], c0);
+            return *(const f32x4*)(a_base[i] + (size_t)ts * p.Cin + c0);
         } else {
             const int tap = k0 / p.Cin;  // 0: x[s0] * W[:,:,phase]; 1: x[s0-1] * W[:,:,phase+r]
             const int c0 = k0 - tap * p.Cin + kq;
-            const int s = a_x[i] - tap;
-            if (s >= 0 && s < p.ct_tin) {
-                v = *(const f32x4*)(a_base[i] + (size_t)s * p.Cin + c0);
-                if (p.pro != DS_PRO_NONE) v = ds_pro(p, v, a_b[i], c0);
-            } else {
-                v = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            int s = a_x[i] - tap;
+            const bool ok = s >= 0 && s < p.ct_tin;
+            s = ok ? s : 0;
+            okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
+            return *(const f32x4*)(a_base[i] + (size_t)s * p.Cin + c0);
+        }
+    };
+    auto stage_finish = [&](int i, int k0, f32x4 v) -> f32x4 {
+        if constexpr (PRO != DS_PRO_NONE) {
+            int ch = k0 + kq;
+            if constexpr (LOADER != DS_LOAD_DENSE) ch = k0 - (k0 / p.Cin) * p.Cin + kq;
+            v = ds_pro<PRO>(p, v, a_b[i], ch);
+        }
+        if constexpr (LOADER == DS_LOAD_CONV2D || LOADER == DS_LOAD_CONVT1D) {
+            if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         return v;
     };
@@ -164,11 +175,11 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
 
     // prologue: tile 0 -> LDS[0]
 #pragma unroll
-    for (int i = 0; i < SA; ++i) ra[i] = load_a(i, 0);
+    for (int i = 0; i < SA; ++i) ra[i] = stage_load(i, 0);
 #pragma unroll
     for (int i = 0; i < SB; ++i) rb[i] = *(const f32x4*)(w_base[i]);
 #pragma unroll
-    for (int i = 0; i < SA; ++i) *(f32x4*)(As + (srow + 32 * i) * LDT + kq) = ra[i];
+    for (int i = 0; i < SA; ++i) *(f32x4*)(As + (srow + 32 * i) * LDT + kq) = stage_finish(i, 0, ra[i]);
 #pragma unroll
     for (int i = 0; i < SB; ++i) *(f32x4*)(Bs + (srow + 32 * i) * LDT + kq) = rb[i];
     __syncthreads();
@@ -176,12 +187,12 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
+        const int k0n = (kt + 1) * BK;
         if (more) {
-            const int k0 = (kt + 1) * BK;
 #pragma unroll
-            for (int i = 0; i < SA; ++i) ra[i] = load_a(i, k0);
+            for (int i = 0; i < SA; ++i) ra[i] = stage_load(i, k0n);
 #pragma unroll
-            for (int i = 0; i < SB; ++i) rb[i] = *(const f32x4*)(w_base[i] + k0);
+            for (int i = 0; i < SB; ++i) rb[i] = *(const f32x4*)(w_base[i] + k0n);
         }
         const float* Ac = As + cur * BM * LDT + (wm * TM * 32 + l31) * LDT + 4 * hh;
         const float* Bc = Bs + cur * BN * LDT + (wn * TN * 32 + l31) * LDT + 4 * hh;
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
             float* An = As + (cur ^ 1) * BM * LDT;
             float* Bn = Bs + (cur ^ 1) * BN * LDT;
 #pragma unroll
-            for (int i = 0; i < SA; ++i) *(f32x4*)(An + (srow + 32 * i) * LDT + kq) = ra[i];
+            for (int i = 0; i < SA; ++i) *(f32x4*)(An + (srow + 32 * i) * LDT + kq) = stage_finish(i, k0n, ra[i]);
 #pragma unroll
             for (int i = 0; i < SB; ++i) *(f32x4*)(Bn + (srow + 32 * i) * LDT + kq) = rb[i];
         }
@@ -248,12 +259,12 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
 }
 
 // ---- host side: tile selection + launch ----------------------------------------------------
-template <int BM, int BN, int LOADER>
+template <int BM, int BN, int LOADER, int PRO>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_kernel<BM, BN, LOADER>,
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_kernel<BM, BN, LOADER, PRO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -263,21 +274,21 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles, p.groups > 0 ? p.groups : 1);
-    hipLaunchKernelGGL((ds_gemm_kernel<BM, BN, LOADER>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((ds_gemm_kernel<BM, BN, LOADER, PRO>), grid, dim3(256), lds, s, p);
     DS_CHECK_LAUNCH();
     return 0;
 }
 
+int g_last_tile = 0;           // tile config of the most recent launch (read by the profiler)
 static int g_force_tile = -1;  // test hook: 0..2 forces a tile config, -1 = auto
 extern "C" void ds_gemm_force_tile(int t) { g_force_tile = t; }
 
-template <int LOADER>
-static int launch_loader(const GemmParams& p, hipStream_t s) {
-    // Pick the tile whose block count quantises best over 256 CUs.  MFMA time per block is
-    // ~BM*BN; smaller tiles pay more L2->LDS traffic per flop (penalty factors, to be tuned
-    // on hardware).
-    struct Cfg { int bm, bn; double pen; };
-    static const Cfg cfgs[3] = {{128, 128, 1.00}, {128, 64, 1.05}, {64, 64, 1.12}};
+template <int LOADER, int PRO>
+static int launch_tile(const GemmParams& p, hipStream_t s) {
+    // Pick the tile whose block count quantises best over the 256 CUs: blocks co-reside
+    // (LDS-limited) 2 / 3 / 4 per CU for 128x128 / 128x64 / 64x64; MFMA time per block ~ BM*BN.
+    struct Cfg { int bm, bn, per_cu; double pen; };
+    static const Cfg cfgs[3] = {{128, 128, 2, 1.00}, {128, 64, 3, 1.03}, {64, 64, 4, 1.06}};
     int best = 0;
     if (g_force_tile >= 0) {
         best = g_force_tile;
@@ -286,15 +297,17 @@ static int launch_loader(const GemmParams& p, hipStream_t s) {
         const int groups = p.groups > 0 ? p.groups : 1;
         for (int c = 0; c < 3; ++c) {
             const long tiles = (long)((p.M + cfgs[c].bm - 1) / cfgs[c].bm) * ((p.N + cfgs[c].bn - 1) / cfgs[c].bn) * groups;
-            const long rounds = (tiles + 255) / 256;
-            const double cost = (double)rounds * cfgs[c].bm * cfgs[c].bn * cfgs[c].pen;
+            // a CU works through ceil(tiles / 256) blocks, per_cu at a time sharing its 4 SIMDs
+            const long per_cu_blocks = (tiles + 255) / 256;
+            const double cost = (double)per_cu_blocks * cfgs[c].bm * cfgs[c].bn * cfgs[c].pen;
             if (cost < bc) { bc = cost; best = c; }
         }
     }
+    g_last_tile = best;
     switch (best) {
-        case 0: return launch_cfg<128, 128, LOADER>(p, s);
-        case 1: return launch_cfg<128, 64, LOADER>(p, s);
-        default: return launch_cfg<64, 64, LOADER>(p, s);
+        case 0: return launch_cfg<128, 128, LOADER, PRO>(p, s);
+        case 1: return launch_cfg<128, 64, LOADER, PRO>(p, s);
+        default: return launch_cfg<64, 64, LOADER, PRO>(p, s);
     }
 }
 
@@ -303,20 +316,41 @@ int ds_launch_gemm(const GemmParams& p, hipStream_t stream, int loader) {
     DS_CHECK_ARG(p.K % BK == 0, "K must be a multiple of 32");
     DS_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "A/W must be 16-byte aligned");
     DS_CHECK_ARG(p.ldw >= p.K && p.ldw % 4 == 0, "ldw must be >= K and a multiple of 4");
+    const bool affine = p.pro == DS_PRO_AFFINE || p.pro == DS_PRO_AFFINE_SWISH;
+    DS_CHECK_ARG(!affine || (p.pro_scale && p.pro_shift && p.Cin > 0), "affine prologue needs scale/shift/Cin");
     switch (loader) {
         case DS_LOAD_DENSE:
             DS_CHECK_ARG(p.lda % 4 == 0, "lda must be a multiple of 4");
-            return launch_loader<DS_LOAD_DENSE>(p, stream);
+            DS_CHECK_ARG(!affine || p.rows_per_sample > 0, "dense affine prologue needs rows_per_sample");
+            switch (p.pro) {
+                case DS_PRO_NONE: return launch_tile<DS_LOAD_DENSE, DS_PRO_NONE>(p, stream);
+                case DS_PRO_AFFINE: return launch_tile<DS_LOAD_DENSE, DS_PRO_AFFINE>(p, stream);
+                case DS_PRO_AFFINE_SWISH: return launch_tile<DS_LOAD_DENSE, DS_PRO_AFFINE_SWISH>(p, stream);
+                case DS_PRO_LRELU: return launch_tile<DS_LOAD_DENSE, DS_PRO_LRELU>(p, stream);
+            }
+            break;
         case DS_LOAD_CONV2D:
             DS_CHECK_ARG(p.Cin % BK == 0 && p.K == 9 * p.Cin, "conv2d: K = 9*Cin, Cin % 32 == 0");
-            return launch_loader<DS_LOAD_CONV2D>(p, stream);
+            switch (p.pro) {
+                case DS_PRO_NONE: return launch_tile<DS_LOAD_CONV2D, DS_PRO_NONE>(p, stream);
+                case DS_PRO_AFFINE_SWISH: return launch_tile<DS_LOAD_CONV2D, DS_PRO_AFFINE_SWISH>(p, stream);
+            }
+            break;
         case DS_LOAD_CONV1D:
             DS_CHECK_ARG(p.Cin % BK == 0 && p.K == p.taps * p.Cin, "conv1d: K = taps*Cin, Cin % 32 == 0");
-            return launch_loader<DS_LOAD_CONV1D>(p, stream);
+            switch (p.pro) {
+                case DS_PRO_NONE: return launch_tile<DS_LOAD_CONV1D, DS_PRO_NONE>(p, stream);
+                case DS_PRO_LRELU: return launch_tile<DS_LOAD_CONV1D, DS_PRO_LRELU>(p, stream);
+            }
+            break;
         case DS_LOAD_CONVT1D:
             DS_CHECK_ARG(p.Cin % BK == 0 && p.K == 2 * p.Cin, "convT1d: K = 2*Cin, Cin % 32 == 0");
-            return launch_loader<DS_LOAD_CONVT1D>(p, stream);
+            switch (p.pro) {
+                case DS_PRO_NONE: return launch_tile<DS_LOAD_CONVT1D, DS_PRO_NONE>(p, stream);
+                case DS_PRO_LRELU: return launch_tile<DS_LOAD_CONVT1D, DS_PRO_LRELU>(p, stream);
+            }
+            break;
     }
-    ds_set_error("gemm: unknown loader %d", loader);
+    ds_set_error("gemm: unsupported loader/prologue combination %d/%d", loader, p.pro);
     return -1;
 }
