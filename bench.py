@@ -5,11 +5,11 @@
 One "step" = one pass of the hot path over one batch: B captions per GPU go through the 100-step
 p_sample loop (19-layer denoiser + fused sampler tail), SpecVQGAN decode and the MelGAN vocoder,
 ending with f32[B, 1, 217088] waveforms in HBM.  Workload = BASELINE.json configs[2] (full pipeline,
-batch 64 per GPU, K=256 codebook) with the CLIP text stage replaced by synthetic caption embeddings
-(unit-norm rows f32[B,77,512]; the CLIP text encoder is scope row 8f-1, not built yet).  Weights are
+batch 64 per GPU, K=256 codebook): synthetic caption token ids (the BPE merge table is not on the
+box) -> CLIP text tower -> 100-step diffusion -> SpecVQGAN decode -> MelGAN.  Weights are
 seeded random-init tensors of the reference's exact shapes (no checkpoints exist offline).
 Multi-GPU: captions shard across ranks (weak scaling, fixed B per GPU); rank 0 scatters the caption
-embeddings and gathers the waveforms over RCCL inside the timed region.
+token ids and gathers the waveforms over RCCL inside the timed region.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).  `roofline` is measured live:
 HIP events around every denoiser GEMM launch in a separate profiled batch (ds_profile_*), algorithmic
@@ -103,15 +103,16 @@ def main():
     from text_to_sound_synthesis_amd.modeling.vocoder import Generator
 
     T, B = args.diffusion_steps, args.batch
-    model = build_model(default_config(n_layer=args.n_layer, diffusion_step=T, n_embed=args.codes))
+    model = build_model(default_config(n_layer=args.n_layer, diffusion_step=T, n_embed=args.codes, with_clip=True))
     synth.synth_init_(model, seed=0)
     model = model.to(dev).eval()
     voc = synth.synth_init_(Generator(80, 32, 3), seed=0).to(dev).eval()
     dt = model.transformer
     dt.truncation_r = 0.85
     n_total = B * world
-    # rank 0 owns the captions' conditioning (stand-in for CLIP output), everyone gets a slice
-    cond_all = synth.synth_cond_emb(n_total, key="bench.cond") if rank == 0 else None
+    # rank 0 owns the captions (token ids i64[n,77]: <SOT> word pieces <EOT>, as clip.tokenize emits); every
+    # rank gets a slice and runs the CLIP text tower on it
+    tok_all = synth.synth_caption_tokens(n_total, key="bench.captions") if rank == 0 else None
     torch.manual_seed(1234 + rank)
     stage = {"scatter": 0.0, "kv": 0.0, "sample": 0.0, "decode": 0.0, "vocode": 0.0, "gather": 0.0}
 
@@ -121,9 +122,9 @@ def main():
                 torch.cuda.synchronize()
             return time.perf_counter()
         t0 = mark()
-        cond = shard.scatter_conditions(cond_all, n_total, (77, 512), dev)
+        toks = shard.scatter_conditions(tok_all, n_total, (77,), dev, dtype=torch.long)
         t1 = mark()
-        out = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0)
+        out = dt.sample(condition_token=toks, condition_mask=None, condition_embed=None, filter_ratio=0)
         t2 = mark()
         mel = model.decode_to_img(out["content_token"], (B, 256, 5, 53))
         t3 = mark()
@@ -196,11 +197,10 @@ def main():
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic caption embeddings (unit-norm f32[B,77,512]) + seeded random-init weights of the "
-                    "reference's shapes",
+            "data": "synthetic caption token ids i64[B,77] + seeded random-init weights of the reference's shapes",
             "config": {"workload": "BASELINE configs[2]: full pipeline, batch %d per GPU, %d diffusion steps, "
-                                   "codebook %d, 19-layer denoiser -> SpecVQGAN decode -> MelGAN 22 kHz; CLIP text "
-                                   "stage replaced by synthetic embeddings" % (B, T, args.codes),
+                                   "codebook %d: CLIP text tower -> 19-layer denoiser -> SpecVQGAN decode -> MelGAN "
+                                   "22 kHz" % (B, T, args.codes),
                        "global_batch": n_total, "n_layer": args.n_layer, "parallelism": "caption-sharded x%d" % world,
                        "denoiser_tflops_effective": round(value * GFLOP_PER_SAMPLE_STEP * T / 1e3, 2)},
         }

@@ -52,6 +52,7 @@ typedef struct ds_gemm_desc {
     int32_t up;              /* conv2d: input is (H/2, W/2), nearest-upsampled on the fly */
     int32_t taps, dil;       /* conv1d (reflect padding) */
     int32_t ct_r, ct_p, ct_tin; /* convT1d polyphase: stride, padding, input length; groups = r */
+    int32_t f16_round;       /* 1: round outputs (and GELU2 intermediates) to the fp16 grid (CLIP text tower) */
 } ds_gemm_desc;
 
 int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream);
@@ -71,6 +72,18 @@ int ds_layernorm(const float* x, float* y, int M, int D, const float* gamma, con
 /* FullAttention / CrossAttention core, transformer_utils.py:43-58, 91-109 (head dim 64, Lk <= 288) */
 int ds_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                  int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
+
+/* causal = 1: key j visible to query i iff j <= i; f16_round = 1: scores, probabilities and outputs are
+ * rounded to the fp16 grid (CLIP's nn.MultiheadAttention in fp16, clip/model.py:166-186) */
+int ds_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                    int B, int heads, int Lq, int Lk, float scale, int causal, int f16_round, ds_stream_t stream);
+/* fp16-semantics row kernels of the CLIP text tower (sound_synthesis/modeling/modules/clip/model.py:150-157,
+ * 341-354; embeddings/clip_text_embedding.py:46-88): fp32 storage, outputs rounded to the fp16 grid */
+int ds_embed_f16(const int64_t* tokens, const float* emb, const float* pos, float* out, int M, int L, int D,
+                 ds_stream_t stream);
+int ds_layernorm_f16(const float* x, float* y, int M, int D, const float* gamma, const float* beta,
+                     ds_stream_t stream);
+int ds_l2norm_rows_f16(const float* x, float* y, int M, int D, ds_stream_t stream);
 
 /* ---- one reverse-diffusion step's per-column tail --------------------------------------------
  * predict_start (diffusion_transformer.py:285-289) + top-r truncation (models/dalle_spec.py:158-174)

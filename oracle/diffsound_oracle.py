@@ -363,3 +363,36 @@ def melgan_generator(sd, mel, pfx="model.", ratios=(8, 8, 2, 2), n_res=3):
 def mel_to_unit(x):
     """generate_samples_batch.py:181-182: spec = (x + 1) / 2 before saving / vocoding."""
     return (x + 1.0) / 2.0
+
+
+# --------------------------------------------------------------------------- A16 (scope row 8f-1)
+def clip_text_embed(sd, tokens, pfx="transformer.condition_emb.", heads=8):
+    """CLIPTextEmbedding.forward with pick_last_embedding False (embeddings/clip_text_embedding.py:46-88):
+    the ViT-B/32 text tower of modules/clip/model.py (ResidualAttentionBlock :166-186, causal mask
+    :313-319, QuickGELU :160-162) run the way the reference runs it: Linear / MHA weights in fp16
+    (convert_weights :373-395), activations fp16, LayerNorm computed in fp32 (:150-157)."""
+    d = sd[pfx + "ln_final.weight"].shape[0]
+    h = lambda k: sd[pfx + k].half()
+    ln = lambda x, n: F.layer_norm(x.float(), (d,), sd[pfx + n + ".weight"].float(), sd[pfx + n + ".bias"].float(),
+                                   1e-5).half()
+    tok = tokens.clamp(min=0)
+    x = sd[pfx + "token_embedding.weight"][tok].half() + sd[pfx + "positional_embedding"].half()
+    x = x.permute(1, 0, 2)                                            # [L, B, D]
+    Ls = x.shape[0]
+    mask = torch.full((Ls, Ls), float("-inf")).triu_(1).half()
+    i = 0
+    while (pfx + "transformer.resblocks.%d.ln_1.weight" % i) in sd:
+        b = "transformer.resblocks.%d." % i
+        y = ln(x, b + "ln_1")
+        a = F.multi_head_attention_forward(
+            y, y, y, d, heads, h(b + "attn.in_proj_weight"), h(b + "attn.in_proj_bias"), None, None, False, 0.0,
+            h(b + "attn.out_proj.weight"), h(b + "attn.out_proj.bias"), training=False, need_weights=False,
+            attn_mask=mask)[0]
+        x = x + a
+        y = F.linear(ln(x, b + "ln_2"), h(b + "mlp.c_fc.weight"), h(b + "mlp.c_fc.bias"))
+        y = y * torch.sigmoid(1.702 * y)
+        x = x + F.linear(y, h(b + "mlp.c_proj.weight"), h(b + "mlp.c_proj.bias"))
+        i += 1
+    x = ln(x.permute(1, 0, 2), "ln_final")
+    x = x / x.norm(dim=-1, keepdim=True)
+    return x.float()

@@ -57,8 +57,25 @@ def state_keys(model, skip=()):
 
 
 @torch.no_grad()
+def text_stage():
+    # ---- (6) text stage: BPE tokens + CLIP text embedding (fp16 tower) -------------------------
+    caps = synth.synth_captions(6) + ["It's 3 o'clock: RAIN &amp; thunder!!  (loud)   <café>", " ".join(["buzzing"] * 90)]
+    tk = rh.reference_tokenize(caps)
+    clip = rh.build_clip_text()
+    emb = clip(tk["token"][:2].clone())
+    with open(os.path.join(OUT, "captions.json"), "w") as f:
+        json.dump(caps, f)
+    save("text_stage", tokens=tk["token"], mask=tk["mask"], cond_emb=emb.float())
+    with open(os.path.join(OUT, "state_dict_keys_clip.json"), "w") as f:
+        json.dump({"transformer.condition_emb." + k: list(v.shape) for k, v in clip.state_dict().items()}, f,
+                  indent=0, sort_keys=True)
+
+
+@torch.no_grad()
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--text-only" in sys.argv:
+        return text_stage()
     torch.manual_seed(0)
     t0 = time.time()
 
@@ -136,6 +153,7 @@ def main():
     save("decode", mel=m2.decode_to_img(tok, (1, 256, 5, 53)))
     mel01 = synth.synth_uniform((1, 80, 848), key="voc.mel")
     save("vocoder", wave=voc(mel01))
+    text_stage()
     print("done in %.1fs" % (time.time() - t0))
 
 

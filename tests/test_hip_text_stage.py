@@ -1,0 +1,105 @@
+"""Scope row 8f-1 on the GPU: the HIP CLIP text tower (fp16 semantics on fp32 storage) against the golden
+output of the reference's CLIPTextEmbedding and against the oracle, plus the kernel variants it adds
+(causal attention, 512-wide LayerNorm, fp16 rounding)."""
+import json
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import diffsound_oracle as O
+from conftest import GOLDEN, golden
+from text_to_sound_synthesis_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+# The reference's fp16 tower is itself only reproducible to ~1e-3 relative across devices/torch builds
+# (fp16 rounding after every op); outputs are unit-norm rows with entries ~0.04.
+COND_TOL = 5e-4
+
+
+def clip_sd():
+    with open(os.path.join(GOLDEN, "state_dict_keys_clip.json")) as f:
+        return synth.synth_state_dict(json.load(f))
+
+
+@pytest.fixture(scope="module")
+def model():
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    m = build_model(default_config(n_layer=1, with_clip=True))
+    missing, unexpected = m.load_state_dict(clip_sd(), strict=False)
+    assert not unexpected
+    return m.cuda().eval()
+
+
+def test_clip_text_vs_reference_golden(model):
+    g = golden("text_stage")
+    out = model.transformer.condition_emb(g["tokens"][:2].cuda()).cpu()
+    ref = g["cond_emb"]
+    err = (out - ref).abs().max().item()
+    print("CLIP text tower: max-abs vs reference %.3e (rows are unit-norm)" % err)
+    assert out.shape == ref.shape == (2, 77, 512)
+    assert err < COND_TOL
+    assert (out.norm(dim=-1) - 1).abs().max() < 2e-3
+
+
+def test_clip_text_vs_oracle_all_captions(model):
+    g = golden("text_stage")
+    toks = g["tokens"]                      # 8 captions incl. punctuation / html entity / truncated one
+    out = model.transformer.condition_emb(toks.cuda()).cpu()
+    ref = O.clip_text_embed(clip_sd(), toks)
+    assert (out - ref).abs().max() < COND_TOL
+
+
+def test_causal_attention_fp32_mode():
+    from text_to_sound_synthesis_amd import _lib as L
+    B, T, H, D = 3, 77, 8, 512
+    q, k, v = [(synth.synth_uniform((B, T, D), key="ca." + n) * 2 - 1) for n in "qkv"]
+    qh, kh, vh = [x.view(B, T, H, 64).transpose(1, 2) for x in (q, k, v)]
+    s = (qh @ kh.transpose(-2, -1)) * 0.125 + torch.full((T, T), float("-inf")).triu_(1)
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, D)
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    out = torch.empty(B * T, D, device="cuda")
+    L.check(L.lib().ds_attention_ex(L.ptr(qc), D, L.ptr(kc), D, L.ptr(vc), D, L.ptr(out), D, B, H, T, T, 0.125, 1, 0,
+                                    L.stream()))
+    assert (out.cpu().view_as(ref) - ref).abs().max() < 2e-5
+
+
+def test_f16_row_kernels():
+    from text_to_sound_synthesis_amd import _lib as L
+    r16 = lambda t: t.half().float()
+    M, D = 154, 512
+    x = r16(synth.synth_uniform((M, D), key="f16.x") * 6 - 3)
+    g, b = synth.synth_uniform((D,), key="f16.g") + 0.5, synth.synth_uniform((D,), key="f16.b") - 0.5
+    xc, gc, bc = x.cuda(), g.cuda(), b.cuda()
+    y = torch.empty(M, D, device="cuda")
+    L.check(L.lib().ds_layernorm_f16(L.ptr(xc), L.ptr(y), M, D, L.ptr(gc), L.ptr(bc), L.stream()))
+    ref = r16(F.layer_norm(x, (D,), g, b, 1e-5))
+    d = (y.cpu() - ref).abs()
+    assert (d > 0).float().mean() < 0.01 and d.max() < 4e-3          # at most a 1-ulp fp16 flip here and there
+    L.check(L.lib().ds_l2norm_rows_f16(L.ptr(xc), L.ptr(y), M, D, L.stream()))
+    ref = r16(x / r16(x.norm(dim=-1, keepdim=True)))
+    assert (y.cpu() - ref).abs().max() < 1e-3
+    # Linear -> QuickGELU epilogue with fp16 rounding after every op
+    N = 256
+    w, bias = r16(synth.synth_uniform((N, D), key="f16.w") * 0.1 - 0.05), r16(synth.synth_uniform((N,), key="f16.bb"))
+    out = torch.empty(M, N, device="cuda")
+    L.gemm(xc, w.cuda(), out, M, N, D, bias=bias.cuda(), act=L.ACT_GELU2, f16_round=1)
+    lin = r16((x.double() @ w.double().t() + bias.double()).float())
+    ref = r16(lin * r16(torch.sigmoid(r16(1.702 * lin))))
+    d = (out.cpu() - ref).abs()
+    # three chained fp16 roundings (1.702x, sigmoid, product): a few ulps (1 ulp = 1e-3 relative) at worst
+    assert (d > 0).float().mean() < 0.02 and (d / ref.abs().clamp(min=1e-2)).max() < 5e-3
+
+
+def test_generate_content_from_tokens_end_to_end(model):
+    """Tokens -> CLIP -> 100-step... shortened: the 1-layer model still exercises the whole wiring."""
+    g = golden("text_stage")
+    torch.manual_seed(1234)
+    out = model.generate_content(batch={"condition_token": g["tokens"][:2]}, filter_ratio=0, replicate=2,
+                                 content_ratio=1, sample_type="top0.85r")
+    assert out["content"].shape == (4, 1, 80, 848) and torch.isfinite(out["content"]).all()
+    assert int(out["content_token"].max()) <= 255

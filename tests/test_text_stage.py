@@ -1,0 +1,62 @@
+"""Scope row 8f-1 on CPU: the BPE tokenizer against token ids produced by the reference's tokenizer, and the
+oracle's CLIP text tower against the reference's CLIPTextEmbedding output (both committed as goldens)."""
+import json
+import os
+
+import pytest
+import torch
+
+import diffsound_oracle as O
+from conftest import GOLDEN, golden
+
+torch.set_grad_enabled(False)
+_REF_BPE = "/root/reference/Diffsound/sound_synthesis/modeling/modules/clip/bpe_simple_vocab_16e6.txt.gz"
+
+
+def _bpe_path():
+    p = os.environ.get("DIFFSOUND_BPE_PATH") or _REF_BPE
+    return p if os.path.exists(p) else None
+
+
+def clip_sd():
+    from text_to_sound_synthesis_amd.synth import synth_state_dict
+    with open(os.path.join(GOLDEN, "state_dict_keys_clip.json")) as f:
+        return synth_state_dict(json.load(f))
+
+
+@pytest.mark.skipif(_bpe_path() is None, reason="CLIP BPE merge table not available on this box")
+def test_tokenizer_matches_reference_ids():
+    from text_to_sound_synthesis_amd.tokenizer import Tokenize
+    caps = json.load(open(os.path.join(GOLDEN, "captions.json")))
+    g = golden("text_stage")
+    t = Tokenize(context_length=77, add_start_and_end=True, with_mask=True, pad_value=0,
+                 tokenizer_config={"params": {"end_idx": 49152}}, bpe_path=_bpe_path())
+    out = t.get_tokens(caps)
+    assert torch.equal(out["token"], g["tokens"])
+    assert torch.equal(out["mask"], g["mask"])
+    assert out["token"][-1, 0] == 49406 and out["token"][-1, -1] == 49407      # truncated caption keeps EOT
+    assert (out["token"][0] == 49407).sum() == 1
+
+
+def test_tokenizer_fails_loudly_without_vocab(monkeypatch, tmp_path):
+    from text_to_sound_synthesis_amd import tokenizer as T
+    monkeypatch.delenv("DIFFSOUND_BPE_PATH", raising=False)
+    with pytest.raises(FileNotFoundError):
+        T.Tokenize(context_length=77, bpe_path=str(tmp_path / "missing.gz")).get_tokens(["a dog"])
+
+
+def test_oracle_clip_text_vs_reference():
+    g = golden("text_stage")
+    out = O.clip_text_embed(clip_sd(), g["tokens"][:2])
+    ref = g["cond_emb"]
+    assert out.shape == ref.shape == (2, 77, 512)
+    assert (out.norm(dim=-1) - 1).abs().max() < 2e-3
+    assert (out - ref).abs().max() < 1e-3      # same fp16 algorithm, same box: only op-fusion noise
+
+
+def test_clip_state_dict_contract():
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    m = build_model(default_config(n_layer=1, with_clip=True))
+    want = json.load(open(os.path.join(GOLDEN, "state_dict_keys_clip.json")))
+    sd = {k: list(v.shape) for k, v in m.state_dict().items() if ".condition_emb." in k}
+    assert sd == want

@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
                 ("loader", _i32), ("pro", _i32), ("act", _i32), ("store", _i32),
                 ("pro_scale", _vp), ("pro_shift", _vp),
                 ("rows_per_sample", _i32), ("Cin", _i32), ("H", _i32), ("Wd", _i32), ("up", _i32),
-                ("taps", _i32), ("dil", _i32), ("ct_r", _i32), ("ct_p", _i32), ("ct_tin", _i32)]
+                ("taps", _i32), ("dil", _i32), ("ct_r", _i32), ("ct_p", _i32), ("ct_tin", _i32),
+                ("f16_round", _i32)]
 
 
 class DenoiserDesc(C.Structure):
@@ -50,6 +51,11 @@ _PROTOS = {
     "ds_layernorm": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ds_attention": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_attention_ex": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_int, _vp]),
+    "ds_embed_f16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_layernorm_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "ds_l2norm_rows_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "ds_sample_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -120,7 +126,7 @@ def stream():
 def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=None, ldr=None,
          groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
          act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
-         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0):
+         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0):
     d = GemmDesc()
     d.A, d.W, d.bias, d.R, d.C = ptr(A), ptr(W), ptr(bias), ptr(R), ptr(C_out)
     d.M, d.N, d.K = M, N, K
@@ -133,5 +139,6 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
     d.pro_scale, d.pro_shift = ptr(pro_scale), ptr(pro_shift)
     d.rows_per_sample, d.Cin, d.H, d.Wd, d.up = rows_per_sample, Cin, H, Wd, up
     d.taps, d.dil, d.ct_r, d.ct_p, d.ct_tin = taps, dil, ct_r, ct_p, ct_tin
+    d.f16_round = f16_round
     check(lib().ds_gemm(C.byref(d), stream()))
     return C_out

@@ -14,11 +14,11 @@ _ALIASES = {
     "sound_synthesis.modeling.codecs.spec_codec.vqgan.VQModel": _PKG + ".modeling.vqgan",
     "specvqgan.modules.transformer.permuter.ColumnMajor": _PKG + ".modeling.vqgan",
     "vocoder.modules.Generator": _PKG + ".modeling.vocoder",
+    "sound_synthesis.modeling.codecs.text_codec.tokenize.Tokenize": _PKG + ".tokenizer",
+    "sound_synthesis.modeling.embeddings.clip_text_embedding.CLIPTextEmbedding": _PKG + ".modeling.clip_text",
 }
 # parts of the reference config that are not on this path: built as None
 _DEFERRED = (
-    "sound_synthesis.modeling.codecs.text_codec.tokenize.Tokenize",
-    "sound_synthesis.modeling.embeddings.clip_text_embedding.CLIPTextEmbedding",
     "specvqgan.modules.losses.DummyLoss",
 )
 
@@ -47,10 +47,26 @@ def build_model(config, args=None):
     return instantiate_from_config(config["model"])
 
 
-def default_config(n_layer=19, diffusion_step=100, n_embed=256):
+def default_config(n_layer=19, diffusion_step=100, n_embed=256, with_clip=False):
     """The shapes of Diffsound/evaluation/caps_text.yaml (values cited in SURVEY.md section 8),
-    expressed with this package's own class paths."""
+    expressed with this package's own class paths.  with_clip attaches the text stage (BPE tokenizer +
+    CLIP ViT-B/32 text tower, caps_text.yaml:30-41,67-76); without it the caption conditioning is
+    passed in as `condition_embed_token`."""
     m = _PKG + ".modeling."
+    cfg = _default_config(m, n_layer, diffusion_step, n_embed)
+    if with_clip:
+        p = cfg["model"]["params"]
+        p["condition_codec_config"] = {"target": _PKG + ".tokenizer.Tokenize", "params": {
+            "context_length": 77, "add_start_and_end": True, "with_mask": True, "pad_value": 0,
+            "clip_embedding": False, "tokenizer_config": {"params": {"end_idx": 49152}}}}
+        p["diffusion_config"]["params"]["condition_emb_config"] = {
+            "target": m + "clip_text.CLIPTextEmbedding", "params": {
+                "clip_name": "ViT-B/32", "num_embed": 49408, "normalize": True, "pick_last_embedding": False,
+                "keep_seq_len_dim": False, "additional_last_embedding": False, "embed_dim": 512}}
+    return cfg
+
+
+def _default_config(m, n_layer, diffusion_step, n_embed):
     return {"model": {"target": m + "dalle.DALLE", "params": {
         "content_info": {"key": "image"},
         "condition_info": {"key": "text"},

@@ -27,7 +27,7 @@ static void fill(GemmParams& p, const ds_gemm_desc* d) {
     p.lda = d->lda; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.ldc = d->ldc; p.ldr = d->ldr;
     p.groups = d->groups > 0 ? d->groups : 1;
     p.a_gstride = d->a_gstride; p.w_gstride = d->w_gstride; p.c_gstride = d->c_gstride;
-    p.pro = d->pro; p.act = d->act; p.store = d->store;
+    p.pro = d->pro; p.act = d->act; p.store = d->store; p.f16_round = d->f16_round;
     p.pro_scale = d->pro_scale; p.pro_shift = d->pro_shift;
     p.rows_per_sample = d->rows_per_sample;
     p.Cin = d->Cin; p.H = d->H; p.W_ = d->Wd; p.up = d->up; p.taps = d->taps; p.dil = d->dil;

@@ -17,12 +17,15 @@
 #define ATT_LD 68
 #define ATT_WAVES 3
 
+// launch bound "2 waves per SIMD": keeps the 144 score accumulators + Q in <= 256 unified registers
+// (218 VGPR, 0 AGPR, no spill) so that two workgroups (2 x 78 KB LDS) co-reside per CU and one
+// group's K/V staging and softmax overlap the other's MFMA passes.
 template <int NKT>
-__global__ __launch_bounds__(ATT_WAVES * 64) void ds_attn_kernel(const float* __restrict__ Q, int ldq,
+__global__ __launch_bounds__(ATT_WAVES * 64, 2) void ds_attn_kernel(const float* __restrict__ Q, int ldq,
                                                                  const float* __restrict__ Kp, int ldk,
                                                                  const float* __restrict__ Vp, int ldv,
                                                                  float* __restrict__ O, int ldo, int Lq, int Lk,
-                                                                 int heads, float scale) {
+                                                                 int heads, float scale, int causal, int f16) {
     extern __shared__ __attribute__((aligned(16))) float kv[];  // [NKT*32][ATT_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -89,7 +92,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void ds_attn_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float v = key < Lk ? s[kt][r] * scale : -INFINITY;
+                // causal: query q attends keys <= q (CLIP's build_attention_mask, clip/model.py:313-319)
+                const bool ok = key < Lk && (!causal || key <= q0 + l31);
+                float v = s[kt][r] * scale;
+                if (f16) v = ds_r16(v);
+                v = ok ? v : -INFINITY;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -108,7 +115,10 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void ds_attn_kernel(const float* __
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+            for (int r = 0; r < 16; ++r) {
+                s[kt][r] *= inv;
+                if (f16) s[kt][r] = ds_r16(s[kt][r]);
+            }
     }
     __syncthreads();  // V is in LDS
 
@@ -131,16 +141,17 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void ds_attn_kernel(const float* __
             const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (qr < Lq) {
                 float* op = O + ((size_t)b * Lq + qr) * ldo + head * 64 + l31;
-                op[0] = o0[r];
-                op[32] = o1[r];
+                op[0] = f16 ? ds_r16(o0[r]) : o0[r];
+                op[32] = f16 ? ds_r16(o1[r]) : o1[r];
             }
         }
     }
 }
 
 // Q: [B*Lq][ldq] (head h at columns h*64..), K/V: [B*Lk][ldk/ldv], O: [B*Lq][ldo]
-extern "C" int ds_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
-                            int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
+extern "C" int ds_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                               int ldo, int B, int heads, int Lq, int Lk, float scale, int causal, int f16_round,
+                               ds_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(q && k && v && o, "null pointer");
     DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "bad shape");
@@ -156,7 +167,7 @@ extern "C" int ds_attention(const float* q, int ldq, const float* k, int ldk, co
             attr3 = true;
         }
         hipLaunchKernelGGL((ds_attn_kernel<3>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
-                           heads, scale);
+                           heads, scale, causal, f16_round);
     } else {
         DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
         const size_t lds = 9 * 32 * ATT_LD * sizeof(float);
@@ -170,8 +181,13 @@ extern "C" int ds_attention(const float* q, int ldq, const float* k, int ldk, co
             attr9 = true;
         }
         hipLaunchKernelGGL((ds_attn_kernel<9>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
-                           heads, scale);
+                           heads, scale, causal, f16_round);
     }
     DS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ds_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                            int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream) {
+    return ds_attention_ex(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Lq, Lk, scale, 0, 0, stream);
 }

@@ -9,6 +9,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DS_WAVE 64
 
+// round-trip through IEEE half (RNE): emulates the reference's fp16 CLIP activations
+// (sound_synthesis/modeling/modules/clip/model.py:432 convert_weights) on fp32 storage
+__device__ __forceinline__ float ds_r16(float x) { return (float)(_Float16)x; }
+
 // ---- error plumbing (C ABI returns int; message kept per thread) -------------------------
 void ds_set_error(const char* fmt, ...);
 #define DS_CHECK_ARG(cond, msg)                                   \
@@ -43,6 +47,7 @@ struct GemmParams {
     int groups;                 // blockIdx.y; A/W/C advance by the strides below
     long long a_gstride, w_gstride, c_gstride;
     int pro, act, store;
+    int f16_round;              // 1: outputs (and GELU2 intermediates) are rounded to the fp16 grid
     // prologue: per-(sample, channel) affine  a' = a*pro_scale[b*Cin+c] + pro_shift[b*Cin+c]
     const float* pro_scale;
     const float* pro_shift;

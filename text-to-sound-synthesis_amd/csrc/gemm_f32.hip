@@ -238,7 +238,13 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bv;
-                if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));
+                if (p.f16_round) {  // fp16 Linear -> QuickGELU chain, each op rounded like the reference
+                    v = ds_r16(v);
+                    if (p.act == DS_ACT_GELU2) {
+                        const float sg = ds_r16(1.f / (1.f + expf(-ds_r16(1.702f * v))));
+                        v = ds_r16(v * sg);
+                    }
+                } else if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));
                 else if (p.act == DS_ACT_TANH) v = tanhf(v);
                 size_t off;
                 if (p.store == DS_STORE_ROW) {
@@ -251,7 +257,10 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
                     const int t = qq * p.ct_r + g - p.ct_p;
                     off = ((size_t)b * p.ct_tin * p.ct_r + t) * p.ldc + col;
                 }
-                if (Rg) v += Rg[(size_t)row * p.ldr + col];
+                if (Rg) {
+                    v += Rg[(size_t)row * p.ldr + col];
+                    if (p.f16_round) v = ds_r16(v);
+                }
                 Cg[off] = v;
             }
         }

@@ -23,7 +23,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __global__ __launch_bounds__(256) void ds_embed_kernel(const int64_t* __restrict__ tok,
                                                        const float* __restrict__ emb,
                                                        const float* __restrict__ pos,
-                                                       float* __restrict__ out, int M, int L, int D) {
+                                                       float* __restrict__ out, int M, int L, int D, int f16) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int lane = threadIdx.x & 63;
@@ -34,7 +34,12 @@ __global__ __launch_bounds__(256) void ds_embed_kernel(const int64_t* __restrict
     float* o = out + (size_t)row * D;
     for (int c = lane * 4; c < D; c += 256) {
         const f32x4 a = *(const f32x4*)(e + c), b = *(const f32x4*)(p + c);
-        *(f32x4*)(o + c) = a + b;
+        f32x4 r = a + b;
+        if (f16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = ds_r16(ds_r16(a[k]) + ds_r16(b[k]));
+        }
+        *(f32x4*)(o + c) = r;
     }
 }
 
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void ds_layernorm_kernel(const float* __restri
                                                            const float* __restrict__ tab,  // [T][2D]
                                                            const int64_t* __restrict__ t,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps) {
+                                                           const float* __restrict__ beta, float eps, int f16) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int lane = threadIdx.x & 63;
@@ -89,6 +94,7 @@ __global__ __launch_bounds__(256) void ds_layernorm_kernel(const float* __restri
         for (int k = 0; k < 4; ++k) {
             const float xn = (v[j][k] - mean) * rstd;
             o[k] = mode == 0 ? xn * (1.f + a[k]) + b[k] : xn * a[k] + b[k];
+            if (f16) o[k] = ds_r16(o[k]);
         }
         *(f32x4*)(yr + c) = o;
     }
@@ -162,7 +168,7 @@ extern "C" int ds_embed(const int64_t* tokens, const float* emb, const float* po
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(tokens && emb && pos && out, "null pointer");
     DS_CHECK_ARG(M > 0 && L > 0 && D % 4 == 0, "bad shape");
-    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D);
+    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D, 0);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -173,7 +179,7 @@ extern "C" int ds_adaln(const float* x, float* y, int M, int L, int D, const flo
     DS_CHECK_ARG(x && y && table && t, "null pointer");
     DS_CHECK_ARG(D == 1024, "only D = 1024 is built");
     hipLaunchKernelGGL((ds_layernorm_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, stream, x, y, M, L, 0, table,
-                       t, (const float*)nullptr, (const float*)nullptr, 1e-5f);
+                       t, (const float*)nullptr, (const float*)nullptr, 1e-5f, 0);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -184,7 +190,7 @@ extern "C" int ds_layernorm(const float* x, float* y, int M, int D, const float*
     DS_CHECK_ARG(x && y && gamma && beta, "null pointer");
     DS_CHECK_ARG(D == 1024, "only D = 1024 is built");
     hipLaunchKernelGGL((ds_layernorm_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, stream, x, y, M, 1, 1,
-                       (const float*)nullptr, (const int64_t*)nullptr, gamma, beta, 1e-5f);
+                       (const float*)nullptr, (const int64_t*)nullptr, gamma, beta, 1e-5f, 0);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -201,6 +207,58 @@ extern "C" int ds_groupnorm_stats(const float* x, int B, int P, int C, int group
     DS_CHECK_LAUNCH();
     hipLaunchKernelGGL(ds_gn_finish_kernel, dim3(B), dim3(256), 0, stream, work, nchunk, P, C, groups, gamma, beta,
                        eps, scale, shift);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- fp16-semantics variants for the CLIP text tower (clip/model.py:150-198, 341-354) -------------------
+// The reference runs CLIP with fp16 weights and activations; here storage stays fp32 and every op's
+// output is rounded to the fp16 grid, which reproduces those semantics up to accumulation order.
+extern "C" int ds_embed_f16(const int64_t* tokens, const float* emb, const float* pos, float* out, int M, int L,
+                            int D, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(tokens && emb && pos && out, "null pointer");
+    DS_CHECK_ARG(M > 0 && L > 0 && D % 4 == 0, "bad shape");
+    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D, 1);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// LayerNorm computed in fp32 on fp16-grid input, output rounded to fp16 (clip/model.py:150-157)
+extern "C" int ds_layernorm_f16(const float* x, float* y, int M, int D, const float* gamma, const float* beta,
+                                ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x && y && gamma && beta, "null pointer");
+    DS_CHECK_ARG(D == 512 || D == 1024, "D must be 512 or 1024");
+    if (D == 512)
+        hipLaunchKernelGGL((ds_layernorm_kernel<512>), dim3((M + 3) / 4), dim3(256), 0, stream, x, y, M, 1, 1,
+                           (const float*)nullptr, (const int64_t*)nullptr, gamma, beta, 1e-5f, 1);
+    else
+        hipLaunchKernelGGL((ds_layernorm_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, stream, x, y, M, 1, 1,
+                           (const float*)nullptr, (const int64_t*)nullptr, gamma, beta, 1e-5f, 1);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// y = x / ||x||_2 per row with the norm and the quotient rounded to fp16
+// (clip_text_embedding.py:79-80 on an fp16 tensor)
+__global__ __launch_bounds__(256) void ds_l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int M,
+                                                             int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
+    const float n = ds_r16(sqrtf(wave_sum(s)));
+    float* yr = y + (size_t)row * D;
+    for (int c = lane; c < D; c += 64) yr[c] = ds_r16(xr[c] / n);
+}
+
+extern "C" int ds_l2norm_rows_f16(const float* x, float* y, int M, int D, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x && y && M > 0 && D > 0, "bad arguments");
+    hipLaunchKernelGGL(ds_l2norm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, y, M, D);
     DS_CHECK_LAUNCH();
     return 0;
 }

@@ -45,9 +45,12 @@ class DALLE(nn.Module):
         if torch.is_tensor(src):
             src = {"condition_embed_token": src}
         emb = src.get("condition_embed_token", src.get("embed_token"))
+        tok = src.get("condition_token", src.get("token"))
         if emb is not None:
             cond["condition_embed_token"] = emb.to(self.device)
             cond["condition_token"] = None
+        elif tok is not None:      # already tokenised captions i64[B, 77]
+            cond["condition_token"] = tok.to(self.device)
         elif self.condition_codec is not None:
             for k, v in self.condition_codec.get_tokens(src[self.condition_info["key"]]).items():
                 cond["condition_" + k] = v.to(self.device) if torch.is_tensor(v) else v

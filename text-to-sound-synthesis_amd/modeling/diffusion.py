@@ -161,11 +161,11 @@ class DiffusionTransformer(nn.Module):
 
         noise_fn(step, shape) may supply the uniforms (tests inject the oracle's noise)."""
         device = self.device
-        if self.condition_emb is not None:
-            cond_emb = self.condition_emb(condition_token).float()
+        if self.condition_emb is not None and condition_token is not None:
+            cond_emb = self.condition_emb(condition_token).float()     # CLIP text tower (:619-621)
         else:
             if condition_embed is None:
-                raise ValueError("no condition_emb module is attached: pass condition_embed [B, 77, 512]")
+                raise ValueError("pass condition_token (with a condition_emb module) or condition_embed [B,77,512]")
             cond_emb = condition_embed.float()
         if int(self.num_timesteps * filter_ratio) != 0:
             raise NotImplementedError("filter_ratio > 0 needs the VQ encoder path (SURVEY.md section 8f-2)")

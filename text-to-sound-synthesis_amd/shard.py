@@ -19,18 +19,19 @@ def shard_bounds(n_items, world_size, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def scatter_conditions(cond_all, n_items, feat_shape, device, group=None):
-    """rank 0 holds cond_all [n_items, *feat_shape]; every rank receives its slice."""
+def scatter_conditions(cond_all, n_items, feat_shape, device, group=None, dtype=torch.float32):
+    """rank 0 holds cond_all [n_items, *feat_shape] (caption token ids i64[.,77] or embeddings
+    f32[.,77,512]); every rank receives its slice."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return cond_all.to(device)
+        return cond_all.to(device=device, dtype=dtype)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(n_items, world, rank)
-    mine = torch.empty((hi - lo,) + tuple(feat_shape), device=device, dtype=torch.float32)
+    mine = torch.empty((hi - lo,) + tuple(feat_shape), device=device, dtype=dtype)
     if rank == 0:
         parts = []
         for r in range(world):
             a, b = shard_bounds(n_items, world, r)
-            parts.append(cond_all[a:b].to(device=device, dtype=torch.float32).contiguous())
+            parts.append(cond_all[a:b].to(device=device, dtype=dtype).contiguous())
         if all(p.shape == parts[0].shape for p in parts):
             dist.scatter(mine, parts, src=0, group=group)
         else:  # ragged shards: point-to-point

@@ -115,3 +115,17 @@ def synth_captions(n, seed=7):
     import random
     r = random.Random(seed)
     return [" ".join(r.choice(_WORDS) for _ in range(r.randint(5, 15))) for _ in range(n)]
+
+
+def synth_caption_tokens(n, context_length=77, seed=7, key="caption_tokens"):
+    """Stand-in for tokenised captions when the BPE merge table is not on the box: <SOT>, 6-20 random
+    word-piece ids, <EOT>, zero padding (same structure as clip.tokenize output)."""
+    g = _gen(seed, key)
+    out = torch.zeros(n, context_length, dtype=torch.long)
+    lens = torch.randint(6, 21, (n,), generator=g)
+    for i in range(n):
+        k = int(lens[i])
+        out[i, 0] = 49406
+        out[i, 1:1 + k] = torch.randint(256, 49406, (k,), generator=g)
+        out[i, 1 + k] = 49407
+    return out
