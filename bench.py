@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16/fp16 dense MFMA peak (~2.5 PF)
 GFLOP_PER_SAMPLE_STEP = 155.02  # SURVEY.md section 8d, hoisted formulation
 
 
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--n-layer", type=int, default=19)
     ap.add_argument("--codes", type=int, default=256)
+    ap.add_argument("--precision", default=os.environ.get("DIFFSOUND_GEMM", "fp32"), choices=("fp32", "bf16x3", "f16x2"),
+                    help="denoiser GEMM arithmetic: fp32 MFMA, or the fp32-accurate 3-way bf16 split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
@@ -109,6 +112,7 @@ def main():
     voc = synth.synth_init_(Generator(80, 32, 3), seed=0).to(dev).eval()
     dt = model.transformer
     dt.truncation_r = 0.85
+    dt.transformer.precision = args.precision
     n_total = B * world
     # rank 0 owns the captions (token ids i64[n,77]: <SOT> word pieces <EOT>, as clip.tokenize emits); every
     # rank gets a slice and runs the CLIP text tower on it
@@ -158,33 +162,50 @@ def main():
     assert torch.isfinite(w).all() and w.shape[-1] == 217088
 
     roof = None
+    extra = {}
     if rank == 0 and not args.no_roofline:
-        # one profiled batch of a few denoiser steps: HIP events around every GEMM launch
+        # profiled legs of a few denoiser steps: HIP events around every GEMM launch (ds_profile_*)
         L = _lib.lib()
         cond = synth.synth_cond_emb(B, key="bench.cond").to(dev)
-        kv = dt.transformer.condition_kv(cond, dt._schedule_table())
-        x = torch.full((B, 265), args.codes, device=dev, dtype=torch.long)
-        u = torch.rand((B, args.codes + 1, 265), device=dev)
-        torch.cuda.synchronize()
-        L.ds_profile_enable(1)
-        for i in range(3):
-            t = torch.full((B,), T - 1 - i, device=dev, dtype=torch.long)
-            x = dt.p_sample_tokens(x, kv, t, u, initial=(i == 0))
-        L.ds_profile_enable(0)
-        ms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
-        _lib.check(L.ds_profile_collect(ms, fl, n))
-        names = ("ds_gemm_kernel<128,128,0,0>", "ds_gemm_kernel<128,64,0,0>", "ds_gemm_kernel<64,64,0,0>")
-        dom = max(range(3), key=lambda c: ms[c])       # the kernel symbol with the largest total time
-        ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
-        allk = sum(fl) / (sum(ms) * 1e-3) / 1e12
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": names[dom] + " (fp32 MFMA 32x32x2, dense loader)", "launches": int(n[dom]),
-                "avg_launch_us": round(ms[dom] * 1e3 / max(1, n[dom]), 2),
-                "avg_launch_gflop": round(fl[dom] / max(1, n[dom]) / 1e9, 3),
-                "all_gemm_tiles": {names[c]: {"launches": int(n[c]), "avg_launch_us": round(ms[c] * 1e3 / max(1, n[c]), 2),
-                                              "tflops": round(fl[c] / max(ms[c], 1e-9) / 1e9, 2)} for c in range(3)},
-                "all_gemm_tflops": round(allk, 2)}
+        # (kernel-symbol prefix, passes of MFMA work per algorithmic flop, MFMA peak of the operand type)
+        KIND = {"fp32": ("ds_gemm_kernel<%d,%d,0,0>", 1, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA 32x32x2"),
+                "bf16x3": ("ds_gemm_bf16x3_kernel<%d,%d>", 6, PEAK_16BIT_MFMA_TFLOPS, "6-pass bf16 MFMA 32x32x16"),
+                "f16x2": ("ds_gemm_f16x2_kernel<%d,%d>", 3, PEAK_16BIT_MFMA_TFLOPS, "3-pass fp16 MFMA 32x32x16")}
+
+        def leg(precision):
+            dt.transformer.precision = precision
+            kv = dt.transformer.condition_kv(cond, dt._schedule_table())
+            x = torch.full((B, 265), args.codes, device=dev, dtype=torch.long)
+            u = torch.rand((B, args.codes + 1, 265), device=dev)
+            t = torch.full((B,), T - 1, device=dev, dtype=torch.long)
+            x = dt.p_sample_tokens(x, kv, t, u, initial=True)            # warm-up (also builds the pack)
+            torch.cuda.synchronize()
+            L.ds_profile_enable(1)
+            for i in range(3):
+                t = torch.full((B,), T - 2 - i, device=dev, dtype=torch.long)
+                x = dt.p_sample_tokens(x, kv, t, u, initial=False)
+            L.ds_profile_enable(0)
+            ms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+            _lib.check(L.ds_profile_collect(ms, fl, n))
+            fmt, passes, mfma_peak, what = KIND[precision]
+            names = [fmt % bb for bb in ((128, 128), (128, 64), (64, 64))]
+            dom = max(range(3), key=lambda c: ms[c])   # the kernel symbol with the largest total time
+            ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
+            peak = mfma_peak / passes                  # ceiling in algorithmic (2MNK) flops of this formulation
+            return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "kernel": "%s (%s, dense loader)" % (names[dom], what), "launches": int(n[dom]),
+                    "avg_launch_us": round(ms[dom] * 1e3 / max(1, n[dom]), 2),
+                    "avg_launch_gflop": round(fl[dom] / max(1, n[dom]) / 1e9, 3),
+                    "mfma_passes_per_flop": passes, "mfma_peak": mfma_peak,
+                    "all_gemm_tiles": {names[c]: {"launches": int(n[c]),
+                                                  "avg_launch_us": round(ms[c] * 1e3 / max(1, n[c]), 2),
+                                                  "tflops": round(fl[c] / max(ms[c], 1e-9) / 1e9, 2)} for c in range(3)},
+                    "all_gemm_tflops": round(sum(fl) / (sum(ms) * 1e-3) / 1e12, 2)}
+        roof = leg(args.precision)
+        if args.precision != "fp32":                   # the exact-fp32 MFMA kernel on the same shapes, for reference
+            extra["roofline_fp32_mfma_kernel"] = leg("fp32")
+            dt.transformer.precision = args.precision
     if args.stage_times and rank == 0:
         one_step(timed_stages=True)
         print("stage seconds (1 step, B=%d): %s" % (B, {k: round(v, 3) for k, v in stage.items()}), file=sys.stderr)
@@ -196,7 +217,9 @@ def main():
             "metric": "10s clips/sec whole-node, 100-step Diffsound sample + VQ decode + vocoder",
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
+            "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16x3": "f32 via 3-way bf16 split (6 MFMA passes, fp32 accumulate)",
+                      "f16x2": "f32 via 2-way fp16 split (3 MFMA passes, fp32 accumulate)"}[args.precision],
             "data": "synthetic caption token ids i64[B,77] + seeded random-init weights of the reference's shapes",
             "config": {"workload": "BASELINE configs[2]: full pipeline, batch %d per GPU, %d diffusion steps, "
                                    "codebook %d: CLIP text tower -> 19-layer denoiser -> SpecVQGAN decode -> MelGAN "
@@ -206,6 +229,7 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
+            line.update(extra)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.n_layer, args.codes, T)
         print(json.dumps(line))

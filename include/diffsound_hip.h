@@ -53,10 +53,22 @@ typedef struct ds_gemm_desc {
     int32_t taps, dil;       /* conv1d (reflect padding) */
     int32_t ct_r, ct_p, ct_tin; /* convT1d polyphase: stride, padding, input length; groups = r */
     int32_t f16_round;       /* 1: round outputs (and GELU2 intermediates) to the fp16 grid (CLIP text tower) */
+    int64_t w3_plane;        /* split kernels only: W holds 3 bf16 / 2 fp16 planes [N][ldw], w3_plane elements apart */
+    float out_scale;         /* ds_gemm_f16x2 only: 2^-s undoing the exact power-of-two pre-scale of W */
 } ds_gemm_desc;
 
 int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream);
 void ds_gemm_force_tile(int cfg); /* test hook: 0..2 pins the block tile, -1 = auto */
+/* The same dense contraction (DS_LOAD_DENSE, DS_PRO_NONE) on the bf16 matrix cores with fp32-class accuracy:
+ * W is pre-split into three bf16 planes (w = w0 + w1 + w2 exactly), A (fp32) is split on the fly, six bf16
+ * MFMA passes per k-step accumulate a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 in fp32 (gemm_bf16x3.hip). */
+int ds_gemm_bf16x3(const ds_gemm_desc* d, ds_stream_t stream);
+void ds_gemm_bf16x3_force_tile(int cfg);
+/* Cheaper variant: W*2^s and A are split into two fp16 planes each (22 significant bits), three fp16 MFMA passes
+ * a0b0 + a0b1 + a1b0 per k-step, epilogue multiplies by out_scale = 2^-s.  |A| must stay below 65504
+ * (gemm_f16x2.hip). */
+int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
+void ds_gemm_f16x2_force_tile(int cfg);
 
 /* ---- row kernels of the denoiser -------------------------------------------------------------- */
 /* DalleMaskImageEmbedding.forward, sound_synthesis/modeling/embeddings/dalle_mask_image_embedding.py:36-58
@@ -125,6 +137,13 @@ int ds_denoiser_create(const ds_denoiser_desc* desc, const void* const* layer_pt
 void ds_denoiser_destroy(ds_denoiser* h);
 int64_t ds_denoiser_workspace_bytes(const ds_denoiser* h, int B);
 int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B);
+/* Switch the denoiser's per-step GEMMs to a split kernel.  mode 1 = bf16x3, 2 = f16x2, 0 = back to fp32 MFMA.
+ * split[layer*DS_LP_COUNT + slot] holds the plane-split of that slot's weight for the DS_LP_W_* slots QKV,
+ * PROJ1, Q2, PROJ2, FC1, FC2 (other slots NULL), out_scales[same index] the 2^-s of mode 2 (ignored in mode 1);
+ * w_logits_split / logits_scale likewise for to_logits.1. */
+enum { DS_SPLIT_NONE = 0, DS_SPLIT_BF16X3 = 1, DS_SPLIT_F16X2 = 2 };
+int ds_denoiser_set_split_weights(ds_denoiser* h, int mode, const void* const* split, const float* out_scales,
+                                  const void* w_logits_split, float logits_scale);
 /* cross-attention K/V depend only on the caption: computed once per batch (CrossAttention.key/value,
  * transformer_utils.py:96,98).  cond [B][Lc][Dc] -> kv [n_layer][B*Lc][2D] */
 int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int B, float* kv, ds_stream_t stream);

@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
                 ("pro_scale", _vp), ("pro_shift", _vp),
                 ("rows_per_sample", _i32), ("Cin", _i32), ("H", _i32), ("Wd", _i32), ("up", _i32),
                 ("taps", _i32), ("dil", _i32), ("ct_r", _i32), ("ct_p", _i32), ("ct_tin", _i32),
-                ("f16_round", _i32)]
+                ("f16_round", _i32), ("w3_plane", _i64), ("out_scale", _f)]
 
 
 class DenoiserDesc(C.Structure):
@@ -46,6 +46,11 @@ _PROTOS = {
     "ds_last_error_string": (C.c_char_p, []),
     "ds_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_gemm_force_tile": (None, [C.c_int]),
+    "ds_gemm_bf16x3": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "ds_gemm_bf16x3_force_tile": (None, [C.c_int]),
+    "ds_gemm_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "ds_gemm_f16x2_force_tile": (None, [C.c_int]),
+    "ds_denoiser_set_split_weights": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_f), _vp, _f]),
     "ds_embed": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_adaln": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ds_layernorm": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -126,7 +131,9 @@ def stream():
 def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=None, ldr=None,
          groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
          act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
-         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0):
+         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split3=False, split2=None):
+    """split3: W is the [3][N][K] bf16 split from split_bf16x3() and the bf16x3 kernel is used.
+    split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used."""
     d = GemmDesc()
     d.A, d.W, d.bias, d.R, d.C = ptr(A), ptr(W), ptr(bias), ptr(R), ptr(C_out)
     d.M, d.N, d.K = M, N, K
@@ -140,5 +147,37 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
     d.rows_per_sample, d.Cin, d.H, d.Wd, d.up = rows_per_sample, Cin, H, Wd, up
     d.taps, d.dil, d.ct_r, d.ct_p, d.ct_tin = taps, dil, ct_r, ct_p, ct_tin
     d.f16_round = f16_round
-    check(lib().ds_gemm(C.byref(d), stream()))
+    if split3:
+        d.w3_plane = N * d.ldw
+        check(lib().ds_gemm_bf16x3(C.byref(d), stream()))
+    elif split2 is not None:
+        d.w3_plane = N * d.ldw
+        d.out_scale = split2
+        check(lib().ds_gemm_f16x2(C.byref(d), stream()))
+    else:
+        check(lib().ds_gemm(C.byref(d), stream()))
     return C_out
+
+
+def split_bf16x3(w):
+    """fp32 [N][K] -> int16 view of [3][N][K] bf16 planes with w == p0 + p1 + p2 (one-time weight prep;
+    torch's fp32->bf16 cast rounds to nearest even, the residual subtractions are exact)."""
+    w = w.detach().float()
+    p0 = w.to(torch.bfloat16)
+    r1 = w - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    return torch.stack((p0, p1, p2)).contiguous().view(torch.int16)
+
+
+def split_f16x2(w):
+    """fp32 [N][K] -> (int16 view of [2][N][K] fp16 planes of W * 2^s, out_scale = 2^-s).  s puts max|W| * 2^s in
+    [2^13, 2^14): both planes stay in fp16's normal range for every weight that matters, nothing overflows."""
+    import math
+    w = w.detach().float()
+    mx = float(w.abs().max())
+    s = 0 if mx == 0.0 else 13 - math.floor(math.log2(mx))
+    ws = w * (2.0 ** s)
+    p0 = ws.to(torch.float16)
+    p1 = (ws - p0.float()).to(torch.float16)
+    return torch.stack((p0, p1)).contiguous().view(torch.int16), 2.0 ** (-s)

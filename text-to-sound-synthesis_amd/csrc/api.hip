@@ -28,6 +28,8 @@ static void fill(GemmParams& p, const ds_gemm_desc* d) {
     p.groups = d->groups > 0 ? d->groups : 1;
     p.a_gstride = d->a_gstride; p.w_gstride = d->w_gstride; p.c_gstride = d->c_gstride;
     p.pro = d->pro; p.act = d->act; p.store = d->store; p.f16_round = d->f16_round;
+    p.w3_plane = d->w3_plane;
+    p.out_scale = d->out_scale;
     p.pro_scale = d->pro_scale; p.pro_shift = d->pro_shift;
     p.rows_per_sample = d->rows_per_sample;
     p.Cin = d->Cin; p.H = d->H; p.W_ = d->Wd; p.up = d->up; p.taps = d->taps; p.dil = d->dil;
@@ -46,12 +48,70 @@ extern "C" int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream) {
     return ds_launch_gemm(p, (hipStream_t)stream, d->loader);
 }
 
+extern "C" int ds_gemm_bf16x3(const ds_gemm_desc* d, ds_stream_t stream) {
+    DS_CHECK_ARG(d && d->A && d->W && d->C, "null pointer");
+    DS_CHECK_ARG(d->loader == DS_LOAD_DENSE && d->pro == DS_PRO_NONE && d->groups <= 1 && !d->f16_round,
+                 "bf16x3 is the dense, no-prologue, ungrouped kernel");
+    DS_CHECK_ARG(d->w3_plane > 0, "w3_plane (plane stride of the split weights) is required");
+    DS_CHECK_ARG(d->store != DS_STORE_BATCH_T || d->rows_per_sample > 0, "BATCH_T store needs rows_per_sample");
+    DS_CHECK_ARG(d->R == nullptr || d->store == DS_STORE_ROW, "residual only with row-major store");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    fill(p, d);
+    return ds_launch_gemm_bf16x3(p, (hipStream_t)stream);
+}
+
+extern "C" int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
+    DS_CHECK_ARG(d && d->A && d->W && d->C, "null pointer");
+    DS_CHECK_ARG(d->loader == DS_LOAD_DENSE && d->pro == DS_PRO_NONE && d->groups <= 1 && !d->f16_round,
+                 "f16x2 is the dense, no-prologue, ungrouped kernel");
+    DS_CHECK_ARG(d->w3_plane > 0, "w3_plane (plane stride of the split weights) is required");
+    DS_CHECK_ARG(d->store != DS_STORE_BATCH_T || d->rows_per_sample > 0, "BATCH_T store needs rows_per_sample");
+    DS_CHECK_ARG(d->R == nullptr || d->store == DS_STORE_ROW, "residual only with row-major store");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    fill(p, d);
+    return ds_launch_gemm_f16x2(p, (hipStream_t)stream);
+}
+
 // ---- denoiser ---------------------------------------------------------------------------------------
 struct ds_denoiser {
     ds_denoiser_desc d;
     std::vector<const float*> lp;  // [n_layer][DS_LP_COUNT]
+    std::vector<const void*> lp3;  // split weights (same indexing), empty = fp32-MFMA mode
+    std::vector<float> osc;        // f16x2: 2^-s per weight
+    const void* w_logits3 = nullptr;
+    float logits_osc = 1.f;
+    int split_mode = DS_SPLIT_NONE;
+    float S3(int layer, int slot) const { return osc.empty() ? 1.f : osc[(size_t)layer * DS_LP_COUNT + slot]; }
     const float* P(int layer, int slot) const { return lp[(size_t)layer * DS_LP_COUNT + slot]; }
+    const void* P3(int layer, int slot) const { return lp3.empty() ? nullptr : lp3[(size_t)layer * DS_LP_COUNT + slot]; }
 };
+
+extern "C" int ds_denoiser_set_split_weights(ds_denoiser* h, int mode, const void* const* split3,
+                                             const float* out_scales, const void* w_logits3, float logits_scale) {
+    DS_CHECK_ARG(h, "null handle");
+    if (mode == DS_SPLIT_NONE || !split3) {
+        h->lp3.clear();
+        h->osc.clear();
+        h->w_logits3 = nullptr;
+        h->split_mode = DS_SPLIT_NONE;
+        return 0;
+    }
+    DS_CHECK_ARG(mode == DS_SPLIT_BF16X3 || mode == DS_SPLIT_F16X2, "unknown split mode");
+    DS_CHECK_ARG(mode != DS_SPLIT_F16X2 || (out_scales && logits_scale > 0.f), "f16x2 needs the output scales");
+    static const int need[6] = {DS_LP_W_QKV, DS_LP_W_PROJ1, DS_LP_W_Q2, DS_LP_W_PROJ2, DS_LP_W_FC1, DS_LP_W_FC2};
+    for (int l = 0; l < h->d.n_layer; ++l)
+        for (int s : need) DS_CHECK_ARG(split3[(size_t)l * DS_LP_COUNT + s], "missing split weight");
+    DS_CHECK_ARG(w_logits3, "missing split logits weight");
+    h->lp3.assign(split3, split3 + (size_t)h->d.n_layer * DS_LP_COUNT);
+    if (mode == DS_SPLIT_F16X2) h->osc.assign(out_scales, out_scales + (size_t)h->d.n_layer * DS_LP_COUNT);
+    else h->osc.clear();
+    h->w_logits3 = w_logits3;
+    h->logits_osc = mode == DS_SPLIT_F16X2 ? logits_scale : 1.f;
+    h->split_mode = mode;
+    return 0;
+}
 
 extern "C" int ds_denoiser_create(const ds_denoiser_desc* desc, const void* const* layer_ptrs, ds_denoiser** out) {
     DS_CHECK_ARG(desc && layer_ptrs && out, "null pointer");
@@ -130,13 +190,23 @@ extern "C" int ds_profile_collect(double* ms, double* flops, int64_t* launches) 
 }
 
 static int dense(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc,
-                 int M, int N, int K, int act, hipStream_t s, int store = DS_STORE_ROW, int rps = 0) {
+                 int M, int N, int K, int act, hipStream_t s, int store = DS_STORE_ROW, int rps = 0,
+                 const void* W3 = nullptr, int split_mode = DS_SPLIT_NONE, float osc = 1.f) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.W = W; p.bias = bias; p.R = R; p.C = C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = K; p.ldc = ldc; p.ldr = ldc;
     p.groups = 1; p.act = act; p.store = store; p.rows_per_sample = rps;
-    if (!g_prof) return ds_launch_gemm(p, s, DS_LOAD_DENSE);
+    if (W3) {  // fp32-class GEMM on the bf16 / fp16 matrix cores
+        p.W = (const float*)W3;
+        p.w3_plane = (long long)N * K;
+        p.out_scale = osc;
+    }
+    auto launch = [&]() {
+        if (!W3) return ds_launch_gemm(p, s, DS_LOAD_DENSE);
+        return split_mode == DS_SPLIT_F16X2 ? ds_launch_gemm_f16x2(p, s) : ds_launch_gemm_bf16x3(p, s);
+    };
+    if (!g_prof) return launch();
     ProfRec r;
     r.flops = 2.0 * M * N * K;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
@@ -144,7 +214,7 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
         return -2;
     }
     (void)hipEventRecord(r.a, s);
-    const int rc = ds_launch_gemm(p, s, DS_LOAD_DENSE);
+    const int rc = launch();
     (void)hipEventRecord(r.b, s);
     r.tile = g_last_tile;
     g_recs.push_back(r);
@@ -175,28 +245,33 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
     for (int l = 0; l < d.n_layer; ++l) {
         // x += attn1(ln1(x, t))
         TRY(ds_adaln(w.x, w.hn, M, L, D, h->P(l, DS_LP_ADALN1), t, s));
-        TRY(dense(w.hn, D, h->P(l, DS_LP_W_QKV), h->P(l, DS_LP_B_QKV), nullptr, w.qkv, 3 * D, M, 3 * D, D, DS_ACT_NONE, s));
+        TRY(dense(w.hn, D, h->P(l, DS_LP_W_QKV), h->P(l, DS_LP_B_QKV), nullptr, w.qkv, 3 * D, M, 3 * D, D, DS_ACT_NONE, s,
+                  DS_STORE_ROW, 0, h->P3(l, DS_LP_W_QKV), h->split_mode, h->S3(l, DS_LP_W_QKV)));
         TRY(ds_attention(w.qkv, 3 * D, w.qkv + D, 3 * D, w.qkv + 2 * D, 3 * D, w.att, D, B, d.n_head, L, L, scale, s));
-        TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ1), h->P(l, DS_LP_B_PROJ1), w.x, w.x, D, M, D, D, DS_ACT_NONE, s));
+        TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ1), h->P(l, DS_LP_B_PROJ1), w.x, w.x, D, M, D, D, DS_ACT_NONE, s,
+                  DS_STORE_ROW, 0, h->P3(l, DS_LP_W_PROJ1), h->split_mode, h->S3(l, DS_LP_W_PROJ1)));
         // x += attn2(ln1_1(x, t), cond)
         TRY(ds_adaln(w.x, w.hn, M, L, D, h->P(l, DS_LP_ADALN2), t, s));
-        TRY(dense(w.hn, D, h->P(l, DS_LP_W_Q2), h->P(l, DS_LP_B_Q2), nullptr, w.qkv, D, M, D, D, DS_ACT_NONE, s));
+        TRY(dense(w.hn, D, h->P(l, DS_LP_W_Q2), h->P(l, DS_LP_B_Q2), nullptr, w.qkv, D, M, D, D, DS_ACT_NONE, s,
+                  DS_STORE_ROW, 0, h->P3(l, DS_LP_W_Q2), h->split_mode, h->S3(l, DS_LP_W_Q2)));
         const float* kvl = kv + (size_t)l * Mc * 2 * D;
         TRY(ds_attention(w.qkv, D, kvl, 2 * D, kvl + D, 2 * D, w.att, D, B, d.n_head, L, d.cond_len, scale, s));
-        TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ2), h->P(l, DS_LP_B_PROJ2), w.x, w.x, D, M, D, D, DS_ACT_NONE, s));
+        TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ2), h->P(l, DS_LP_B_PROJ2), w.x, w.x, D, M, D, D, DS_ACT_NONE, s,
+                  DS_STORE_ROW, 0, h->P3(l, DS_LP_W_PROJ2), h->split_mode, h->S3(l, DS_LP_W_PROJ2)));
         // x += mlp(ln2(x))
         TRY(ds_layernorm(w.x, w.hn, M, D, h->P(l, DS_LP_LN2_G), h->P(l, DS_LP_LN2_B), s));
         TRY(dense(w.hn, D, h->P(l, DS_LP_W_FC1), h->P(l, DS_LP_B_FC1), nullptr, w.fc, D * d.mlp_mult, M, D * d.mlp_mult, D,
-                  DS_ACT_GELU2, s));
+                  DS_ACT_GELU2, s, DS_STORE_ROW, 0, h->P3(l, DS_LP_W_FC1), h->split_mode, h->S3(l, DS_LP_W_FC1)));
         TRY(dense(w.fc, D * d.mlp_mult, h->P(l, DS_LP_W_FC2), h->P(l, DS_LP_B_FC2), w.x, w.x, D, M, D, D * d.mlp_mult,
-                  DS_ACT_NONE, s));
+                  DS_ACT_NONE, s, DS_STORE_ROW, 0, h->P3(l, DS_LP_W_FC2), h->split_mode, h->S3(l, DS_LP_W_FC2)));
     }
     TRY(ds_layernorm(w.x, w.hn, M, D, d.lnf_g, d.lnf_b, s));
     if (layout == 0)
-        TRY(dense(w.hn, D, d.w_logits, d.b_logits, nullptr, logits, d.n_codes, M, d.n_codes, D, DS_ACT_NONE, s));
+        TRY(dense(w.hn, D, d.w_logits, d.b_logits, nullptr, logits, d.n_codes, M, d.n_codes, D, DS_ACT_NONE, s,
+                  DS_STORE_ROW, 0, h->w_logits3, h->split_mode, h->logits_osc));
     else
         TRY(dense(w.hn, D, d.w_logits, d.b_logits, nullptr, logits, L, M, d.n_codes, D, DS_ACT_NONE, s,
-                  DS_STORE_BATCH_T, L));
+                  DS_STORE_BATCH_T, L, h->w_logits3, h->split_mode, h->logits_osc));
     return 0;
 }
 

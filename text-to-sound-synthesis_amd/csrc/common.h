@@ -48,6 +48,8 @@ struct GemmParams {
     long long a_gstride, w_gstride, c_gstride;
     int pro, act, store;
     int f16_round;              // 1: outputs (and GELU2 intermediates) are rounded to the fp16 grid
+    long long w3_plane;         // split kernels: W = 3 bf16 / 2 fp16 planes of [N][ldw], this many elements apart
+    float out_scale;            // f16x2 kernel: 2^-s undoing the weight pre-scale
     // prologue: per-(sample, channel) affine  a' = a*pro_scale[b*Cin+c] + pro_shift[b*Cin+c]
     const float* pro_scale;
     const float* pro_shift;
@@ -61,3 +63,5 @@ struct GemmParams {
 };
 
 int ds_launch_gemm(const GemmParams& p, hipStream_t stream, int loader);
+int ds_launch_gemm_bf16x3(const GemmParams& p, hipStream_t stream);  // gemm_bf16x3.hip
+int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream);   // gemm_f16x2.hip

@@ -9,6 +9,7 @@ called.  `Text2ImageTransformer.forward` packs the weights once (QKV concatenati
 cross-attention K/V weights) and runs the whole stack through ds_denoiser_forward.
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -128,6 +129,10 @@ class Text2ImageTransformer(nn.Module):
         self.condition_dim, self.diffusion_step, self.mlp_hidden_times = condition_dim, diffusion_step, mlp_hidden_times
         self.num_codes = out_cls
         self.apply(self._init_weights)
+        # GEMM arithmetic of the denoiser: "fp32" = v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain);
+        # "bf16x3" = fp32-accurate 3-way bf16 split on the bf16 matrix cores (csrc/gemm_bf16x3.hip);
+        # "f16x2" = 2-way fp16 split, 3 MFMA passes, fp32-class (csrc/gemm_f16x2.hip)
+        self.precision = os.environ.get("DIFFSOUND_GEMM", "fp32")
         self._packed = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: self.invalidate())
 
@@ -160,17 +165,20 @@ class Text2ImageTransformer(nn.Module):
     @torch.no_grad()
     def packed(self, sched=None):
         """Device-side packed weights + ds_denoiser handle (built once, on first use)."""
-        if self._packed is not None and (sched is None or self._packed["sched_src"] is sched):
+        if self._packed is not None and (sched is None or self._packed["sched_src"] is sched) \
+                and self._packed.get("precision") == self.precision:
             return self._packed
         self.invalidate()
         dev = self.to_logits[1].weight.device
         if dev.type != "cuda":
             _lib.ptr(self.to_logits[1].weight)  # raises: no CPU path
         keep = []  # owns every packed tensor the handle points into
+        keep_by_ptr = {}
 
         def own(t):
             t = t.detach().to(torch.float32).contiguous()
             keep.append(t)
+            keep_by_ptr[t.data_ptr()] = t
             return t
 
         ptrs = (C.c_void_p * (self.n_layer * _lib.LP_COUNT))()
@@ -210,7 +218,28 @@ class Text2ImageTransformer(nn.Module):
         d.sched = own(sched_t).data_ptr()
         h = C.c_void_p()
         _lib.check(_lib.lib().ds_denoiser_create(C.byref(d), ptrs, C.byref(h)))
-        self._packed = {"handle": h, "keep": keep, "sched_src": sched, "ws": {}, "device": dev}
+        if self.precision in ("bf16x3", "f16x2"):
+            n = self.n_layer * _lib.LP_COUNT
+            ptrs3, scales = (C.c_void_p * n)(), (C.c_float * n)()
+
+            def split(w):
+                if self.precision == "bf16x3":
+                    return _lib.split_bf16x3(w), 1.0
+                return _lib.split_f16x2(w)
+            for l in range(self.n_layer):
+                for s in (_lib.LP_W_QKV, _lib.LP_W_PROJ1, _lib.LP_W_Q2, _lib.LP_W_PROJ2, _lib.LP_W_FC1, _lib.LP_W_FC2):
+                    t3, sc = split(keep_by_ptr[ptrs[l * _lib.LP_COUNT + s]])
+                    keep.append(t3)
+                    ptrs3[l * _lib.LP_COUNT + s] = t3.data_ptr()
+                    scales[l * _lib.LP_COUNT + s] = sc
+            wl3, lsc = split(self.to_logits[1].weight)
+            keep.append(wl3)
+            mode = 1 if self.precision == "bf16x3" else 2
+            _lib.check(_lib.lib().ds_denoiser_set_split_weights(h, mode, ptrs3, scales, wl3.data_ptr(), lsc))
+        elif self.precision != "fp32":
+            raise ValueError("precision must be 'fp32', 'bf16x3' or 'f16x2', got %r" % (self.precision,))
+        self._packed = {"handle": h, "keep": keep, "sched_src": sched, "ws": {}, "device": dev,
+                        "precision": self.precision}
         return self._packed
 
     def workspace(self, B, sched=None):

@@ -24,7 +24,7 @@ def load_vocoder(ckpt_vocoder, eval_mode=True):
 
 class Diffsound:
     def __init__(self, config=None, path=None, ckpt_vocoder=None, device="cuda"):
-        cfg = default_config() if config is None else (load_yaml_config(config) if isinstance(config, str) else config)
+        cfg = default_config(with_clip=True) if config is None else (load_yaml_config(config) if isinstance(config, str) else config)
         self.model = build_model(cfg)
         self.epoch = 0
         if path and os.path.exists(path):
@@ -42,12 +42,67 @@ class Diffsound:
 
     @torch.no_grad()
     def generate_sample_with_condition(self, cond, truncation_rate=0.85, replicate=1):
-        """cond: f32[B,77,512] caption embeddings -> (mel01 f32[B,80,848], wave f32[B,1,217088], tokens)."""
-        out = self.model.generate_content(batch={"condition_embed_token": cond}, filter_ratio=0,
-                                          replicate=replicate, content_ratio=1, return_att_weight=False,
-                                          sample_type="top" + str(truncation_rate) + "r")
+        """Captions -> (mel01 f32[B,80,848], wave f32[B,1,217088], tokens), everything left on the GPU.
+        `cond` is a list of caption strings (needs the text stage: tokenizer + CLIP in the config),
+        token ids i64[B,77], or caption embeddings f32[B,77,512]."""
+        if isinstance(cond, (list, tuple, str)):
+            batch = {"text": [cond] if isinstance(cond, str) else list(cond)}
+        elif cond.dtype == torch.long:
+            batch = {"condition_token": cond}
+        else:
+            batch = {"condition_embed_token": cond}
+        out = self.model.generate_content(batch=batch, filter_ratio=0, replicate=replicate, content_ratio=1,
+                                          return_att_weight=False, sample_type="top" + str(truncation_rate) + "r")
         mel = out["content"]                                   # [B,1,80,848] in ~[-1,1]
         wave = self.vocoder(mel[:, 0], scale=0.5, shift=0.5)   # spec = (x+1)/2, :182
         return (mel[:, 0] + 1) / 2, wave, out["content_token"]
 
     inference_generate_sample_with_condition = generate_sample_with_condition
+
+    @staticmethod
+    def read_tsv(val_path):
+        """file_name,caption CSV -> {file_name: [captions]} (generate_samples_batch.py:125-141)."""
+        import csv
+        caps = {}
+        with open(val_path, newline="") as f:
+            for row in csv.DictReader(f):
+                caps.setdefault(row["file_name"], []).append(row["caption"])
+        return caps
+
+    @torch.no_grad()
+    def generate_sample(self, val_path, truncation_rate, save_root, fast=False, replicate=2):
+        """The reference's file-writing driver (generate_samples_batch.py:143-187): per audio file, all of
+        its captions x `replicate` are sampled in one batch; every sample is written as
+        `{base}_mel_sample_{i}.npy` (mel in [0,1], f32[80,848]) and `{base}_mel_sample_{i}.wav`
+        (22 050 Hz, PCM_24).  Unlike the reference the vocoder runs on the whole batch at once."""
+        if fast:
+            raise NotImplementedError("'fast' skip-step sampling: SURVEY.md section 8f-4")
+        import numpy as np
+        os.makedirs(save_root, exist_ok=True)
+        written = []
+        for key, captions in self.read_tsv(val_path).items():
+            base = key.split(".")[0] + "_mel_sample_"
+            mel01, wave, _ = self.generate_sample_with_condition(list(captions), truncation_rate, replicate)
+            mel01, wave = mel01.cpu().numpy(), wave[:, 0].cpu().numpy()
+            for i in range(mel01.shape[0]):
+                path = os.path.join(save_root, base + str(i))
+                np.save(path + ".npy", mel01[i])
+                write_wav_pcm24(path + ".wav", wave[i], 22050)
+                written.append(path)
+        return written
+
+
+def write_wav_pcm24(path, samples, rate):
+    """Mono float waveform in [-1, 1] -> RIFF/WAVE with 24-bit little-endian PCM, as
+    soundfile.write(path, x, rate, 'PCM_24') produces (generate_samples_batch.py:186)."""
+    import struct
+
+    import numpy as np
+    x = np.asarray(samples, dtype=np.float64).reshape(-1)
+    q = np.clip(np.rint(x * 8388608.0), -8388608, 8388607).astype("<i4")   # libsndfile: scale 2^23, clip
+    raw = q.view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, rate, rate * 3, 3, 24))
+        f.write(b"data" + struct.pack("<I", len(raw)))
+        f.write(raw)
