@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--n-layer", type=int, default=19)
     ap.add_argument("--codes", type=int, default=256)
-    ap.add_argument("--precision", default=os.environ.get("DIFFSOUND_GEMM", "fp32"), choices=("fp32", "bf16x3", "f16x2"),
+    ap.add_argument("--precision", default=os.environ.get("DIFFSOUND_GEMM", "f16x2"), choices=("fp32", "bf16x3", "f16x2"),
                     help="denoiser GEMM arithmetic: fp32 MFMA, or the fp32-accurate 3-way bf16 split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

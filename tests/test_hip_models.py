@@ -23,7 +23,8 @@ def build(n_layer, T=100):
         sd = {k: (v[:T] if k.endswith(("ln1.emb.weight", "ln1_1.emb.weight")) else v) for k, v in sd.items()}
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(".mask" in k or "shuffle_idx" in k or ".log_" in k or ".Lt_" in k for k in missing)
-    return m.cuda().eval()
+    m.transformer.transformer.precision = "fp32"   # this file pins the exact-fp32 MFMA path; the split
+    return m.cuda().eval()                         # GEMM modes are covered by test_hip_split_gemm.py
 
 
 @pytest.fixture(scope="module")

@@ -15,8 +15,9 @@
 // an a1 that falls into the fp16 subnormal range keeps an absolute precision of 2^-25.
 //
 // 256 threads = 4 waves (2x2), block tile BM x BN x 32, two fp16 planes per operand, LDS rows padded to
-// 40 halves (conflict-free ds_read_b128), double-buffered LDS (one barrier per k-tile), register
-// prefetch of the next k-tile issued before the MFMAs.
+// 40 halves (conflict-free ds_read_b128), double-buffered LDS (one barrier per k-tile), two register sets
+// so that global loads run two k-tiles ahead and the split + LDS write of the next tile is scheduled
+// into the shadow of the current tile's MFMAs.
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -81,26 +82,30 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[SA];
-    u32x4 rb0[SB], rb1[SB];
+    // Two register sets: while the MFMAs of k-tile t run, set X (tile t+1, loaded one iteration ago and
+    // therefore already landed) is split and written to the other LDS stage, and set Y receives the
+    // global loads of tile t+2.  The body is branch-free (past-the-end tiles re-read the last tile and
+    // write an unused stage), so the scheduler can interleave the split/ds_write VALU work with the MFMAs.
+    f32x4 raX[SA], raY[SA];
+    u32x4 rb0X[SB], rb1X[SB], rb0Y[SB], rb1Y[SB];
     const size_t pl1 = (size_t)p.w3_plane;
-#define H_ISSUE_LOADS(k0_)                                                                          \
+#define H_ISSUE_LOADS(RA, RB0, RB1, k0_)                                                            \
     do {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < SA; ++i) ra[i] = *(const f32x4*)(a_base[i] + (k0_));  \
+        _Pragma("unroll") for (int i = 0; i < SA; ++i) RA[i] = *(const f32x4*)(a_base[i] + (k0_));  \
         _Pragma("unroll") for (int j = 0; j < SB; ++j) {                                            \
-            rb0[j] = *(const u32x4*)(b_base[j] + (k0_));                                            \
-            rb1[j] = *(const u32x4*)(b_base[j] + pl1 + (k0_));                                      \
+            RB0[j] = *(const u32x4*)(b_base[j] + (k0_));                                            \
+            RB1[j] = *(const u32x4*)(b_base[j] + pl1 + (k0_));                                      \
         }                                                                                           \
     } while (0)
-#define H_WRITE_LDS(stage_)                                                                         \
+#define H_WRITE_LDS(RA, RB0, RB1, stage_)                                                           \
     do {                                                                                            \
         _Float16* As_ = smem + (stage_) * STAGE;                                                    \
         _Float16* Bs_ = As_ + 2 * APL;                                                              \
         _Pragma("unroll") for (int i = 0; i < SA; ++i) {                                            \
             h4 s0, s1;                                                                              \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
+                const float a = RA[i][e];                                                           \
                 /* saturate instead of overflowing to inf: |a| up to 2*65504 stays finite */         \
-                const float a = ra[i][e];                                                           \
                 const _Float16 q0 = (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);        \
                 s0[e] = q0;                                                                         \
                 /* a - q0 is exact in fp32; the clamp only acts beyond the fp16 range */            \
@@ -112,50 +117,68 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
         }                                                                                           \
         _Pragma("unroll") for (int j = 0; j < SB; ++j) {                                            \
             _Float16* dst = Bs_ + b_row[j] * HLD + b_k8[j];                                         \
-            *(u32x4*)(dst) = rb0[j];                                                                \
-            *(u32x4*)(dst + BPL) = rb1[j];                                                          \
+            *(u32x4*)(dst) = RB0[j];                                                                \
+            *(u32x4*)(dst + BPL) = RB1[j];                                                          \
+        }                                                                                           \
+    } while (0)
+#define H_COMPUTE(cur_)                                                                             \
+    do {                                                                                            \
+        const _Float16* Ac = smem + (cur_) * STAGE + (wm * TM * 32 + l31) * HLD + hh * 8;           \
+        const _Float16* Bc = smem + (cur_) * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD + hh * 8; \
+        _Pragma("unroll") for (int ks = 0; ks < HBK / 16; ++ks) {                                   \
+            h8 fa0[TM], fa1[TM], fb0[TN], fb1[TN];                                                  \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+                fa0[i] = *(const h8*)(Ac + i * 32 * HLD + ks * 16);                                 \
+                fa1[i] = *(const h8*)(Ac + APL + i * 32 * HLD + ks * 16);                           \
+            }                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
+                fb0[j] = *(const h8*)(Bc + j * 32 * HLD + ks * 16);                                 \
+                fb1[j] = *(const h8*)(Bc + BPL + j * 32 * HLD + ks * 16);                           \
+            }                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                    \
+                    f32x16 c = acc[i][j];                                                           \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[i], fb0[j], c, 0, 0, 0);         \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[i], fb1[j], c, 0, 0, 0);         \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[i], fb0[j], c, 0, 0, 0);         \
+                    acc[i][j] = c;                                                                  \
+                }                                                                                   \
+        }                                                                                           \
+    } while (0)
+    // one k-tile: X holds tile kt+1, Y receives tile kt+2
+#define H_BODY(RAX, RB0X, RB1X, RAY, RB0Y, RB1Y)                                                    \
+    do {                                                                                            \
+        const int kn2 = (kt + 2 < nk ? kt + 2 : nk - 1) * HBK;                                      \
+        H_ISSUE_LOADS(RAY, RB0Y, RB1Y, kn2);                                                        \
+        H_COMPUTE(cur);                                                                             \
+        H_WRITE_LDS(RAX, RB0X, RB1X, cur ^ 1);                                                      \
+        INTERLEAVE_HINTS();                                                                         \
+        __syncthreads();                                                                            \
+        cur ^= 1;                                                                                   \
+        ++kt;                                                                                       \
+    } while (0)
+    // ask the scheduler for  MFMA, 3 x VALU, (DS write)  groups: the split runs in the MFMA shadow
+#define INTERLEAVE_HINTS()                                                                          \
+    do {                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 3 * TM * TN * (HBK / 16); ++q) {                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */                           \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* VALU */                           \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); /* DS write */                       \
         }                                                                                           \
     } while (0)
 
     const int nk = p.K / HBK;
-    H_ISSUE_LOADS(0);
-    H_WRITE_LDS(0);
+    H_ISSUE_LOADS(raX, rb0X, rb1X, 0);
+    H_WRITE_LDS(raX, rb0X, rb1X, 0);
+    H_ISSUE_LOADS(raX, rb0X, rb1X, (nk > 1 ? 1 : 0) * HBK);
     __syncthreads();
 
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) H_ISSUE_LOADS((kt + 1) * HBK);
-        const _Float16* Ac = smem + cur * STAGE + (wm * TM * 32 + l31) * HLD + hh * 8;
-        const _Float16* Bc = smem + cur * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD + hh * 8;
-#pragma unroll
-        for (int ks = 0; ks < HBK / 16; ++ks) {
-            h8 fa0[TM], fa1[TM], fb0[TN], fb1[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                fa0[i] = *(const h8*)(Ac + i * 32 * HLD + ks * 16);
-                fa1[i] = *(const h8*)(Ac + APL + i * 32 * HLD + ks * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                fb0[j] = *(const h8*)(Bc + j * 32 * HLD + ks * 16);
-                fb1[j] = *(const h8*)(Bc + BPL + j * 32 * HLD + ks * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[i], fb0[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[i], fb1[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[i], fb0[j], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-        }
-        if (more) H_WRITE_LDS(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    int cur = 0, kt = 0;
+    while (kt + 1 < nk) {
+        H_BODY(raX, rb0X, rb1X, raY, rb0Y, rb1Y);
+        H_BODY(raY, rb0Y, rb1Y, raX, rb0X, rb1X);
     }
+    if (kt < nk) H_BODY(raX, rb0X, rb1X, raY, rb0Y, rb1Y);
 
     const float osc = p.out_scale;
 #pragma unroll
@@ -216,18 +239,15 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(p.store == DS_STORE_ROW || p.store == DS_STORE_BATCH_T, "unsupported store mode");
     DS_CHECK_ARG(p.act == DS_ACT_NONE || p.act == DS_ACT_GELU2, "unsupported activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
-    struct Cfg { int bm, bn; double pen; };
-    static const Cfg cfgs[3] = {{128, 128, 1.00}, {128, 64, 1.05}, {64, 64, 1.12}};
-    int best = 0;
+    // Tile choice from the measured sweep (profiles/r01_gemm_tile_sweep_f16x2.txt): 128x128 runs ~235 TF-eq once
+    // the grid has >= ~3 rounds of 512 resident blocks (or >= 2 rounds with a long K); below that the 64x64
+    // tile (~195 TF-eq, 4x the blocks) quantises better.  128x64 never won.
+    int best;
     if (g_force_tile_h >= 0) {
         best = g_force_tile_h;
     } else {
-        double bc = 1e300;
-        for (int c = 0; c < 3; ++c) {
-            const long tiles = (long)((p.M + cfgs[c].bm - 1) / cfgs[c].bm) * ((p.N + cfgs[c].bn - 1) / cfgs[c].bn);
-            const double cost = (double)((tiles + 255) / 256) * cfgs[c].bm * cfgs[c].bn * cfgs[c].pen;
-            if (cost < bc) { bc = cost; best = c; }
-        }
+        const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        best = (t128 >= 1500 || (p.K >= 4096 && t128 >= 1000)) ? 0 : 2;
     }
     g_last_tile = best;
     switch (best) {

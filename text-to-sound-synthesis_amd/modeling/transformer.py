@@ -129,10 +129,12 @@ class Text2ImageTransformer(nn.Module):
         self.condition_dim, self.diffusion_step, self.mlp_hidden_times = condition_dim, diffusion_step, mlp_hidden_times
         self.num_codes = out_cls
         self.apply(self._init_weights)
-        # GEMM arithmetic of the denoiser: "fp32" = v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain);
-        # "bf16x3" = fp32-accurate 3-way bf16 split on the bf16 matrix cores (csrc/gemm_bf16x3.hip);
-        # "f16x2" = 2-way fp16 split, 3 MFMA passes, fp32-class (csrc/gemm_f16x2.hip)
-        self.precision = os.environ.get("DIFFSOUND_GEMM", "fp32")
+        # GEMM arithmetic of the denoiser (all three are fp32-class; measured error vs float64 in
+        # tests/test_hip_split_gemm.py: f16x2 1.3e-6 <= bf16x3 1.5e-6 <= fp32 2.1e-6 at K = 1024):
+        #   "f16x2"  2-way fp16 split of both operands, 3 fp16-MFMA passes (csrc/gemm_f16x2.hip)  [default]
+        #   "bf16x3" 3-way bf16 split, 6 bf16-MFMA passes (csrc/gemm_bf16x3.hip)
+        #   "fp32"   v_mfma_f32_32x32x2_f32, the exact fp32 FMA chain (csrc/gemm_f32.hip)
+        self.precision = os.environ.get("DIFFSOUND_GEMM", "f16x2")
         self._packed = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: self.invalidate())
 
