@@ -14,8 +14,8 @@
 // must stay below 65504 (true for this network: LayerNorm outputs, attention outputs, GELU2 outputs);
 // an a1 that falls into the fp16 subnormal range keeps an absolute precision of 2^-25.
 //
-// 256 threads = 4 waves (2x2), block tile BM x BN x 32, two fp16 planes per operand, LDS rows padded to
-// 40 halves (conflict-free ds_read_b128), double-buffered LDS (one barrier per k-tile), two register sets
+// 256 threads = 4 waves (2x2), block tile BM x BN x 32, two fp16 planes per operand, unpadded 64-byte LDS
+// rows with an XOR chunk swizzle (conflict-free ds_read_b128 and ds_write_b128), double-buffered LDS (one barrier per k-tile), two register sets
 // so that global loads run two k-tiles ahead and the split + LDS write of the next tile is scheduled
 // into the shadow of the current tile's MFMAs.
 #include "common.h"
@@ -25,13 +25,17 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define HBK 32
-#define HLD 40  // halves per LDS row
+#define HLD 32  // halves per LDS row: unpadded 64-byte rows, 16-byte chunks XOR-swizzled by (row>>2)&3
+// Swizzle: logical chunk c of row r lives at chunk c ^ ((r >> 2) & 3).  A ds_read_b128 lane group covers 16
+// rows at one logical chunk -> 16 distinct 4-bank slots (conflict-free); a ds_write_b128 lane group covers
+// two consecutive rows x 4 chunks -> 32 distinct banks.  (With the earlier 80-byte padded rows the reads were
+// clean but every staging write was a 2-way conflict: SQ_LDS_BANK_CONFLICT = 1/3 of the LDS busy cycles.)
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int SA = BM / 32;   // fp32 float4 staging slots per thread (A)
+    constexpr int SA = BM / 64;   // 8-element (2 x float4) staging chunks per thread (A)
     constexpr int SB = BN / 64;   // 16-byte staging chunks per thread per plane (B)
     constexpr int APL = BM * HLD, BPL = BN * HLD;       // plane strides (halves)
     constexpr int STAGE = 2 * (APL + BPL);              // halves per pipeline stage
@@ -53,13 +57,19 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
     const int m0 = (bid / tiles_n) * BM;
     const int n0 = (bid % tiles_n) * BN;
 
-    const int srow = tid >> 3, kq = (tid & 7) * 4;
+    // A and B use the same chunking: chunk c = tid + 256 i covers row c>>2 and the 8 consecutive k at (c&3)*8
+    // (A: two float4 loads -> one 16-byte ds_write per fp16 plane; 4 lanes cover one 128-byte row segment)
     const float* a_base[SA];
+    int a_row[SA], a_k8[SA];
 #pragma unroll
     for (int i = 0; i < SA; ++i) {
-        int m = m0 + srow + 32 * i;
+        const int c = tid + 256 * i;
+        a_row[i] = c >> 2;
+        const int ck = c & 3;
+        a_k8[i] = (ck ^ ((a_row[i] >> 2) & 3)) * 8;          // swizzled LDS position of this chunk
+        int m = m0 + a_row[i];
         if (m >= p.M) m = p.M - 1;
-        a_base[i] = p.A + (size_t)m * p.lda + kq;
+        a_base[i] = p.A + (size_t)m * p.lda + ck * 8;
     }
     const unsigned short* w2 = (const unsigned short*)p.W;
     const unsigned short* b_base[SB];
@@ -68,12 +78,16 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
     for (int j = 0; j < SB; ++j) {
         const int c = tid + 256 * j;
         b_row[j] = c >> 2;
-        b_k8[j] = (c & 3) * 8;
+        const int ck = c & 3;
+        b_k8[j] = (ck ^ ((b_row[j] >> 2) & 3)) * 8;
         int n = n0 + b_row[j];
         if (n >= p.N) n = p.N - 1;
-        b_base[j] = w2 + (size_t)n * p.ldw + b_k8[j];
+        b_base[j] = w2 + (size_t)n * p.ldw + ck * 8;
     }
 
+    // fragment reads: k-step ks, lane half hh -> logical chunk 2ks+hh; every fragment row of this lane is
+    // l31 plus a multiple of 32, so the swizzle term depends on l31 only
+    const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -86,12 +100,15 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
     // therefore already landed) is split and written to the other LDS stage, and set Y receives the
     // global loads of tile t+2.  The body is branch-free (past-the-end tiles re-read the last tile and
     // write an unused stage), so the scheduler can interleave the split/ds_write VALU work with the MFMAs.
-    f32x4 raX[SA], raY[SA];
+    f32x4 raX[2 * SA], raY[2 * SA];
     u32x4 rb0X[SB], rb1X[SB], rb0Y[SB], rb1Y[SB];
     const size_t pl1 = (size_t)p.w3_plane;
 #define H_ISSUE_LOADS(RA, RB0, RB1, k0_)                                                            \
     do {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < SA; ++i) RA[i] = *(const f32x4*)(a_base[i] + (k0_));  \
+        _Pragma("unroll") for (int i = 0; i < SA; ++i) {                                            \
+            RA[2 * i] = *(const f32x4*)(a_base[i] + (k0_));                                         \
+            RA[2 * i + 1] = *(const f32x4*)(a_base[i] + (k0_) + 4);                                 \
+        }                                                                                           \
         _Pragma("unroll") for (int j = 0; j < SB; ++j) {                                            \
             RB0[j] = *(const u32x4*)(b_base[j] + (k0_));                                            \
             RB1[j] = *(const u32x4*)(b_base[j] + pl1 + (k0_));                                      \
@@ -102,18 +119,18 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
         _Float16* As_ = smem + (stage_) * STAGE;                                                    \
         _Float16* Bs_ = As_ + 2 * APL;                                                              \
         _Pragma("unroll") for (int i = 0; i < SA; ++i) {                                            \
-            h4 s0, s1;                                                                              \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
-                const float a = RA[i][e];                                                           \
+            h8 s0, s1;                                                                              \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                         \
+                const float a = RA[2 * i + (e >> 2)][e & 3];                                        \
                 /* saturate instead of overflowing to inf: |a| up to 2*65504 stays finite */         \
                 const _Float16 q0 = (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);        \
                 s0[e] = q0;                                                                         \
                 /* a - q0 is exact in fp32; the clamp only acts beyond the fp16 range */            \
                 s1[e] = (_Float16)__builtin_amdgcn_fmed3f(a - (float)q0, -65504.f, 65504.f);        \
             }                                                                                       \
-            _Float16* dst = As_ + (srow + 32 * i) * HLD + kq;                                       \
-            *(h4*)(dst) = s0;                                                                       \
-            *(h4*)(dst + APL) = s1;                                                                 \
+            _Float16* dst = As_ + a_row[i] * HLD + a_k8[i];                                         \
+            *(h8*)(dst) = s0;                                                                       \
+            *(h8*)(dst + APL) = s1;                                                                 \
         }                                                                                           \
         _Pragma("unroll") for (int j = 0; j < SB; ++j) {                                            \
             _Float16* dst = Bs_ + b_row[j] * HLD + b_k8[j];                                         \
@@ -123,17 +140,17 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
     } while (0)
 #define H_COMPUTE(cur_)                                                                             \
     do {                                                                                            \
-        const _Float16* Ac = smem + (cur_) * STAGE + (wm * TM * 32 + l31) * HLD + hh * 8;           \
-        const _Float16* Bc = smem + (cur_) * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD + hh * 8; \
+        const _Float16* Ac = smem + (cur_) * STAGE + (wm * TM * 32 + l31) * HLD;                    \
+        const _Float16* Bc = smem + (cur_) * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD;          \
         _Pragma("unroll") for (int ks = 0; ks < HBK / 16; ++ks) {                                   \
             h8 fa0[TM], fa1[TM], fb0[TN], fb1[TN];                                                  \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
-                fa0[i] = *(const h8*)(Ac + i * 32 * HLD + ks * 16);                                 \
-                fa1[i] = *(const h8*)(Ac + APL + i * 32 * HLD + ks * 16);                           \
+                fa0[i] = *(const h8*)(Ac + i * 32 * HLD + swz[ks]);                                 \
+                fa1[i] = *(const h8*)(Ac + APL + i * 32 * HLD + swz[ks]);                           \
             }                                                                                       \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
-                fb0[j] = *(const h8*)(Bc + j * 32 * HLD + ks * 16);                                 \
-                fb1[j] = *(const h8*)(Bc + BPL + j * 32 * HLD + ks * 16);                           \
+                fb0[j] = *(const h8*)(Bc + j * 32 * HLD + swz[ks]);                                 \
+                fb1[j] = *(const h8*)(Bc + BPL + j * 32 * HLD + swz[ks]);                           \
             }                                                                                       \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                    \
@@ -239,15 +256,15 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(p.store == DS_STORE_ROW || p.store == DS_STORE_BATCH_T, "unsupported store mode");
     DS_CHECK_ARG(p.act == DS_ACT_NONE || p.act == DS_ACT_GELU2, "unsupported activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
-    // Tile choice from the measured sweep (profiles/r01_gemm_tile_sweep_f16x2.txt): 128x128 runs ~235 TF-eq once
-    // the grid has >= ~3 rounds of 512 resident blocks (or >= 2 rounds with a long K); below that the 64x64
-    // tile (~195 TF-eq, 4x the blocks) quantises better.  128x64 never won.
+    // Tile choice from the measured sweep (profiles/r01_gemm_tile_sweep_f16x2.txt, B=64): 128x128 reaches
+    // ~235-250 TF-eq once the grid has >= 3 rounds of 512 resident blocks; below that 128x64 (3 blocks/CU,
+    // ~205-230 TF-eq) quantises better; 64x64 (~190) only wins for tiny grids.
     int best;
     if (g_force_tile_h >= 0) {
         best = g_force_tile_h;
     } else {
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        best = (t128 >= 1500 || (p.K >= 4096 && t128 >= 1000)) ? 0 : 2;
+        best = t128 >= 1500 ? 0 : (t128 >= 128 ? 1 : 2);
     }
     g_last_tile = best;
     switch (best) {
