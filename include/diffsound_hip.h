@@ -89,6 +89,10 @@ int ds_attention(const float* q, int ldq, const float* k, int ldk, const float* 
  * rounded to the fp16 grid (CLIP's nn.MultiheadAttention in fp16, clip/model.py:166-186) */
 int ds_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                     int B, int heads, int Lq, int Lk, float scale, int causal, int f16_round, ds_stream_t stream);
+/* the same attention (no mask, head dim 64) on the fp16 matrix cores with the f16x2 split: fp32-class results,
+ * ~5x fewer MFMA cycles (attention_f16x2.hip); used by the denoiser in f16x2 mode */
+int ds_attention_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                       int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
 /* fp16-semantics row kernels of the CLIP text tower (sound_synthesis/modeling/modules/clip/model.py:150-157,
  * 341-354; embeddings/clip_text_embedding.py:46-88): fp32 storage, outputs rounded to the fp16 grid */
 int ds_embed_f16(const int64_t* tokens, const float* emb, const float* pos, float* out, int M, int L, int D,

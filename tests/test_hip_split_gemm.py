@@ -124,3 +124,49 @@ def test_denoiser_split_steps_and_trajectory_tokens_exact(mode):
     out = m.transformer.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0,
                                noise_fn=lambda t, shp: synth.synth_uniform(shp, key="traj.u%d" % t))
     assert (out["content_token"].cpu() != g["tokens"]).sum().item() == 0
+
+
+@pytest.mark.parametrize("Lk,B", [(265, 2), (77, 3), (32, 1), (288, 1)])
+def test_attention_f16x2_matches_oracle(Lk, B):
+    """ds_attention_f16x2 against the same reference and tolerance as the fp32-MFMA kernel."""
+    import math
+    import diffsound_oracle as O
+    from text_to_sound_synthesis_amd import _lib as L
+    Lq, H, D = 265, 16, 1024
+    q, k, v = rnd((B, Lq, D), "at.q"), rnd((B, Lk, D), "at.k"), rnd((B, Lk, D), "at.v", 2.0)
+    k[:, 5] *= 6.0                      # a spiked key: far-from-uniform softmax rows
+    v[:, 3, :7] = torch.tensor([1e-6, -3e-5, 250.0, 0.0, -1e-3, 7.5, 1e-8])
+    ref = O._mha(q.double(), k.double(), v.double(), H).float()
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    out = torch.full((B * Lq, D), float("nan"), device="cuda")
+    L.check(L.lib().ds_attention_f16x2(L.ptr(qc), D, L.ptr(kc), D, L.ptr(vc), D, L.ptr(out), D, B, H, Lq, Lk,
+                                       1.0 / math.sqrt(64), L.stream()))
+    f32 = torch.empty(B * Lq, D, device="cuda")
+    L.check(L.lib().ds_attention(L.ptr(qc), D, L.ptr(kc), D, L.ptr(vc), D, L.ptr(f32), D, B, H, Lq, Lk,
+                                 1.0 / math.sqrt(64), L.stream()))
+    e16, e32 = (out.cpu().view_as(ref) - ref).abs().max().item(), (f32.cpu().view_as(ref) - ref).abs().max().item()
+    print("attention Lk=%d: f16x2 max-abs %.2e, fp32-MFMA max-abs %.2e (vs float64)" % (Lk, e16, e32))
+    assert e16 < 2e-5
+
+
+def test_attention_f16x2_strided_qkv_and_speed():
+    import diffsound_oracle as O
+    from text_to_sound_synthesis_amd import _lib as L
+    B, Lq, H, D = 64, 265, 16, 1024
+    qkv = torch.randn(B, Lq, 3 * D, device="cuda")
+    out = torch.empty(B * Lq, D, device="cuda")
+    args = (qkv.data_ptr(), 3 * D, qkv.data_ptr() + 4 * D, 3 * D, qkv.data_ptr() + 8 * D, 3 * D, L.ptr(out), D, B, H,
+            Lq, Lq, 0.125, L.stream())
+    L.check(L.lib().ds_attention_f16x2(*args))
+    ref = O._mha(qkv[:2, :, :D].cpu(), qkv[:2, :, D:2 * D].cpu(), qkv[:2, :, 2 * D:].cpu(), H)
+    assert (out.view(B, Lq, D)[:2].cpu() - ref).abs().max() < 2e-5
+    for name, fn in (("f16x2", L.lib().ds_attention_f16x2), ("fp32", L.lib().ds_attention)):
+        for _ in range(3):
+            fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        print("self-attention B=64 %s: %.1f us" % (name, e0.elapsed_time(e1) * 100))

@@ -58,6 +58,8 @@ _PROTOS = {
                                C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_attention_ex": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_int, _vp]),
+    "ds_attention_f16x2": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_embed_f16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_layernorm_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ds_l2norm_rows_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),

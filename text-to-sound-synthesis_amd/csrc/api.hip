@@ -241,13 +241,15 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
     const ds_denoiser_desc& d = h->d;
     const int D = d.n_embd, L = d.seq_len, M = B * L, Mc = B * d.cond_len;
     const float scale = 0.125f;  // 1/sqrt(64), transformer_utils.py:48
+    const bool f16 = h->split_mode == DS_SPLIT_F16X2;  // attention follows the GEMM arithmetic mode
     TRY(ds_embed(tokens, d.tok_emb, d.pos_emb, w.x, M, L, D, s));
     for (int l = 0; l < d.n_layer; ++l) {
         // x += attn1(ln1(x, t))
         TRY(ds_adaln(w.x, w.hn, M, L, D, h->P(l, DS_LP_ADALN1), t, s));
         TRY(dense(w.hn, D, h->P(l, DS_LP_W_QKV), h->P(l, DS_LP_B_QKV), nullptr, w.qkv, 3 * D, M, 3 * D, D, DS_ACT_NONE, s,
                   DS_STORE_ROW, 0, h->P3(l, DS_LP_W_QKV), h->split_mode, h->S3(l, DS_LP_W_QKV)));
-        TRY(ds_attention(w.qkv, 3 * D, w.qkv + D, 3 * D, w.qkv + 2 * D, 3 * D, w.att, D, B, d.n_head, L, L, scale, s));
+        TRY((f16 ? ds_attention_f16x2 : ds_attention)(w.qkv, 3 * D, w.qkv + D, 3 * D, w.qkv + 2 * D, 3 * D, w.att, D, B,
+                                                       d.n_head, L, L, scale, s));
         TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ1), h->P(l, DS_LP_B_PROJ1), w.x, w.x, D, M, D, D, DS_ACT_NONE, s,
                   DS_STORE_ROW, 0, h->P3(l, DS_LP_W_PROJ1), h->split_mode, h->S3(l, DS_LP_W_PROJ1)));
         // x += attn2(ln1_1(x, t), cond)
@@ -255,7 +257,8 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
         TRY(dense(w.hn, D, h->P(l, DS_LP_W_Q2), h->P(l, DS_LP_B_Q2), nullptr, w.qkv, D, M, D, D, DS_ACT_NONE, s,
                   DS_STORE_ROW, 0, h->P3(l, DS_LP_W_Q2), h->split_mode, h->S3(l, DS_LP_W_Q2)));
         const float* kvl = kv + (size_t)l * Mc * 2 * D;
-        TRY(ds_attention(w.qkv, D, kvl, 2 * D, kvl + D, 2 * D, w.att, D, B, d.n_head, L, d.cond_len, scale, s));
+        TRY((f16 ? ds_attention_f16x2 : ds_attention)(w.qkv, D, kvl, 2 * D, kvl + D, 2 * D, w.att, D, B, d.n_head, L,
+                                                       d.cond_len, scale, s));
         TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ2), h->P(l, DS_LP_B_PROJ2), w.x, w.x, D, M, D, D, DS_ACT_NONE, s,
                   DS_STORE_ROW, 0, h->P3(l, DS_LP_W_PROJ2), h->split_mode, h->S3(l, DS_LP_W_PROJ2)));
         // x += mlp(ln2(x))

@@ -42,11 +42,21 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void ds_attn_kernel(const float*
     const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
 
     // ---- stage K into LDS (zero rows beyond Lk) ----
-    for (int f = tid; f < NKT * 32 * 16; f += ATT_WAVES * 64) {
-        const int row = f >> 4, c4 = (f & 15) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < Lk) v = *(const f32x4*)(kb + (size_t)row * ldk + c4);
-        *(f32x4*)(kv + row * ATT_LD + c4) = v;
+    for (int it0 = 0; it0 < NKT * 32 * 16 / (ATT_WAVES * 64); it0 += 4) {   // 4 loads in flight per thread
+        f32x4 t8[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + (it0 + u) * (ATT_WAVES * 64);
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            t8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < Lk) t8[u] = *(const f32x4*)(kb + (size_t)row * ldk + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + (it0 + u) * (ATT_WAVES * 64);
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            *(f32x4*)(kv + row * ATT_LD + c4) = t8[u];
+        }
     }
     // ---- Q fragment: lane (q = l31, half hh) keeps Q[q][8c + 4hh + j], c = 0..7, j = 0..3 ----
     f32x4 qf[8];
@@ -77,11 +87,21 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void ds_attn_kernel(const float*
     }
     __syncthreads();  // everyone is done reading K
     // ---- stage V into the same buffer (overlaps with the softmax below) ----
-    for (int f = tid; f < NKT * 32 * 16; f += ATT_WAVES * 64) {
-        const int row = f >> 4, c4 = (f & 15) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < Lk) v = *(const f32x4*)(vb + (size_t)row * ldv + c4);
-        *(f32x4*)(kv + row * ATT_LD + c4) = v;
+    for (int it0 = 0; it0 < NKT * 32 * 16 / (ATT_WAVES * 64); it0 += 2) {   // 2 loads in flight (the 144 score registers are live here)
+        f32x4 t8[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = tid + (it0 + u) * (ATT_WAVES * 64);
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            t8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < Lk) t8[u] = *(const f32x4*)(vb + (size_t)row * ldv + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = tid + (it0 + u) * (ATT_WAVES * 64);
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            *(f32x4*)(kv + row * ATT_LD + c4) = t8[u];
+        }
     }
 
     // ---- softmax over keys: lane holds keys kt*32 + (r&3) + 8*(r>>2) + 4*hh of query l31 ----

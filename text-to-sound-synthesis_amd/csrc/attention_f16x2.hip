@@ -1,0 +1,265 @@
+// Fused multi-head attention (head dim 64) on the fp16 matrix cores with the 2-way fp16 split of
+// gemm_f16x2.hip: fp32-class results at 3 fp16-MFMA passes per contraction instead of the fp32 MFMA's
+// 16x slower rate.  Same contract as ds_attention (attention.hip); replaces FullAttention /
+// CrossAttention cores (transformer_utils.py:43-58, :91-109) when the denoiser runs in f16x2 mode.
+//
+//   pass 1  S^T[key][q] = sum_d K[key][d] Q[q][d]:  k = k0 + k1, q = q0 + q1 (fp16), MFMAs k1q0 + k0q1 + k0q0.
+//           A operand = K rows from LDS (two fp16 planes, 128-byte rows, 16-byte chunks XOR-swizzled by
+//           (key>>1)&7 -> conflict-free ds_read_b128), B operand = the wave's own Q rows in registers.
+//           Transposed scores: lane&31 is the query, the keys of a tile are spread over the 16 accumulator
+//           registers, so the softmax is in-lane + one cross-half shuffle (as in attention.hip).
+//   pass 2  O[q][d] = sum_key P[q][key] V[key][d]:  the P registers are split (p0 + p1) and packed straight
+//           into the MFMA A operand: k-step s of a 32-key tile takes registers 8s..8s+7, i.e. keys
+//           (e&3) + 8(e>>2) + 16s + 4*half.  V is staged TRANSPOSED and key-permuted to match:
+//           VT[plane][d][tile*32 + s*16 + half*8 + e], so the B operand is one ds_read_b128 per plane
+//           (rows swizzled by (d>>2)&3).  MFMAs p1v0 + p0v1 + p0v0.
+// K and V^T share one 72 KB LDS buffer (K first), so two workgroups fit per CU.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define AH_WAVES 3
+
+__device__ __forceinline__ _Float16 ah_hi(float a) { return (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); }
+__device__ __forceinline__ _Float16 ah_lo(float a, _Float16 h) {
+    return (_Float16)__builtin_amdgcn_fmed3f(a - (float)h, -65504.f, 65504.f);
+}
+
+template <int NKT>
+__global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const float* __restrict__ Q, int ldq,
+                                                                        const float* __restrict__ Kp, int ldk,
+                                                                        const float* __restrict__ Vp, int ldv,
+                                                                        float* __restrict__ O, int ldo, int Lq, int Lk,
+                                                                        int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NKEY = NKT * 32;
+    constexpr int KPL = NKEY * 64;   // halves per K plane   ([key][64 d])
+    constexpr int VPL = 64 * NKEY;   // halves per V^T plane ([d][NKEY keys, permuted])
+    _Float16* buf = (_Float16*)smem_raw;   // K: [2][NKEY][64]   then   V^T: [2][64][NKEY]   (same size)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.x % heads;
+    const int grp = blockIdx.x / heads;
+    const int b = blockIdx.y;
+    const int q0 = (grp * AH_WAVES + wave) * 32;
+    const bool active = q0 < Lq;   // wave-uniform
+
+    const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
+    const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
+
+    // ---- stage K: fp32 -> two fp16 planes, 8-byte half-chunks, chunk swizzle (key>>1)&7 ----
+    // (loads are issued 8 deep before the first dependent conversion: a load -> convert -> ds_write chain
+    //  per iteration would serialise 24 L2/HBM round trips per thread)
+    constexpr int NIT = NKEY * 16 / (AH_WAVES * 64);   // 24 (self) / 8 (cross), exact
+    static_assert(NIT % 8 == 0, "staging loop is unrolled 8 deep");
+    for (int it0 = 0; it0 < NIT; it0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + (it0 + u) * (AH_WAVES * 64);
+            const int row = f >> 4, c4 = f & 15;          // 4 consecutive d at c4*4
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < Lk) v[u] = *(const f32x4*)(kb + (size_t)row * ldk + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + (it0 + u) * (AH_WAVES * 64);
+            const int row = f >> 4, c4 = f & 15;
+            h4 s0, s1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0[e] = ah_hi(v[u][e]);
+                s1[e] = ah_lo(v[u][e], s0[e]);
+            }
+            const int chunk = (c4 >> 1) ^ ((row >> 1) & 7);
+            _Float16* dst = buf + row * 64 + chunk * 8 + (c4 & 1) * 4;
+            *(h4*)dst = s0;
+            *(h4*)(dst + KPL) = s1;
+        }
+    }
+    // ---- Q operand: lane (q = l31, half hh) keeps Q[q][16 ks + 8 hh + 0..7], ks = 0..3, both planes ----
+    h8 q_hi[4], q_lo[4];
+    {
+        int qr = q0 + l31;
+        if (qr >= Lq) qr = Lq - 1;
+        const float* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 64 + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 a = *(const f32x4*)(qp + 16 * ks), c = *(const f32x4*)(qp + 16 * ks + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                q_hi[ks][e] = ah_hi(a[e]);
+                q_lo[ks][e] = ah_lo(a[e], q_hi[ks][e]);
+                q_hi[ks][4 + e] = ah_hi(c[e]);
+                q_lo[ks][4 + e] = ah_lo(c[e], q_hi[ks][4 + e]);
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 s[NKT];
+    if (active) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            const int key = kt * 32 + l31;
+            const _Float16* kr = buf + key * 64;
+            const int sw = (key >> 1) & 7;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = ((2 * ks + hh) ^ sw) * 8;
+                const h8 k0 = *(const h8*)(kr + off), k1 = *(const h8*)(kr + KPL + off);
+                f32x16 c = s[kt];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q_hi[ks], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q_lo[ks], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q_hi[ks], c, 0, 0, 0);
+                s[kt] = c;
+            }
+        }
+    }
+    __syncthreads();  // everyone is done reading K
+
+    // ---- stage V transposed + key-permuted: VT[plane][d][kt*32 + s*16 + half*8 + e], chunk swizzle (d>>2)&3 ----
+    // Work item = (group of 4 consecutive keys, 4 consecutive d): the 4 keys are e&3 = 0..3 of one (tile, s, half,
+    // e>>2) slot, i.e. 4 contiguous halves of a V^T row -> one ds_write_b64 per (d, plane) instead of four b16 writes.
+    constexpr int NITV = NKEY / 4 * 16 / (AH_WAVES * 64);   // 6 (self) / 2 (cross)
+#pragma unroll
+    for (int it = 0; it < NITV; ++it) {
+        const int f = tid + it * (AH_WAVES * 64);
+        const int kg = f >> 4, c4 = f & 15;                 // keys 4kg .. 4kg+3, d = 4 c4 .. 4 c4 + 3
+        f32x4 v[4];
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int key = 4 * kg + kx;
+            v[kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (key < Lk) v[kx] = *(const f32x4*)(vb + (size_t)key * ldv + c4 * 4);
+        }
+        const int kk = (4 * kg) & 31;                       // kk & 3 == 0
+        const int e0 = ((kk >> 3) & 1) << 2;                // e = e0 + kx
+        const int chunk = ((4 * kg) >> 5) * 4 + (kk >> 4) * 2 + ((kk >> 2) & 1);   // tile*4 + s*2 + half
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = c4 * 4 + j;
+            h4 s0, s1;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                s0[kx] = ah_hi(v[kx][j]);
+                s1[kx] = ah_lo(v[kx][j], s0[kx]);
+            }
+            _Float16* dst = buf + d * NKEY + ((chunk ^ ((d >> 2) & 3)) * 8) + e0;
+            *(h4*)dst = s0;
+            *(h4*)(dst + VPL) = s1;
+        }
+    }
+
+    // ---- softmax over keys (fp32, in registers) ----
+    if (active) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = key < Lk ? s[kt][r] * scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+    }
+    __syncthreads();  // V^T is in LDS
+
+    if (active) {
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        const _Float16* v0r = buf + l31 * NKEY;          // d = l31
+        const _Float16* v1r = buf + (32 + l31) * NKEY;   // d = 32 + l31   ((d>>2)&3 is the same for both)
+        const int sw = (l31 >> 2) & 3;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                h8 p0, p1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = s[kt][8 * st + e];
+                    p0[e] = (_Float16)pv;                 // p in [0, 1]
+                    p1[e] = (_Float16)(pv - (float)p0[e]);
+                }
+                const int off = ((kt * 4 + st * 2 + hh) ^ sw) * 8;
+                const h8 va0 = *(const h8*)(v0r + off), va1 = *(const h8*)(v0r + VPL + off);
+                const h8 vb0 = *(const h8*)(v1r + off), vb1 = *(const h8*)(v1r + VPL + off);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, va0, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, va1, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, va0, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, vb0, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, vb1, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, vb0, o1, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (qr < Lq) {
+                float* op = O + ((size_t)b * Lq + qr) * ldo + head * 64 + l31;
+                op[0] = o0[r];
+                op[32] = o1[r];
+            }
+        }
+    }
+}
+
+extern "C" int ds_attention_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                                  int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(q && k && v && o, "null pointer");
+    DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "bad shape");
+    DS_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "leading dims must be multiples of 4");
+    const int qtiles = (Lq + 31) / 32;
+    const int groups = (qtiles + AH_WAVES - 1) / AH_WAVES;
+    dim3 grid(groups * heads, B), block(AH_WAVES * 64);
+    static bool attr9 = false, attr3 = false;
+    if (Lk <= 96) {
+        const size_t lds = (size_t)2 * 96 * 64 * sizeof(unsigned short);
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((ds_attn_f16x2_kernel<3>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
+                           heads, scale);
+    } else {
+        DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
+        const size_t lds = (size_t)2 * 288 * 64 * sizeof(unsigned short);
+        if (!attr9) {
+            hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<9>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                ds_set_error("attention_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return -2;
+            }
+            attr9 = true;
+        }
+        hipLaunchKernelGGL((ds_attn_f16x2_kernel<9>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
+                           heads, scale);
+    }
+    DS_CHECK_LAUNCH();
+    return 0;
+}
