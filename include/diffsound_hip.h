@@ -55,6 +55,13 @@ typedef struct ds_gemm_desc {
     int32_t f16_round;       /* 1: round outputs (and GELU2 intermediates) to the fp16 grid (CLIP text tower) */
     int64_t w3_plane;        /* split kernels only: W holds 3 bf16 / 2 fp16 planes [N][ldw], w3_plane elements apart */
     float out_scale;         /* ds_gemm_f16x2 only: 2^-s undoing the exact power-of-two pre-scale of W */
+    /* ds_gemm_f16x2 only -- "packed split planes" of X[R][K] (K % 32 == 0): two fp16 planes (hi, lo), each
+       [ceil(R/16)][K/32][16 rows][4 chunks][8 halves] with 16-byte chunk c of row r stored at chunk c ^ ((r>>2)&3);
+       element (r,k) at ((r/16)*(K/32) + k/32)*512 + (r%16)*32 + (((k/8)%4) ^ ((r/4)%4))*8 + k%8.
+       a_split: A AND W are given in that layout (lda = ldw = K; planes a_plane / w3_plane halves apart), staged by
+       LDS-DMA.  c_split: C is written in that layout with row length ldc (planes c_plane halves apart). */
+    int32_t a_split, c_split;
+    int64_t a_plane, c_plane;
 } ds_gemm_desc;
 
 int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream);
@@ -93,6 +100,14 @@ int ds_attention_ex(const float* q, int ldq, const float* k, int ldk, const floa
  * ~5x fewer MFMA cycles (attention_f16x2.hip); used by the denoiser in f16x2 mode */
 int ds_attention_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                        int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
+/* producers that write packed split planes for ds_gemm_f16x2 (a_split): yh / oh = 2 planes of ceil16(rows) * (D or
+   ldo) halves, layout as described at ds_gemm_desc.a_split */
+int ds_adaln_split(const float* x, void* yh, int M, int L, int D, const float* table, const int64_t* t,
+                   ds_stream_t stream);
+int ds_layernorm_split(const float* x, void* yh, int M, int D, const float* gamma, const float* beta,
+                       ds_stream_t stream);
+int ds_attention_f16x2_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, void* oh,
+                             int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
 /* fp16-semantics row kernels of the CLIP text tower (sound_synthesis/modeling/modules/clip/model.py:150-157,
  * 341-354; embeddings/clip_text_embedding.py:46-88): fp32 storage, outputs rounded to the fp16 grid */
 int ds_embed_f16(const int64_t* tokens, const float* emb, const float* pos, float* out, int M, int L, int D,

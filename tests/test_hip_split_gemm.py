@@ -170,3 +170,81 @@ def test_attention_f16x2_strided_qkv_and_speed():
         e1.record()
         torch.cuda.synchronize()
         print("self-attention B=64 %s: %.1f us" % (name, e0.elapsed_time(e1) * 100))
+
+
+# ---- packed split planes: producers write them, the GEMM stages them by LDS-DMA -------------------------------------
+def torch_split(a):
+    """ds_split_hi/lo (csrc/common.h) in torch: hi = fp16(clamp(a)), lo = fp16(clamp(a - hi))."""
+    hi = a.clamp(-65504.0, 65504.0).half()
+    lo = (a - hi.float()).clamp(-65504.0, 65504.0).half()
+    return torch.stack((hi, lo)).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(530, 1024, 1024), (300, 256, 1024), (530, 1024, 4096), (64, 96, 32), (1, 32, 64),
+                                   (2100, 1024, 1024)])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+def test_f16x2_packed_operands_bit_identical(M, N, K, tile):
+    """A and W handed over as packed split planes (LDS-DMA staging) give the same bits as the loader-split GEMM on
+    row-major operands; C written packed is the packed split of C."""
+    from text_to_sound_synthesis_amd import _lib as L
+    A, W, b = rnd((M, K), "psA", 3.0), rnd((N, K), "psW", 0.1), rnd((N,), "psb")
+    A[0, :6] = torch.tensor([1e-6, -3e4, 7e4, -1e5, -1e-9, 0.0])       # includes values past the fp16 range
+    Ac, bc = A.cuda(), b.cuda()
+    W2, sc = L.split_f16x2(W.cuda())
+    W2p, scp = L.split_f16x2(W.cuda(), packed=True)
+    assert sc == scp
+    A2p = L.pack_planes(torch_split(Ac))
+    M16 = (M + 15) // 16 * 16
+    L.lib().ds_gemm_f16x2_force_tile(tile)
+    try:
+        for act in (L.ACT_NONE, L.ACT_GELU2):
+            ref = torch.empty(M, N, device="cuda")
+            L.gemm(Ac, W2, ref, M, N, K, bias=bc, act=act, split2=sc)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            L.gemm(A2p, W2p, out, M, N, K, bias=bc, act=act, split2=sc, a_plane=M16 * K)
+            assert torch.equal(out, ref)
+            if N % 32 == 0:
+                outs = torch.zeros(2, M16 * N, device="cuda", dtype=torch.float16)
+                L.gemm(A2p, W2p, outs, M, N, K, bias=bc, act=act, split2=sc, a_plane=M16 * K, c_plane=M16 * N)
+                assert torch.equal(L.unpack_planes(outs, M, N), torch_split(ref))
+    finally:
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+
+
+def test_split_producers_bit_identical():
+    """ds_adaln_split / ds_layernorm_split / ds_attention_f16x2_split == packed split of the fp32-output kernels."""
+    from text_to_sound_synthesis_amd import _lib as L
+    M, Lr, D, H = 530, 265, 1024, 16
+    M16 = (M + 15) // 16 * 16
+    x = rnd((M, D), "pp.x", 4.0).cuda()
+    tab = rnd((100, 2 * D), "pp.tab").cuda()
+    t = torch.tensor([3, 97], dtype=torch.int64).cuda()
+    g, b = rnd((D,), "pp.g").cuda(), rnd((D,), "pp.b").cuda()
+    y, ys = torch.empty(M, D, device="cuda"), torch.zeros(2, M16 * D, device="cuda", dtype=torch.float16)
+    L.check(L.lib().ds_adaln(L.ptr(x), L.ptr(y), M, Lr, D, L.ptr(tab), L.ptr(t), L.stream()))
+    L.check(L.lib().ds_adaln_split(L.ptr(x), L.ptr(ys), M, Lr, D, L.ptr(tab), L.ptr(t), L.stream()))
+    assert torch.equal(L.unpack_planes(ys, M, D), torch_split(y))
+    ys.zero_()
+    L.check(L.lib().ds_layernorm(L.ptr(x), L.ptr(y), M, D, L.ptr(g), L.ptr(b), L.stream()))
+    L.check(L.lib().ds_layernorm_split(L.ptr(x), L.ptr(ys), M, D, L.ptr(g), L.ptr(b), L.stream()))
+    assert torch.equal(L.unpack_planes(ys, M, D), torch_split(y))
+    for Lk in (265, 77):
+        q, k, v = rnd((2, Lr, D), "pp.q").cuda(), rnd((2, Lk, D), "pp.k").cuda(), rnd((2, Lk, D), "pp.v", 300.0).cuda()
+        ys.zero_()
+        args = (L.ptr(q), D, L.ptr(k), D, L.ptr(v), D)
+        L.check(L.lib().ds_attention_f16x2(*args, L.ptr(y), D, 2, H, Lr, Lk, 0.125, L.stream()))
+        L.check(L.lib().ds_attention_f16x2_split(*args, L.ptr(ys), D, 2, H, Lr, Lk, 0.125, L.stream()))
+        assert torch.equal(L.unpack_planes(ys, M, D), torch_split(y))
+
+
+def test_packed_gemm_argument_checks():
+    from text_to_sound_synthesis_amd import _lib as L
+    A2 = torch.zeros(2, 16 * 32, device="cuda", dtype=torch.float16)
+    W2, sc = L.split_f16x2(torch.ones(32, 32, device="cuda"), packed=True)
+    out = torch.empty(8, 32, device="cuda")
+    with pytest.raises(L.DiffsoundHipError):        # plane stride smaller than ceil16(M) * K
+        L.gemm(A2, W2, out, 8, 32, 32, split2=sc, a_plane=8 * 32)
+    with pytest.raises(L.DiffsoundHipError):        # a packed output cannot take a residual
+        L.gemm(A2, W2, out, 8, 32, 32, R=out, split2=sc, a_plane=16 * 32, c_plane=16 * 32)
+    L.gemm(A2, W2, out, 8, 32, 32, split2=sc, a_plane=16 * 32)
+    assert torch.equal(out, torch.zeros_like(out))

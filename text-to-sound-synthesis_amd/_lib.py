@@ -30,7 +30,8 @@ class GemmDesc(C.Structure):
                 ("pro_scale", _vp), ("pro_shift", _vp),
                 ("rows_per_sample", _i32), ("Cin", _i32), ("H", _i32), ("Wd", _i32), ("up", _i32),
                 ("taps", _i32), ("dil", _i32), ("ct_r", _i32), ("ct_p", _i32), ("ct_tin", _i32),
-                ("f16_round", _i32), ("w3_plane", _i64), ("out_scale", _f)]
+                ("f16_round", _i32), ("w3_plane", _i64), ("out_scale", _f),
+                ("a_split", _i32), ("c_split", _i32), ("a_plane", _i64), ("c_plane", _i64)]
 
 
 class DenoiserDesc(C.Structure):
@@ -60,6 +61,10 @@ _PROTOS = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_int, _vp]),
     "ds_attention_f16x2": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_adaln_split": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "ds_layernorm_split": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "ds_attention_f16x2_split": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_embed_f16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_layernorm_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ds_l2norm_rows_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
@@ -133,9 +138,12 @@ def stream():
 def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=None, ldr=None,
          groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
          act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
-         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split3=False, split2=None):
+         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split3=False, split2=None,
+         a_plane=0, c_plane=0):
     """split3: W is the [3][N][K] bf16 split from split_bf16x3() and the bf16x3 kernel is used.
-    split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used."""
+    split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used;
+    a_plane / c_plane > 0 (f16x2 only): A and W are given / C is written as packed split planes (pack_planes())
+    that many halves apart."""
     d = GemmDesc()
     d.A, d.W, d.bias, d.R, d.C = ptr(A), ptr(W), ptr(bias), ptr(R), ptr(C_out)
     d.M, d.N, d.K = M, N, K
@@ -155,6 +163,10 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
     elif split2 is not None:
         d.w3_plane = N * d.ldw
         d.out_scale = split2
+        d.a_split, d.a_plane = int(a_plane > 0), a_plane
+        if a_plane > 0:
+            d.w3_plane = (N + 15) // 16 * 16 * d.ldw          # packed W: rows padded to 16
+        d.c_split, d.c_plane = int(c_plane > 0), c_plane
         check(lib().ds_gemm_f16x2(C.byref(d), stream()))
     else:
         check(lib().ds_gemm(C.byref(d), stream()))
@@ -172,9 +184,35 @@ def split_bf16x3(w):
     return torch.stack((p0, p1, p2)).contiguous().view(torch.int16)
 
 
-def split_f16x2(w):
+def pack_planes(x2):
+    """[2][R][K] fp16 planes -> the packed layout of include/diffsound_hip.h (ds_gemm_desc.a_split):
+    [2][ceil(R/16)][K/32][16][4][8], chunk c of row r at position c ^ ((r >> 2) & 3); rows zero-padded to 16."""
+    two, R, K = x2.shape
+    assert two == 2 and K % 32 == 0
+    R16 = (R + 15) // 16 * 16
+    x = torch.zeros(2, R16, K, dtype=x2.dtype, device=x2.device)
+    x[:, :R] = x2
+    x = x.view(2, R16 // 16, 16, K // 32, 4, 8).permute(0, 1, 3, 2, 4, 5)       # [2][rg][kt][16 rows][4 chunks][8]
+    r = torch.arange(16, device=x2.device)
+    src = torch.arange(4, device=x2.device)[None, :] ^ ((r[:, None] >> 2) & 3)    # position p holds chunk p ^ swz(r)
+    idx = src[None, None, None, :, :, None].expand(2, R16 // 16, K // 32, 16, 4, 8)
+    return torch.gather(x, 4, idx).contiguous()
+
+
+def unpack_planes(xp, R, K):
+    """inverse of pack_planes: packed planes -> [2][R][K]"""
+    xp = xp.reshape(2, -1, K // 32, 16, 4, 8)
+    r = torch.arange(16, device=xp.device)
+    src = torch.arange(4, device=xp.device)[None, :] ^ ((r[:, None] >> 2) & 3)    # the swizzle is an involution
+    idx = src[None, None, None, :, :, None].expand(xp.shape)
+    x = torch.gather(xp, 4, idx).permute(0, 1, 3, 2, 4, 5).reshape(2, -1, K)
+    return x[:, :R].contiguous()
+
+
+def split_f16x2(w, packed=False):
     """fp32 [N][K] -> (int16 view of [2][N][K] fp16 planes of W * 2^s, out_scale = 2^-s).  s puts max|W| * 2^s in
-    [2^13, 2^14): both planes stay in fp16's normal range for every weight that matters, nothing overflows."""
+    [2^13, 2^14): both planes stay in fp16's normal range for every weight that matters, nothing overflows.
+    packed=True returns the planes in the packed layout (pack_planes) for GEMMs whose A operand is packed too."""
     import math
     w = w.detach().float()
     mx = float(w.abs().max())
@@ -182,4 +220,7 @@ def split_f16x2(w):
     ws = w * (2.0 ** s)
     p0 = ws.to(torch.float16)
     p1 = (ws - p0.float()).to(torch.float16)
-    return torch.stack((p0, p1)).contiguous().view(torch.int16), 2.0 ** (-s)
+    planes = torch.stack((p0, p1)).contiguous()
+    if packed:
+        planes = pack_planes(planes)
+    return planes.view(torch.int16), 2.0 ** (-s)

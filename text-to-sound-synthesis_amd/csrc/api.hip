@@ -30,6 +30,7 @@ static void fill(GemmParams& p, const ds_gemm_desc* d) {
     p.pro = d->pro; p.act = d->act; p.store = d->store; p.f16_round = d->f16_round;
     p.w3_plane = d->w3_plane;
     p.out_scale = d->out_scale;
+    p.a_split = d->a_split; p.c_split = d->c_split; p.a_plane = d->a_plane; p.c_plane = d->c_plane;
     p.pro_scale = d->pro_scale; p.pro_shift = d->pro_shift;
     p.rows_per_sample = d->rows_per_sample;
     p.Cin = d->Cin; p.H = d->H; p.W_ = d->Wd; p.up = d->up; p.taps = d->taps; p.dil = d->dil;
@@ -138,6 +139,7 @@ struct Carve {
 };
 static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c) {
     const size_t M = (size_t)B * h->d.seq_len, D = h->d.n_embd;
+    const size_t M16 = (M + 15) & ~(size_t)15;   // hn / att / fc double as packed split planes (rows padded to 16)
     size_t off = 0;
     auto take = [&](size_t n) {
         float* p = ws ? (float*)ws + off : nullptr;
@@ -146,10 +148,10 @@ static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c) {
     };
     Carve t;
     t.x = take(M * D);
-    t.hn = take(M * D);
+    t.hn = take(M16 * D);
     t.qkv = take(M * 3 * D);
-    t.att = take(M * D);
-    t.fc = take(M * D * h->d.mlp_mult);
+    t.att = take(M16 * D);
+    t.fc = take(M16 * D * h->d.mlp_mult);
     t.logits = take(M * h->d.n_codes);
     if (c) *c = t;
     return off * sizeof(float);
@@ -191,7 +193,8 @@ extern "C" int ds_profile_collect(double* ms, double* flops, int64_t* launches) 
 
 static int dense(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc,
                  int M, int N, int K, int act, hipStream_t s, int store = DS_STORE_ROW, int rps = 0,
-                 const void* W3 = nullptr, int split_mode = DS_SPLIT_NONE, float osc = 1.f) {
+                 const void* W3 = nullptr, int split_mode = DS_SPLIT_NONE, float osc = 1.f,
+                 long long a_plane = 0, long long c_plane = 0) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.W = W; p.bias = bias; p.R = R; p.C = C;
@@ -201,6 +204,9 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
         p.W = (const float*)W3;
         p.w3_plane = (long long)N * K;
         p.out_scale = osc;
+        p.a_split = a_plane > 0; p.a_plane = a_plane;   // f16x2 only: A and W are packed split planes
+        if (a_plane > 0) p.w3_plane = (long long)((N + 15) & ~15) * K;
+        p.c_split = c_plane > 0; p.c_plane = c_plane;
     }
     auto launch = [&]() {
         if (!W3) return ds_launch_gemm(p, s, DS_LOAD_DENSE);
@@ -239,42 +245,57 @@ extern "C" int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int 
 static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64_t* t, const float* kv, int B,
                         const Carve& w, float* logits, int layout, hipStream_t s) {
     const ds_denoiser_desc& d = h->d;
-    const int D = d.n_embd, L = d.seq_len, M = B * L, Mc = B * d.cond_len;
+    const int D = d.n_embd, L = d.seq_len, M = B * L, Mc = B * d.cond_len, F = D * d.mlp_mult;
     const float scale = 0.125f;  // 1/sqrt(64), transformer_utils.py:48
-    const bool f16 = h->split_mode == DS_SPLIT_F16X2;  // attention follows the GEMM arithmetic mode
+    // f16x2 mode: attention follows the GEMM arithmetic, and every GEMM input is produced as PACKED SPLIT PLANES
+    // (common.h ds_packed_off; two fp16 planes in the bytes of the fp32 buffer, rows padded to 16) by the kernel
+    // before it, with the same ds_split_hi/lo code the GEMM loader would run -- results are bit-identical to
+    // splitting in the loader, and the GEMM stages its tiles by LDS-DMA.
+    const bool f16 = h->split_mode == DS_SPLIT_F16X2;
+    const long long M16 = (M + 15) & ~15;
+    const long long pD = f16 ? M16 * D : 0, pF = f16 ? M16 * F : 0;
+    auto adaln = [&](int l, int slot) {
+        return f16 ? ds_adaln_split(w.x, w.hn, M, L, D, h->P(l, slot), t, s)
+                   : ds_adaln(w.x, w.hn, M, L, D, h->P(l, slot), t, s);
+    };
+    auto lnorm = [&](const float* g, const float* b_) {
+        return f16 ? ds_layernorm_split(w.x, w.hn, M, D, g, b_, s) : ds_layernorm(w.x, w.hn, M, D, g, b_, s);
+    };
+    auto attn = [&](const float* q, int ldq, const float* k, const float* v, int ldkv, int Lk) {
+        return f16 ? ds_attention_f16x2_split(q, ldq, k, ldkv, v, ldkv, w.att, D, B, d.n_head, L, Lk, scale, s)
+                   : ds_attention(q, ldq, k, ldkv, v, ldkv, w.att, D, B, d.n_head, L, Lk, scale, s);
+    };
+    // y = act(A W^T + b) (+ R) for layer-l weight `slot`; A (and optionally C) pre-split in f16x2 mode
+    auto lin = [&](int l, int slot, int bslot, const float* A, int lda, long long ap, const float* R, float* C, int N,
+                   int K, int act, long long cp) {
+        return dense(A, lda, h->P(l, slot), h->P(l, bslot), R, C, N, M, N, K, act, s, DS_STORE_ROW, 0, h->P3(l, slot),
+                     h->split_mode, h->S3(l, slot), ap, cp);
+    };
     TRY(ds_embed(tokens, d.tok_emb, d.pos_emb, w.x, M, L, D, s));
     for (int l = 0; l < d.n_layer; ++l) {
         // x += attn1(ln1(x, t))
-        TRY(ds_adaln(w.x, w.hn, M, L, D, h->P(l, DS_LP_ADALN1), t, s));
-        TRY(dense(w.hn, D, h->P(l, DS_LP_W_QKV), h->P(l, DS_LP_B_QKV), nullptr, w.qkv, 3 * D, M, 3 * D, D, DS_ACT_NONE, s,
-                  DS_STORE_ROW, 0, h->P3(l, DS_LP_W_QKV), h->split_mode, h->S3(l, DS_LP_W_QKV)));
-        TRY((f16 ? ds_attention_f16x2 : ds_attention)(w.qkv, 3 * D, w.qkv + D, 3 * D, w.qkv + 2 * D, 3 * D, w.att, D, B,
-                                                       d.n_head, L, L, scale, s));
-        TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ1), h->P(l, DS_LP_B_PROJ1), w.x, w.x, D, M, D, D, DS_ACT_NONE, s,
-                  DS_STORE_ROW, 0, h->P3(l, DS_LP_W_PROJ1), h->split_mode, h->S3(l, DS_LP_W_PROJ1)));
+        TRY(adaln(l, DS_LP_ADALN1));
+        TRY(lin(l, DS_LP_W_QKV, DS_LP_B_QKV, w.hn, D, pD, nullptr, w.qkv, 3 * D, D, DS_ACT_NONE, 0));
+        TRY(attn(w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, L));
+        TRY(lin(l, DS_LP_W_PROJ1, DS_LP_B_PROJ1, w.att, D, pD, w.x, w.x, D, D, DS_ACT_NONE, 0));
         // x += attn2(ln1_1(x, t), cond)
-        TRY(ds_adaln(w.x, w.hn, M, L, D, h->P(l, DS_LP_ADALN2), t, s));
-        TRY(dense(w.hn, D, h->P(l, DS_LP_W_Q2), h->P(l, DS_LP_B_Q2), nullptr, w.qkv, D, M, D, D, DS_ACT_NONE, s,
-                  DS_STORE_ROW, 0, h->P3(l, DS_LP_W_Q2), h->split_mode, h->S3(l, DS_LP_W_Q2)));
+        TRY(adaln(l, DS_LP_ADALN2));
+        TRY(lin(l, DS_LP_W_Q2, DS_LP_B_Q2, w.hn, D, pD, nullptr, w.qkv, D, D, DS_ACT_NONE, 0));
         const float* kvl = kv + (size_t)l * Mc * 2 * D;
-        TRY((f16 ? ds_attention_f16x2 : ds_attention)(w.qkv, D, kvl, 2 * D, kvl + D, 2 * D, w.att, D, B, d.n_head, L,
-                                                       d.cond_len, scale, s));
-        TRY(dense(w.att, D, h->P(l, DS_LP_W_PROJ2), h->P(l, DS_LP_B_PROJ2), w.x, w.x, D, M, D, D, DS_ACT_NONE, s,
-                  DS_STORE_ROW, 0, h->P3(l, DS_LP_W_PROJ2), h->split_mode, h->S3(l, DS_LP_W_PROJ2)));
+        TRY(attn(w.qkv, D, kvl, kvl + D, 2 * D, d.cond_len));
+        TRY(lin(l, DS_LP_W_PROJ2, DS_LP_B_PROJ2, w.att, D, pD, w.x, w.x, D, D, DS_ACT_NONE, 0));
         // x += mlp(ln2(x))
-        TRY(ds_layernorm(w.x, w.hn, M, D, h->P(l, DS_LP_LN2_G), h->P(l, DS_LP_LN2_B), s));
-        TRY(dense(w.hn, D, h->P(l, DS_LP_W_FC1), h->P(l, DS_LP_B_FC1), nullptr, w.fc, D * d.mlp_mult, M, D * d.mlp_mult, D,
-                  DS_ACT_GELU2, s, DS_STORE_ROW, 0, h->P3(l, DS_LP_W_FC1), h->split_mode, h->S3(l, DS_LP_W_FC1)));
-        TRY(dense(w.fc, D * d.mlp_mult, h->P(l, DS_LP_W_FC2), h->P(l, DS_LP_B_FC2), w.x, w.x, D, M, D, D * d.mlp_mult,
-                  DS_ACT_NONE, s, DS_STORE_ROW, 0, h->P3(l, DS_LP_W_FC2), h->split_mode, h->S3(l, DS_LP_W_FC2)));
+        TRY(lnorm(h->P(l, DS_LP_LN2_G), h->P(l, DS_LP_LN2_B)));
+        TRY(lin(l, DS_LP_W_FC1, DS_LP_B_FC1, w.hn, D, pD, nullptr, w.fc, F, D, DS_ACT_GELU2, pF));
+        TRY(lin(l, DS_LP_W_FC2, DS_LP_B_FC2, w.fc, F, pF, w.x, w.x, D, F, DS_ACT_NONE, 0));
     }
-    TRY(ds_layernorm(w.x, w.hn, M, D, d.lnf_g, d.lnf_b, s));
+    TRY(lnorm(d.lnf_g, d.lnf_b));
     if (layout == 0)
         TRY(dense(w.hn, D, d.w_logits, d.b_logits, nullptr, logits, d.n_codes, M, d.n_codes, D, DS_ACT_NONE, s,
-                  DS_STORE_ROW, 0, h->w_logits3, h->split_mode, h->logits_osc));
+                  DS_STORE_ROW, 0, h->w_logits3, h->split_mode, h->logits_osc, pD));
     else
         TRY(dense(w.hn, D, d.w_logits, d.b_logits, nullptr, logits, L, M, d.n_codes, D, DS_ACT_NONE, s,
-                  DS_STORE_BATCH_T, L, h->w_logits3, h->split_mode, h->logits_osc));
+                  DS_STORE_BATCH_T, L, h->w_logits3, h->split_mode, h->logits_osc, pD));
     return 0;
 }
 

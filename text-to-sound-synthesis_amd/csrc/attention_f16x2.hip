@@ -21,17 +21,15 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define AH_WAVES 3
 
-__device__ __forceinline__ _Float16 ah_hi(float a) { return (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); }
-__device__ __forceinline__ _Float16 ah_lo(float a, _Float16 h) {
-    return (_Float16)__builtin_amdgcn_fmed3f(a - (float)h, -65504.f, 65504.f);
-}
+__device__ __forceinline__ _Float16 ah_hi(float a) { return ds_split_hi(a); }
+__device__ __forceinline__ _Float16 ah_lo(float a, _Float16 h) { return ds_split_lo(a, h); }
 
 template <int NKT>
 __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const float* __restrict__ Q, int ldq,
                                                                         const float* __restrict__ Kp, int ldk,
                                                                         const float* __restrict__ Vp, int ldv,
                                                                         float* __restrict__ O, int ldo, int Lq, int Lk,
-                                                                        int heads, float scale) {
+                                                                        int heads, float scale, long long o_plane) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NKEY = NKT * 32;
     constexpr int KPL = NKEY * 64;   // halves per K plane   ([key][64 d])
@@ -218,17 +216,27 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
         for (int r = 0; r < 16; ++r) {
             const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (qr < Lq) {
-                float* op = O + ((size_t)b * Lq + qr) * ldo + head * 64 + l31;
-                op[0] = o0[r];
-                op[32] = o1[r];
+                const size_t off = ((size_t)b * Lq + qr) * ldo + head * 64 + l31;
+                if (o_plane > 0) {   // packed split planes for the f16x2 projection GEMM (K = ldo)
+                    _Float16* oh = (_Float16*)O;
+                    const size_t p0 = ds_packed_off(b * Lq + qr, head * 64 + l31, ldo >> 5), p1 = p0 + 512;  // next k tile
+                    const _Float16 a0 = ds_split_hi(o0[r]), a1 = ds_split_hi(o1[r]);
+                    oh[p0] = a0;
+                    oh[p1] = a1;
+                    oh[o_plane + p0] = ds_split_lo(o0[r], a0);
+                    oh[o_plane + p1] = ds_split_lo(o1[r], a1);
+                } else {
+                    O[off] = o0[r];
+                    O[off + 32] = o1[r];
+                }
             }
         }
     }
 }
 
-extern "C" int ds_attention_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
-                                  int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int attn_f16x2_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                             int ldo, int B, int heads, int Lq, int Lk, float scale, long long o_plane,
+                             hipStream_t stream) {
     DS_CHECK_ARG(q && k && v && o, "null pointer");
     DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "bad shape");
     DS_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "leading dims must be multiples of 4");
@@ -244,7 +252,7 @@ extern "C" int ds_attention_f16x2(const float* q, int ldq, const float* k, int l
             attr3 = true;
         }
         hipLaunchKernelGGL((ds_attn_f16x2_kernel<3>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
-                           heads, scale);
+                           heads, scale, o_plane);
     } else {
         DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
         const size_t lds = (size_t)2 * 288 * 64 * sizeof(unsigned short);
@@ -258,8 +266,22 @@ extern "C" int ds_attention_f16x2(const float* q, int ldq, const float* k, int l
             attr9 = true;
         }
         hipLaunchKernelGGL((ds_attn_f16x2_kernel<9>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
-                           heads, scale);
+                           heads, scale, o_plane);
     }
     DS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ds_attention_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                                  int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream) {
+    return attn_f16x2_launch(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Lq, Lk, scale, 0, (hipStream_t)stream);
+}
+
+// output written as packed split planes (2 planes of ceil16(B*Lq) * ldo halves), ldo % 32 == 0
+extern "C" int ds_attention_f16x2_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                        void* oh, int ldo, int B, int heads, int Lq, int Lk, float scale,
+                                        ds_stream_t stream) {
+    DS_CHECK_ARG(ldo % 32 == 0 && ldo >= heads * 64, "packed output needs ldo % 32 == 0");
+    return attn_f16x2_launch(q, ldq, k, ldk, v, ldv, (float*)oh, ldo, B, heads, Lq, Lk, scale,
+                             (long long)((B * Lq + 15) & ~15) * ldo, (hipStream_t)stream);
 }

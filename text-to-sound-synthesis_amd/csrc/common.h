@@ -13,6 +13,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (sound_synthesis/modeling/modules/clip/model.py:432 convert_weights) on fp32 storage
 __device__ __forceinline__ float ds_r16(float x) { return (float)(_Float16)x; }
 
+// the f16x2 split  a = hi + lo  (gemm_f16x2.hip): identical code in every producer and consumer, so a value
+// split by a producing kernel is bit-identical to the split the GEMM loader would have computed itself
+__device__ __forceinline__ _Float16 ds_split_hi(float a) {
+    return (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);  // saturate instead of overflowing to inf
+}
+__device__ __forceinline__ _Float16 ds_split_lo(float a, _Float16 hi) {
+    return (_Float16)__builtin_amdgcn_fmed3f(a - (float)hi, -65504.f, 65504.f);  // a - hi is exact in fp32
+}
+
+// "Packed split planes": the HBM layout of every pre-split f16x2 GEMM operand (activations written by the
+// ds_*_split producers and the GEMM's c_split epilogue; weights packed once by _lib.split_f16x2(packed=True)).
+// For X[R][K], K % 32 == 0, each of the two fp16 planes is  [ceil(R/16)][K/32][16 rows][4 chunks][8 halves]:
+// a 16-row x 32-k tile is one contiguous KB that already is the GEMM's LDS image (16-byte chunk c of row r sits
+// at chunk position c ^ ((r >> 2) & 3), the bank swizzle of the fragment reads), so one global_load_lds_dwordx4
+// per wave moves it verbatim: full-cacheline requests, no address math, no staging registers.
+__device__ __forceinline__ size_t ds_packed_off(int row, int col, int ktiles) {
+    return ((size_t)(row >> 4) * ktiles + (col >> 5)) * 512 + (row & 15) * 32 +
+           ((((col >> 3) & 3) ^ ((row >> 2) & 3)) << 3) + (col & 7);
+}
+
 // ---- error plumbing (C ABI returns int; message kept per thread) -------------------------
 void ds_set_error(const char* fmt, ...);
 #define DS_CHECK_ARG(cond, msg)                                   \
@@ -50,6 +70,8 @@ struct GemmParams {
     int f16_round;              // 1: outputs (and GELU2 intermediates) are rounded to the fp16 grid
     long long w3_plane;         // split kernels: W = 3 bf16 / 2 fp16 planes of [N][ldw], this many elements apart
     float out_scale;            // f16x2 kernel: 2^-s undoing the weight pre-scale
+    int a_split, c_split;       // f16x2 kernel: A (and then W too) is given / C is written as packed split planes
+    long long a_plane, c_plane; //   (ds_packed_off); plane strides in halves; lda / ldc = the row length K of that matrix
     // prologue: per-(sample, channel) affine  a' = a*pro_scale[b*Cin+c] + pro_shift[b*Cin+c]
     const float* pro_scale;
     const float* pro_shift;

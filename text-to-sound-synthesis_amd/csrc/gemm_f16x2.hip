@@ -31,7 +31,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // two consecutive rows x 4 chunks -> 32 distinct banks.  (With the earlier 80-byte padded rows the reads were
 // clean but every staging write was a 2-way conflict: SQ_LDS_BANK_CONFLICT = 1/3 of the LDS busy cycles.)
 
-template <int BM, int BN>
+// AMODE 0: A is fp32 row-major and is split by the loader (register staging: global -> VGPR -> split -> ds_write);
+//          W = two row-major fp16 planes [2][N][ldw].
+// AMODE 2: A and W are packed split planes (common.h ds_packed_off: 16-row x 32-k tiles of 1 KB that already are
+//          the LDS image) and are staged by LDS-DMA, one global_load_lds_dwordx4 per wave per KB.  Measured on the
+//          denoiser's shapes (tools/probe): with row-major planes the loop was bound by the L2 -> CU path (64-byte
+//          half-cacheline requests at a 2-8 KB row stride: ~13 TB/s delivered, as long as the whole kernel); packed
+//          tiles fetch 1.6x faster and leave the MFMA pipe as the busiest unit.
+typedef __attribute__((address_space(1))) const void* ds_gptr;
+typedef __attribute__((address_space(3))) void* ds_lptr;
+
+template <int BM, int BN, int AMODE>
 __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -54,8 +64,17 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
         const int q = nblk >> 3, r = nblk & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    // grouped raster inside the XCD's contiguous range: 8 row tiles x all column tiles per group, column-major
+    // inside the group, so the ~64 workgroups resident on an XCD share each A / W k-slice 8 ways in its L2
+    int m0, n0;
+    {
+        const int tiles_m = (p.M + BM - 1) / BM;
+        const int per = 8 * tiles_n, grp = bid / per, first = grp * 8;
+        const int gsz = tiles_m - first < 8 ? tiles_m - first : 8;
+        const int in = bid - grp * per;
+        m0 = (first + in % gsz) * BM;
+        n0 = (in / gsz) * BN;
+    }
 
     // A and B use the same chunking: chunk c = tid + 256 i covers row c>>2 and the 8 consecutive k at (c&3)*8
     // (A: two float4 loads -> one 16-byte ds_write per fp16 plane; 4 lanes cover one 128-byte row segment)
@@ -119,16 +138,13 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
         _Float16* As_ = smem + (stage_) * STAGE;                                                    \
         _Float16* Bs_ = As_ + 2 * APL;                                                              \
         _Pragma("unroll") for (int i = 0; i < SA; ++i) {                                            \
+            _Float16* dst = As_ + a_row[i] * HLD + a_k8[i];                                         \
             h8 s0, s1;                                                                              \
             _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                         \
                 const float a = RA[2 * i + (e >> 2)][e & 3];                                        \
-                /* saturate instead of overflowing to inf: |a| up to 2*65504 stays finite */         \
-                const _Float16 q0 = (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);        \
-                s0[e] = q0;                                                                         \
-                /* a - q0 is exact in fp32; the clamp only acts beyond the fp16 range */            \
-                s1[e] = (_Float16)__builtin_amdgcn_fmed3f(a - (float)q0, -65504.f, 65504.f);        \
+                s0[e] = ds_split_hi(a);                                                             \
+                s1[e] = ds_split_lo(a, s0[e]);                                                      \
             }                                                                                       \
-            _Float16* dst = As_ + a_row[i] * HLD + a_k8[i];                                         \
             *(h8*)(dst) = s0;                                                                       \
             *(h8*)(dst + APL) = s1;                                                                 \
         }                                                                                           \
@@ -185,17 +201,86 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
     } while (0)
 
     const int nk = p.K / HBK;
-    H_ISSUE_LOADS(raX, rb0X, rb1X, 0);
-    H_WRITE_LDS(raX, rb0X, rb1X, 0);
-    H_ISSUE_LOADS(raX, rb0X, rb1X, (nk > 1 ? 1 : 0) * HBK);
-    __syncthreads();
+    if constexpr (AMODE == 2) {
+        // LDS image of a stage = 2*(BM+BN) rows of 64 B: A hi rows, A lo rows, B hi rows, B lo rows.  One DMA
+        // instruction of a wave fills 16 consecutive rows = one packed 16-row x 32-k tile (lane l -> bytes 16 l);
+        // the wave owns the 16-row groups g = wave + 4 i.
+        constexpr int G = (BM + BN) / 32;
+        const _Float16* src[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            int r = 16 * (wave + 4 * i);                     // first row of the group within the stage image
+            const _Float16* base;
+            int rg, rgs;
+            if (r < 2 * BM) {
+                base = (const _Float16*)p.A;
+                if (r >= BM) { r -= BM; base += p.a_plane; }
+                rg = (m0 + r) >> 4; rgs = (p.M + 15) >> 4;
+            } else {
+                r -= 2 * BM;
+                base = (const _Float16*)p.W;
+                if (r >= BN) { r -= BN; base += pl1; }
+                rg = (n0 + r) >> 4; rgs = (p.N + 15) >> 4;
+            }
+            if (rg >= rgs) rg = rgs - 1;                     // tail groups re-read the last group (never stored)
+            src[i] = base + (size_t)rg * nk * 512 + lane * 8;
+        }
+#define H_DMA(stage_, k0_)                                                                          \
+    do {                                                                                            \
+        unsigned char* d_ = smem_raw + (stage_) * (STAGE * 2) + wave * 1024;                        \
+        _Pragma("unroll") for (int i = 0; i < G; ++i)                                               \
+            __builtin_amdgcn_global_load_lds((ds_gptr)(src[i] + (k0_)), (ds_lptr)(d_ + i * 4096), 16, 0, 0); \
+    } while (0)
+        // all 4 (TM + TN) fragment reads of the k-tile are issued back to back, then its 6 TM TN MFMAs: the LDS
+        // latency is paid once per tile and the other resident workgroups' MFMAs fill it
+#define H_COMPUTE_ALL(cur_)                                                                         \
+    do {                                                                                            \
+        const _Float16* Ac = smem + (cur_) * STAGE + (wm * TM * 32 + l31) * HLD;                    \
+        const _Float16* Bc = smem + (cur_) * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD;          \
+        h8 fa0[2][TM], fa1[2][TM], fb0[2][TN], fb1[2][TN];                                          \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+                fa0[ks][i] = *(const h8*)(Ac + i * 32 * HLD + swz[ks]);                             \
+                fa1[ks][i] = *(const h8*)(Ac + APL + i * 32 * HLD + swz[ks]);                       \
+            }                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
+                fb0[ks][j] = *(const h8*)(Bc + j * 32 * HLD + swz[ks]);                             \
+                fb1[ks][j] = *(const h8*)(Bc + BPL + j * 32 * HLD + swz[ks]);                       \
+            }                                                                                       \
+        }                                                                                           \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                    \
+                    f32x16 c = acc[i][j];                                                           \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[ks][i], fb0[ks][j], c, 0, 0, 0); \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb1[ks][j], c, 0, 0, 0); \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb0[ks][j], c, 0, 0, 0); \
+                    acc[i][j] = c;                                                                  \
+                }                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0); /* DS reads */               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);   /* MFMA */                   \
+    } while (0)
+        static_assert(HBK == 32, "two 16-wide k-steps per tile");
+        H_DMA(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();   // tile kt has landed (vmcnt(0) precedes the barrier) and stage (kt+1)&1 is free
+            if (kt + 1 < nk) H_DMA((kt + 1) & 1, (kt + 1) * 512);
+            H_COMPUTE_ALL(kt & 1);
+        }
+    } else {
+        const int nk = p.K / HBK;
+        H_ISSUE_LOADS(raX, rb0X, rb1X, 0);
+        H_WRITE_LDS(raX, rb0X, rb1X, 0);
+        H_ISSUE_LOADS(raX, rb0X, rb1X, (nk > 1 ? 1 : 0) * HBK);
+        __syncthreads();
 
-    int cur = 0, kt = 0;
-    while (kt + 1 < nk) {
-        H_BODY(raX, rb0X, rb1X, raY, rb0Y, rb1Y);
-        H_BODY(raY, rb0Y, rb1Y, raX, rb0X, rb1X);
+        int cur = 0, kt = 0;
+        while (kt + 1 < nk) {
+            H_BODY(raX, rb0X, rb1X, raY, rb0Y, rb1Y);
+            H_BODY(raY, rb0Y, rb1Y, raX, rb0X, rb1X);
+        }
+        if (kt < nk) H_BODY(raX, rb0X, rb1X, raY, rb0Y, rb1Y);
     }
-    if (kt < nk) H_BODY(raX, rb0X, rb1X, raY, rb0Y, rb1Y);
 
     const float osc = p.out_scale;
 #pragma unroll
@@ -219,18 +304,25 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
                     off = ((size_t)b * p.N + col) * p.ldc + pp;
                 }
                 if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                p.C[off] = v;
+                if (p.c_split) {   // written as packed split planes for the next f16x2 GEMM (its K = ldc)
+                    _Float16* ch = (_Float16*)p.C + ds_packed_off(row, col, p.ldc >> 5);
+                    const _Float16 hi = ds_split_hi(v);
+                    ch[0] = hi;
+                    ch[p.c_plane] = ds_split_lo(v, hi);
+                } else {
+                    p.C[off] = v;
+                }
             }
         }
     }
 }
 
-template <int BM, int BN>
-static int launch_h(const GemmParams& p, hipStream_t s) {
+template <int BM, int BN, int AMODE>
+static int launch_h2(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_kernel<BM, BN>,
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_kernel<BM, BN, AMODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -239,20 +331,31 @@ static int launch_h(const GemmParams& p, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN>), dim3(tiles), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE>), dim3(tiles), dim3(256), lds, s, p);
     DS_CHECK_LAUNCH();
     return 0;
 }
+static int g_force_tile_h = -1;
+template <int BM, int BN>
+static int launch_h(const GemmParams& p, hipStream_t s) {
+    return p.a_split ? launch_h2<BM, BN, 2>(p, s) : launch_h2<BM, BN, 0>(p, s);
+}
 
 extern int g_last_tile;
-static int g_force_tile_h = -1;
 extern "C" void ds_gemm_f16x2_force_tile(int t) { g_force_tile_h = t; }
 
-// p.W: 2 planes of [N][ldw] fp16 holding W * 2^s, plane stride p.w3_plane (elements); p.out_scale = 2^-s.
+// p.W: 2 fp16 planes holding W * 2^s, plane stride p.w3_plane (halves); p.out_scale = 2^-s.  Row-major planes
+// [N][ldw] with an fp32 A (a_split 0); packed split planes for both A and W when a_split is set.
 int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % HBK == 0, "K must be a positive multiple of 32");
     DS_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && p.lda % 4 == 0, "alignment");
     DS_CHECK_ARG(p.ldw >= p.K && p.ldw % 8 == 0 && p.w3_plane % 8 == 0, "split-weight strides must be multiples of 8");
+    DS_CHECK_ARG(!p.a_split || (p.lda == p.K && p.ldw == p.K && p.a_plane >= (long long)((p.M + 15) / 16) * 16 * p.K &&
+                                p.a_plane % 8 == 0 && p.w3_plane >= (long long)((p.N + 15) / 16) * 16 * p.K),
+                 "packed operands: lda = ldw = K, planes of ceil16(rows) * K halves");
+    DS_CHECK_ARG(!p.c_split || (p.ldc % 32 == 0 && p.N <= p.ldc && p.c_plane >= (long long)((p.M + 15) / 16) * 16 * p.ldc &&
+                                p.store == DS_STORE_ROW && !p.R),
+                 "packed output: ldc % 32 == 0, plane of ceil16(M) * ldc halves, row store, no residual");
     DS_CHECK_ARG(p.store == DS_STORE_ROW || p.store == DS_STORE_BATCH_T, "unsupported store mode");
     DS_CHECK_ARG(p.act == DS_ACT_NONE || p.act == DS_ACT_GELU2, "unsupported activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
@@ -264,7 +367,8 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
         best = g_force_tile_h;
     } else {
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        best = t128 >= 1500 ? 0 : (t128 >= 128 ? 1 : 2);
+        // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups
+        best = t128 >= (p.a_split ? 1000 : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
     }
     g_last_tile = best;
     switch (best) {

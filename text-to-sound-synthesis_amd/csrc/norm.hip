@@ -94,9 +94,22 @@ __global__ __launch_bounds__(256) void ds_layernorm_kernel(const float* __restri
         for (int k = 0; k < 4; ++k) {
             const float xn = (v[j][k] - mean) * rstd;
             o[k] = mode == 0 ? xn * (1.f + a[k]) + b[k] : xn * a[k] + b[k];
-            if (f16) o[k] = ds_r16(o[k]);
+            if (f16 == 1) o[k] = ds_r16(o[k]);
         }
-        *(f32x4*)(yr + c) = o;
+        if (f16 == 2) {  // packed split planes (common.h ds_packed_off) for the f16x2 GEMM's A operand
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hi[k] = ds_split_hi(o[k]);
+                lo[k] = ds_split_lo(o[k], hi[k]);
+            }
+            _Float16* yh = (_Float16*)y + ds_packed_off(row, c, D / 32);   // 4 halves inside one 16-byte chunk
+            *(h4*)yh = hi;
+            *(h4*)(yh + (size_t)((M + 15) & ~15) * D) = lo;
+        } else {
+            *(f32x4*)(yr + c) = o;
+        }
     }
 }
 
@@ -259,6 +272,29 @@ extern "C" int ds_l2norm_rows_f16(const float* x, float* y, int M, int D, ds_str
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(x && y && M > 0 && D > 0, "bad arguments");
     hipLaunchKernelGGL(ds_l2norm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, y, M, D);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- the same norms writing packed split planes for the f16x2 GEMM: yh = 2 planes of ceil16(M) * D halves ----
+extern "C" int ds_adaln_split(const float* x, void* yh, int M, int L, int D, const float* table, const int64_t* t,
+                              ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x && yh && table && t, "null pointer");
+    DS_CHECK_ARG(D == 1024, "only D = 1024 is built");
+    hipLaunchKernelGGL((ds_layernorm_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, stream, x, (float*)yh, M, L, 0,
+                       table, t, (const float*)nullptr, (const float*)nullptr, 1e-5f, 2);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_layernorm_split(const float* x, void* yh, int M, int D, const float* gamma, const float* beta,
+                                  ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x && yh && gamma && beta, "null pointer");
+    DS_CHECK_ARG(D == 1024, "only D = 1024 is built");
+    hipLaunchKernelGGL((ds_layernorm_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, stream, x, (float*)yh, M, 1, 1,
+                       (const float*)nullptr, (const int64_t*)nullptr, gamma, beta, 1e-5f, 2);
     DS_CHECK_LAUNCH();
     return 0;
 }

@@ -227,7 +227,7 @@ class Text2ImageTransformer(nn.Module):
             def split(w):
                 if self.precision == "bf16x3":
                     return _lib.split_bf16x3(w), 1.0
-                return _lib.split_f16x2(w)
+                return _lib.split_f16x2(w, packed=True)   # the denoiser's f16x2 GEMMs take packed operands
             for l in range(self.n_layer):
                 for s in (_lib.LP_W_QKV, _lib.LP_W_PROJ1, _lib.LP_W_Q2, _lib.LP_W_PROJ2, _lib.LP_W_FC1, _lib.LP_W_FC2):
                     t3, sc = split(keep_by_ptr[ptrs[l * _lib.LP_COUNT + s]])
