@@ -88,6 +88,26 @@ def cpu_baseline(n_layer, codes, T):
                       "1 vocode (%.2f s), extrapolated to %d steps" % (nsteps, T, t_step, t_dec, t_voc, T)}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over one denoiser step at
+    B=64 (profiles/r01_pmc_denoiser_step_b64.json, made by tools/pmc_step.py + tools/pmc_summarize.py with the
+    gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); PMC counters cannot be read inside this process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_denoiser_step_b64.json")
+    if not os.path.exists(path):
+        return None, None
+    table = json.load(open(path))
+    want = kernel.replace(" ", "")
+    for name, r in table.items():
+        key = name.replace(" ", "")
+        if key.startswith(want[:-1]) and r.get("hbm_read_MB_per_launch") is not None:   # "<128,128" matches "<128,128,2>"
+            rd, wr = r["hbm_read_MB_per_launch"], r["hbm_write_MB_per_launch"] or 0.0
+            return round((rd + wr) * 1e6), ("bytes per launch = %.0f MB read (2 x FETCH_SIZE) + %.0f MB written (WRITE_SIZE), "
+                                            "mean of %d dispatches, L2 hit rate %.2f; algorithmic operand + result bytes of "
+                                            "the same launches average 276 MB (DESIGN.md section 3); source profiles/"
+                                            "r01_pmc_denoiser_step_b64.json" % (rd, wr, r["dispatches"], r["l2_hit_rate"]))
+    return None, None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,8 +212,11 @@ def main():
             dom = max(range(3), key=lambda c: ms[c])   # the kernel symbol with the largest total time
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             peak = mfma_peak / passes                  # ceiling in algorithmic (2MNK) flops of this formulation
+            # the committed PMC passes ran the default f16x2 step at B=64; other legs / sizes have no measurement
+            measured = precision == "f16x2" and (B, args.n_layer, args.codes) == (64, 19, 256)
+            traffic, traffic_note = pmc_traffic(names[dom]) if measured else (None, None)
             return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": "%s (%s, dense loader)" % (names[dom], what), "launches": int(n[dom]),
                     "avg_launch_us": round(ms[dom] * 1e3 / max(1, n[dom]), 2),
                     "avg_launch_gflop": round(fl[dom] / max(1, n[dom]) / 1e9, 3),
