@@ -96,10 +96,11 @@ def pmc_traffic(kernel):
     if not os.path.exists(path):
         return None, None
     table = json.load(open(path))
-    want = kernel.replace(" ", "")
+    want = kernel.split(" (")[0].replace(" ", "")
+    want = want[:-1] if want.endswith(">") else want     # "<128,128" also matches "<128,128,2>"
     for name, r in table.items():
         key = name.replace(" ", "")
-        if key.startswith(want[:-1]) and r.get("hbm_read_MB_per_launch") is not None:   # "<128,128" matches "<128,128,2>"
+        if key.startswith(want) and r.get("hbm_read_MB_per_launch") is not None:
             rd, wr = r["hbm_read_MB_per_launch"], r["hbm_write_MB_per_launch"] or 0.0
             return round((rd + wr) * 1e6), ("bytes per launch = %.0f MB read (2 x FETCH_SIZE) + %.0f MB written (WRITE_SIZE), "
                                             "mean of %d dispatches, L2 hit rate %.2f; algorithmic operand + result bytes of "
@@ -209,6 +210,8 @@ def main():
             _lib.check(L.ds_profile_collect(ms, fl, n))
             fmt, passes, mfma_peak, what = KIND[precision]
             names = [fmt % bb for bb in ((128, 128), (128, 64), (64, 64))]
+            if precision == "f16x2":   # packed-operand launches of the 128x128 config go through the balanced kernel
+                names[0] = "ds_gemm_f16x2_hybrid_kernel (128x128 tiles + 64x64 tail tiles)"
             dom = max(range(3), key=lambda c: ms[c])   # the kernel symbol with the largest total time
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             peak = mfma_peak / passes                  # ceiling in algorithmic (2MNK) flops of this formulation

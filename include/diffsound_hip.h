@@ -76,6 +76,9 @@ void ds_gemm_bf16x3_force_tile(int cfg);
  * (gemm_f16x2.hip). */
 int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 void ds_gemm_f16x2_force_tile(int cfg);
+/* packed-operand launches that pick the 128x128 tile are balanced: 128x128 tiles over the leading rows that fill
+   whole rounds of `slots` resident workgroups (default 512 = 256 CUs x 2), 64x64 tiles over the rest.  Test hook. */
+void ds_gemm_f16x2_set_balance_slots(int slots);
 
 /* ---- row kernels of the denoiser -------------------------------------------------------------- */
 /* DalleMaskImageEmbedding.forward, sound_synthesis/modeling/embeddings/dalle_mask_image_embedding.py:36-58

@@ -211,6 +211,36 @@ def test_f16x2_packed_operands_bit_identical(M, N, K, tile):
         L.lib().ds_gemm_f16x2_force_tile(-1)
 
 
+@pytest.mark.parametrize("M,N,K,slots", [(530, 1024, 1024, 8), (2100, 1024, 1024, 16), (700, 256, 4096, 2), (1000, 96, 64, 1)])
+def test_f16x2_balanced_hybrid_launch_bit_identical(M, N, K, slots):
+    """128x128 tiles over the leading rows + 64x64 tiles over the tail rows == the loader-split GEMM, for row-major
+    (with residual) and packed outputs; `slots` shrinks the balance unit so these small shapes take the hybrid path."""
+    from text_to_sound_synthesis_amd import _lib as L
+    A, W, b, R = rnd((M, K), "hyA", 3.0), rnd((N, K), "hyW", 0.1), rnd((N,), "hyb"), rnd((M, N), "hyR")
+    Ac, bc, Rc = A.cuda(), b.cuda(), R.cuda()
+    W2, sc = L.split_f16x2(W.cuda())
+    W2p, _ = L.split_f16x2(W.cuda(), packed=True)
+    A2p = L.pack_planes(torch_split(Ac))
+    M16 = (M + 15) // 16 * 16
+    ref = torch.empty(M, N, device="cuda")
+    L.gemm(Ac, W2, ref, M, N, K, bias=bc, R=Rc, split2=sc)
+    refg = torch.empty(M, N, device="cuda")
+    L.gemm(Ac, W2, refg, M, N, K, bias=bc, act=L.ACT_GELU2, split2=sc)
+    L.lib().ds_gemm_f16x2_force_tile(0)
+    L.lib().ds_gemm_f16x2_set_balance_slots(slots)
+    try:
+        out = torch.full((M, N), float("nan"), device="cuda")
+        L.gemm(A2p, W2p, out, M, N, K, bias=bc, R=Rc, split2=sc, a_plane=M16 * K)
+        assert torch.equal(out, ref)
+        if N % 32 == 0:
+            outs = torch.zeros(2, M16 * N, device="cuda", dtype=torch.float16)
+            L.gemm(A2p, W2p, outs, M, N, K, bias=bc, act=L.ACT_GELU2, split2=sc, a_plane=M16 * K, c_plane=M16 * N)
+            assert torch.equal(L.unpack_planes(outs, M, N), torch_split(refg))
+    finally:
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+        L.lib().ds_gemm_f16x2_set_balance_slots(512)
+
+
 def test_split_producers_bit_identical():
     """ds_adaln_split / ds_layernorm_split / ds_attention_f16x2_split == packed split of the fp32-output kernels."""
     from text_to_sound_synthesis_amd import _lib as L

@@ -41,9 +41,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* ds_gptr;
 typedef __attribute__((address_space(3))) void* ds_lptr;
 
+// the whole workgroup program for output tile `bid` of `nblk` (both as launched; remapped below)
 template <int BM, int BN, int AMODE>
-__global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid, const int nblk,
+                                                   unsigned char* smem_raw) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int SA = BM / 64;   // 8-element (2 x float4) staging chunks per thread (A)
     constexpr int SB = BN / 64;   // 16-byte staging chunks per thread per plane (B)
@@ -57,8 +58,6 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
     {
         const int xcd = bid & 7, idx = bid >> 3;
         const int q = nblk >> 3, r = nblk & 7;
@@ -318,6 +317,25 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
 }
 
 template <int BM, int BN, int AMODE>
+__global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    ds_gemm_f16x2_body<BM, BN, AMODE>(p, blockIdx.x, gridDim.x, smem_dyn);
+}
+
+// Balanced launch for packed operands: the first `nbig` workgroups compute 128x128 tiles of the leading rows
+// (pb: a whole number of rounds of the chip's resident-workgroup slots), the rest 64x64 tiles of the remaining
+// rows (ps: the same problem with the row origin moved).  At M = 16960, N = 1024 a plain 128x128 grid is 1064
+// tiles = 2.08 rounds of 512 slots and the 40 stragglers cost a full extra tile time (255 vs 303 TF-eq measured
+// against an exactly divisible M, tools/probe); the quarter-size tail tiles fill that hole instead.
+__global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_hybrid_kernel(const GemmParams pb, const GemmParams ps,
+                                                                     const int nbig) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    const int bid = blockIdx.x;   // uniform branch: a workgroup runs one of the two programs
+    if (bid < nbig) ds_gemm_f16x2_body<128, 128, 2>(pb, bid, nbig, smem_dyn);
+    else ds_gemm_f16x2_body<64, 64, 2>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
+}
+
+template <int BM, int BN, int AMODE>
 static int launch_h2(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * sizeof(unsigned short);
     static bool attr_set = false;
@@ -343,6 +361,43 @@ static int launch_h(const GemmParams& p, hipStream_t s) {
 
 extern int g_last_tile;
 extern "C" void ds_gemm_f16x2_force_tile(int t) { g_force_tile_h = t; }
+
+// resident 128x128 workgroups on the chip (256 CUs x 2); a test hook shrinks it so small shapes take the hybrid path
+static int g_balance_slots = 512;
+extern "C" void ds_gemm_f16x2_set_balance_slots(int n) { g_balance_slots = n > 0 ? n : 512; }
+
+// 128x128 tiles for the largest row range that fills whole rounds of slots, 64x64 tiles for the rows after it
+static int launch_hybrid(const GemmParams& p, hipStream_t s) {
+    const int tn = (p.N + 127) / 128;
+    int rb = p.M / 128;                              // full 128-row tiles available
+    while (rb > 0 && ((long)rb * tn) % g_balance_slots != 0) --rb;
+    const int m_off = rb * 128;
+    if (rb == 0 || m_off == p.M || p.store != DS_STORE_ROW) return launch_h2<128, 128, 2>(p, s);
+    GemmParams pb = p, ps = p;
+    pb.M = m_off;
+    ps.M = p.M - m_off;
+    const size_t rg = (size_t)m_off / 16;
+    ps.A = (const float*)((const _Float16*)p.A + rg * (p.K / HBK) * 512);           // packed planes: row-group offset
+    if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
+    else ps.C = p.C + (size_t)m_off * p.ldc;
+    if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
+    const int nbig = rb * tn;
+    const int nsmall = ((ps.M + 63) / 64) * ((p.N + 63) / 64);
+    const size_t lds = (size_t)2 * 2 * (128 + 128) * HLD * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_hybrid_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
 
 // p.W: 2 fp16 planes holding W * 2^s, plane stride p.w3_plane (halves); p.out_scale = 2^-s.  Row-major planes
 // [N][ldw] with an fp32 A (a_split 0); packed split planes for both A and W when a_split is set.
@@ -372,7 +427,7 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     }
     g_last_tile = best;
     switch (best) {
-        case 0: return launch_h<128, 128>(p, stream);
+        case 0: return p.a_split ? launch_hybrid(p, stream) : launch_h<128, 128>(p, stream);
         case 1: return launch_h<128, 64>(p, stream);
         default: return launch_h<64, 64>(p, stream);
     }
