@@ -128,6 +128,12 @@ int ds_sample_tail(const float* logits, const int64_t* xt, const int64_t* t, con
                    int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc, float* dbg_post, int B, int L,
                    int K, int T, int initial, float trunc_r, ds_stream_t stream);
 
+/* + top-k truncation ('top{k}p', dalle_spec.py:147-157): trunc_k > 0 keeps the k largest log-probs of a column
+ * (exclusive with trunc_r >= 0) */
+int ds_sample_tail_ex(const float* logits, const int64_t* xt, const int64_t* t, const float* u, const float* sched,
+                      int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc, float* dbg_post, int B, int L,
+                      int K, int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream);
+
 /* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
 enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */
     DS_LP_ADALN1 = 0,  /* [T][2D]  ln1 table   */
@@ -176,6 +182,12 @@ int ds_denoiser_forward(const ds_denoiser* h, const int64_t* tokens, const int64
 int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const float* kv,
                      const float* u, int B, int initial, float trunc_r, void* workspace, int64_t* tokens_out,
                      ds_stream_t stream);
+
+/* the same with the posterior's own timestep vector t_post (NULL = t; sample_fast's skip-step sampler,
+ * diffusion_transformer.py:796-803) and top-k truncation */
+int ds_denoiser_step_ex(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const int64_t* t_post,
+                        const float* kv, const float* u, int B, int initial, float trunc_r, int trunc_k,
+                        void* workspace, int64_t* tokens_out, ds_stream_t stream);
 
 /* per-launch HIP-event timing of the denoiser's GEMM launches (measurement only, bench.py) */
 int ds_profile_enable(int on);

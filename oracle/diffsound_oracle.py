@@ -160,6 +160,13 @@ def truncate_top_r(log_pred, r):
     return torch.where(keep, log_pred, torch.full_like(log_pred, -70.0))
 
 
+def truncate_top_k(log_pred, k):
+    """Top-k ('p') truncation wrapper, models/dalle_spec.py:147-157: the k largest log-probs of a column (over all
+    K+1 rows) keep their value, every other row becomes -70."""
+    val, ind = log_pred.topk(k=k, dim=1)
+    return torch.full_like(log_pred, -70.0).scatter(1, ind, val)
+
+
 # --------------------------------------------------------------------------- A9
 def _lae(a, b):
     """log(exp a + exp b), diffusion_transformer.py:28-30."""
@@ -214,15 +221,20 @@ def gumbel_sample(log_prob, u):
 
 
 # --------------------------------------------------------------------------- A4 / A5
-def p_sample_step(sd, sched, log_z, cond_emb, t, u, trunc_r=0.85, n_head=16, detail=False):
+def p_sample_step(sd, sched, log_z, cond_emb, t, u, trunc_r=0.85, n_head=16, detail=False, trunc_k=None,
+                  t_post=None):
     """One reverse step, :342-357 with the truncation wrapper of dalle_spec.py:208-210
-    installed: argmax -> transformer -> log-softmax(f64) -> top-r -> posterior -> Gumbel."""
+    installed: argmax -> transformer -> log-softmax(f64) -> top-r (or top-k) -> posterior -> Gumbel.
+    t_post: timestep of the posterior when it differs from the network's (sample_fast, :796-803)."""
     K = sd["transformer.transformer.to_logits.1.weight"].shape[0]
     x_t = log_z.argmax(1)
     logits = transformer_forward(sd, x_t, cond_emb, t, n_head=n_head)
     log_pred = predict_start(logits)
-    trunc = truncate_top_r(log_pred, trunc_r) if trunc_r is not None else log_pred
-    post = q_posterior(sched, trunc, log_z, t)
+    if trunc_k is not None:
+        trunc = truncate_top_k(log_pred, trunc_k)
+    else:
+        trunc = truncate_top_r(log_pred, trunc_r) if trunc_r is not None else log_pred
+    post = q_posterior(sched, trunc, log_z, t if t_post is None else t_post)
     tok = gumbel_sample(post, u)
     new_log_z = log_onehot(tok, K + 1)
     if detail:
@@ -244,6 +256,46 @@ def sample_loop(sd, cond_emb, noise_fn, num_timesteps=100, trunc_r=0.85, n_head=
         t = torch.full((B,), step, dtype=torch.long)
         log_z = p_sample_step(sd, sched, log_z, cond_emb, t, noise_fn(step, log_z.shape),
                               trunc_r, n_head)
+        if record is not None:
+            record.append(log_z.argmax(1).clone())
+    return log_z.argmax(1)
+
+
+def sample_loop_fast(sd, cond_emb, noise_fn, skip_step, num_timesteps=100, trunc_r=0.85, n_head=16, record=None):
+    """DiffusionTransformer.sample_fast, :748-812: timesteps T-1, T-2-skip, ... with 0 appended; the network sees
+    t, q_posterior sees t - skip_step while t > skip_step.  noise_fn(step_t, shape) as in sample_loop."""
+    K = sd["transformer.transformer.to_logits.1.weight"].shape[0]
+    B = cond_emb.shape[0]
+    sched = make_schedule(num_timesteps, K + 1)
+    log_z = initial_log_z(B, K + 1, 265)
+    steps = list(range(num_timesteps - 1, -1, -1 - skip_step))
+    if steps[-1] != 0:
+        steps.append(0)
+    for step in steps:
+        t = torch.full((B,), step, dtype=torch.long)
+        log_z = p_sample_step(sd, sched, log_z, cond_emb, t, noise_fn(step, log_z.shape), trunc_r, n_head,
+                              t_post=t - skip_step if step > skip_step else t)
+        if record is not None:
+            record.append(log_z.argmax(1).clone())
+    return log_z.argmax(1)
+
+
+def sample_loop_repeat(sd, cond_emb, noise_fn, rate, rng, num_timesteps=100, trunc_r=0.85, n_head=16, record=None):
+    """sample() with the 'q' wrapper on p_sample, dalle_spec.py:135-143: after every step, with probability `rate`
+    (one rng.random() per step, Python's `random` in the reference) the step is applied again at the same t.
+    noise_fn(call_index, shape): one draw per p_sample call."""
+    K = sd["transformer.transformer.to_logits.1.weight"].shape[0]
+    B = cond_emb.shape[0]
+    sched = make_schedule(num_timesteps, K + 1)
+    log_z = initial_log_z(B, K + 1, 265)
+    calls = 0
+    for step in range(num_timesteps - 1, -1, -1):
+        t = torch.full((B,), step, dtype=torch.long)
+        log_z = p_sample_step(sd, sched, log_z, cond_emb, t, noise_fn(calls, log_z.shape), trunc_r, n_head)
+        calls += 1
+        if rng.random() < rate:
+            log_z = p_sample_step(sd, sched, log_z, cond_emb, t, noise_fn(calls, log_z.shape), trunc_r, n_head)
+            calls += 1
         if record is not None:
             record.append(log_z.argmax(1).clone())
     return log_z.argmax(1)

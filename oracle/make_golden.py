@@ -72,10 +72,61 @@ def text_stage():
 
 
 @torch.no_grad()
+def samplers():
+    """top-k ('p') truncation, the skip-step sampler and the 'q' repeat-step sampler, each
+    driven through the reference's own generate_content mini-language on the 2-layer T=10 model (B=2)."""
+    import random
+    torch.manual_seed(0)
+    cond = synth.synth_cond_emb(2, key="traj.cond")
+    arrs = {}
+
+    # the reference's prepare_condition / decode are bypassed: call transformer.sample* the way generate_content does
+    def drive(sample_type, key, seed=None):
+        m = rh.build_dalle(n_layer=2, diffusion_step=10, n_embed=256)
+        m.this_save_path = None
+        dt = m.transformer
+        parts = sample_type.split(",")
+        if len(parts) > 1 and parts[1][:1] == "q":
+            dt.p_sample = m.p_sample_with_truncation(dt.p_sample, parts[1])          # dalle_spec.py:205-206
+        dt.predict_start = m.predict_start_with_truncation(dt.predict_start, parts[0])  # :207-209
+        if seed is not None:
+            random.seed(seed)
+        n = [0]
+
+        def noise(shp):
+            n[0] += 1
+            return synth.synth_uniform(shp, key="%s.u%d" % (key, n[0] - 1))
+        with InjectNoise(noise):
+            if len(parts) == 2 and parts[1][:4] == "fast":
+                # sample_fast reads the batch size off condition_token (:769); its values are unused without CLIP
+                out = dt.sample_fast(condition_token=torch.zeros(2, 77, dtype=torch.long), condition_mask=None,
+                                     condition_embed=cond, filter_ratio=0, skip_step=int(parts[1][4:]))
+            else:
+                out = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0,
+                                batch_size=2)
+        return m, out["content_token"], n[0]
+
+    m, tok, n = drive("top100p", "topk")
+    arrs.update(topk_tokens=tok, topk_calls=torch.tensor(n))
+    # teacher-forced top-k step (T=10 model, t=5): the wrapper's output on a half-masked state
+    from sound_synthesis.modeling.transformers.diffusion_transformer import index_to_log_onehot
+    dt = m.transformer
+    log_z = index_to_log_onehot(synth.synth_tokens(2, mask_frac=0.5, key="topk.xt"), 257)
+    tvec = torch.tensor([5, 5])
+    arrs.update(topk_trunc=dt.predict_start(log_z, cond, tvec)[:, :, ::POS_STRIDE])
+    _, tok, n = drive("top0.85r,fast2", "fast")
+    arrs.update(fast2_tokens=tok, fast2_calls=torch.tensor(n))
+    _, tok, n = drive("top0.85r,q0.5", "rep", seed=7)
+    arrs.update(q05_tokens=tok, q05_calls=torch.tensor(n))
+    save("samplers_T10_L2", pos_stride=POS_STRIDE, **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--text-only" in sys.argv:
         return text_stage()
+    if "--samplers-only" in sys.argv:
+        return samplers()
     torch.manual_seed(0)
     t0 = time.time()
 
@@ -154,6 +205,7 @@ def main():
     mel01 = synth.synth_uniform((1, 80, 848), key="voc.mel")
     save("vocoder", wave=voc(mel01))
     text_stage()
+    samplers()
     print("done in %.1fs" % (time.time() - t0))
 
 

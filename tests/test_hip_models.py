@@ -113,6 +113,56 @@ def test_trajectory_T10_then_decode_vocode_vs_reference(voc):
     assert (wave[0, 0, :65536].cpu() - g["wave0_head"]).pow(2).mean().sqrt() < WAVE_RMS_TOL
 
 
+def test_alternative_samplers_vs_reference():
+    """SURVEY.md 8f-4 through generate_content's sample_type mini-language: 'top100p' (top-k), 'top0.85r,fast2'
+    (skip-step), 'top0.85r,q0.5' (repeat-step) reproduce the reference's tokens with the same injected noise."""
+    import random
+    g = golden("samplers_T10_L2")
+    cond = synth.synth_cond_emb(2, key="traj.cond").cuda()
+
+    def run(sample_type, noise_fn, seed=None):
+        m = build(2, T=10)                      # fresh model: the truncation choice is sticky, as in the reference
+        tr = m.transformer
+        if seed is not None:
+            random.seed(seed)
+        orig = {"sample": tr.sample, "sample_fast": tr.sample_fast}
+        tr.sample = lambda **kw: orig["sample"](noise_fn=noise_fn, **kw)
+        tr.sample_fast = lambda **kw: orig["sample_fast"](noise_fn=noise_fn, **kw)
+        out = m.generate_content(batch={"condition_embed_token": cond}, filter_ratio=0, replicate=1, content_ratio=1,
+                                 sample_type=sample_type)
+        assert out["content"].shape == (2, 1, 80, 848)
+        return m, out["content_token"].cpu()
+
+    m, tok = run("top100p", lambda t, shp: synth.synth_uniform(shp, key="topk.u%d" % (9 - t)))
+    assert (tok != g["topk_tokens"]).sum().item() == 0
+    assert m.transformer.truncation_k == 100 and m.transformer.truncation_r is None
+    # the wrapped predict_start (top-k) on a half-masked state
+    log_z = torch.log(torch.nn.functional.one_hot(synth.synth_tokens(2, mask_frac=0.5, key="topk.xt"), 257)
+                      .permute(0, 2, 1).float().clamp(min=1e-30)).cuda()
+    trunc = m.transformer.predict_start(log_z, cond, torch.tensor([5, 5]).cuda()).cpu()
+    ref, s = g["topk_trunc"], slice(None, None, int(g["pos_stride"]))
+    assert ((trunc[:, :, s] > -70) == (ref > -70)).all() and (trunc[:, :, s] - ref).abs().max() < 2e-4
+    order = {9: 0, 6: 1, 3: 2, 0: 3}
+    _, tok = run("top0.85r,fast2", lambda t, shp: synth.synth_uniform(shp, key="fast.u%d" % order[t]))
+    assert (tok != g["fast2_tokens"]).sum().item() == 0
+    calls = []
+    _, tok = run("top0.85r,q0.5", lambda c, shp: (calls.append(c), synth.synth_uniform(shp, key="rep.u%d" % c))[1], seed=7)
+    assert len(calls) == int(g["q05_calls"])
+    assert (tok != g["q05_tokens"]).sum().item() == 0
+
+
+def test_sample_tail_top_k_argument_checks():
+    from text_to_sound_synthesis_amd import _lib as L
+    z = torch.zeros(265, 256, device="cuda")
+    x = torch.zeros(1, 265, dtype=torch.long, device="cuda")
+    t = torch.zeros(1, dtype=torch.long, device="cuda")
+    u = torch.rand(1, 257, 265, device="cuda")
+    sched = torch.zeros(8, 101, device="cuda")
+    with pytest.raises(L.DiffsoundHipError):     # top-k and top-r are exclusive
+        L.check(L.lib().ds_sample_tail_ex(L.ptr(z), L.ptr(x), L.ptr(t), L.ptr(u), L.ptr(sched), L.ptr(x), None, None,
+                                          None, 1, 265, 256, 100, 0, 0.85, 10, L.stream()))
+
+
 def test_decode_vs_reference_and_api_forms(m2):
     tok = synth.synth_tokens(1, mask_frac=0.0, key="dec.tokens").cuda()
     ref = golden("decode")["mel"]

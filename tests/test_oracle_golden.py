@@ -84,6 +84,46 @@ def test_trajectory_T10_decode_vocode(sd_dalle_l2, sd_vocoder):
     assert (wave[0, 0, :65536] - g["wave0_head"]).pow(2).mean().sqrt() < 1e-5
 
 
+def test_alternative_samplers_T10(sd_dalle_l2):
+    """SURVEY.md 8f-4 against the reference's own wrappers (goldens from oracle/make_golden.py samplers()):
+    top-k truncation, the skip-step sampler, the 'q' repeat-step sampler."""
+    import random
+    g = golden("samplers_T10_L2")
+    cond = synth.synth_cond_emb(2, key="traj.cond")
+    K = 256
+    sched = O.make_schedule(10, K + 1)
+    # top-k wrapper output on a half-masked state, t = 5
+    log_z = O.log_onehot(synth.synth_tokens(2, mask_frac=0.5, key="topk.xt"), K + 1)
+    t = torch.tensor([5, 5])
+    logits = O.transformer_forward(sd_dalle_l2, log_z.argmax(1), cond, t)
+    trunc = O.truncate_top_k(O.predict_start(logits), 100)
+    ref = g["topk_trunc"]
+    s = slice(None, None, int(g["pos_stride"]))
+    assert ((trunc[:, :, s] > -70) == (ref > -70)).all() and (trunc[:, :, s] - ref).abs().max() < 2e-4
+    assert ((trunc > -70).sum(1) <= 100).all()
+    # top-k trajectory: sample() with the wrapper installed; noise keyed by p_sample call index
+    log_z = O.initial_log_z(2, K + 1, 265)
+    for i, step in enumerate(range(9, -1, -1)):
+        tt = torch.full((2,), step, dtype=torch.long)
+        log_z = O.p_sample_step(sd_dalle_l2, sched, log_z, cond, tt, synth.synth_uniform(log_z.shape, key="topk.u%d" % i),
+                                trunc_r=None, trunc_k=100)
+    assert torch.equal(log_z.argmax(1), g["topk_tokens"])
+    # skip-step sampler, skip 2: steps 9, 6, 3, 0
+    order = {9: 0, 6: 1, 3: 2, 0: 3}
+    rec = []
+    tok = O.sample_loop_fast(sd_dalle_l2, cond, lambda st, shp: synth.synth_uniform(shp, key="fast.u%d" % order[st]),
+                             skip_step=2, num_timesteps=10, record=rec)
+    assert len(rec) == int(g["fast2_calls"]) == 4
+    assert torch.equal(tok, g["fast2_tokens"])
+    # repeat-step sampler: Python's random decides, seeded like the golden run
+    calls = []
+    tok = O.sample_loop_repeat(sd_dalle_l2, cond,
+                               lambda c, shp: (calls.append(c), synth.synth_uniform(shp, key="rep.u%d" % c))[1],
+                               rate=0.5, rng=random.Random(7), num_timesteps=10)
+    assert len(calls) == int(g["q05_calls"])
+    assert torch.equal(tok, g["q05_tokens"])
+
+
 def test_decode(sd_dalle_l2):
     tok = synth.synth_tokens(1, mask_frac=0.0, key="dec.tokens")
     mel = O.decode_tokens(sd_dalle_l2, tok)

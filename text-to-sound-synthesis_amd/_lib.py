@@ -71,6 +71,8 @@ _PROTOS = {
     "ds_l2norm_rows_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "ds_sample_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_sample_tail_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, _vp]),
     "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),
     "ds_denoiser_destroy": (None, [_vp]),
     "ds_denoiser_workspace_bytes": (_i64, [_vp, C.c_int]),
@@ -78,6 +80,7 @@ _PROTOS = {
     "ds_denoiser_cond_kv": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "ds_denoiser_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "ds_denoiser_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f, _vp, _vp, _vp]),
+    "ds_denoiser_step_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f, C.c_int, _vp, _vp, _vp]),
     "ds_profile_enable": (C.c_int, [C.c_int]),
     "ds_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ds_codebook_gather": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -307,13 +307,22 @@ extern "C" int ds_denoiser_forward(const ds_denoiser* h, const int64_t* tokens, 
     return forward_impl(h, tokens, t, kv, B, w, logits, logits_layout, (hipStream_t)stream);
 }
 
-extern "C" int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const float* kv,
-                                const float* u, int B, int initial, float trunc_r, void* workspace,
-                                int64_t* tokens_out, ds_stream_t stream) {
+// t drives the network (AdaLN), t_post the posterior: they differ only for the skip-step sampler
+// (sample_fast, diffusion_transformer.py:796-803 calls q_posterior with t - skip_step)
+extern "C" int ds_denoiser_step_ex(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t,
+                                   const int64_t* t_post, const float* kv, const float* u, int B, int initial,
+                                   float trunc_r, int trunc_k, void* workspace, int64_t* tokens_out,
+                                   ds_stream_t stream) {
     DS_CHECK_ARG(h && tokens_in && t && kv && u && workspace && tokens_out && B > 0, "bad arguments");
     Carve w;
     carve(h, B, workspace, &w);
     TRY(forward_impl(h, tokens_in, t, kv, B, w, w.logits, 0, (hipStream_t)stream));
-    return ds_sample_tail(w.logits, tokens_in, t, u, h->d.sched, tokens_out, nullptr, nullptr, nullptr, B,
-                          h->d.seq_len, h->d.n_codes, h->d.n_steps, initial, trunc_r, stream);
+    return ds_sample_tail_ex(w.logits, tokens_in, t_post ? t_post : t, u, h->d.sched, tokens_out, nullptr, nullptr,
+                             nullptr, B, h->d.seq_len, h->d.n_codes, h->d.n_steps, initial, trunc_r, trunc_k, stream);
+}
+
+extern "C" int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const float* kv,
+                                const float* u, int B, int initial, float trunc_r, void* workspace,
+                                int64_t* tokens_out, ds_stream_t stream) {
+    return ds_denoiser_step_ex(h, tokens_in, t, nullptr, kv, u, B, initial, trunc_r, 0, workspace, tokens_out, stream);
 }

@@ -54,7 +54,8 @@ struct SampleParams {
     float* dbg_post;          // optional
     int B, L, T;
     int initial;              // 1: x_t is the all-[MASK] start state (log one-hot = 0 / -inf)
-    float trunc_r;            // < 0: no truncation
+    float trunc_r;            // < 0: no top-r truncation
+    int trunc_k;              // > 0: top-k truncation instead ('top{k}p', dalle_spec.py:147-157)
 };
 
 template <int NPL>
@@ -95,9 +96,28 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
         if (lane == 0) p.dbg_log_pred[dbg_base + (size_t)K * p.L] = -70.f;
     }
 
-    // ---- top-r truncation ----
+    // ---- truncation: top-r (probability mass ranked ahead < r) or top-k (rank < k) ----
+    // top-k, dalle_spec.py:147-157: topk over the K+1 rows, everything else -70.  The [MASK] row is -70 and a
+    // kept -70 is indistinguishable from a dropped one, so ranking the K real classes is equivalent.
     float tr[NPL];
-    if (p.trunc_r >= 0.f) {
+    if (p.trunc_k > 0) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) s_lp[w][j * 64 + lane] = lp[j];
+        __syncthreads();
+        int rank[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) rank[j] = 0;
+        for (int c = 0; c < K; ++c) {
+            const float ol = s_lp[w][c];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int me = j * 64 + lane;
+                rank[j] += (ol > lp[j] || (ol == lp[j] && c < me)) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) tr[j] = rank[j] < p.trunc_k ? lp[j] : -70.f;
+    } else if (p.trunc_r >= 0.f) {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             s_lp[w][j * 64 + lane] = lp[j];
@@ -207,14 +227,16 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
     if (lane == 0 && live) p.out_tokens[col] = bidx;
 }
 
-extern "C" int ds_sample_tail(const float* logits, const int64_t* xt, const int64_t* t, const float* u,
-                              const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc,
-                              float* dbg_post, int B, int L, int K, int T, int initial, float trunc_r,
-                              ds_stream_t stream_) {
+extern "C" int ds_sample_tail_ex(const float* logits, const int64_t* xt, const int64_t* t, const float* u,
+                                 const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc,
+                                 float* dbg_post, int B, int L, int K, int T, int initial, float trunc_r,
+                                 int trunc_k, ds_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(logits && xt && t && u && sched && out_tokens, "null pointer");
     DS_CHECK_ARG(K == 256 || K == 512, "codebook size must be 256 or 512");
-    SampleParams p{logits, xt, t, u, sched, out_tokens, dbg_log_pred, dbg_trunc, dbg_post, B, L, T, initial, trunc_r};
+    DS_CHECK_ARG(trunc_k >= 0 && !(trunc_k > 0 && trunc_r >= 0.f), "top-k and top-r truncation are exclusive");
+    SampleParams p{logits, xt, t, u, sched, out_tokens, dbg_log_pred, dbg_trunc, dbg_post, B, L, T, initial, trunc_r,
+                   trunc_k};
     const int cols = B * L;
     if (K == 256)
         hipLaunchKernelGGL((ds_sample_tail_kernel<4>), dim3((cols + 3) / 4), dim3(256), 0, stream, p);
@@ -222,4 +244,12 @@ extern "C" int ds_sample_tail(const float* logits, const int64_t* xt, const int6
         hipLaunchKernelGGL((ds_sample_tail_kernel<8>), dim3((cols + 3) / 4), dim3(256), 0, stream, p);
     DS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ds_sample_tail(const float* logits, const int64_t* xt, const int64_t* t, const float* u,
+                              const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc,
+                              float* dbg_post, int B, int L, int K, int T, int initial, float trunc_r,
+                              ds_stream_t stream) {
+    return ds_sample_tail_ex(logits, xt, t, u, sched, out_tokens, dbg_log_pred, dbg_trunc, dbg_post, B, L, K, T, initial,
+                             trunc_r, 0, stream);
 }

@@ -70,19 +70,26 @@ class DALLE(nn.Module):
                 if condition[k] is not None:
                     condition[k] = torch.cat([condition[k] for _ in range(replicate)], dim=0)
         parts = sample_type.split(",")
-        if parts[0][:3] == "top":
-            if parts[0][-1] != "r":
-                raise NotImplementedError("top-k ('p') truncation: SURVEY.md section 8f-4")
-            self.transformer.truncation_r = float(parts[0][3:-1])
-            self.truncation_forward = True   # sticky, like the reference's wrapper (:208-210)
-        if len(parts) > 1:
-            raise NotImplementedError("'fast'/'q' samplers: SURVEY.md section 8f-4")
-        trans_out = self.transformer.sample(condition_token=condition.get("condition_token"),
-                                            condition_mask=condition.get("condition_mask"),
-                                            condition_embed=condition.get("condition_embed_token"),
-                                            content_token=None, filter_ratio=filter_ratio, temperature=temperature,
-                                            return_att_weight=return_att_weight, return_logits=False,
-                                            print_log=False, sample_type=sample_type)
+        tr = self.transformer
+        if len(parts) > 1 and parts[1][:1] == "q":           # repeat-step sampler (:135-143, :205-206)
+            tr.repeat_rate = float(parts[1].replace("q", ""))
+        if parts[0][:3] == "top" and not self.truncation_forward:
+            # installed once and sticky, like the reference's predict_start wrapper (:207-209)
+            if parts[0][-1] == "p":
+                tr.truncation_k, tr.truncation_r = int(parts[0][:-1].replace("top", "")), None
+            elif parts[0][-1] == "r":
+                tr.truncation_r, tr.truncation_k = float(parts[0][:-1].replace("top", "")), None
+            else:
+                print("wrong sample type")                    # the reference's reaction (:176-177)
+            self.truncation_forward = True
+        kw = dict(condition_token=condition.get("condition_token"), condition_mask=condition.get("condition_mask"),
+                  condition_embed=condition.get("condition_embed_token"), content_token=None,
+                  filter_ratio=filter_ratio, temperature=temperature, return_att_weight=return_att_weight,
+                  return_logits=False, print_log=False, sample_type=sample_type)
+        if len(parts) == 2 and parts[1][:4] == "fast":       # skip-step sampler (:211-222)
+            trans_out = tr.sample_fast(skip_step=int(parts[1][4:]), **kw)
+        else:
+            trans_out = tr.sample(**kw)
         tokens = trans_out["content_token"]
         zshape = (tokens.shape[0], 256, 5, 53)   # hard-coded in the reference too (:236)
         content = self.decode_to_img(tokens, zshape)

@@ -55,6 +55,8 @@ class DiffusionTransformer(nn.Module):
         self.adaptive_auxiliary_loss = adaptive_auxiliary_loss
         self.mask_weight = mask_weight
         self.truncation_r = None  # set by DALLE.generate_content from sample_type "top{r}r"
+        self.truncation_k = None  # ... or "top{k}p" (top-k, dalle_spec.py:147-157); exclusive with truncation_r
+        self.repeat_rate = None   # "q{rate}": repeat a step with this probability (dalle_spec.py:135-143)
         assert alpha_init_type == "alpha1", "Diffsound uses alpha_init_type='alpha1'"
         at, bt, ct, att, btt, ctt = alpha_schedule(self.num_timesteps, N=self.num_classes)
         f64 = lambda x: torch.tensor(x.astype("float64"))
@@ -94,12 +96,18 @@ class DiffusionTransformer(nn.Module):
         dev = logits_rows.device
         dump = {k: torch.empty(B, K + 1, L, device=dev) for k in want}
         out = torch.empty(B, L, device=dev, dtype=torch.long)
-        r = -1.0 if self.truncation_r is None else float(self.truncation_r)
-        _lib.check(_lib.lib().ds_sample_tail(
+        r, k = self._truncation()
+        _lib.check(_lib.lib().ds_sample_tail_ex(
             _lib.ptr(logits_rows), _lib.ptr(x_t), _lib.ptr(t), _lib.ptr(u), _lib.ptr(self._schedule_table()),
             _lib.ptr(out), _lib.ptr(dump.get("log_pred")), _lib.ptr(dump.get("trunc")), _lib.ptr(dump.get("post")),
-            B, L, K, self.num_timesteps, int(initial), r, _lib.stream()))
+            B, L, K, self.num_timesteps, int(initial), r, k, _lib.stream()))
         return out, dump
+
+    def _truncation(self):
+        """(trunc_r, trunc_k) for the C ABI: top-k wins if set (the reference installs exactly one wrapper)."""
+        if self.truncation_k is not None:
+            return -1.0, int(self.truncation_k)
+        return (-1.0 if self.truncation_r is None else float(self.truncation_r)), 0
 
     @staticmethod
     def _is_initial(log_x):
@@ -126,7 +134,7 @@ class DiffusionTransformer(nn.Module):
         x_t = log_x_t.argmax(1)
         u = torch.full((x_t.shape[0], self.num_classes, self.content_seq_len), 0.5, device=x_t.device)
         _, d = self.step_detail(x_t, cond_emb, t, u, self._is_initial(log_x_t))
-        return d["trunc"] if self.truncation_r is not None else d["log_pred"]
+        return d["trunc"] if (self.truncation_r is not None or self.truncation_k is not None) else d["log_pred"]
 
     @torch.no_grad()
     def p_sample(self, log_x, cond_emb, t):
@@ -139,18 +147,53 @@ class DiffusionTransformer(nn.Module):
         return torch.log(oh.clamp(min=1e-30))
 
     @torch.no_grad()
-    def p_sample_tokens(self, x_t, kv, t, u, initial, out=None):
-        """x_t i64[B,L] -> x_{t-1} i64[B,L]; kv from transformer.condition_kv()."""
+    def p_sample_tokens(self, x_t, kv, t, u, initial, out=None, t_post=None):
+        """x_t i64[B,L] -> x_{t-1} i64[B,L]; kv from transformer.condition_kv().  t_post: the posterior's timestep
+        vector when it differs from the network's (sample_fast)."""
         tr = self.transformer
         sched = self._schedule_table()
         p = tr.packed(sched)
         B = x_t.shape[0]
         if out is None:
             out = torch.empty_like(x_t)
-        r = -1.0 if self.truncation_r is None else float(self.truncation_r)
-        _lib.check(_lib.lib().ds_denoiser_step(p["handle"], _lib.ptr(x_t), _lib.ptr(t), _lib.ptr(kv), _lib.ptr(u), B,
-                                               int(initial), r, _lib.ptr(tr.workspace(B, sched)), _lib.ptr(out),
-                                               _lib.stream()))
+        r, k = self._truncation()
+        _lib.check(_lib.lib().ds_denoiser_step_ex(p["handle"], _lib.ptr(x_t), _lib.ptr(t), _lib.ptr(t_post), _lib.ptr(kv),
+                                                  _lib.ptr(u), B, int(initial), r, k, _lib.ptr(tr.workspace(B, sched)),
+                                                  _lib.ptr(out), _lib.stream()))
+        return out
+
+    def _cond(self, condition_token, condition_embed):
+        if self.condition_emb is not None and condition_token is not None:
+            return self.condition_emb(condition_token).float()          # CLIP text tower (:619-621)
+        if condition_embed is None:
+            raise ValueError("pass condition_token (with a condition_emb module) or condition_embed [B,77,512]")
+        return condition_embed.float()
+
+    def _reverse(self, cond_emb, steps, noise_fn, return_logits):
+        """steps: list of (t, t_post) pairs, first one from the all-[MASK] state.  The 'q' repeat sampler
+        (dalle_spec.py:135-143: with probability `repeat_rate` a step is applied twice at the same t) draws from
+        Python's `random` exactly like the reference's wrapper: one random.random() per step."""
+        import random
+        device = self.device
+        B = cond_emb.shape[0]
+        K1, L = self.num_classes, self.content_seq_len
+        kv = self.transformer.condition_kv(cond_emb.to(device), self._schedule_table())
+        x = torch.full((B, L), K1 - 1, device=device, dtype=torch.long)  # all [MASK]
+        nxt = torch.empty_like(x)
+        calls = 0
+        for i, (step, step_post) in enumerate(steps):
+            t = torch.full((B,), step, device=device, dtype=torch.long)
+            tp = None if step_post == step else torch.full((B,), step_post, device=device, dtype=torch.long)
+            repeats = 2 if (self.repeat_rate is not None and random.random() < self.repeat_rate) else 1
+            for rep in range(repeats):
+                u = noise_fn(step if self.repeat_rate is None else calls, (B, K1, L)).to(device) \
+                    if noise_fn is not None else torch.rand((B, K1, L), device=device)
+                calls += 1
+                self.p_sample_tokens(x, kv, t, u.contiguous(), initial=(i == 0 and rep == 0), out=nxt, t_post=tp)
+                x, nxt = nxt, x
+        out = {"content_token": x}
+        if return_logits:
+            out["logits"] = torch.nn.functional.one_hot(x, K1).permute(0, 2, 1).float()
         return out
 
     @torch.no_grad()
@@ -159,29 +202,29 @@ class DiffusionTransformer(nn.Module):
                print_log=True, noise_fn=None, **kwargs):
         """Reverse diffusion from the all-[MASK] state (:587-659, filter_ratio == 0 branch).
 
-        noise_fn(step, shape) may supply the uniforms (tests inject the oracle's noise)."""
-        device = self.device
-        if self.condition_emb is not None and condition_token is not None:
-            cond_emb = self.condition_emb(condition_token).float()     # CLIP text tower (:619-621)
-        else:
-            if condition_embed is None:
-                raise ValueError("pass condition_token (with a condition_emb module) or condition_embed [B,77,512]")
-            cond_emb = condition_embed.float()
+        noise_fn(step, shape) may supply the uniforms (tests inject the oracle's noise; with the 'q' repeat sampler
+        active the first argument is the running p_sample call index instead of the timestep)."""
+        cond_emb = self._cond(condition_token, condition_embed)
         if int(self.num_timesteps * filter_ratio) != 0:
             raise NotImplementedError("filter_ratio > 0 needs the VQ encoder path (SURVEY.md section 8f-2)")
-        B = cond_emb.shape[0]
-        K1, L, T = self.num_classes, self.content_seq_len, self.num_timesteps
-        cond_emb = cond_emb.to(device)
-        kv = self.transformer.condition_kv(cond_emb, self._schedule_table())
-        x = torch.full((B, L), K1 - 1, device=device, dtype=torch.long)  # all [MASK]
-        nxt = torch.empty_like(x)
-        for step in range(T - 1, -1, -1):
-            t = torch.full((B,), step, device=device, dtype=torch.long)
-            u = noise_fn(step, (B, K1, L)).to(device) if noise_fn is not None else \
-                torch.rand((B, K1, L), device=device)
-            self.p_sample_tokens(x, kv, t, u.contiguous(), initial=(step == T - 1), out=nxt)
-            x, nxt = nxt, x
-        out = {"content_token": x}
-        if return_logits:
-            out["logits"] = torch.nn.functional.one_hot(x, K1).permute(0, 2, 1).float()
-        return out
+        T = self.num_timesteps
+        return self._reverse(cond_emb, [(s_, s_) for s_ in range(T - 1, -1, -1)], noise_fn, return_logits)
+
+    @torch.no_grad()
+    def sample_fast(self, condition_token, condition_mask, condition_embed, content_token=None, filter_ratio=0.5,
+                    temperature=1.0, return_att_weight=False, return_logits=False, content_logits=None,
+                    print_log=True, skip_step=1, noise_fn=None, **kwargs):
+        """Skip-step sampler (:748-812): timesteps T-1, T-2-skip, ... (0 appended), the network sees t, the
+        posterior t - skip_step while t > skip_step.  The reference calls p_pred's pieces directly, so the 'q'
+        wrapper on p_sample never applies here."""
+        cond_emb = self._cond(condition_token, condition_embed)
+        assert int(self.num_timesteps * filter_ratio) == 0     # the reference asserts start_step == 0 (:787)
+        lst = list(range(self.num_timesteps - 1, -1, -1 - skip_step))
+        if lst[-1] != 0:
+            lst.append(0)
+        keep, self.repeat_rate = self.repeat_rate, None
+        try:
+            return self._reverse(cond_emb, [(s_, s_ - skip_step if s_ > skip_step else s_) for s_ in lst], noise_fn,
+                                 return_logits)
+        finally:
+            self.repeat_rate = keep
