@@ -49,7 +49,8 @@ typedef struct ds_gemm_desc {
     int32_t rows_per_sample; /* dense prologue / DS_STORE_BATCH_T: rows of one sample */
     int32_t Cin;             /* channels per tap (conv loaders; dense prologue: = K) */
     int32_t H, Wd;           /* conv2d: output H, W; conv1d / convT1d: Wd = output length / phase rows */
-    int32_t up;              /* conv2d: input is (H/2, W/2), nearest-upsampled on the fly */
+    int32_t up;              /* conv2d: 1 = source is (H/2, W/2), nearest-upsampled on the fly; 2 = stride-2 conv over a
+                                (2H, 2W) source zero-padded right/bottom only (Downsample, model.py:60-77) */
     int32_t taps, dil;       /* conv1d (reflect padding) */
     int32_t ct_r, ct_p, ct_tin; /* convT1d polyphase: stride, padding, input length; groups = r */
     int32_t f16_round;       /* 1: round outputs (and GELU2 intermediates) to the fp16 grid (CLIP text tower) */
@@ -134,6 +135,11 @@ int ds_sample_tail_ex(const float* logits, const int64_t* xt, const int64_t* t, 
                       int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc, float* dbg_post, int B, int L,
                       int K, int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream);
 
+/* q_sample (diffusion_transformer.py:370-377): x_t ~ q(x_t | x_0) on token ids, u [B][K+1][L] uniforms; used by
+ * sample()'s filter_ratio > 0 branch (:643-651) */
+int ds_q_sample(const int64_t* x0, const int64_t* t, const float* u, const float* sched, int64_t* out_tokens, int B,
+                int L, int K, int T, ds_stream_t stream);
+
 /* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
 enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */
     DS_LP_ADALN1 = 0,  /* [T][2D]  ln1 table   */
@@ -198,6 +204,10 @@ int ds_profile_collect(double* ms, double* flops, int64_t* launches);
 /* ColumnMajor(reverse) + get_codebook_entry (permuter.py:31-55, quantize.py:88-103) -> [B][H][W][C] */
 int ds_codebook_gather(const int64_t* tokens, const float* codebook, float* out, int B, int H, int W, int C,
                        int K, ds_stream_t stream);
+/* VectorQuantizer.forward's nearest-code search (vqvae/quantize.py:46-53): z [M][C] encoder output rows,
+ * ze [M][K] = z E^T (ds_gemm), ee [K] = row norms^2 of the codebook -> idx [M] (first minimum), dmin [M] optional */
+int ds_vq_argmin(const float* z, const float* ze, const float* ee, int64_t* idx, float* dmin, int M, int C, int K,
+                 ds_stream_t stream);
 /* GroupNorm(groups, C, eps) statistics of x [B][P][C] folded into per-(b,c) scale/shift
  * (model.py:34-35); work >= B*ceil(P/256)*2*C doubles */
 int ds_groupnorm_stats(const float* x, int B, int P, int C, int groups, const float* gamma, const float* beta,

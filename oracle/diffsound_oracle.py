@@ -378,6 +378,72 @@ def decode_tokens(sd, tokens, pfx="content_codec."):
     return vq_decode(sd, codebook_gather(sd, tokens, pfx=pfx), pfx=pfx)
 
 
+# --------------------------------------------------------------------------- scope row 8f-2
+def vq_encoder(sd, x, pfx="content_codec.", num_resolutions=5, num_res_blocks=2):
+    """Encoder.forward (specvqgan/modules/diffusionmodules/model.py:467-500) + quant_conv
+    (spec_codec/vqgan.py:54-56): mel image [B, 1, 80, 848] -> pre-quantisation latent [B, 256, 5, 53].
+    Downsample = zero pad (0,1,0,1) then 3x3 stride-2 conv (:60-77); attention only where the blocks carry it
+    (the 53-wide level)."""
+    e = pfx + "encoder."
+    h = _conv2d(sd, e + "conv_in", x, 1)
+    for lvl in range(num_resolutions):
+        for ib in range(num_res_blocks):
+            h = _res_block(sd, e + "down.%d.block.%d." % (lvl, ib), h)
+            if (e + "down.%d.attn.%d.norm.weight" % (lvl, ib)) in sd:
+                h = _attn_block(sd, e + "down.%d.attn.%d." % (lvl, ib), h)
+        if lvl != num_resolutions - 1:
+            name = e + "down.%d.downsample.conv" % lvl
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[name + ".weight"], sd[name + ".bias"], stride=2)
+    h = _res_block(sd, e + "mid.block_1.", h)
+    h = _attn_block(sd, e + "mid.attn_1.", h)
+    h = _res_block(sd, e + "mid.block_2.", h)
+    h = _conv2d(sd, e + "conv_out", _gn_swish(sd, e + "norm_out", h), 1)
+    return _conv2d(sd, pfx + "quant_conv", h, 0)
+
+
+def vq_quantize(sd, h, pfx="content_codec."):
+    """VectorQuantizer.forward's code search, vqvae/quantize.py:31-53: rows of h (channels last) against the
+    codebook with d = |z|^2 + |e|^2 - 2 z.e, argmin.  Returns (indices [B, H*W] row-major, d [B*H*W, K])."""
+    E = sd[pfx + "quantize.embedding.weight"]
+    z = h.permute(0, 2, 3, 1).contiguous().view(-1, E.shape[1])
+    d = torch.sum(z ** 2, dim=1, keepdim=True) + torch.sum(E ** 2, dim=1) - 2 * torch.matmul(z, E.t())
+    return torch.argmin(d, dim=1).view(h.shape[0], -1), d
+
+
+def encode_tokens(sd, mel, pfx="content_codec.", hw=(5, 53)):
+    """DALLE.get_tokens, dalle_spec.py:70-77: encode -> indices -> ColumnMajor (sequence item w*H + h is cell (h, w),
+    permuter.py:21-55)."""
+    idx, _ = vq_quantize(sd, vq_encoder(sd, mel, pfx), pfx)
+    H, W = hw
+    return idx.view(-1, H, W).transpose(1, 2).reshape(idx.shape[0], H * W)
+
+
+def q_sample(sched, tokens, t, u, num_classes):
+    """q_sample, diffusion_transformer.py:370-377: x_t ~ q(x_t | x_0) via q_pred (:253-267) and the Gumbel
+    sampler with injected uniforms u [B, K+1, L].  Returns the log-one-hot state."""
+    T = sched["log_at"].numel()
+    log_x0 = log_onehot(tokens, num_classes)
+    return log_onehot(gumbel_sample(_q_pred(sched, log_x0, t, T), u), num_classes)
+
+
+def sample_loop_partial(sd, cond_emb, content_token, filter_ratio, noise_fn, num_timesteps=100, trunc_r=0.85,
+                        n_head=16):
+    """sample() with filter_ratio > 0, :643-651: diffuse the given tokens forward to t = start_step - 1, then run the
+    reverse chain from there.  noise_fn(call_index, shape): call 0 is q_sample's draw."""
+    K = sd["transformer.transformer.to_logits.1.weight"].shape[0]
+    B = cond_emb.shape[0]
+    sched = make_schedule(num_timesteps, K + 1)
+    start = int(num_timesteps * filter_ratio)
+    t = torch.full((B,), start - 1, dtype=torch.long)
+    log_z = q_sample(sched, content_token, t, noise_fn(0, (B, K + 1, content_token.shape[1])), K + 1)
+    calls = 1
+    for step in range(start - 1, -1, -1):
+        t = torch.full((B,), step, dtype=torch.long)
+        log_z = p_sample_step(sd, sched, log_z, cond_emb, t, noise_fn(calls, log_z.shape), trunc_r, n_head)
+        calls += 1
+    return log_z.argmax(1)
+
+
 # --------------------------------------------------------------------------- A15
 def _wn(sd, name):
     """weight_norm fold: w = g * v / ||v||, norm over all dims but 0 (vocoder/modules.py:18-23;

@@ -121,10 +121,50 @@ def samplers():
     save("samplers_T10_L2", pos_stride=POS_STRIDE, **arrs)
 
 
+def encoder():
+    """VQModel.encode (Encoder + quant_conv + nearest-code search), DALLE.get_tokens, and
+    sample()'s filter_ratio > 0 branch (q_sample of given tokens, then the reverse chain)."""
+    torch.manual_seed(0)
+    m = rh.build_dalle(n_layer=2, diffusion_step=10, n_embed=256, with_encoder=True)
+    with open(os.path.join(OUT, "state_dict_keys_encoder.json"), "w") as f:
+        keys = state_keys(m)
+        keep = lambda k: k.startswith(("content_codec.encoder.", "content_codec.quant_conv."))
+        json.dump({"encoder": {"params": {k: v for k, v in keys["params"].items() if keep(k)},
+                               "buffers": {k: v for k, v in keys["buffers"].items() if keep(k)}}},
+                  f, indent=0, sort_keys=True)
+    mel = synth.synth_uniform((2, 1, 80, 848), key="enc.mel") * 2 - 1
+    codec = m.content_codec
+    h = codec.quant_conv(codec.encoder(mel))
+    quant, _, info = codec.encode(mel)
+    _, tokens = m.get_tokens(mel)
+    E = codec.quantize.embedding.weight
+    z = h.permute(0, 2, 3, 1).reshape(-1, 256)
+    d = (z ** 2).sum(1, keepdim=True) + (E ** 2).sum(1) - 2 * z @ E.t()
+    top2 = d.topk(2, dim=1, largest=False).values
+    arrs = dict(h=h, indices=info[2].view(2, -1), tokens=tokens, gap=(top2[:, 1] - top2[:, 0]).view(2, -1),
+                quant_sample=quant[:, :, :, ::13])
+    # partial re-sampling: the tokens above, filter_ratio 0.5 on the T=10 model -> q_sample at t=4, 5 reverse steps
+    dt = m.transformer
+    dt.predict_start = m.predict_start_with_truncation(dt.predict_start, "top0.85r")
+    cond = synth.synth_cond_emb(2, key="traj.cond")
+    n = [0]
+
+    def noise(shp):
+        n[0] += 1
+        return synth.synth_uniform(shp, key="part.u%d" % (n[0] - 1))
+    with InjectNoise(noise):
+        out = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, content_token=tokens,
+                        filter_ratio=0.5, batch_size=2)
+    arrs.update(partial_tokens=out["content_token"], partial_calls=torch.tensor(n[0]))
+    save("encoder_T10_L2", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--text-only" in sys.argv:
         return text_stage()
+    if "--encoder-only" in sys.argv:
+        return encoder()
     if "--samplers-only" in sys.argv:
         return samplers()
     torch.manual_seed(0)
@@ -206,6 +246,7 @@ def main():
     save("vocoder", wave=voc(mel01))
     text_stage()
     samplers()
+    encoder()
     print("done in %.1fs" % (time.time() - t0))
 
 

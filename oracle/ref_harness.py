@@ -81,8 +81,9 @@ def ref_config(n_layer=19, diffusion_step=100, n_embed=256):
     return cfg
 
 
-def build_dalle(n_layer=19, diffusion_step=100, n_embed=256, seed=0):
-    """Reference DALLE (without CLIP) carrying synth weights keyed by state-dict name."""
+def build_dalle(n_layer=19, diffusion_step=100, n_embed=256, seed=0, with_encoder=False):
+    """Reference DALLE (without CLIP) carrying synth weights keyed by state-dict name.  with_encoder also gives the
+    VQ encoder + quant_conv synth weights (scope row 8f-2); weights are keyed by name, so nothing else changes."""
     install()
     from sound_synthesis.modeling.build import build_model
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -90,8 +91,8 @@ def build_dalle(n_layer=19, diffusion_step=100, n_embed=256, seed=0):
     cfg = ref_config(n_layer, diffusion_step, n_embed)
     model = build_model(cfg).eval()
     # the VQ encoder / loss are not on the path; leave them at their defaults
-    synth_init_(model, seed=seed,
-                skip=("content_codec.encoder.", "content_codec.quant_conv.", "content_codec.loss."))
+    synth_init_(model, seed=seed, skip=("content_codec.loss.",) if with_encoder else
+                ("content_codec.encoder.", "content_codec.quant_conv.", "content_codec.loss."))
     for p in model.parameters():
         p.requires_grad_(False)
     return model

@@ -25,7 +25,10 @@ def golden(name):
 
 def key_contract():
     with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
-        return json.load(f)
+        c = json.load(f)
+    with open(os.path.join(GOLDEN, "state_dict_keys_encoder.json")) as f:   # scope row 8f-2, generated separately
+        c.update(json.load(f))
+    return c
 
 
 _SD_CACHE = {}
@@ -51,6 +54,12 @@ def synth_sd(which, n_layer=19, seed=0):
 @pytest.fixture(scope="session")
 def sd_dalle_l2():
     return synth_sd("dalle", 2)
+
+
+@pytest.fixture(scope="session")
+def sd_encoder():
+    """content_codec.encoder.* + content_codec.quant_conv.* (the VQ encode side)"""
+    return synth_sd("encoder")
 
 
 @pytest.fixture(scope="session")

@@ -33,6 +33,8 @@ def test_state_dict_contract_matches_reference():
     for name, mod in (("dalle", build_model(default_config(n_layer=19))), ("generator", Generator(80, 32, 3))):
         sd = {k: list(v.shape) for k, v in mod.state_dict().items()}
         want = dict(ref[name]["params"], **ref[name]["buffers"])
+        if name == "dalle":   # + the VQ encode side (scope row 8f-2), listed in its own golden file
+            want.update(ref["encoder"]["params"], **ref["encoder"]["buffers"])
         assert sd == want, (set(sd) ^ set(want))
 
 
@@ -96,5 +98,6 @@ def test_sample_type_language():
     m = build_model(default_config(n_layer=1))
     with pytest.raises(NotImplementedError):       # no tokenizer / CLIP attached in this config
         m.generate_content(batch={"text": ["a dog barks"]})
-    with pytest.raises(NotImplementedError):
-        m.generate_content(batch={"condition_embed_token": torch.zeros(1, 77, 512)}, sample_type="top100p")
+    with pytest.raises(ValueError):                # filter_ratio > 0 re-samples given content tokens
+        m.transformer.sample(condition_token=None, condition_mask=None, condition_embed=torch.zeros(1, 77, 512),
+                             filter_ratio=0.5)

@@ -19,6 +19,7 @@ def build(n_layer, T=100):
     from text_to_sound_synthesis_amd.config import build_model, default_config
     m = build_model(default_config(n_layer=n_layer, diffusion_step=T))
     sd = dict(synth_sd("dalle", n_layer))
+    sd.update(synth_sd("encoder"))
     if T != 100:   # the timestep-embedding tables have one row per step (values are a prefix)
         sd = {k: (v[:T] if k.endswith(("ln1.emb.weight", "ln1_1.emb.weight")) else v) for k, v in sd.items()}
     missing, unexpected = m.load_state_dict(sd, strict=False)
@@ -149,6 +150,56 @@ def test_alternative_samplers_vs_reference():
     _, tok = run("top0.85r,q0.5", lambda c, shp: (calls.append(c), synth.synth_uniform(shp, key="rep.u%d" % c))[1], seed=7)
     assert len(calls) == int(g["q05_calls"])
     assert (tok != g["q05_tokens"]).sum().item() == 0
+
+
+def test_vq_encode_get_tokens_and_partial_resample_vs_reference():
+    """VQModel.encode / DALLE.get_tokens / prepare_content on the HIP path, and sample() with
+    filter_ratio > 0 (q_sample + reverse chain) -- all against the reference's outputs."""
+    g = golden("encoder_T10_L2")
+    m = build(2, T=10)
+    m.transformer.truncation_r = 0.85
+    mel = (synth.synth_uniform((2, 1, 80, 848), key="enc.mel") * 2 - 1).cuda()
+    h = m.content_codec.encode_latent(mel).cpu()
+    err = (h - g["h"]).abs().max().item()
+    print("encoder latent max-abs err vs reference %.2e (|h| max %.2f)" % (err, g["h"].abs().max()))
+    assert h.shape == (2, 256, 5, 53) and err < 1e-4
+    quant, loss, info = m.content_codec.encode(mel)
+    idx = info[2].view(2, -1).cpu()
+    clear = g["gap"] > 1e-3                       # the best two codes are further apart than the latent's error allows
+    assert clear.float().mean() > 0.7 and torch.equal(idx[clear], g["indices"][clear])
+    assert quant.shape == (2, 256, 5, 53) and info[1].shape == (530, 256) and torch.isfinite(loss)
+    E = m.content_codec.quantize.embedding.weight
+    assert torch.equal(quant.permute(0, 2, 3, 1).reshape(-1, 256), E[info[2][:, 0]])       # z_q rows are code vectors
+    qz, tokens = m.get_tokens(mel)
+    cm = clear.view(2, 5, 53).transpose(1, 2).reshape(2, -1)
+    assert torch.equal(tokens.cpu()[cm], g["tokens"][cm])
+    pc = m.prepare_content({"image": mel})
+    assert torch.equal(pc["content_token"], tokens) and pc["content_quant"].shape == (2, 256, 5, 53)
+    # the nearest-code search itself, on the reference's latent: exact except at rounding-level ties
+    _, _, info2 = m.content_codec.quantize(g["h"].cuda())
+    tight = g["gap"] > 1e-5
+    assert torch.equal(info2[2].view(2, -1).cpu()[tight], g["indices"][tight])
+    # partial re-sampling from the reference's tokens (filter_ratio 0.5 of T = 10)
+    cond = synth.synth_cond_emb(2, key="traj.cond").cuda()
+    calls = []
+    out = m.transformer.sample(condition_token=None, condition_mask=None, condition_embed=cond,
+                               content_token=g["tokens"].cuda(), filter_ratio=0.5,
+                               noise_fn=lambda c, shp: (calls.append(c), synth.synth_uniform(shp, key="part.u%d" % c))[1])
+    assert calls == list(range(int(g["partial_calls"])))
+    assert (out["content_token"].cpu() != g["partial_tokens"]).sum().item() == 0
+
+
+def test_q_sample_matches_oracle():
+    import diffsound_oracle as O
+    m = build(2, T=100)
+    dt = m.transformer
+    x0 = synth.synth_tokens(3, mask_frac=0.2, key="qs.x0")
+    for tt in (0, 37, 99):
+        t = torch.full((3,), tt, dtype=torch.long)
+        u = synth.synth_uniform((3, 257, 265), key="qs.u%d" % tt)
+        ref = O.q_sample(O.make_schedule(100, 257), x0, t, u, 257).argmax(1)
+        got = dt.q_sample_tokens(x0.cuda(), t.cuda(), u.cuda()).cpu()
+        assert (got != ref).sum().item() == 0
 
 
 def test_sample_tail_top_k_argument_checks():

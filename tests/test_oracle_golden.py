@@ -124,6 +124,33 @@ def test_alternative_samplers_T10(sd_dalle_l2):
     assert torch.equal(tok, g["q05_tokens"])
 
 
+def test_vq_encode_and_partial_resample(sd_dalle_l2, sd_encoder):
+    """Encoder + quant_conv + nearest-code search + ColumnMajor, and sample()'s filter_ratio > 0
+    branch, against the reference (goldens from oracle/make_golden.py encoder())."""
+    g = golden("encoder_T10_L2")
+    sd = dict(sd_dalle_l2)
+    sd.update(sd_encoder)
+    mel = synth.synth_uniform((2, 1, 80, 848), key="enc.mel") * 2 - 1
+    h = O.vq_encoder(sd, mel)
+    assert h.shape == (2, 256, 5, 53) and (h - g["h"]).abs().max() < 2e-5
+    idx, d = O.vq_quantize(sd, h)
+    clear = g["gap"] > 1e-4                      # positions whose best two codes are not a rounding-level tie
+    assert clear.float().mean() > 0.9 and torch.equal(idx[clear], g["indices"][clear])
+    best = d.gather(1, g["indices"].view(-1, 1)).view(2, -1)   # the reference's pick is (near-)optimal here too
+    assert (best - d.min(1).values.view(2, -1)).max() < 1e-4
+    tok = O.encode_tokens(sd, mel)
+    assert torch.equal(tok[clear.view(2, 5, 53).transpose(1, 2).reshape(2, -1)],
+                       g["tokens"][clear.view(2, 5, 53).transpose(1, 2).reshape(2, -1)])
+    # partial re-sampling from the reference's tokens: q_sample to t = 4, then 5 reverse steps
+    cond = synth.synth_cond_emb(2, key="traj.cond")
+    calls = []
+    out = O.sample_loop_partial(sd_dalle_l2, cond, g["tokens"], 0.5,
+                                lambda c, shp: (calls.append(c), synth.synth_uniform(shp, key="part.u%d" % c))[1],
+                                num_timesteps=10)
+    assert len(calls) == int(g["partial_calls"]) == 6
+    assert torch.equal(out, g["partial_tokens"])
+
+
 def test_decode(sd_dalle_l2):
     tok = synth.synth_tokens(1, mask_frac=0.0, key="dec.tokens")
     mel = O.decode_tokens(sd_dalle_l2, tok)

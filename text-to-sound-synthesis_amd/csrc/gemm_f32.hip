@@ -126,11 +126,18 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
             const int c0 = k0 - tap * p.Cin + kq;
             const int ky = tap / 3, kx = tap - ky * 3;
             int sy = a_y[i] + ky - 1, sx = a_x[i] + kx - 1;
-            const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W_;
+            bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W_;
             sy = ok ? sy : a_y[i];
             sx = ok ? sx : a_x[i];
             int hs = p.H, ws = p.W_;
-            if (p.up) { sy >>= 1; sx >>= 1; hs >>= 1; ws >>= 1; }
+            if (p.up == 1) { sy >>= 1; sx >>= 1; hs >>= 1; ws >>= 1; }   // nearest-2x upsample of the source
+            if (p.up == 2) {   // stride-2 conv over a (2H x 2W) source zero-padded on the right/bottom only
+                hs = 2 * p.H; ws = 2 * p.W_;        // (Downsample, diffusionmodules/model.py:60-77)
+                sy = 2 * a_y[i] + ky; sx = 2 * a_x[i] + kx;
+                ok = sy < hs && sx < ws;
+                sy = ok ? sy : 2 * a_y[i];
+                sx = ok ? sx : 2 * a_x[i];
+            }
             okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
             return *(const f32x4*)(a_base[i] + ((size_t)(a_b[i] * hs + sy) * ws + sx) * p.Cin + c0);
         } else if constexpr (LOADER == DS_LOAD_CONV1D) {

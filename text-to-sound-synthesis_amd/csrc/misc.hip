@@ -89,7 +89,50 @@ __global__ __launch_bounds__(256) void ds_mel_to_cl_kernel(const float* __restri
     out[i] = c < C ? a * mel[((size_t)b * C + c) * T + t] + bb : 0.f;
 }
 
+// ---- nearest-code search of VectorQuantizer.forward (vqvae/quantize.py:46-53) --------------------------
+// d[k] = (sum_c z[c]^2 + ee[k]) - 2 * ze[k] with ze = z E^T from the GEMM and ee[k] = sum_c E[k][c]^2 -- the
+// reference's expression, same association; argmin with the first index winning ties (torch.argmin).
+__global__ __launch_bounds__(256) void ds_vq_argmin_kernel(const float* __restrict__ z, const float* __restrict__ ze,
+                                                           const float* __restrict__ ee, int64_t* __restrict__ idx,
+                                                           float* __restrict__ dmin, int M, int C, int K) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    float zz = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = z[(size_t)row * C + c];
+        zz += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o);
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {   // ascending k within a lane keeps the first minimum
+        const float d = (zz + ee[k]) - 2.f * ze[(size_t)row * K + k];
+        if (d < best) { best = d; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+        idx[row] = bi;
+        if (dmin) dmin[row] = best;
+    }
+}
+
 // ---- C ABI ----------------------------------------------------------------------------------------
+extern "C" int ds_vq_argmin(const float* z, const float* ze, const float* ee, int64_t* idx, float* dmin, int M, int C,
+                            int K, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(z && ze && ee && idx && M > 0 && C > 0 && K > 0, "bad arguments");
+    hipLaunchKernelGGL(ds_vq_argmin_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, z, ze, ee, idx, dmin, M, C, K);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ds_codebook_gather(const int64_t* tokens, const float* codebook, float* out, int B, int H, int W,
                                   int C, int K, ds_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

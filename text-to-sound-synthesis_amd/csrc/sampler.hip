@@ -227,6 +227,47 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
     if (lane == 0 && live) p.out_tokens[col] = bidx;
 }
 
+// ---- q_sample (diffusion_transformer.py:370-377): x_t ~ q(x_t | x_0) for token ids, Gumbel-argmax ----------
+// log q(x_t = c | x_0) = log_add_exp(log_onehot(x_0)[c] + log_cumprod_at[t], log_cumprod_bt[t]) for the K classes,
+// log_add_exp(log_onehot(x_0)[K] + log_1_min_cumprod_ct[t], log_cumprod_ct[t]) for [MASK]  (q_pred, :253-267)
+__global__ __launch_bounds__(256) void ds_q_sample_kernel(const int64_t* __restrict__ x0, const int64_t* __restrict__ t,
+                                                          const float* __restrict__ u, const float* __restrict__ sched,
+                                                          int64_t* __restrict__ out, int B, int L, int K, int T) {
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= B * L) return;
+    const int lane = threadIdx.x & 63;
+    const int b = col / L, pos = col - b * L;
+    const int T1 = T + 1, tt = (int)t[b];
+    const float lcat = sched[4 * T1 + tt], lcbt = sched[5 * T1 + tt], lcct = sched[6 * T1 + tt],
+                l1mcct = sched[7 * T1 + tt];
+    const int x = (int)x0[col];
+    const float hit = lae(0.f + lcat, lcbt), off = lae(LOG_ZERO_F + lcat, lcbt);
+    const float* up = u + (size_t)b * (K + 1) * L + pos;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c <= K; c += 64) {
+        const float lq = c < K ? (c == x ? hit : off) : lae((x == K ? 0.f : LOG_ZERO_F) + l1mcct, lcct);
+        const float g = -logf(-logf(up[(size_t)c * L] + 1e-30f) + 1e-30f) + lq;
+        if (g > best) { best = g; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) out[col] = bi;
+}
+
+extern "C" int ds_q_sample(const int64_t* x0, const int64_t* t, const float* u, const float* sched, int64_t* out,
+                           int B, int L, int K, int T, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x0 && t && u && sched && out && B > 0 && L > 0 && K > 0 && T > 0, "bad arguments");
+    hipLaunchKernelGGL(ds_q_sample_kernel, dim3((B * L + 3) / 4), dim3(256), 0, stream, x0, t, u, sched, out, B, L, K, T);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ds_sample_tail_ex(const float* logits, const int64_t* xt, const int64_t* t, const float* u,
                                  const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc,
                                  float* dbg_post, int B, int L, int K, int T, int initial, float trunc_r,

@@ -33,6 +33,25 @@ class DALLE(nn.Module):
         return self.transformer
 
     @torch.no_grad()
+    @torch.no_grad()
+    def get_tokens(self, spec):
+        """mel image [B, 1, 80, 848] -> (quant_z, token ids [B, 265] in sequence order) (dalle_spec.py:70-77)."""
+        quant_z, _, info = self.content_codec.encode(spec)
+        indices = self.first_stage_permuter(info[2].view(quant_z.shape[0], -1))
+        self.zshape = quant_z.shape
+        return quant_z, indices
+
+    @torch.no_grad()
+    def prepare_content(self, batch, with_mask=False):
+        """batch[content key] -> {'content_token', 'content_quant'} (dalle_spec.py:107-126, with_mask=False branch)."""
+        if with_mask:
+            raise NotImplementedError("masked content encoding is not part of the sound pipeline (:118-120)")
+        cont = batch[self.content_info["key"]]
+        if torch.is_tensor(cont):
+            cont = cont.to(self.device)
+        quant_z, indices = self.get_tokens(cont)
+        return {"content_token": indices, "content_quant": quant_z}
+
     def decode_to_img(self, index, zshape, stage="first"):
         """tokens (sequence order) -> mel image [B, 1, 80, 848] (:80-91)."""
         assert stage == "first"

@@ -169,8 +169,19 @@ class DiffusionTransformer(nn.Module):
             raise ValueError("pass condition_token (with a condition_emb module) or condition_embed [B,77,512]")
         return condition_embed.float()
 
-    def _reverse(self, cond_emb, steps, noise_fn, return_logits):
-        """steps: list of (t, t_post) pairs, first one from the all-[MASK] state.  The 'q' repeat sampler
+    @torch.no_grad()
+    def q_sample_tokens(self, x0, t, u):
+        """x_t ~ q(x_t | x_0) on token ids (q_sample, :370-377); u f32[B, K+1, L] uniforms."""
+        out = torch.empty_like(x0)
+        _lib.check(_lib.lib().ds_q_sample(_lib.ptr(x0.contiguous()), _lib.ptr(t.contiguous()), _lib.ptr(u.contiguous()),
+                                          _lib.ptr(self._schedule_table()), _lib.ptr(out), x0.shape[0],
+                                          self.content_seq_len, self.num_classes - 1, self.num_timesteps,
+                                          _lib.stream()))
+        return out
+
+    def _reverse(self, cond_emb, steps, noise_fn, return_logits, start_tokens=None):
+        """steps: list of (t, t_post) pairs, first one from the all-[MASK] state (or from start_tokens, already
+        diffused to the first t).  The 'q' repeat sampler
         (dalle_spec.py:135-143: with probability `repeat_rate` a step is applied twice at the same t) draws from
         Python's `random` exactly like the reference's wrapper: one random.random() per step."""
         import random
@@ -178,7 +189,10 @@ class DiffusionTransformer(nn.Module):
         B = cond_emb.shape[0]
         K1, L = self.num_classes, self.content_seq_len
         kv = self.transformer.condition_kv(cond_emb.to(device), self._schedule_table())
-        x = torch.full((B, L), K1 - 1, device=device, dtype=torch.long)  # all [MASK]
+        if start_tokens is None:
+            x = torch.full((B, L), K1 - 1, device=device, dtype=torch.long)  # all [MASK]
+        else:
+            x = start_tokens.to(device).clone()
         nxt = torch.empty_like(x)
         calls = 0
         for i, (step, step_post) in enumerate(steps):
@@ -189,7 +203,8 @@ class DiffusionTransformer(nn.Module):
                 u = noise_fn(step if self.repeat_rate is None else calls, (B, K1, L)).to(device) \
                     if noise_fn is not None else torch.rand((B, K1, L), device=device)
                 calls += 1
-                self.p_sample_tokens(x, kv, t, u.contiguous(), initial=(i == 0 and rep == 0), out=nxt, t_post=tp)
+                self.p_sample_tokens(x, kv, t, u.contiguous(), initial=(start_tokens is None and i == 0 and rep == 0),
+                                     out=nxt, t_post=tp)
                 x, nxt = nxt, x
         out = {"content_token": x}
         if return_logits:
@@ -205,10 +220,24 @@ class DiffusionTransformer(nn.Module):
         noise_fn(step, shape) may supply the uniforms (tests inject the oracle's noise; with the 'q' repeat sampler
         active the first argument is the running p_sample call index instead of the timestep)."""
         cond_emb = self._cond(condition_token, condition_embed)
-        if int(self.num_timesteps * filter_ratio) != 0:
-            raise NotImplementedError("filter_ratio > 0 needs the VQ encoder path (SURVEY.md section 8f-2)")
         T = self.num_timesteps
-        return self._reverse(cond_emb, [(s_, s_) for s_ in range(T - 1, -1, -1)], noise_fn, return_logits)
+        start_step = int(T * filter_ratio)
+        if start_step == 0:
+            return self._reverse(cond_emb, [(s_, s_) for s_ in range(T - 1, -1, -1)], noise_fn, return_logits)
+        # partial re-sampling (:643-651): diffuse the given tokens (e.g. DALLE.get_tokens of a mel) forward to
+        # t = start_step - 1, then run the reverse chain from there.  With noise_fn, call 0 is q_sample's draw and
+        # the reverse steps get the running call index 1.. instead of the timestep.
+        if content_token is None:
+            raise ValueError("filter_ratio > 0 re-samples given content: pass content_token i64[B, 265]")
+        device, B = self.device, cond_emb.shape[0]
+        shape = (B, self.num_classes, self.content_seq_len)
+        t = torch.full((B,), start_step - 1, device=device, dtype=torch.long)
+        u = noise_fn(0, shape).to(device) if noise_fn is not None else torch.rand(shape, device=device)
+        x = self.q_sample_tokens(content_token.to(device), t, u)
+        steps = list(range(start_step - 1, -1, -1))
+        nf = None if noise_fn is None else (lambda st, shp: noise_fn(1 + steps.index(st), shp)) \
+            if self.repeat_rate is None else (lambda c, shp: noise_fn(1 + c, shp))
+        return self._reverse(cond_emb, [(s_, s_) for s_ in steps], nf, return_logits, start_tokens=x)
 
     @torch.no_grad()
     def sample_fast(self, condition_token, condition_mask, condition_embed, content_token=None, filter_ratio=0.5,

@@ -1,4 +1,4 @@
-"""Drop-in for the SpecVQGAN decode side, HIP-backed.
+"""Drop-in for the SpecVQGAN codec (decode side on the generation path; encode side = SURVEY.md 8f-2), HIP-backed.
 
 Mirrors sound_synthesis/modeling/codecs/spec_codec/vqgan.py:VQModel (decode :62-65),
 specvqgan/modules/diffusionmodules/model.py (Decoder :570-671, ResnetBlock :92-151, AttnBlock
@@ -29,6 +29,16 @@ class Upsample(nn.Module):
         self.with_conv = with_conv
         if with_conv:
             self.conv = nn.Conv2d(c, c, 3, 1, 1)
+
+
+class Downsample(nn.Module):
+    """zero pad (0,1,0,1) + 3x3 stride-2 conv (diffusionmodules/model.py:60-77)"""
+
+    def __init__(self, c, with_conv=True):
+        super().__init__()
+        assert with_conv
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(c, c, 3, 2, 0)
 
 
 class ResnetBlock(nn.Module):
@@ -89,12 +99,69 @@ class Decoder(nn.Module):
         self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
 
 
+class Encoder(nn.Module):
+    """Parameter container with the reference's attribute names (diffusionmodules/model.py:410-465)."""
+
+    def __init__(self, *, ch, out_ch=None, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, **ignore):
+        super().__init__()
+        assert resamp_with_conv
+        self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, 1, 1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            down = nn.Module()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, True)
+                curr_res = curr_res // 2
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, 1, 1)
+
+
 class VectorQuantizer(nn.Module):
     def __init__(self, n_e, e_dim, beta=0.25):
         super().__init__()
         self.n_e, self.e_dim, self.beta = n_e, e_dim, beta
         self.embedding = nn.Embedding(n_e, e_dim)
         self.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)
+
+    @torch.no_grad()
+    def forward(self, z):
+        """z f32[B, C, H, W] -> (z_q [B, C, H, W], loss, (perplexity, min_encodings [M, n_e], indices [M, 1])) as
+        vqvae/quantize.py:31-86.  The code search runs on the GPU: z E^T by the gather-GEMM, then
+        d = |z|^2 + |e|^2 - 2 z.e and the first argmin per row (ds_vq_argmin)."""
+        B, Cc, H, W = z.shape
+        E = self.embedding.weight.detach().float().contiguous()
+        zf = z.permute(0, 2, 3, 1).contiguous().float().view(-1, Cc)
+        M = zf.shape[0]
+        ze = torch.empty(M, self.n_e, device=z.device)
+        _lib.gemm(zf, E, ze, M, self.n_e, Cc)
+        idx = torch.empty(M, device=z.device, dtype=torch.long)
+        _lib.check(_lib.lib().ds_vq_argmin(_lib.ptr(zf), _lib.ptr(ze), _lib.ptr((E * E).sum(1).contiguous()),
+                                           _lib.ptr(idx), None, M, Cc, self.n_e, _lib.stream()))
+        z_q = E[idx]
+        loss = torch.mean((z_q - zf) ** 2) * (1.0 + self.beta)              # forward value of :70
+        min_encodings = torch.nn.functional.one_hot(idx, self.n_e).to(zf.dtype)
+        e_mean = min_encodings.mean(0)
+        perplexity = torch.exp(-torch.sum(e_mean * torch.log(e_mean + 1e-10)))
+        z_q = z_q.view(B, H, W, Cc).permute(0, 3, 1, 2).contiguous()
+        return z_q, loss, (perplexity, min_encodings, idx.unsqueeze(1))
 
     @torch.no_grad()
     def get_codebook_entry(self, indices, shape):
@@ -137,23 +204,26 @@ class VQModel(nn.Module):
                  image_key="image", colorize_nlabels=None, monitor=None):
         super().__init__()
         self.image_key = image_key
+        self.encoder = Encoder(**ddconfig)
         self.decoder = Decoder(**ddconfig)
         self.quantize = VectorQuantizer(n_embed, embed_dim, beta=0.25)
+        self.quant_conv = nn.Conv2d(ddconfig["z_channels"], embed_dim, 1)
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        self._pke = None
         self.ddconfig = dict(ddconfig)
         self._pk = None
         self.decode_chunk = 16  # samples decoded at once (bounds the full-resolution workspace)
-        self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
+        self._register_load_state_dict_pre_hook(lambda *a, **k: (setattr(self, "_pk", None), setattr(self, "_pke", None)))
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys)
 
     def init_from_ckpt(self, path, ignore_keys=list()):
         sd = torch.load(path, map_location="cpu")["state_dict"]
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
-        self.load_state_dict(sd, strict=False)  # encoder / loss keys are not on this path
+        self.load_state_dict(sd, strict=False)  # loss / discriminator keys are not part of this module
 
     def _apply(self, fn, *a, **k):
-        self._pk = None
+        self._pk = self._pke = None
         return super()._apply(fn, *a, **k)
 
     # ---- packing -------------------------------------------------------------------------------------
@@ -190,6 +260,39 @@ class VQModel(nn.Module):
         w = d.conv_out.weight.detach().float()  # [1, C, 3, 3] -> [9 taps][C]
         pk["conv_out"] = (w[0].permute(1, 2, 0).reshape(9, -1).contiguous(), float(d.conv_out.bias.item()))
         self._pk = pk
+        return pk
+
+    @torch.no_grad()
+    def _packed_encoder(self):
+        if self._pke is not None:
+            return self._pke
+        gb = lambda n: (n.weight.detach().float().contiguous(), n.bias.detach().float().contiguous())
+
+        def res(b):
+            r = {"n1": gb(b.norm1), "c1": _pack_conv3(b.conv1), "n2": gb(b.norm2), "c2": _pack_conv3(b.conv2),
+                 "cin": b.in_channels, "cout": b.out_channels}
+            if b.in_channels != b.out_channels:
+                r["nin"] = _pack_conv1(b.nin_shortcut)
+            return r
+
+        def att(a):
+            qw, qb = _pack_conv1(a.q)
+            kw, kb = _pack_conv1(a.k)
+            return {"n": gb(a.norm), "qk": (torch.cat((qw, kw), 0).contiguous(), torch.cat((qb, kb), 0).contiguous()),
+                    "v": _pack_conv1(a.v), "proj": _pack_conv1(a.proj_out), "c": a.in_channels}
+        e = self.encoder
+        # conv_in has one input channel: its 9-tap K axis is zero-padded to the GEMM's 32-wide channel granule
+        w = e.conv_in.weight.detach().float()                                   # [ch, 1, 3, 3]
+        w_in = torch.zeros(w.shape[0], 9, 32, device=w.device)
+        w_in[:, :, 0] = w[:, 0].reshape(w.shape[0], 9)
+        pk = {"conv_in": (w_in.reshape(w.shape[0], -1).contiguous(), e.conv_in.bias.detach().float().contiguous()),
+              "down": [], "mid": (res(e.mid.block_1), att(e.mid.attn_1), res(e.mid.block_2)),
+              "norm_out": gb(e.norm_out), "conv_out": _pack_conv3(e.conv_out), "quant": _pack_conv1(self.quant_conv)}
+        for lvl in range(e.num_resolutions):
+            dn = e.down[lvl]
+            pk["down"].append({"block": [res(b) for b in dn.block], "attn": [att(a) for a in dn.attn],
+                               "downsample": _pack_conv3(dn.downsample.conv) if lvl != e.num_resolutions - 1 else None})
+        self._pke = pk
         return pk
 
     # ---- HIP op helpers (channels-last) ------------------------------------------------------------------
@@ -280,7 +383,54 @@ class VQModel(nn.Module):
         _lib.check(_lib.lib().ds_stencil9(_lib.ptr(taps), 16, pk["conv_out"][1], _lib.ptr(out), B, H, W, _lib.stream()))
         return out
 
+    @torch.no_grad()
+    def _encode_cl(self, x, B, H, W):
+        """x: [B, H, W, 32] channels-last image with channel 0 = the mel, the rest zero -> latent [B, H/16, W/16, C]
+        (Encoder.forward, diffusionmodules/model.py:467-500, + quant_conv)."""
+        pk, e = self._packed_encoder(), self.encoder
+        h = self._conv3(x, B, H, W, 32, pk["conv_in"])
+        for lvl in range(e.num_resolutions):
+            dn = pk["down"][lvl]
+            for i, r in enumerate(dn["block"]):
+                h = self._res(h, B, H, W, r)
+                if dn["attn"]:
+                    h = self._attn(h, B, H, W, dn["attn"][i])
+            if dn["downsample"] is not None:
+                H, W = H // 2, W // 2
+                h = self._conv3(h, B, H, W, h.shape[-1], dn["downsample"], up=2)    # stride-2, pad right/bottom
+        r1, a1, r2 = pk["mid"]
+        h = self._res(h, B, H, W, r1)
+        h = self._attn(h, B, H, W, a1)
+        h = self._res(h, B, H, W, r2)
+        Cc = h.shape[-1]
+        h = self._conv3(h, B, H, W, Cc, pk["conv_out"], gn=self._gn(h, B, H * W, Cc, pk["norm_out"]))
+        return self._conv1(h, B * H * W, h.shape[-1], pk["quant"]).view(B, H, W, -1)
+
     # ---- reference-facing API -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x):
+        """x f32[B, 1, 80, 848] -> (quant [B, 256, 5, 53], emb_loss, (perplexity, min_encodings, indices [B*265, 1]))
+        (spec_codec/vqgan.py:54-60).  H and W must be multiples of 16 (four stride-2 stages)."""
+        B, Cin, H, W = x.shape
+        assert Cin == 1 and H % 16 == 0 and W % 16 == 0
+        hs = []
+        for s in range(0, B, self.decode_chunk):
+            xc = x[s:s + self.decode_chunk].float()
+            b = xc.shape[0]
+            xin = torch.zeros(b, H, W, 32, device=x.device)
+            xin[..., 0] = xc[:, 0]
+            hs.append(self._encode_cl(xin, b, H, W))
+        h = (torch.cat(hs, 0) if len(hs) > 1 else hs[0]).permute(0, 3, 1, 2).contiguous()
+        return self.quantize(h)
+
+    @torch.no_grad()
+    def encode_latent(self, x):
+        """quant_conv(encoder(x)) -> [B, 256, 5, 53] (the pre-quantisation latent; tests / partial pipelines)"""
+        B, _, H, W = x.shape
+        xin = torch.zeros(B, H, W, 32, device=x.device)
+        xin[..., 0] = x[:, 0].float()
+        return self._encode_cl(xin, B, H, W).permute(0, 3, 1, 2).contiguous()
+
     @torch.no_grad()
     def decode(self, quant):
         """quant f32[B, 256, 5, 53] -> f32[B, 1, 80, 848] (spec_codec/vqgan.py:62-65)."""
