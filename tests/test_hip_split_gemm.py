@@ -267,6 +267,78 @@ def test_split_producers_bit_identical():
         assert torch.equal(L.unpack_planes(ys, M, D), torch_split(y))
 
 
+@pytest.mark.parametrize("Lk,B", [(265, 2), (77, 3)])
+def test_attention_ready_operands_bit_identical(Lk, B):
+    """ds_attention_f16x2_ready on host-packed Q planes / K, V^T images, and on images made by ds_attn_pack_kv,
+    equals ds_attention_f16x2_split on the fp32 tensors (same split values -> same bits)."""
+    from text_to_sound_synthesis_amd import _lib as L
+    Lq, H, D = 265, 16, 1024
+    q, k, v = rnd((B, Lq, D), "ar.q").cuda(), rnd((B, Lk, D), "ar.k").cuda(), rnd((B, Lk, D), "ar.v", 50.0).cuda()
+    M16 = (B * Lq + 15) // 16 * 16
+    ref = torch.zeros(2, M16 * D, device="cuda", dtype=torch.float16)
+    L.check(L.lib().ds_attention_f16x2_split(L.ptr(q), D, L.ptr(k), D, L.ptr(v), D, L.ptr(ref), D, B, H, Lq, Lk, 0.125,
+                                             L.stream()))
+    heads = lambda x, n: torch_split(x).view(2, B, n, H, 64).permute(0, 1, 3, 2, 4).contiguous()   # [2][B][H][n][64]
+    qh = heads(q, Lq)
+    nkey = L.lib().ds_attn_nkey(Lk)
+    img = L.attn_images(heads(k, Lk), heads(v, Lk), nkey)
+    out = torch.zeros_like(ref)
+    L.check(L.lib().ds_attention_f16x2_ready(L.ptr(qh), B * H * Lq * 64, L.ptr(img), L.ptr(out), D, B, H, Lq, Lk, 0.125,
+                                             L.stream()))
+    assert torch.equal(out, ref)
+    kv = torch.cat((k, v), dim=2).contiguous()                       # [B*Lk][2D] rows: K | V
+    img2 = torch.full_like(img, float("nan"))
+    L.check(L.lib().ds_attn_pack_kv(L.ptr(kv), 2 * D, D, L.ptr(img2), B, H, Lk, L.stream()))
+    assert torch.equal(img2, img)
+
+
+def test_gemm_attention_store_bit_identical():
+    """The fused QKV projection written attention-ready -- Q planes + K image from the Q | K columns (STORE_ATTN),
+    the V^T image from the transposed product W_v A^T (STORE_ATTN_VT, row bias) -- against the same GEMM written
+    row-major, split and packed on the host (Q, K bit-identical); also through the balanced hybrid launch."""
+    from text_to_sound_synthesis_amd import _lib as L
+    B, Lq, H, D = 3, 265, 16, 1024
+    M, N, K = B * Lq, 3 * D, D
+    A, W, b = rnd((M, K), "as.A", 2.0).cuda(), rnd((N, K), "as.W", 0.05).cuda(), rnd((N,), "as.b").cuda()
+    W2p, sc = L.split_f16x2(W, packed=True)
+    A2p = L.pack_planes(torch_split(A))
+    M16 = (M + 15) // 16 * 16
+    ref = torch.empty(M, N, device="cuda")
+    L.gemm(A2p, W2p, ref, M, N, K, bias=b, split2=sc, a_plane=M16 * K)
+    heads = lambda x: torch_split(x.contiguous()).view(2, B, Lq, H, 64).permute(0, 1, 3, 2, 4).contiguous()
+    q_ref = heads(ref[:, :D])
+    img_ref = L.attn_images(heads(ref[:, D:2 * D]), heads(ref[:, 2 * D:]), 288)
+    Wq2p, scq = L.split_f16x2(W[:D].contiguous(), packed=True)        # the cross-attention query projection alone
+    refq = torch.empty(M, D, device="cuda")
+    L.gemm(A2p, Wq2p, refq, M, D, K, bias=b, split2=scq, a_plane=M16 * K)
+    wv = W2p.view(-1)[2 * D * K:]                                     # rows 2D.. of the packed weight (hi plane)
+    for slots in (512, 8):                         # 8: small enough that these shapes take the hybrid path
+        L.lib().ds_gemm_f16x2_set_balance_slots(slots)
+        L.lib().ds_gemm_f16x2_force_tile(0 if slots == 8 else -1)
+        try:
+            qh = torch.full((2, B, H, Lq, 64), float("nan"), device="cuda", dtype=torch.float16)
+            img = torch.zeros(B, H, 4, 288 * 64, device="cuda", dtype=torch.float16)
+            L.gemm(A2p, W2p, qh, M, 2 * D, K, bias=b, split2=sc, a_plane=M16 * K, store=L.STORE_ATTN, rows_per_sample=Lq,
+                   attn=(img, H, 288, B * H * Lq * 64), w_plane=3 * D * K)
+            L.gemm(wv, A2p, qh, D, M, K, bias=b[2 * D:], split2=sc, a_plane=3 * D * K, store=L.STORE_ATTN_VT,
+                   rows_per_sample=Lq, attn=(img, H, 288, 0), bias_rows=1, w_plane=M16 * K)
+            assert torch.equal(qh, q_ref)
+            assert torch.equal(img[:, :, :2], img_ref[:, :, :2])          # K image
+            # V^T image: the transposed product adds the two cross terms in the other order, so it agrees with the
+            # untransposed GEMM to fp32 rounding rather than bit for bit
+            vt, vt_ref = img[:, :, 2].float() + img[:, :, 3].float(), img_ref[:, :, 2].float() + img_ref[:, :, 3].float()
+            assert (vt - vt_ref).abs().max() <= 2e-6 * vt_ref.abs().max()
+            assert torch.equal(vt == 0, vt_ref == 0)                      # same footprint (padding stays zero)
+            # Q alone (the cross-attention query projection): N = heads * 64, no images
+            qh.fill_(float("nan"))
+            L.gemm(A2p, Wq2p, qh, M, D, K, bias=b, split2=scq, a_plane=M16 * K, store=L.STORE_ATTN, rows_per_sample=Lq,
+                   attn=(None, H, 288, B * H * Lq * 64))
+            assert torch.equal(qh, heads(refq))
+        finally:
+            L.lib().ds_gemm_f16x2_set_balance_slots(512)
+            L.lib().ds_gemm_f16x2_force_tile(-1)
+
+
 def test_packed_gemm_argument_checks():
     from text_to_sound_synthesis_amd import _lib as L
     A2 = torch.zeros(2, 16 * 32, device="cuda", dtype=torch.float16)

@@ -11,7 +11,10 @@ OBJ = os.path.join(HERE, "csrc", "obj")
 LIB = os.path.join(HERE, "libdiffsound_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_f16x2.hip", "norm.hip", "attention.hip", "attention_f16x2.hip", "sampler.hip", "misc.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
-         "-I", CSRC, "-Wall", "-Wno-unused-function"]
+         "-I", CSRC, "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
+# kernels that must not touch scratch memory: a register demotion in one of them is a silent 3x slowdown
+# (it happened once: accumulators of the f16x2 GEMM went to scratch when its epilogue grew a second store family)
+NO_SCRATCH = ("ds_gemm_f16x2", "ds_gemm_bf16x3", "ds_attn_f16x2", "ds_gemm_kernel", "ds_sample_tail")
 
 
 def _hipcc():
@@ -26,6 +29,20 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _check_scratch(src, remarks):
+    """Parse -Rpass-analysis=kernel-resource-usage remarks: 'Function Name: X' ... 'ScratchSize [bytes/lane]: N'."""
+    import re
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and int(m.group(1)) > 0 and any(k in name for k in NO_SCRATCH):
+            raise RuntimeError("%s: kernel %s uses %s bytes/lane of scratch (register demotion) -- restructure it"
+                               % (src, name, m.group(1)))
 
 
 def build(force=False, verbose=False):
@@ -43,8 +60,9 @@ def build(force=False, verbose=False):
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
-            if verbose and r.stderr.strip():
-                print(r.stderr)
+            _check_scratch(src, r.stderr)
+            if verbose:
+                print("\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l))
         return o
 
     with ThreadPoolExecutor(max_workers=6) as ex:

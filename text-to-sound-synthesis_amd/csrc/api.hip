@@ -31,6 +31,8 @@ static void fill(GemmParams& p, const ds_gemm_desc* d) {
     p.w3_plane = d->w3_plane;
     p.out_scale = d->out_scale;
     p.a_split = d->a_split; p.c_split = d->c_split; p.a_plane = d->a_plane; p.c_plane = d->c_plane;
+    p.attn_kv = d->attn_kv; p.attn_heads = d->attn_heads; p.attn_nkey = d->attn_nkey; p.attn_qplane = d->attn_qplane;
+    p.row_off = 0; p.bias_rows = d->bias_rows;
     p.pro_scale = d->pro_scale; p.pro_shift = d->pro_shift;
     p.rows_per_sample = d->rows_per_sample;
     p.Cin = d->Cin; p.H = d->H; p.W_ = d->Wd; p.up = d->up; p.taps = d->taps; p.dil = d->dil;
@@ -136,7 +138,10 @@ extern "C" void ds_denoiser_destroy(ds_denoiser* h) { delete h; }
 // workspace carve (floats): x, hn, qkv, att, fc, logits
 struct Carve {
     float *x, *hn, *qkv, *att, *fc, *logits;
+    float* kvimg;   // f16x2 mode: self-attention K / V^T images, inside the qkv region after the Q planes
 };
+// floats occupied by the K / V^T images of one attention over Lk keys (4 fp16 planes of nkey*64 per sample and head)
+static size_t attn_img_floats(int B, int heads, int Lk) { return (size_t)B * heads * 4 * ds_attn_nkey(Lk) * 64 / 2; }
 static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c) {
     const size_t M = (size_t)B * h->d.seq_len, D = h->d.n_embd;
     const size_t M16 = (M + 15) & ~(size_t)15;   // hn / att / fc double as packed split planes (rows padded to 16)
@@ -149,7 +154,10 @@ static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c) {
     Carve t;
     t.x = take(M * D);
     t.hn = take(M16 * D);
-    t.qkv = take(M * 3 * D);
+    // fp32 modes: [M][3D] rows.  f16x2 mode: Q planes (M*D floats) + the K / V^T images (padded to nkey key slots)
+    const size_t qkv_ready = M * D + attn_img_floats(B, h->d.n_head, h->d.seq_len);
+    t.qkv = take(qkv_ready > M * 3 * D ? qkv_ready : M * 3 * D);
+    t.kvimg = t.qkv ? t.qkv + M * D : nullptr;
     t.att = take(M16 * D);
     t.fc = take(M16 * D * h->d.mlp_mult);
     t.logits = take(M * h->d.n_codes);
@@ -160,8 +168,14 @@ static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c) {
 extern "C" int64_t ds_denoiser_workspace_bytes(const ds_denoiser* h, int B) {
     return h && B > 0 ? (int64_t)carve(h, B, nullptr, nullptr) : -1;
 }
+// caption K/V cache: fp32 modes [n_layer][B*cond_len][2D]; f16x2 mode [n_layer] K / V^T images + one layer of fp32
+// rows as scratch for ds_denoiser_cond_kv.  The buffer is sized for either.
+static size_t kv_layer_img_floats(const ds_denoiser* h, int B) { return attn_img_floats(B, h->d.n_head, h->d.cond_len); }
 extern "C" int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B) {
-    return h && B > 0 ? (int64_t)h->d.n_layer * B * h->d.cond_len * 2 * h->d.n_embd * (int64_t)sizeof(float) : -1;
+    if (!h || B <= 0) return -1;
+    const size_t rows = (size_t)B * h->d.cond_len * 2 * h->d.n_embd;
+    const size_t f32 = (size_t)h->d.n_layer * rows, img = (size_t)h->d.n_layer * kv_layer_img_floats(h, B) + rows;
+    return (int64_t)((f32 > img ? f32 : img) * sizeof(float));
 }
 
 // ---- optional per-launch timing of the denoiser's GEMMs (bench.py's roofline leg) ---------------
@@ -194,7 +208,8 @@ extern "C" int ds_profile_collect(double* ms, double* flops, int64_t* launches) 
 static int dense(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc,
                  int M, int N, int K, int act, hipStream_t s, int store = DS_STORE_ROW, int rps = 0,
                  const void* W3 = nullptr, int split_mode = DS_SPLIT_NONE, float osc = 1.f,
-                 long long a_plane = 0, long long c_plane = 0) {
+                 long long a_plane = 0, long long c_plane = 0, void* attn_kv = nullptr, int attn_heads = 0,
+                 int attn_nkey = 0, long long attn_qplane = 0, int bias_rows = 0, long long w_plane = 0) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.W = W; p.bias = bias; p.R = R; p.C = C;
@@ -207,6 +222,9 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
         p.a_split = a_plane > 0; p.a_plane = a_plane;   // f16x2 only: A and W are packed split planes
         if (a_plane > 0) p.w3_plane = (long long)((N + 15) & ~15) * K;
         p.c_split = c_plane > 0; p.c_plane = c_plane;
+        p.attn_kv = attn_kv; p.attn_heads = attn_heads; p.attn_nkey = attn_nkey; p.attn_qplane = attn_qplane;
+        p.bias_rows = bias_rows;
+        if (w_plane > 0) p.w3_plane = w_plane;   // a row range of a larger packed weight keeps that weight's stride
     }
     auto launch = [&]() {
         if (!W3) return ds_launch_gemm(p, s, DS_LOAD_DENSE);
@@ -236,6 +254,16 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
 extern "C" int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int B, float* kv, ds_stream_t stream) {
     DS_CHECK_ARG(h && cond && kv && B > 0, "bad arguments");
     const int D = h->d.n_embd, Mc = B * h->d.cond_len;
+    if (h->split_mode == DS_SPLIT_F16X2) {   // attention-ready K / V^T images per layer (see ds_denoiser_kv_bytes)
+        const size_t per = kv_layer_img_floats(h, B);
+        float* rows = kv + (size_t)h->d.n_layer * per;
+        for (int l = 0; l < h->d.n_layer; ++l) {
+            TRY(dense(cond, h->d.cond_dim, h->P(l, DS_LP_W_KV2), h->P(l, DS_LP_B_KV2), nullptr, rows, 2 * D, Mc, 2 * D,
+                      h->d.cond_dim, DS_ACT_NONE, (hipStream_t)stream));
+            TRY(ds_attn_pack_kv(rows, 2 * D, D, kv + (size_t)l * per, B, h->d.n_head, h->d.cond_len, stream));
+        }
+        return 0;
+    }
     for (int l = 0; l < h->d.n_layer; ++l)
         TRY(dense(cond, h->d.cond_dim, h->P(l, DS_LP_W_KV2), h->P(l, DS_LP_B_KV2), nullptr,
                   kv + (size_t)l * Mc * 2 * D, 2 * D, Mc, 2 * D, h->d.cond_dim, DS_ACT_NONE, (hipStream_t)stream));
@@ -262,9 +290,27 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
         return f16 ? ds_layernorm_split(w.x, w.hn, M, D, g, b_, s) : ds_layernorm(w.x, w.hn, M, D, g, b_, s);
     };
     auto attn = [&](const float* q, int ldq, const float* k, const float* v, int ldkv, int Lk) {
-        return f16 ? ds_attention_f16x2_split(q, ldq, k, ldkv, v, ldkv, w.att, D, B, d.n_head, L, Lk, scale, s)
-                   : ds_attention(q, ldq, k, ldkv, v, ldkv, w.att, D, B, d.n_head, L, Lk, scale, s);
+        return ds_attention(q, ldq, k, ldkv, v, ldkv, w.att, D, B, d.n_head, L, Lk, scale, s);
     };
+    // f16x2 mode: the QKV / cross-Q GEMMs write attention-ready operands (Q planes at w.qkv, K / V^T images at
+    // w.kvimg; the caption images come from ds_denoiser_cond_kv) and the attention kernel stages them by LDS-DMA
+    const long long qpl = (long long)M * D;   // halves per Q plane ([B][heads][L][64])
+    const int nkS = ds_attn_nkey(L);
+    auto lin_attn = [&](int l, int slot, int bslot, int N, int n_weight, void* imgs) {
+        return dense(w.hn, D, h->P(l, slot), h->P(l, bslot), nullptr, w.qkv, N, M, N, D, DS_ACT_NONE, s, DS_STORE_ATTN, L,
+                     h->P3(l, slot), h->split_mode, h->S3(l, slot), pD, 0, imgs, d.n_head, nkS, qpl, 0,
+                     (long long)n_weight * D);
+    };
+    auto attn_ready = [&](const void* imgs, int Lk) {
+        return ds_attention_f16x2_ready(w.qkv, qpl, imgs, w.att, D, B, d.n_head, L, Lk, scale, s);
+    };
+    if (f16) {   // key slots L..nkey-1 of the self-attention images are never written: they must read as zero
+        hipError_t e = hipMemsetAsync(w.kvimg, 0, attn_img_floats(B, d.n_head, L) * sizeof(float), s);
+        if (e != hipSuccess) {
+            ds_set_error("forward: hipMemsetAsync: %s", hipGetErrorString(e));
+            return -2;
+        }
+    }
     // y = act(A W^T + b) (+ R) for layer-l weight `slot`; A (and optionally C) pre-split in f16x2 mode
     auto lin = [&](int l, int slot, int bslot, const float* A, int lda, long long ap, const float* R, float* C, int N,
                    int K, int act, long long cp) {
@@ -275,14 +321,30 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
     for (int l = 0; l < d.n_layer; ++l) {
         // x += attn1(ln1(x, t))
         TRY(adaln(l, DS_LP_ADALN1));
-        TRY(lin(l, DS_LP_W_QKV, DS_LP_B_QKV, w.hn, D, pD, nullptr, w.qkv, 3 * D, D, DS_ACT_NONE, 0));
-        TRY(attn(w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, L));
+        if (f16) {
+            // Q | K columns: attention-ready Q planes + K image.  V: the transposed product W_v hn^T (both operands
+            // are packed planes of the same tile layout, so the roles simply swap), written as the V^T image.
+            TRY(lin_attn(l, DS_LP_W_QKV, DS_LP_B_QKV, 2 * D, 3 * D, w.kvimg));
+            const _Float16* wv = (const _Float16*)h->P3(l, DS_LP_W_QKV) + (size_t)2 * D * D;   // rows 2D.. of the weight
+            TRY(dense((const float*)wv, D, h->P(l, DS_LP_W_QKV), h->P(l, DS_LP_B_QKV) + 2 * D, nullptr, w.qkv, M, D, M, D,
+                      DS_ACT_NONE, s, DS_STORE_ATTN_VT, L, w.hn, h->split_mode, h->S3(l, DS_LP_W_QKV), (long long)3 * D * D,
+                      0, w.kvimg, d.n_head, nkS, 0, 1));
+            TRY(attn_ready(w.kvimg, L));
+        } else {
+            TRY(lin(l, DS_LP_W_QKV, DS_LP_B_QKV, w.hn, D, pD, nullptr, w.qkv, 3 * D, D, DS_ACT_NONE, 0));
+            TRY(attn(w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, L));
+        }
         TRY(lin(l, DS_LP_W_PROJ1, DS_LP_B_PROJ1, w.att, D, pD, w.x, w.x, D, D, DS_ACT_NONE, 0));
         // x += attn2(ln1_1(x, t), cond)
         TRY(adaln(l, DS_LP_ADALN2));
-        TRY(lin(l, DS_LP_W_Q2, DS_LP_B_Q2, w.hn, D, pD, nullptr, w.qkv, D, D, DS_ACT_NONE, 0));
-        const float* kvl = kv + (size_t)l * Mc * 2 * D;
-        TRY(attn(w.qkv, D, kvl, kvl + D, 2 * D, d.cond_len));
+        if (f16) {
+            TRY(lin_attn(l, DS_LP_W_Q2, DS_LP_B_Q2, D, D, nullptr));
+            TRY(attn_ready(kv + (size_t)l * kv_layer_img_floats(h, B), d.cond_len));
+        } else {
+            TRY(lin(l, DS_LP_W_Q2, DS_LP_B_Q2, w.hn, D, pD, nullptr, w.qkv, D, D, DS_ACT_NONE, 0));
+            const float* kvl = kv + (size_t)l * Mc * 2 * D;
+            TRY(attn(w.qkv, D, kvl, kvl + D, 2 * D, d.cond_len));
+        }
         TRY(lin(l, DS_LP_W_PROJ2, DS_LP_B_PROJ2, w.att, D, pD, w.x, w.x, D, D, DS_ACT_NONE, 0));
         // x += mlp(ln2(x))
         TRY(lnorm(h->P(l, DS_LP_LN2_G), h->P(l, DS_LP_LN2_B)));

@@ -14,6 +14,12 @@
 //           VT[plane][d][tile*32 + s*16 + half*8 + e], so the B operand is one ds_read_b128 per plane
 //           (rows swizzled by (d>>2)&3).  MFMAs p1v0 + p0v1 + p0v0.
 // K and V^T share one 72 KB LDS buffer (K first), so two workgroups fit per CU.
+//
+// READY variant (the denoiser's path): Q arrives as two fp16 planes and K / V^T as ready-made LDS images
+// (common.h "attention-ready operands", written by the QKV / cross-Q GEMM epilogues and ds_attn_pack_kv), so
+// staging is 1 KB LDS-DMA transfers with no conversion work, and the V^T transfer runs under the softmax.
+// The generic variant below converts fp32 Q / K / V itself and was latency-bound on that staging (per workgroup
+// ~12 us of load -> convert -> ds_write chains against ~4 us of MFMA work).
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -24,12 +30,16 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ _Float16 ah_hi(float a) { return ds_split_hi(a); }
 __device__ __forceinline__ _Float16 ah_lo(float a, _Float16 h) { return ds_split_lo(a, h); }
 
-template <int NKT>
+typedef __attribute__((address_space(1))) const void* ah_gptr;
+typedef __attribute__((address_space(3))) void* ah_lptr;
+
+template <int NKT, bool READY>
 __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const float* __restrict__ Q, int ldq,
                                                                         const float* __restrict__ Kp, int ldk,
                                                                         const float* __restrict__ Vp, int ldv,
                                                                         float* __restrict__ O, int ldo, int Lq, int Lk,
-                                                                        int heads, float scale, long long o_plane) {
+                                                                        int heads, float scale, long long o_plane,
+                                                                        long long q_plane) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NKEY = NKT * 32;
     constexpr int KPL = NKEY * 64;   // halves per K plane   ([key][64 d])
@@ -47,39 +57,61 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
     const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
     const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
 
-    // ---- stage K: fp32 -> two fp16 planes, 8-byte half-chunks, chunk swizzle (key>>1)&7 ----
-    // (loads are issued 8 deep before the first dependent conversion: a load -> convert -> ds_write chain
-    //  per iteration would serialise 24 L2/HBM round trips per thread)
-    constexpr int NIT = NKEY * 16 / (AH_WAVES * 64);   // 24 (self) / 8 (cross), exact
-    static_assert(NIT % 8 == 0, "staging loop is unrolled 8 deep");
-    for (int it0 = 0; it0 < NIT; it0 += 8) {
-        f32x4 v[8];
+    // READY: this (sample, head)'s image  K hi | K lo | V^T hi | V^T lo  (bytes), NKEY/4 KB per operand
+    const unsigned char* img = (const unsigned char*)Kp + ((size_t)b * heads + head) * (size_t)(8 * KPL);
+    constexpr int NDMA = NKEY / 4 / AH_WAVES;   // 1 KB transfers per wave per operand: 24 (self) / 8 (cross)
+    static_assert(NKEY / 4 % AH_WAVES == 0, "whole transfers per wave");
+    if constexpr (READY) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int f = tid + (it0 + u) * (AH_WAVES * 64);
-            const int row = f >> 4, c4 = f & 15;          // 4 consecutive d at c4*4
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < Lk) v[u] = *(const f32x4*)(kb + (size_t)row * ldk + c4 * 4);
+        for (int j = 0; j < NDMA; ++j) {
+            const int piece = j * AH_WAVES + wave;
+            __builtin_amdgcn_global_load_lds((ah_gptr)(img + piece * 1024 + lane * 16),
+                                             (ah_lptr)(smem_raw + piece * 1024), 16, 0, 0);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int f = tid + (it0 + u) * (AH_WAVES * 64);
-            const int row = f >> 4, c4 = f & 15;
-            h4 s0, s1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0[e] = ah_hi(v[u][e]);
-                s1[e] = ah_lo(v[u][e], s0[e]);
+    } else {
+        // ---- stage K: fp32 -> two fp16 planes, 8-byte half-chunks, chunk swizzle (key>>1)&7 ----
+        // (loads are issued 8 deep before the first dependent conversion: a load -> convert -> ds_write chain
+        //  per iteration would serialise 24 L2/HBM round trips per thread)
+        constexpr int NIT = NKEY * 16 / (AH_WAVES * 64);   // 24 (self) / 8 (cross), exact
+        static_assert(NIT % 8 == 0, "staging loop is unrolled 8 deep");
+        for (int it0 = 0; it0 < NIT; it0 += 8) {
+            f32x4 v[8];
+    #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = tid + (it0 + u) * (AH_WAVES * 64);
+                const int row = f >> 4, c4 = f & 15;          // 4 consecutive d at c4*4
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < Lk) v[u] = *(const f32x4*)(kb + (size_t)row * ldk + c4 * 4);
             }
-            const int chunk = (c4 >> 1) ^ ((row >> 1) & 7);
-            _Float16* dst = buf + row * 64 + chunk * 8 + (c4 & 1) * 4;
-            *(h4*)dst = s0;
-            *(h4*)(dst + KPL) = s1;
+    #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = tid + (it0 + u) * (AH_WAVES * 64);
+                const int row = f >> 4, c4 = f & 15;
+                h4 s0, s1;
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0[e] = ah_hi(v[u][e]);
+                    s1[e] = ah_lo(v[u][e], s0[e]);
+                }
+                const int chunk = (c4 >> 1) ^ ((row >> 1) & 7);
+                _Float16* dst = buf + row * 64 + chunk * 8 + (c4 & 1) * 4;
+                *(h4*)dst = s0;
+                *(h4*)(dst + KPL) = s1;
+            }
         }
     }
     // ---- Q operand: lane (q = l31, half hh) keeps Q[q][16 ks + 8 hh + 0..7], ks = 0..3, both planes ----
     h8 q_hi[4], q_lo[4];
-    {
+    if constexpr (READY) {
+        int qr = q0 + l31;
+        if (qr >= Lq) qr = Lq - 1;
+        const _Float16* qp = (const _Float16*)Q + (((size_t)b * heads + head) * Lq + qr) * 64 + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            q_hi[ks] = *(const h8*)(qp + 16 * ks);
+            q_lo[ks] = *(const h8*)(qp + q_plane + 16 * ks);
+        }
+    } else {
         int qr = q0 + l31;
         if (qr >= Lq) qr = Lq - 1;
         const float* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 64 + 8 * hh;
@@ -120,36 +152,45 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
     }
     __syncthreads();  // everyone is done reading K
 
-    // ---- stage V transposed + key-permuted: VT[plane][d][kt*32 + s*16 + half*8 + e], chunk swizzle (d>>2)&3 ----
-    // Work item = (group of 4 consecutive keys, 4 consecutive d): the 4 keys are e&3 = 0..3 of one (tile, s, half,
-    // e>>2) slot, i.e. 4 contiguous halves of a V^T row -> one ds_write_b64 per (d, plane) instead of four b16 writes.
-    constexpr int NITV = NKEY / 4 * 16 / (AH_WAVES * 64);   // 6 (self) / 2 (cross)
-#pragma unroll
-    for (int it = 0; it < NITV; ++it) {
-        const int f = tid + it * (AH_WAVES * 64);
-        const int kg = f >> 4, c4 = f & 15;                 // keys 4kg .. 4kg+3, d = 4 c4 .. 4 c4 + 3
-        f32x4 v[4];
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            const int key = 4 * kg + kx;
-            v[kx] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (key < Lk) v[kx] = *(const f32x4*)(vb + (size_t)key * ldv + c4 * 4);
+    if constexpr (READY) {   // the V^T image replaces K in the same buffer; the transfer runs under the softmax
+#pragma unroll 4   // (the score registers are live here: a fully unrolled loop's 24 address pairs would spill)
+        for (int j = 0; j < NDMA; ++j) {
+            const int piece = j * AH_WAVES + wave;
+            __builtin_amdgcn_global_load_lds((ah_gptr)(img + 4 * KPL + piece * 1024 + lane * 16),
+                                             (ah_lptr)(smem_raw + piece * 1024), 16, 0, 0);
         }
-        const int kk = (4 * kg) & 31;                       // kk & 3 == 0
-        const int e0 = ((kk >> 3) & 1) << 2;                // e = e0 + kx
-        const int chunk = ((4 * kg) >> 5) * 4 + (kk >> 4) * 2 + ((kk >> 2) & 1);   // tile*4 + s*2 + half
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int d = c4 * 4 + j;
-            h4 s0, s1;
-#pragma unroll
+    } else {
+        // ---- stage V transposed + key-permuted: VT[plane][d][kt*32 + s*16 + half*8 + e], chunk swizzle (d>>2)&3 ----
+        // Work item = (group of 4 consecutive keys, 4 consecutive d): the 4 keys are e&3 = 0..3 of one (tile, s, half,
+        // e>>2) slot, i.e. 4 contiguous halves of a V^T row -> one ds_write_b64 per (d, plane) instead of four b16 writes.
+        constexpr int NITV = NKEY / 4 * 16 / (AH_WAVES * 64);   // 6 (self) / 2 (cross)
+    #pragma unroll
+        for (int it = 0; it < NITV; ++it) {
+            const int f = tid + it * (AH_WAVES * 64);
+            const int kg = f >> 4, c4 = f & 15;                 // keys 4kg .. 4kg+3, d = 4 c4 .. 4 c4 + 3
+            f32x4 v[4];
+    #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
-                s0[kx] = ah_hi(v[kx][j]);
-                s1[kx] = ah_lo(v[kx][j], s0[kx]);
+                const int key = 4 * kg + kx;
+                v[kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (key < Lk) v[kx] = *(const f32x4*)(vb + (size_t)key * ldv + c4 * 4);
             }
-            _Float16* dst = buf + d * NKEY + ((chunk ^ ((d >> 2) & 3)) * 8) + e0;
-            *(h4*)dst = s0;
-            *(h4*)(dst + VPL) = s1;
+            const int kk = (4 * kg) & 31;                       // kk & 3 == 0
+            const int e0 = ((kk >> 3) & 1) << 2;                // e = e0 + kx
+            const int chunk = ((4 * kg) >> 5) * 4 + (kk >> 4) * 2 + ((kk >> 2) & 1);   // tile*4 + s*2 + half
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = c4 * 4 + j;
+                h4 s0, s1;
+    #pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    s0[kx] = ah_hi(v[kx][j]);
+                    s1[kx] = ah_lo(v[kx][j], s0[kx]);
+                }
+                _Float16* dst = buf + d * NKEY + ((chunk ^ ((d >> 2) & 3)) * 8) + e0;
+                *(h4*)dst = s0;
+                *(h4*)(dst + VPL) = s1;
+            }
         }
     }
 
@@ -234,12 +275,13 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
     }
 }
 
+template <bool READY>
 static int attn_f16x2_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                              int ldo, int B, int heads, int Lq, int Lk, float scale, long long o_plane,
-                             hipStream_t stream) {
-    DS_CHECK_ARG(q && k && v && o, "null pointer");
+                             long long q_plane, hipStream_t stream) {
+    DS_CHECK_ARG(q && k && (READY || v) && o, "null pointer");
     DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "bad shape");
-    DS_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "leading dims must be multiples of 4");
+    DS_CHECK_ARG(READY || (ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0), "leading dims must be multiples of 4");
     const int qtiles = (Lq + 31) / 32;
     const int groups = (qtiles + AH_WAVES - 1) / AH_WAVES;
     dim3 grid(groups * heads, B), block(AH_WAVES * 64);
@@ -247,17 +289,17 @@ static int attn_f16x2_launch(const float* q, int ldq, const float* k, int ldk, c
     if (Lk <= 96) {
         const size_t lds = (size_t)2 * 96 * 64 * sizeof(unsigned short);
         if (!attr3) {
-            (void)hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
+            (void)hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<3, READY>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr3 = true;
         }
-        hipLaunchKernelGGL((ds_attn_f16x2_kernel<3>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
-                           heads, scale, o_plane);
+        hipLaunchKernelGGL((ds_attn_f16x2_kernel<3, READY>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq,
+                           Lk, heads, scale, o_plane, q_plane);
     } else {
         DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
         const size_t lds = (size_t)2 * 288 * 64 * sizeof(unsigned short);
         if (!attr9) {
-            hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<9>,
+            hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<9, READY>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) {
                 ds_set_error("attention_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -265,8 +307,8 @@ static int attn_f16x2_launch(const float* q, int ldq, const float* k, int ldk, c
             }
             attr9 = true;
         }
-        hipLaunchKernelGGL((ds_attn_f16x2_kernel<9>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
-                           heads, scale, o_plane);
+        hipLaunchKernelGGL((ds_attn_f16x2_kernel<9, READY>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq,
+                           Lk, heads, scale, o_plane, q_plane);
     }
     DS_CHECK_LAUNCH();
     return 0;
@@ -274,7 +316,7 @@ static int attn_f16x2_launch(const float* q, int ldq, const float* k, int ldk, c
 
 extern "C" int ds_attention_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                                   int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream) {
-    return attn_f16x2_launch(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Lq, Lk, scale, 0, (hipStream_t)stream);
+    return attn_f16x2_launch<false>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Lq, Lk, scale, 0, 0, (hipStream_t)stream);
 }
 
 // output written as packed split planes (2 planes of ceil16(B*Lq) * ldo halves), ldo % 32 == 0
@@ -282,6 +324,71 @@ extern "C" int ds_attention_f16x2_split(const float* q, int ldq, const float* k,
                                         void* oh, int ldo, int B, int heads, int Lq, int Lk, float scale,
                                         ds_stream_t stream) {
     DS_CHECK_ARG(ldo % 32 == 0 && ldo >= heads * 64, "packed output needs ldo % 32 == 0");
-    return attn_f16x2_launch(q, ldq, k, ldk, v, ldv, (float*)oh, ldo, B, heads, Lq, Lk, scale,
-                             (long long)((B * Lq + 15) & ~15) * ldo, (hipStream_t)stream);
+    return attn_f16x2_launch<false>(q, ldq, k, ldk, v, ldv, (float*)oh, ldo, B, heads, Lq, Lk, scale,
+                                    (long long)((B * Lq + 15) & ~15) * ldo, 0, (hipStream_t)stream);
+}
+
+// nkey of the K / V^T images for Lk keys: the kernel is built for 96 (cross) and 288 (self) key slots
+extern "C" int ds_attn_nkey(int Lk) { return Lk <= 96 ? 96 : (Lk <= 288 ? 288 : -1); }
+
+// Attention on attention-ready operands (common.h): qh = Q planes [2][B][heads][Lq][64] (q_plane halves apart),
+// kv_img = [B][heads][4][nkey*64] halves (K hi | K lo | V^T hi | V^T lo, rows of keys >= Lk zero), output as in
+// ds_attention_f16x2_split.  Bit-identical to ds_attention_f16x2_split on the same values.
+extern "C" int ds_attention_f16x2_ready(const void* qh, long long q_plane, const void* kv_img, void* oh, int ldo, int B,
+                                        int heads, int Lq, int Lk, float scale, ds_stream_t stream) {
+    DS_CHECK_ARG(ldo % 32 == 0 && ldo >= heads * 64, "packed output needs ldo % 32 == 0");
+    DS_CHECK_ARG(q_plane >= (long long)B * heads * Lq * 64 && q_plane % 8 == 0, "Q plane stride");
+    DS_CHECK_ARG(((uintptr_t)qh & 15) == 0 && ((uintptr_t)kv_img & 15) == 0, "operands must be 16-byte aligned");
+    return attn_f16x2_launch<true>((const float*)qh, 0, (const float*)kv_img, 0, nullptr, 0, (float*)oh, ldo, B, heads,
+                                   Lq, Lk, scale, (long long)((B * Lq + 15) & ~15) * ldo, q_plane, (hipStream_t)stream);
+}
+
+// fp32 K | V rows (kv [B*Lk][ld], K of head h at column h*64, V at v_col + h*64) -> K / V^T images, zero rows
+// beyond Lk.  One thread per (sample, head, key, 4 consecutive d).  Used once per batch for the caption K/V.
+__global__ __launch_bounds__(256) void ds_attn_pack_kv_kernel(const float* __restrict__ kv, int ld, int v_col,
+                                                              _Float16* __restrict__ img, int B, int heads, int Lk,
+                                                              int nkey) {
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * heads * nkey * 16;
+    if (f >= total) return;
+    const int c4 = (int)(f & 15);
+    const int key = (int)((f >> 4) % nkey);
+    const long long bh = (f >> 4) / nkey;
+    const int head = (int)(bh % heads), b = (int)(bh / heads);
+    f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+    if (key < Lk) {
+        const float* r = kv + ((size_t)b * Lk + key) * ld + head * 64 + c4 * 4;
+        kx = *(const f32x4*)r;
+        vx = *(const f32x4*)(r + v_col);
+    }
+    const int pl = nkey * 64;
+    _Float16* im = img + (size_t)bh * 4 * pl;
+    h4 k0, k1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        k0[e] = ds_split_hi(kx[e]);
+        k1[e] = ds_split_lo(kx[e], k0[e]);
+    }
+    const int ko = ds_attn_k_off(key, c4 * 4);      // 4 consecutive d stay inside one 8-half chunk
+    *(h4*)(im + ko) = k0;
+    *(h4*)(im + pl + ko) = k1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int vo = 2 * pl + ds_attn_vt_off(key, c4 * 4 + e, nkey);
+        const _Float16 hi = ds_split_hi(vx[e]);
+        im[vo] = hi;
+        im[vo + pl] = ds_split_lo(vx[e], hi);
+    }
+}
+
+extern "C" int ds_attn_pack_kv(const float* kv, int ld, int v_col, void* img, int B, int heads, int Lk,
+                               ds_stream_t stream) {
+    DS_CHECK_ARG(kv && img && B > 0 && heads > 0 && Lk > 0 && ld % 4 == 0 && v_col % 4 == 0, "bad arguments");
+    const int nkey = ds_attn_nkey(Lk);
+    DS_CHECK_ARG(nkey > 0, "at most 288 keys are supported");
+    const long long total = (long long)B * heads * nkey * 16;
+    hipLaunchKernelGGL(ds_attn_pack_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kv,
+                       ld, v_col, (_Float16*)img, B, heads, Lk, nkey);
+    DS_CHECK_LAUNCH();
+    return 0;
 }

@@ -281,38 +281,74 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
         if (kt < nk) H_BODY(raX, rb0X, rb1X, raY, rb0Y, rb1Y);
     }
 
+    // Epilogue.  One fully unrolled, branch-nested (no `continue`) copy of the loop per store family: with the
+    // destinations of all families inside one loop body the accumulators were demoted to scratch (320 B/lane,
+    // every GEMM 3x slower).
     const float osc = p.out_scale;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * osc + bv;
-                if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));
-                size_t off;
-                if (p.store == DS_STORE_ROW) {
-                    off = (size_t)row * p.ldc + col;
-                } else {  // DS_STORE_BATCH_T
-                    const int b = row / p.rows_per_sample, pp = row - b * p.rows_per_sample;
-                    off = ((size_t)b * p.N + col) * p.ldc + pp;
-                }
-                if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                if (p.c_split) {   // written as packed split planes for the next f16x2 GEMM (its K = ldc)
-                    _Float16* ch = (_Float16*)p.C + ds_packed_off(row, col, p.ldc >> 5);
-                    const _Float16 hi = ds_split_hi(v);
-                    ch[0] = hi;
-                    ch[p.c_plane] = ds_split_lo(v, hi);
-                } else {
-                    p.C[off] = v;
-                }
+#define H_EPILOGUE(...)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
+            const int col = n0 + (wn * TN + j) * 32 + l31;                                          \
+            if (col < p.N) {                                                                        \
+                const float bv = (p.bias && !p.bias_rows) ? p.bias[col] : 0.f;                      \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;      \
+                    if (row < p.M) {                                                                \
+                        float v = acc[i][j][r] * osc + bv;                                          \
+                        if (p.bias_rows) v += p.bias[row + p.row_off];                              \
+                        if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));               \
+                        __VA_ARGS__                                                                 \
+                    }                                                                               \
+                }                                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+    }
+    if (p.store == DS_STORE_ATTN) {          // attention-ready Q planes / K image (common.h)
+        const int hw = p.attn_heads * 64, pl = p.attn_nkey * 64;
+        H_EPILOGUE({
+            const int arow = row + p.row_off;
+            const int b = arow / p.rows_per_sample, pos = arow - b * p.rows_per_sample;
+            const int which = col / hw, hc = col - which * hw, head = hc >> 6, d = hc & 63;
+            const _Float16 hi = ds_split_hi(v), lo = ds_split_lo(v, hi);
+            const size_t bh = (size_t)b * p.attn_heads + head;
+            if (which == 0) {
+                _Float16* q = (_Float16*)p.C + (bh * p.rows_per_sample + pos) * 64 + d;
+                q[0] = hi;
+                q[p.attn_qplane] = lo;
+            } else {
+                _Float16* img = (_Float16*)p.attn_kv + bh * (4 * (size_t)pl) + ds_attn_k_off(pos, d);
+                img[0] = hi;
+                img[pl] = lo;
             }
-        }
+        })
+    } else if (p.store == DS_STORE_ATTN_VT) {   // V^T image from the transposed product: lanes run along the keys
+        const int pl = p.attn_nkey * 64;
+        H_EPILOGUE({
+            const int hd = row + p.row_off, head = hd >> 6, d = hd & 63;
+            const int b = col / p.rows_per_sample, pos = col - b * p.rows_per_sample;
+            _Float16* img = (_Float16*)p.attn_kv + ((size_t)b * p.attn_heads + head) * (4 * (size_t)pl) + 2 * pl +
+                            ds_attn_vt_off(pos, d, p.attn_nkey);
+            const _Float16 hi = ds_split_hi(v);
+            img[0] = hi;
+            img[pl] = ds_split_lo(v, hi);
+        })
+    } else if (p.c_split) {                     // packed split planes for the next f16x2 GEMM (its K = ldc)
+        H_EPILOGUE({
+            _Float16* ch = (_Float16*)p.C + ds_packed_off(row, col, p.ldc >> 5);
+            const _Float16 hi = ds_split_hi(v);
+            ch[0] = hi;
+            ch[p.c_plane] = ds_split_lo(v, hi);
+        })
+    } else if (p.store == DS_STORE_ROW) {
+        H_EPILOGUE({
+            if (p.R) v += p.R[(size_t)row * p.ldr + col];
+            p.C[(size_t)row * p.ldc + col] = v;
+        })
+    } else {                                    // DS_STORE_BATCH_T
+        H_EPILOGUE({
+            const int b = row / p.rows_per_sample, pp = row - b * p.rows_per_sample;
+            p.C[((size_t)b * p.N + col) * p.ldc + pp] = v;
+        })
     }
 }
 
@@ -372,13 +408,16 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     int rb = p.M / 128;                              // full 128-row tiles available
     while (rb > 0 && ((long)rb * tn) % g_balance_slots != 0) --rb;
     const int m_off = rb * 128;
-    if (rb == 0 || m_off == p.M || p.store != DS_STORE_ROW) return launch_h2<128, 128, 2>(p, s);
+    if (rb == 0 || m_off == p.M || (p.store != DS_STORE_ROW && p.store != DS_STORE_ATTN && p.store != DS_STORE_ATTN_VT))
+        return launch_h2<128, 128, 2>(p, s);
     GemmParams pb = p, ps = p;
     pb.M = m_off;
     ps.M = p.M - m_off;
     const size_t rg = (size_t)m_off / 16;
     ps.A = (const float*)((const _Float16*)p.A + rg * (p.K / HBK) * 512);           // packed planes: row-group offset
-    if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
+    if (p.store == DS_STORE_ATTN || p.store == DS_STORE_ATTN_VT)
+        ps.row_off = p.row_off + m_off;   // destinations (and a row bias) are computed from absolute rows
+    else if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
     else ps.C = p.C + (size_t)m_off * p.ldc;
     if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
     const int nbig = rb * tn;
@@ -411,7 +450,19 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(!p.c_split || (p.ldc % 32 == 0 && p.N <= p.ldc && p.c_plane >= (long long)((p.M + 15) / 16) * 16 * p.ldc &&
                                 p.store == DS_STORE_ROW && !p.R),
                  "packed output: ldc % 32 == 0, plane of ceil16(M) * ldc halves, row store, no residual");
-    DS_CHECK_ARG(p.store == DS_STORE_ROW || p.store == DS_STORE_BATCH_T, "unsupported store mode");
+    DS_CHECK_ARG(p.store == DS_STORE_ROW || p.store == DS_STORE_BATCH_T || p.store == DS_STORE_ATTN ||
+                     p.store == DS_STORE_ATTN_VT,
+                 "unsupported store mode");
+    DS_CHECK_ARG(!p.bias_rows || (p.bias && p.store != DS_STORE_BATCH_T), "row bias needs a bias vector");
+    DS_CHECK_ARG(p.store != DS_STORE_ATTN_VT ||
+                     (p.attn_heads > 0 && p.M == p.attn_heads * 64 && p.rows_per_sample > 0 && p.attn_kv &&
+                      p.attn_nkey >= p.rows_per_sample && p.attn_nkey % 32 == 0 && !p.R && !p.c_split),
+                 "V^T store: M = heads * 64 rows of the weight, images with nkey >= rows per sample");
+    DS_CHECK_ARG(p.store != DS_STORE_ATTN ||
+                     (p.attn_heads > 0 && p.N % (p.attn_heads * 64) == 0 && p.N / (p.attn_heads * 64) <= 2 &&
+                      p.rows_per_sample > 0 && p.attn_qplane > 0 && !p.R && !p.c_split &&
+                      (p.N == p.attn_heads * 64 || (p.attn_kv && p.attn_nkey >= p.rows_per_sample && p.attn_nkey % 32 == 0))),
+                 "attention store: N = (1 or 3) * heads * 64, Q plane stride, K/V images with nkey >= rows per sample");
     DS_CHECK_ARG(p.act == DS_ACT_NONE || p.act == DS_ACT_GELU2, "unsupported activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
     // Tile choice from the measured sweep (profiles/r01_gemm_tile_sweep_f16x2.txt, B=64): 128x128 reaches

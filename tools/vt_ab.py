@@ -1,0 +1,63 @@
+"""Cost of the attention-ready stores: the QKV projection's pieces timed with row-major fp32 stores vs their
+attention-ready stores (B=64).  Run on the GPU box: python tools/vt_ab.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from text_to_sound_synthesis_amd import _lib as L
+
+B, Lq, H, D = 64, 265, 16, 1024
+M, K = B * Lq, D
+M16 = (M + 15) // 16 * 16
+
+
+def split(a):
+    hi = a.clamp(-65504.0, 65504.0).half()
+    return torch.stack((hi, (a - hi.float()).clamp(-65504.0, 65504.0).half())).contiguous()
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+A = torch.randn(M, K, device="cuda")
+W = torch.randn(3 * D, K, device="cuda") * 0.05
+b = torch.randn(3 * D, device="cuda")
+W2p, sc = L.split_f16x2(W, packed=True)
+A2p = L.pack_planes(split(A))
+wv = W2p.view(-1)[2 * D * K:]
+qh = torch.empty(2, B, H, Lq, 64, device="cuda", dtype=torch.float16)
+img = torch.zeros(B, H, 4, 288 * 64, device="cuda", dtype=torch.float16)
+out = torch.empty(M, 2 * D, device="cuda")
+outT = torch.empty(D, M, device="cuda")
+t = timeit(lambda: L.gemm(A2p, W2p, out, M, 2 * D, K, bias=b, split2=sc, a_plane=M16 * K, w_plane=3 * D * K))
+print("Q|K columns  row-major fp32 store   %7.1f us" % t)
+t = timeit(lambda: L.gemm(A2p, W2p, qh, M, 2 * D, K, bias=b, split2=sc, a_plane=M16 * K, w_plane=3 * D * K,
+                          store=L.STORE_ATTN, rows_per_sample=Lq, attn=(img, H, 288, B * H * Lq * 64)))
+print("Q|K columns  attention-ready store  %7.1f us" % t)
+t = timeit(lambda: L.gemm(wv, A2p, outT, D, M, K, bias=b[2 * D:], split2=sc, a_plane=3 * D * K, w_plane=M16 * K, bias_rows=1))
+print("V transposed row-major fp32 store   %7.1f us" % t)
+t = timeit(lambda: L.gemm(wv, A2p, qh, D, M, K, bias=b[2 * D:], split2=sc, a_plane=3 * D * K, w_plane=M16 * K, bias_rows=1,
+                          store=L.STORE_ATTN_VT, rows_per_sample=Lq, attn=(img, H, 288, 0)))
+print("V transposed V^T image store        %7.1f us" % t)
+out1 = torch.empty(M, D, device="cuda")
+t = timeit(lambda: L.gemm(A2p, W2p, out1, M, D, K, bias=b, split2=sc, a_plane=M16 * K, w_plane=3 * D * K))
+print("N=1024 untransposed row-major       %7.1f us" % t)
+# FC1: row-major fp32 store vs packed split planes (c_split), GELU2 epilogue
+F = 4 * D
+W1 = torch.randn(F, K, device="cuda") * 0.05
+b1 = torch.randn(F, device="cuda")
+W1p, sc1 = L.split_f16x2(W1, packed=True)
+o32 = torch.empty(M, F, device="cuda")
+o16 = torch.zeros(2, M16 * F, device="cuda", dtype=torch.float16)
+t = timeit(lambda: L.gemm(A2p, W1p, o32, M, F, K, bias=b1, act=L.ACT_GELU2, split2=sc1, a_plane=M16 * K))
+print("FC1 row-major fp32 store            %7.1f us" % t)
+t = timeit(lambda: L.gemm(A2p, W1p, o16, M, F, K, bias=b1, act=L.ACT_GELU2, split2=sc1, a_plane=M16 * K, c_plane=M16 * F))
+print("FC1 packed split planes (c_split)   %7.1f us" % t)
