@@ -31,7 +31,7 @@ const char* ds_last_error_string(void);
 enum { DS_LOAD_DENSE = 0, DS_LOAD_CONV2D = 1, DS_LOAD_CONV1D = 2, DS_LOAD_CONVT1D = 3 };
 enum { DS_PRO_NONE = 0, DS_PRO_AFFINE = 1, DS_PRO_AFFINE_SWISH = 2, DS_PRO_LRELU = 3 };
 enum { DS_ACT_NONE = 0, DS_ACT_GELU2 = 1, DS_ACT_TANH = 2 };
-enum { DS_STORE_ROW = 0, DS_STORE_BATCH_T = 1, DS_STORE_CONVT = 2, DS_STORE_ATTN = 3, DS_STORE_ATTN_VT = 4 };
+enum { DS_STORE_ROW = 0, DS_STORE_BATCH_T = 1, DS_STORE_CONVT = 2, DS_STORE_ATTN = 3 };
 
 typedef struct ds_gemm_desc {
     const float* A;        /* activation base */
@@ -63,16 +63,13 @@ typedef struct ds_gemm_desc {
        LDS-DMA.  c_split: C is written in that layout with row length ldc (planes c_plane halves apart). */
     int32_t a_split, c_split;
     int64_t a_plane, c_plane;
-    /* ds_gemm_f16x2, store = DS_STORE_ATTN: column n = which*heads*64 + head*64 + d (which 0 Q, 1 K; N = 1 or 2
-       times heads*64), row = sample*rows_per_sample + position.  C = the Q planes (attn_qplane halves apart),
-       attn_kv = the K / V^T images with attn_nkey key slots (see ds_attention_f16x2_ready).
-       store = DS_STORE_ATTN_VT: the transposed product for the V^T image -- A = the V rows of the (packed) weight,
-       W = the (packed) activations, so row m = head*64 + d and column n = sample*rows_per_sample + position; bias is
-       indexed by the row (bias_rows = 1).  Only the K / V^T images pointer is used. */
+    /* ds_gemm_f16x2, store = DS_STORE_ATTN (packed operands only): column n = which*heads*64 + head*64 + d (which 0 Q,
+       1 K, 2 V; N = 1..3 times heads*64), row = sample*rows_per_sample + position (rows_per_sample >= 128).
+       C = the Q planes (attn_qplane halves apart), attn_kv = the K / V^T images with attn_nkey key slots
+       (see ds_attention_f16x2_ready). */
     void* attn_kv;
     int32_t attn_heads, attn_nkey;
     int64_t attn_qplane;
-    int32_t bias_rows;
 } ds_gemm_desc;
 
 int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream);
@@ -124,7 +121,8 @@ int ds_attention_f16x2_split(const float* q, int ldq, const float* k, int ldk, c
                              int ldo, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
 /* Attention on "attention-ready" operands, the denoiser's default path: Q as two fp16 planes [B][heads][Lq][64]
  * (q_plane halves apart), K and V^T as per-(sample, head) LDS images  K hi | K lo | V^T hi | V^T lo  of nkey*64 halves
- * each (nkey = ds_attn_nkey(Lk); layouts: csrc/common.h ds_attn_k_off / ds_attn_vt_off; rows of keys >= Lk zero).
+ * each (nkey = ds_attn_nkey(Lk); K[key][64] with 16-byte chunk c at c ^ ((key>>1)&7), V^T[d][nkey] with the 16-byte
+ * chunk of keys 8c..8c+7 at c ^ ((d>>2)&3): csrc/common.h ds_attn_k_off / ds_attn_vt_off; rows of keys >= Lk zero).
  * Producers: ds_gemm_f16x2 with store = DS_STORE_ATTN (Q | K | V columns of the fused QKV projection, or Q alone),
  * ds_attn_pack_kv (fp32 K | V rows, e.g. the caption K/V).  Output: packed split planes as ds_attention_f16x2_split. */
 int ds_attn_nkey(int Lk);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdiffsound_hip.so")
 LOAD_DENSE, LOAD_CONV2D, LOAD_CONV1D, LOAD_CONVT1D = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LRELU = 0, 1, 2, 3
 ACT_NONE, ACT_GELU2, ACT_TANH = 0, 1, 2
-STORE_ROW, STORE_BATCH_T, STORE_CONVT, STORE_ATTN, STORE_ATTN_VT = 0, 1, 2, 3, 4
+STORE_ROW, STORE_BATCH_T, STORE_CONVT, STORE_ATTN = 0, 1, 2, 3
 (LP_ADALN1, LP_W_QKV, LP_B_QKV, LP_W_PROJ1, LP_B_PROJ1, LP_ADALN2, LP_W_Q2, LP_B_Q2, LP_W_KV2, LP_B_KV2,
  LP_W_PROJ2, LP_B_PROJ2, LP_LN2_G, LP_LN2_B, LP_W_FC1, LP_B_FC1, LP_W_FC2, LP_B_FC2, LP_COUNT) = range(19)
 
@@ -32,8 +32,7 @@ class GemmDesc(C.Structure):
                 ("taps", _i32), ("dil", _i32), ("ct_r", _i32), ("ct_p", _i32), ("ct_tin", _i32),
                 ("f16_round", _i32), ("w3_plane", _i64), ("out_scale", _f),
                 ("a_split", _i32), ("c_split", _i32), ("a_plane", _i64), ("c_plane", _i64),
-                ("attn_kv", _vp), ("attn_heads", _i32), ("attn_nkey", _i32), ("attn_qplane", _i64),
-                ("bias_rows", _i32)]
+                ("attn_kv", _vp), ("attn_heads", _i32), ("attn_nkey", _i32), ("attn_qplane", _i64)]
 
 
 class DenoiserDesc(C.Structure):
@@ -150,7 +149,7 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
          groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
          act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
          Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split3=False, split2=None,
-         a_plane=0, c_plane=0, attn=None, bias_rows=0, w_plane=None):
+         a_plane=0, c_plane=0, attn=None, w_plane=None):
     """split3: W is the [3][N][K] bf16 split from split_bf16x3() and the bf16x3 kernel is used.
     split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used;
     a_plane / c_plane > 0 (f16x2 only): A and W are given / C is written as packed split planes (pack_planes())
@@ -178,10 +177,9 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
         if a_plane > 0:
             d.w3_plane = (N + 15) // 16 * 16 * d.ldw          # packed W: rows padded to 16
         d.c_split, d.c_plane = int(c_plane > 0), c_plane
-        d.bias_rows = bias_rows
         if w_plane is not None:
             d.w3_plane = w_plane
-        if attn is not None:        # (kv images tensor or None, heads, nkey, q plane stride): STORE_ATTN / STORE_ATTN_VT
+        if attn is not None:        # (kv images tensor or None, heads, nkey, q plane stride): STORE_ATTN
             d.attn_kv, d.attn_heads, d.attn_nkey, d.attn_qplane = ptr(attn[0]), attn[1], attn[2], attn[3]
         check(lib().ds_gemm_f16x2(C.byref(d), stream()))
     else:
@@ -233,10 +231,7 @@ def attn_images(k2, v2, nkey):
     key = torch.arange(Lk, device=dev)[:, None]
     d = torch.arange(64, device=dev)[None, :]
     koff = key * 64 + ((((d >> 3) ^ ((key >> 1) & 7))) << 3) + (d & 7)
-    kk = key & 31
-    chunk = (key >> 5) * 4 + ((kk >> 4) & 1) * 2 + ((kk >> 2) & 1)
-    e = (kk & 3) + (((kk >> 3) & 1) << 2)
-    voff = d * nkey + ((chunk ^ ((d >> 2) & 3)) << 3) + e
+    voff = d * nkey + (((key >> 3) ^ ((d >> 2) & 3)) << 3) + (key & 7)
     img = torch.zeros(B, H, 4, nkey * 64, dtype=torch.float16, device=dev)
     for pl in range(2):
         img[:, :, pl, koff.reshape(-1)] = k2[pl].reshape(B, H, -1)

@@ -32,7 +32,7 @@ static void fill(GemmParams& p, const ds_gemm_desc* d) {
     p.out_scale = d->out_scale;
     p.a_split = d->a_split; p.c_split = d->c_split; p.a_plane = d->a_plane; p.c_plane = d->c_plane;
     p.attn_kv = d->attn_kv; p.attn_heads = d->attn_heads; p.attn_nkey = d->attn_nkey; p.attn_qplane = d->attn_qplane;
-    p.row_off = 0; p.bias_rows = d->bias_rows;
+    p.row_off = 0;
     p.pro_scale = d->pro_scale; p.pro_shift = d->pro_shift;
     p.rows_per_sample = d->rows_per_sample;
     p.Cin = d->Cin; p.H = d->H; p.W_ = d->Wd; p.up = d->up; p.taps = d->taps; p.dil = d->dil;
@@ -209,7 +209,7 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
                  int M, int N, int K, int act, hipStream_t s, int store = DS_STORE_ROW, int rps = 0,
                  const void* W3 = nullptr, int split_mode = DS_SPLIT_NONE, float osc = 1.f,
                  long long a_plane = 0, long long c_plane = 0, void* attn_kv = nullptr, int attn_heads = 0,
-                 int attn_nkey = 0, long long attn_qplane = 0, int bias_rows = 0, long long w_plane = 0) {
+                 int attn_nkey = 0, long long attn_qplane = 0, long long w_plane = 0) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.W = W; p.bias = bias; p.R = R; p.C = C;
@@ -223,7 +223,6 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
         if (a_plane > 0) p.w3_plane = (long long)((N + 15) & ~15) * K;
         p.c_split = c_plane > 0; p.c_plane = c_plane;
         p.attn_kv = attn_kv; p.attn_heads = attn_heads; p.attn_nkey = attn_nkey; p.attn_qplane = attn_qplane;
-        p.bias_rows = bias_rows;
         if (w_plane > 0) p.w3_plane = w_plane;   // a row range of a larger packed weight keeps that weight's stride
     }
     auto launch = [&]() {
@@ -298,7 +297,7 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
     const int nkS = ds_attn_nkey(L);
     auto lin_attn = [&](int l, int slot, int bslot, int N, int n_weight, void* imgs) {
         return dense(w.hn, D, h->P(l, slot), h->P(l, bslot), nullptr, w.qkv, N, M, N, D, DS_ACT_NONE, s, DS_STORE_ATTN, L,
-                     h->P3(l, slot), h->split_mode, h->S3(l, slot), pD, 0, imgs, d.n_head, nkS, qpl, 0,
+                     h->P3(l, slot), h->split_mode, h->S3(l, slot), pD, 0, imgs, d.n_head, nkS, qpl,
                      (long long)n_weight * D);
     };
     auto attn_ready = [&](const void* imgs, int Lk) {
@@ -322,13 +321,7 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
         // x += attn1(ln1(x, t))
         TRY(adaln(l, DS_LP_ADALN1));
         if (f16) {
-            // Q | K columns: attention-ready Q planes + K image.  V: the transposed product W_v hn^T (both operands
-            // are packed planes of the same tile layout, so the roles simply swap), written as the V^T image.
-            TRY(lin_attn(l, DS_LP_W_QKV, DS_LP_B_QKV, 2 * D, 3 * D, w.kvimg));
-            const _Float16* wv = (const _Float16*)h->P3(l, DS_LP_W_QKV) + (size_t)2 * D * D;   // rows 2D.. of the weight
-            TRY(dense((const float*)wv, D, h->P(l, DS_LP_W_QKV), h->P(l, DS_LP_B_QKV) + 2 * D, nullptr, w.qkv, M, D, M, D,
-                      DS_ACT_NONE, s, DS_STORE_ATTN_VT, L, w.hn, h->split_mode, h->S3(l, DS_LP_W_QKV), (long long)3 * D * D,
-                      0, w.kvimg, d.n_head, nkS, 0, 1));
+            TRY(lin_attn(l, DS_LP_W_QKV, DS_LP_B_QKV, 3 * D, 3 * D, w.kvimg));   // Q planes + K / V^T images
             TRY(attn_ready(w.kvimg, L));
         } else {
             TRY(lin(l, DS_LP_W_QKV, DS_LP_B_QKV, w.hn, D, pD, nullptr, w.qkv, 3 * D, D, DS_ACT_NONE, 0));

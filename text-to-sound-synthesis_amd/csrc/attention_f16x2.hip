@@ -8,11 +8,13 @@
 //           (key>>1)&7 -> conflict-free ds_read_b128), B operand = the wave's own Q rows in registers.
 //           Transposed scores: lane&31 is the query, the keys of a tile are spread over the 16 accumulator
 //           registers, so the softmax is in-lane + one cross-half shuffle (as in attention.hip).
+//           MFMA row i of a 32-key tile is fed with key pi(i) (bits 2 and 3 of i swapped, ds_attn_pi), so that
+//           accumulator register r of lane half h holds key (r&3) + 4((r>>2)&1) + 8h + 16(r>>3): the 8 registers
+//           of a k-step are 8 CONSECUTIVE keys.
 //   pass 2  O[q][d] = sum_key P[q][key] V[key][d]:  the P registers are split (p0 + p1) and packed straight
-//           into the MFMA A operand: k-step s of a 32-key tile takes registers 8s..8s+7, i.e. keys
-//           (e&3) + 8(e>>2) + 16s + 4*half.  V is staged TRANSPOSED and key-permuted to match:
-//           VT[plane][d][tile*32 + s*16 + half*8 + e], so the B operand is one ds_read_b128 per plane
-//           (rows swizzled by (d>>2)&3).  MFMAs p1v0 + p0v1 + p0v0.
+//           into the MFMA A operand: k-step s of a 32-key tile takes registers 8s..8s+7 = keys 16s + 8*half + e.
+//           V is staged TRANSPOSED in natural key order, VT[plane][d][key], so the B operand is one ds_read_b128
+//           per plane (16-byte chunks swizzled by (d>>2)&3).  MFMAs p1v0 + p0v1 + p0v0.
 // K and V^T share one 72 KB LDS buffer (K first), so two workgroups fit per CU.
 //
 // READY variant (the denoiser's path): Q arrives as two fp16 planes and K / V^T as ready-made LDS images
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-            const int key = kt * 32 + l31;
+            const int key = kt * 32 + ds_attn_pi(l31);
             const _Float16* kr = buf + key * 64;
             const int sw = (key >> 1) & 7;
 #pragma unroll
@@ -175,9 +177,8 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
                 v[kx] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (key < Lk) v[kx] = *(const f32x4*)(vb + (size_t)key * ldv + c4 * 4);
             }
-            const int kk = (4 * kg) & 31;                       // kk & 3 == 0
-            const int e0 = ((kk >> 3) & 1) << 2;                // e = e0 + kx
-            const int chunk = ((4 * kg) >> 5) * 4 + (kk >> 4) * 2 + ((kk >> 2) & 1);   // tile*4 + s*2 + half
+            const int e0 = (4 * kg) & 7;                        // e = e0 + kx inside the 8-key chunk
+            const int chunk = (4 * kg) >> 3;
     #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int d = c4 * 4 + j;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int key = kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hh + 16 * (r >> 3);   // pi(MFMA row)
                 const float v = key < Lk ? s[kt][r] * scale : -INFINITY;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);

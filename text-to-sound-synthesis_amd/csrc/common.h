@@ -33,21 +33,21 @@ __device__ __forceinline__ size_t ds_packed_off(int row, int col, int ktiles) {
            ((((col >> 3) & 3) ^ ((row >> 2) & 3)) << 3) + (col & 7);
 }
 
-// "Attention-ready" operands (attention_f16x2.hip): what the QKV / cross-Q GEMM epilogues and ds_attn_pack_kv write
+// "Attention-ready" operands (attention_f16x2.hip): what the QKV / cross-Q GEMM epilogue and ds_attn_pack_kv write
 // so that the attention kernel stages K and V^T by LDS-DMA and reads Q fragments with plain 16-byte loads.
 //   Q     : two fp16 planes [B][heads][Lq][64]
 //   K,V^T : per (sample, head) one image  K hi | K lo | V^T hi | V^T lo,  each nkey*64 halves, = the kernel's LDS
-//           layout: K[key][64] with 16-byte chunks swizzled by (key>>1)&7; V^T[d][nkey] with the keys of a 32-tile
-//           permuted into MFMA k-step order and chunks swizzled by (d>>2)&3.  Rows of keys >= Lk must be zero.
+//           layout: K[key][64] with 16-byte chunks swizzled by (key>>1)&7; V^T[d][nkey] in natural key order with
+//           16-byte chunks (8 keys) swizzled by (d>>2)&3.  Rows of keys >= Lk must be zero.
+// The kernel feeds MFMA row i of a 32-key tile with key ds_attn_pi(i) (bits 2 and 3 swapped), which makes the score
+// registers of a lane hold 8 consecutive keys per k-step -- so the V^T operand is a plain transpose.
 __device__ __forceinline__ int ds_attn_k_off(int key, int d) {
     return key * 64 + ((((d >> 3) ^ ((key >> 1) & 7))) << 3) + (d & 7);
 }
 __device__ __forceinline__ int ds_attn_vt_off(int key, int d, int nkey) {
-    const int kk = key & 31;
-    const int chunk = (key >> 5) * 4 + ((kk >> 4) & 1) * 2 + ((kk >> 2) & 1);   // tile*4 + k-step*2 + lane half
-    const int e = (kk & 3) + (((kk >> 3) & 1) << 2);
-    return d * nkey + ((chunk ^ ((d >> 2) & 3)) << 3) + e;
+    return d * nkey + (((key >> 3) ^ ((d >> 2) & 3)) << 3) + (key & 7);
 }
+__device__ __forceinline__ int ds_attn_pi(int i) { return (i & 0x13) | (((i >> 3) & 1) << 2) | (((i >> 2) & 1) << 3); }
 
 // ---- error plumbing (C ABI returns int; message kept per thread) -------------------------
 void ds_set_error(const char* fmt, ...);
@@ -87,14 +87,10 @@ struct GemmParams {
     long long w3_plane;         // split kernels: W = 3 bf16 / 2 fp16 planes of [N][ldw], this many elements apart
     float out_scale;            // f16x2 kernel: 2^-s undoing the weight pre-scale
     // f16x2 kernel, store == DS_STORE_ATTN: column n = which*heads*64 + head*64 + d (which: 0 Q, 1 K, 2 V), row =
-    // sample*rows_per_sample + pos; C = the Q planes (attn_qplane halves apart), attn_kv = the K / V^T images
-    // store == DS_STORE_ATTN_VT: the TRANSPOSED product (A = the V rows of the weight, W = the activations): row m =
-    // head*64 + d, column n = sample*rows_per_sample + pos -> the V^T image, whose key axis then runs along the
-    // lanes (2-byte stores of 32 consecutive keys: a scattered V^T write from the untransposed product costs one
-    // L2 request per element, measured 3x the whole GEMM); bias_rows: bias is indexed by the row.
+    // sample*rows_per_sample + pos; C = the Q planes (attn_qplane halves apart), attn_kv = the K / V^T images.
+    // The tile is staged through LDS and leaves as 16-byte stores (8 d of a row for Q / K, 8 keys of a d for V^T).
     void* attn_kv;
     int attn_heads, attn_nkey, row_off;   // row_off: rows of this (sub-)problem start at this absolute row
-    int bias_rows;
     long long attn_qplane;
     int a_split, c_split;       // f16x2 kernel: A (and then W too) is given / C is written as packed split planes
     long long a_plane, c_plane; //   (ds_packed_off); plane strides in halves; lda / ldc = the row length K of that matrix

@@ -290,12 +290,11 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
             const int col = n0 + (wn * TN + j) * 32 + l31;                                          \
             if (col < p.N) {                                                                        \
-                const float bv = (p.bias && !p.bias_rows) ? p.bias[col] : 0.f;                      \
+                const float bv = p.bias ? p.bias[col] : 0.f;                                        \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
                     const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;      \
                     if (row < p.M) {                                                                \
                         float v = acc[i][j][r] * osc + bv;                                          \
-                        if (p.bias_rows) v += p.bias[row + p.row_off];                              \
                         if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));               \
                         __VA_ARGS__                                                                 \
                     }                                                                               \
@@ -303,42 +302,81 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
             }                                                                                       \
         }                                                                                           \
     }
-    if (p.store == DS_STORE_ATTN) {          // attention-ready Q planes / K image (common.h)
-        const int hw = p.attn_heads * 64, pl = p.attn_nkey * 64;
+    if (p.store == DS_STORE_ATTN || p.c_split) {
+        // fp16 split outputs (packed planes for the next GEMM, or attention-ready Q / K / V^T): the tile is split,
+        // staged in LDS as T[plane][BM][BN] halves and leaves as 16-byte stores -- 2-byte stores straight from the
+        // accumulator layout cost +3..+25 % of the GEMM (one L2 write request per few bytes)
+        __syncthreads();                                  // every wave is done with the operand stages
+        _Float16* T = smem;
         H_EPILOGUE({
-            const int arow = row + p.row_off;
-            const int b = arow / p.rows_per_sample, pos = arow - b * p.rows_per_sample;
-            const int which = col / hw, hc = col - which * hw, head = hc >> 6, d = hc & 63;
-            const _Float16 hi = ds_split_hi(v), lo = ds_split_lo(v, hi);
-            const size_t bh = (size_t)b * p.attn_heads + head;
-            if (which == 0) {
-                _Float16* q = (_Float16*)p.C + (bh * p.rows_per_sample + pos) * 64 + d;
-                q[0] = hi;
-                q[p.attn_qplane] = lo;
-            } else {
-                _Float16* img = (_Float16*)p.attn_kv + bh * (4 * (size_t)pl) + ds_attn_k_off(pos, d);
-                img[0] = hi;
-                img[pl] = lo;
+            const _Float16 hi = ds_split_hi(v);
+            const int tl = (row - m0) * BN + (col - n0);
+            T[tl] = hi;
+            T[BM * BN + tl] = ds_split_lo(v, hi);
+        })
+        __syncthreads();
+        const int hw = p.attn_heads * 64;
+        const int which = p.c_split ? 0 : n0 / hw;        // block-uniform: Q, K or V columns
+        if (p.c_split || which < 2) {                     // 8 consecutive columns of a row per store
+            constexpr int CPR = BN / 8;
+            for (int c = tid; c < 2 * BM * CPR; c += 256) {
+                const int cc = c % CPR, rl = (c / CPR) % BM, pl = c / (CPR * BM);
+                const int row = m0 + rl, col = n0 + cc * 8;
+                if (row < p.M && col < p.N) {
+                    const u32x4 val = *(const u32x4*)(T + (pl * BM + rl) * BN + cc * 8);
+                    _Float16* dst;
+                    if (p.c_split) {
+                        dst = (_Float16*)p.C + (size_t)pl * p.c_plane + ds_packed_off(row, col, p.ldc >> 5);
+                    } else {
+                        const int arow = row + p.row_off;
+                        const int b = arow / p.rows_per_sample, pos = arow - b * p.rows_per_sample;
+                        const int hc = col - which * hw, head = hc >> 6, d = hc & 63;
+                        const size_t bh = (size_t)b * p.attn_heads + head;
+                        if (which == 0)
+                            dst = (_Float16*)p.C + (size_t)pl * p.attn_qplane + (bh * p.rows_per_sample + pos) * 64 + d;
+                        else
+                            dst = (_Float16*)p.attn_kv + (bh * 4 + pl) * ((size_t)p.attn_nkey * 64) + ds_attn_k_off(pos, d);
+                    }
+                    *(u32x4*)dst = val;
+                }
             }
-        })
-    } else if (p.store == DS_STORE_ATTN_VT) {   // V^T image from the transposed product: lanes run along the keys
-        const int pl = p.attn_nkey * 64;
-        H_EPILOGUE({
-            const int hd = row + p.row_off, head = hd >> 6, d = hd & 63;
-            const int b = col / p.rows_per_sample, pos = col - b * p.rows_per_sample;
-            _Float16* img = (_Float16*)p.attn_kv + ((size_t)b * p.attn_heads + head) * (4 * (size_t)pl) + 2 * pl +
-                            ds_attn_vt_off(pos, d, p.attn_nkey);
-            const _Float16 hi = ds_split_hi(v);
-            img[0] = hi;
-            img[pl] = ds_split_lo(v, hi);
-        })
-    } else if (p.c_split) {                     // packed split planes for the next f16x2 GEMM (its K = ldc)
-        H_EPILOGUE({
-            _Float16* ch = (_Float16*)p.C + ds_packed_off(row, col, p.ldc >> 5);
-            const _Float16 hi = ds_split_hi(v);
-            ch[0] = hi;
-            ch[p.c_plane] = ds_split_lo(v, hi);
-        })
+        } else {                                           // V^T: 8 consecutive keys of one d per store
+            // The tile's rows belong to at most two samples; units of 8 keys are aligned in a sample's own key
+            // index, so the first / last unit of each sample segment can be partial (2-byte stores for those).
+            const int L = p.rows_per_sample, g0 = m0 + p.row_off;        // absolute first row
+            const int b0 = g0 / L, pos0 = g0 - b0 * L;
+            const int rows_here = (p.M - m0 < BM ? p.M - m0 : BM);       // valid rows of this tile
+            const int seg0 = (L - pos0 < rows_here ? L - pos0 : rows_here);   // rows in sample b0
+            const int u0 = ((pos0 + seg0 + 7) >> 3) - (pos0 >> 3);       // units touching sample b0
+            const int seg1 = rows_here - seg0;                           // rows in sample b0 + 1 (from key 0)
+            const int units = u0 + ((seg1 + 7) >> 3);
+            const int pln = p.attn_nkey * 64;
+            for (int c = tid; c < 2 * BN * units; c += 256) {
+                const int cl = c % BN, u = (c / BN) % units, pl = c / (BN * units);
+                const int col = n0 + cl;
+                if (col < p.N) {
+                    const bool first = u < u0;
+                    const int b = first ? b0 : b0 + 1;
+                    const int k0 = first ? ((pos0 >> 3) + u) * 8 : (u - u0) * 8;   // first key of the unit
+                    const int rl0 = first ? k0 - pos0 : seg0 + k0;                 // its tile-local row (may be < 0)
+                    const int lo_ok = first ? 0 : seg0, hi_ok = first ? seg0 : rows_here;   // local rows of this sample
+                    const int hc = col - 2 * hw, head = hc >> 6, d = hc & 63;
+                    _Float16* dst = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2 + pl) * (size_t)pln +
+                                    ds_attn_vt_off(k0, d, p.attn_nkey);
+                    const _Float16* src = T + (pl * BM) * BN + cl;
+                    if (rl0 >= lo_ok && rl0 + 8 <= hi_ok) {
+                        h8 val;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) val[e] = src[(rl0 + e) * BN];
+                        *(h8*)dst = val;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (rl0 + e >= lo_ok && rl0 + e < hi_ok) dst[e] = src[(rl0 + e) * BN];
+                    }
+                }
+            }
+        }
     } else if (p.store == DS_STORE_ROW) {
         H_EPILOGUE({
             if (p.R) v += p.R[(size_t)row * p.ldr + col];
@@ -408,15 +446,14 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     int rb = p.M / 128;                              // full 128-row tiles available
     while (rb > 0 && ((long)rb * tn) % g_balance_slots != 0) --rb;
     const int m_off = rb * 128;
-    if (rb == 0 || m_off == p.M || (p.store != DS_STORE_ROW && p.store != DS_STORE_ATTN && p.store != DS_STORE_ATTN_VT))
+    if (rb == 0 || m_off == p.M || (p.store != DS_STORE_ROW && p.store != DS_STORE_ATTN))
         return launch_h2<128, 128, 2>(p, s);
     GemmParams pb = p, ps = p;
     pb.M = m_off;
     ps.M = p.M - m_off;
     const size_t rg = (size_t)m_off / 16;
     ps.A = (const float*)((const _Float16*)p.A + rg * (p.K / HBK) * 512);           // packed planes: row-group offset
-    if (p.store == DS_STORE_ATTN || p.store == DS_STORE_ATTN_VT)
-        ps.row_off = p.row_off + m_off;   // destinations (and a row bias) are computed from absolute rows
+    if (p.store == DS_STORE_ATTN) ps.row_off = p.row_off + m_off;   // destinations are computed from absolute rows
     else if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
     else ps.C = p.C + (size_t)m_off * p.ldc;
     if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
@@ -450,19 +487,15 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(!p.c_split || (p.ldc % 32 == 0 && p.N <= p.ldc && p.c_plane >= (long long)((p.M + 15) / 16) * 16 * p.ldc &&
                                 p.store == DS_STORE_ROW && !p.R),
                  "packed output: ldc % 32 == 0, plane of ceil16(M) * ldc halves, row store, no residual");
-    DS_CHECK_ARG(p.store == DS_STORE_ROW || p.store == DS_STORE_BATCH_T || p.store == DS_STORE_ATTN ||
-                     p.store == DS_STORE_ATTN_VT,
+    DS_CHECK_ARG(p.store == DS_STORE_ROW || p.store == DS_STORE_BATCH_T || p.store == DS_STORE_ATTN,
                  "unsupported store mode");
-    DS_CHECK_ARG(!p.bias_rows || (p.bias && p.store != DS_STORE_BATCH_T), "row bias needs a bias vector");
-    DS_CHECK_ARG(p.store != DS_STORE_ATTN_VT ||
-                     (p.attn_heads > 0 && p.M == p.attn_heads * 64 && p.rows_per_sample > 0 && p.attn_kv &&
-                      p.attn_nkey >= p.rows_per_sample && p.attn_nkey % 32 == 0 && !p.R && !p.c_split),
-                 "V^T store: M = heads * 64 rows of the weight, images with nkey >= rows per sample");
     DS_CHECK_ARG(p.store != DS_STORE_ATTN ||
-                     (p.attn_heads > 0 && p.N % (p.attn_heads * 64) == 0 && p.N / (p.attn_heads * 64) <= 2 &&
-                      p.rows_per_sample > 0 && p.attn_qplane > 0 && !p.R && !p.c_split &&
+                     (p.a_split && p.attn_heads > 0 && p.N % (p.attn_heads * 64) == 0 && p.N / (p.attn_heads * 64) <= 3 &&
+                      p.rows_per_sample >= 128 && p.attn_qplane > 0 && !p.R && !p.c_split &&
                       (p.N == p.attn_heads * 64 || (p.attn_kv && p.attn_nkey >= p.rows_per_sample && p.attn_nkey % 32 == 0))),
-                 "attention store: N = (1 or 3) * heads * 64, Q plane stride, K/V images with nkey >= rows per sample");
+                 "attention store: packed operands, N = (1..3) * heads * 64, >= 128 rows per sample, Q plane stride, "
+                 "K/V images with nkey >= rows per sample");
+    DS_CHECK_ARG(!p.c_split || p.N % 8 == 0, "packed output needs N % 8 == 0");
     DS_CHECK_ARG(p.act == DS_ACT_NONE || p.act == DS_ACT_GELU2, "unsupported activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
     // Tile choice from the measured sweep (profiles/r01_gemm_tile_sweep_f16x2.txt, B=64): 128x128 reaches

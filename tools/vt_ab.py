@@ -32,24 +32,20 @@ W = torch.randn(3 * D, K, device="cuda") * 0.05
 b = torch.randn(3 * D, device="cuda")
 W2p, sc = L.split_f16x2(W, packed=True)
 A2p = L.pack_planes(split(A))
-wv = W2p.view(-1)[2 * D * K:]
 qh = torch.empty(2, B, H, Lq, 64, device="cuda", dtype=torch.float16)
 img = torch.zeros(B, H, 4, 288 * 64, device="cuda", dtype=torch.float16)
-out = torch.empty(M, 2 * D, device="cuda")
-outT = torch.empty(D, M, device="cuda")
-t = timeit(lambda: L.gemm(A2p, W2p, out, M, 2 * D, K, bias=b, split2=sc, a_plane=M16 * K, w_plane=3 * D * K))
-print("Q|K columns  row-major fp32 store   %7.1f us" % t)
-t = timeit(lambda: L.gemm(A2p, W2p, qh, M, 2 * D, K, bias=b, split2=sc, a_plane=M16 * K, w_plane=3 * D * K,
-                          store=L.STORE_ATTN, rows_per_sample=Lq, attn=(img, H, 288, B * H * Lq * 64)))
-print("Q|K columns  attention-ready store  %7.1f us" % t)
-t = timeit(lambda: L.gemm(wv, A2p, outT, D, M, K, bias=b[2 * D:], split2=sc, a_plane=3 * D * K, w_plane=M16 * K, bias_rows=1))
-print("V transposed row-major fp32 store   %7.1f us" % t)
-t = timeit(lambda: L.gemm(wv, A2p, qh, D, M, K, bias=b[2 * D:], split2=sc, a_plane=3 * D * K, w_plane=M16 * K, bias_rows=1,
-                          store=L.STORE_ATTN_VT, rows_per_sample=Lq, attn=(img, H, 288, 0)))
-print("V transposed V^T image store        %7.1f us" % t)
+out = torch.empty(M, 3 * D, device="cuda")
+t = timeit(lambda: L.gemm(A2p, W2p, out, M, 3 * D, K, bias=b, split2=sc, a_plane=M16 * K))
+print("QKV  row-major fp32 store           %7.1f us" % t)
+t = timeit(lambda: L.gemm(A2p, W2p, qh, M, 3 * D, K, bias=b, split2=sc, a_plane=M16 * K, store=L.STORE_ATTN,
+                          rows_per_sample=Lq, attn=(img, H, 288, B * H * Lq * 64)))
+print("QKV  attention-ready store          %7.1f us" % t)
 out1 = torch.empty(M, D, device="cuda")
 t = timeit(lambda: L.gemm(A2p, W2p, out1, M, D, K, bias=b, split2=sc, a_plane=M16 * K, w_plane=3 * D * K))
-print("N=1024 untransposed row-major       %7.1f us" % t)
+print("N=1024 row-major fp32 store         %7.1f us" % t)
+t = timeit(lambda: L.gemm(A2p, W2p, qh, M, D, K, bias=b, split2=sc, a_plane=M16 * K, w_plane=3 * D * K, store=L.STORE_ATTN,
+                          rows_per_sample=Lq, attn=(None, H, 288, B * H * Lq * 64)))
+print("N=1024 Q planes store               %7.1f us" % t)
 # FC1: row-major fp32 store vs packed split planes (c_split), GELU2 epilogue
 F = 4 * D
 W1 = torch.randn(F, K, device="cuda") * 0.05
