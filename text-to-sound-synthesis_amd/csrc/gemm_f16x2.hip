@@ -377,6 +377,23 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
                 }
             }
         }
+    } else if (p.store == DS_STORE_ROW && ((p.N | p.ldc | p.ldr) & 3) == 0 &&
+               (((uintptr_t)p.C | (uintptr_t)p.R) & 15) == 0) {
+        // row-major fp32 (+ residual): the same staging, T[BM][BN] floats, 16-byte residual loads and stores
+        __syncthreads();
+        float* Tf = (float*)smem;
+        H_EPILOGUE({ Tf[(row - m0) * BN + (col - n0)] = v; })
+        __syncthreads();
+        constexpr int CPR = BN / 4;
+        for (int c = tid; c < BM * CPR; c += 256) {
+            const int cc = c % CPR, rl = c / CPR;
+            const int row = m0 + rl, col = n0 + cc * 4;
+            if (row < p.M && col < p.N) {
+                f32x4 val = *(const f32x4*)(Tf + rl * BN + cc * 4);
+                if (p.R) val += *(const f32x4*)(p.R + (size_t)row * p.ldr + col);
+                *(f32x4*)(p.C + (size_t)row * p.ldc + col) = val;
+            }
+        }
     } else if (p.store == DS_STORE_ROW) {
         H_EPILOGUE({
             if (p.R) v += p.R[(size_t)row * p.ldr + col];
