@@ -197,13 +197,16 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
 
     // ---- softmax over keys (fp32, in registers) ----
     if (active) {
+        // exp(x) = 2^(x log2 e): the scores are scaled into the log2 domain once and each exponential is one
+        // v_exp_f32 (expf costs ~6 VALU per element; the softmax is the longest stretch of a workgroup's life)
+        const float sl = scale * 1.4426950408889634f;
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hh + 16 * (r >> 3);   // pi(MFMA row)
-                const float v = key < Lk ? s[kt][r] * scale : -INFINITY;
+                const float v = key < Lk ? s[kt][r] * sl : -INFINITY;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(s[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
                 s[kt][r] = e;
                 sum += e;
             }
@@ -226,10 +229,10 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
     }
     __syncthreads();  // V^T is in LDS
 
-    if (active) {
-        f32x16 o0, o1;
+    f32x16 o0, o1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    if (active) {
         const _Float16* v0r = buf + l31 * NKEY;          // d = l31
         const _Float16* v1r = buf + (32 + l31) * NKEY;   // d = 32 + l31   ((d>>2)&3 is the same for both)
         const int sw = (l31 >> 2) & 3;
@@ -254,23 +257,41 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, vb1, o1, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, vb0, o1, 0, 0, 0);
             }
+    }
+    if (o_plane > 0) {
+        // packed split planes for the f16x2 projection GEMM (K = ldo): each wave stages its 32 x 64 tile (hi, lo) in
+        // the now free LDS and stores 16-byte chunks (8 d of one row) instead of 2-byte pieces
+        __syncthreads();                                   // every wave is done reading V^T
+        if (active) {
+            _Float16* T = buf + wave * (2 * 32 * 64);      // [plane][32 rows][64 d]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const _Float16 a0 = ds_split_hi(o0[r]), a1 = ds_split_hi(o1[r]);
+                T[rl * 64 + l31] = a0;
+                T[rl * 64 + 32 + l31] = a1;
+                T[2048 + rl * 64 + l31] = ds_split_lo(o0[r], a0);
+                T[2048 + rl * 64 + 32 + l31] = ds_split_lo(o1[r], a1);
+            }
+            // (LDS operations of one wave complete in order: no barrier between its own writes and reads)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int c = lane + 64 * it, pl = c >> 8, rl = (c >> 3) & 31, ch = c & 7;
+                const int qr = q0 + rl;
+                if (qr < Lq) {
+                    const h8 val = *(const h8*)(T + pl * 2048 + rl * 64 + ch * 8);
+                    *(h8*)((_Float16*)O + (size_t)pl * o_plane + ds_packed_off(b * Lq + qr, head * 64 + ch * 8, ldo >> 5)) = val;
+                }
+            }
+        }
+    } else if (active) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (qr < Lq) {
                 const size_t off = ((size_t)b * Lq + qr) * ldo + head * 64 + l31;
-                if (o_plane > 0) {   // packed split planes for the f16x2 projection GEMM (K = ldo)
-                    _Float16* oh = (_Float16*)O;
-                    const size_t p0 = ds_packed_off(b * Lq + qr, head * 64 + l31, ldo >> 5), p1 = p0 + 512;  // next k tile
-                    const _Float16 a0 = ds_split_hi(o0[r]), a1 = ds_split_hi(o1[r]);
-                    oh[p0] = a0;
-                    oh[p1] = a1;
-                    oh[o_plane + p0] = ds_split_lo(o0[r], a0);
-                    oh[o_plane + p1] = ds_split_lo(o1[r], a1);
-                } else {
-                    O[off] = o0[r];
-                    O[off + 32] = o1[r];
-                }
+                O[off] = o0[r];
+                O[off + 32] = o1[r];
             }
         }
     }
