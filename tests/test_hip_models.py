@@ -236,6 +236,20 @@ def test_decoder_stages_vs_oracle(m2):
     assert (got - ref).abs().max() < MEL_TOL
 
 
+def test_decode_full_batch_chunk_is_sample_independent(m2):
+    """BASELINE configs[2] decodes 64 clips in one chunk (4.3 M implicit-GEMM rows at full resolution): every sample
+    of a batch of identical tokens must equal the single-sample decode bit for bit (no cross-sample leakage, no
+    32-bit index overflow)."""
+    tok1 = synth.synth_tokens(1, mask_frac=0.0, key="dec.tokens").cuda()
+    one = m2.decode_to_img(tok1, (1, 256, 5, 53))
+    assert m2.content_codec.decode_chunk >= 64
+    many = m2.decode_to_img(tok1.expand(64, -1).contiguous(), (64, 256, 5, 53))
+    assert many.shape == (64, 1, 80, 848)
+    assert torch.equal(many, one.expand(64, -1, -1, -1))
+    del many
+    torch.cuda.empty_cache()
+
+
 def test_vocoder_vs_reference(voc):
     mel01 = synth.synth_uniform((1, 80, 848), key="voc.mel").cuda()
     wave = voc(mel01).cpu()
