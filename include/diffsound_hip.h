@@ -83,6 +83,10 @@ void ds_gemm_bf16x3_force_tile(int cfg);
  * a0b0 + a0b1 + a1b0 per k-step, epilogue multiplies by out_scale = 2^-s.  |A| must stay below 65504
  * (gemm_f16x2.hip). */
 int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
+/* the DS_LOAD_CONV2D contraction (3x3 conv over a channels-last image: Cin, H, Wd, up; prologue none or GroupNorm
+   affine + swish; bias, residual, row store) in the same fp32-class 3-pass formulation: A fp32, W = the two fp16
+   planes [N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart), out_scale = 2^-s */
+int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 void ds_gemm_f16x2_force_tile(int cfg);
 /* packed-operand launches that pick the 128x128 tile are balanced: 128x128 tiles over the leading rows that fill
    whole rounds of `slots` resident workgroups (default 512 = 256 CUs x 2), 64x64 tiles over the rest.  Test hook. */

@@ -243,6 +243,46 @@ def test_conv2d_3x3(L, up, gn):
     assert relerr(out.cpu(), ref) < 3e-6
 
 
+@pytest.mark.parametrize("up", [0, 1, 2])
+@pytest.mark.parametrize("gn", [False, True])
+@pytest.mark.parametrize("shape", [(2, 10, 106, 64, 96), (1, 40, 424, 128, 128), (3, 5, 53, 32, 512)])
+def test_conv2d_3x3_f16x2_and_stride2(L, up, gn, shape):
+    """The 3x3 conv on the fp16 matrix cores (csrc/conv_f16x2.hip, both tile configs) and the fp32 gather-GEMM, all
+    geometries: same-size, nearest-2x upsampled source, stride 2 with right/bottom padding (Downsample); with and
+    without the GroupNorm-affine + swish prologue and a residual; both against float64."""
+    B, H, W, Cin, Cout = shape
+    hs, ws = (H // 2, W // 2) if up == 1 else ((2 * H, 2 * W) if up == 2 else (H, W))
+    if up == 1 and (H % 2 or W % 2):
+        pytest.skip("upsampled output needs even H, W")
+    x = rnd((B, hs, ws, Cin), "c2h.x", 2.0)
+    w, bias = rnd((Cout, Cin, 3, 3), "c2h.w", 0.1), rnd((Cout,), "c2h.b")
+    R = rnd((B, H, W, Cout), "c2h.r")
+    xin = x.permute(0, 3, 1, 2).double()
+    sc = sh = None
+    if gn:
+        sc, sh = rnd((B, Cin), "c2h.s") + 1.5, rnd((B, Cin), "c2h.o")
+        xin = xin * sc.double()[:, :, None, None] + sh.double()[:, :, None, None]
+        xin = xin * torch.sigmoid(xin)
+    if up == 1:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if up == 2:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w.double(), bias.double(), stride=2)
+    else:
+        ref = F.conv2d(xin, w.double(), bias.double(), padding=1)
+    ref = (ref.permute(0, 2, 3, 1) + R.double()).float()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().cuda()
+    kw = dict(bias=bias.cuda(), R=R.cuda(), loader=L.LOAD_CONV2D, pro=L.PRO_AFFINE_SWISH if gn else L.PRO_NONE,
+              pro_scale=sc.cuda() if gn else None, pro_shift=sh.cuda() if gn else None, Cin=Cin, H=H, Wd=W, up=up)
+    xc = x.cuda()
+    o32 = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    L.gemm(xc, wp, o32, B * H * W, Cout, 9 * Cin, **kw)
+    w2, scale = L.split_f16x2(wp)
+    o16 = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    L.gemm(xc, w2, o16, B * H * W, Cout, 9 * Cin, split2=scale, conv_split=True, **kw)
+    e32, e16 = relerr(o32.cpu(), ref), relerr(o16.cpu(), ref)
+    assert e32 < 3e-6 and e16 < max(3e-6, 1.2 * e32)
+
+
 @pytest.mark.parametrize("taps,dil", [(7, 1), (3, 1), (3, 3), (3, 9)])
 def test_conv1d_reflect(L, taps, dil):
     B, T, Cin, Cout = 2, 212, 64, 96

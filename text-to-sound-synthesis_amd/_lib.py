@@ -51,6 +51,7 @@ _PROTOS = {
     "ds_gemm_bf16x3": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_gemm_bf16x3_force_tile": (None, [C.c_int]),
     "ds_gemm_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "ds_conv2d_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_gemm_f16x2_force_tile": (None, [C.c_int]),
     "ds_gemm_f16x2_set_balance_slots": (None, [C.c_int]),
     "ds_denoiser_set_split_weights": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_f), _vp, _f]),
@@ -149,7 +150,7 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
          groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
          act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
          Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split3=False, split2=None,
-         a_plane=0, c_plane=0, attn=None, w_plane=None):
+         a_plane=0, c_plane=0, attn=None, w_plane=None, conv_split=False):
     """split3: W is the [3][N][K] bf16 split from split_bf16x3() and the bf16x3 kernel is used.
     split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used;
     a_plane / c_plane > 0 (f16x2 only): A and W are given / C is written as packed split planes (pack_planes())
@@ -170,6 +171,10 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
     if split3:
         d.w3_plane = N * d.ldw
         check(lib().ds_gemm_bf16x3(C.byref(d), stream()))
+    elif split2 is not None and conv_split:        # 3x3 conv on the fp16 matrix cores (conv_f16x2.hip)
+        d.w3_plane = N * d.ldw
+        d.out_scale = split2
+        check(lib().ds_conv2d_f16x2(C.byref(d), stream()))
     elif split2 is not None:
         d.w3_plane = N * d.ldw
         d.out_scale = split2

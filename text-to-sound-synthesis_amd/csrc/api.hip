@@ -64,6 +64,16 @@ extern "C" int ds_gemm_bf16x3(const ds_gemm_desc* d, ds_stream_t stream) {
     return ds_launch_gemm_bf16x3(p, (hipStream_t)stream);
 }
 
+// 3x3 conv (DS_LOAD_CONV2D geometry of the descriptor) on the fp16 matrix cores; W = split_f16x2 planes
+extern "C" int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
+    DS_CHECK_ARG(d && d->A && d->W && d->C, "null pointer");
+    DS_CHECK_ARG(d->w3_plane > 0, "w3_plane (plane stride of the split weights) is required");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    fill(p, d);
+    return ds_launch_conv2d_f16x2(p, (hipStream_t)stream);
+}
+
 extern "C" int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
     DS_CHECK_ARG(d && d->A && d->W && d->C, "null pointer");
     DS_CHECK_ARG(d->loader == DS_LOAD_DENSE && d->pro == DS_PRO_NONE && d->groups <= 1 && !d->f16_round,

@@ -1,0 +1,254 @@
+// 3x3 convolution over channels-last images as an implicit GEMM on the fp16 matrix cores with the 2-way fp16 split
+// of gemm_f16x2.hip (fp32-class results, 3 MFMA passes):  the SpecVQGAN decoder / encoder convolutions
+// (specvqgan/modules/diffusionmodules/model.py:37-77,92-151), which ran on the 16x slower fp32 MFMA
+// (gemm_f32.hip, DS_LOAD_CONV2D: same loader semantics, same prologue, same epilogue).
+//
+//   C[m][n] = sum_{tap, c} pro(X)[pixel(m) + tap][c] * W[n][tap][c] * 2^s ... * 2^-s + bias[n] (+ R[m][n])
+//
+// A is gathered and split while it is staged (zero padding, nearest-2x upsample or stride-2 as index math; the
+// GroupNorm affine + swish prologue is applied before the split); W arrives as two row-major fp16 planes of
+// W * 2^s (_lib.split_f16x2).  256 threads = 4 waves (2x2), block tile BM x BN x 32, the LDS layout and fragment
+// reads of gemm_f16x2.hip (64-byte rows, 16-byte chunks XOR-swizzled by (row>>2)&3), register-staged double
+// buffering: the raw loads of tile t+1 are issued before the MFMAs of tile t, prologue + split + LDS write after.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CLD 32  // halves per LDS row
+
+template <int BM, int BN, int PRO>
+__global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int SA = BM / 64, SB = BN / 64;            // 8-element staging chunks per thread
+    constexpr int APL = BM * CLD, BPL = BN * CLD;        // plane strides (halves)
+    constexpr int STAGE = 2 * (APL + BPL);
+    _Float16* smem = (_Float16*)smem_raw;                // [2 stages]{ A[2][BM][32], B[2][BN][32] }
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+
+    // staging chunk c = tid + 256 i: row c>>2, the 8 consecutive k at (c&3)*8 of the 32-wide k-tile
+    int a_b[SA], a_y[SA], a_x[SA], a_dst[SA];
+    const int ck8 = (tid & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < SA; ++i) {
+        const int row = (tid + 256 * i) >> 2;
+        int m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        const int hw = p.H * p.W_;
+        a_b[i] = m / hw;
+        const int rem = m - a_b[i] * hw;
+        a_y[i] = rem / p.W_;
+        a_x[i] = rem - a_y[i] * p.W_;
+        a_dst[i] = row * CLD + (((tid & 3) ^ ((row >> 2) & 3)) * 8);
+    }
+    const unsigned short* w2 = (const unsigned short*)p.W;
+    const unsigned short* b_base[SB];
+    int b_dst[SB];
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+        const int row = (tid + 256 * j) >> 2;
+        int n = n0 + row;
+        if (n >= p.N) n = p.N - 1;
+        b_base[j] = w2 + (size_t)n * p.ldw + ck8;
+        b_dst[j] = row * CLD + (((tid & 3) ^ ((row >> 2) & 3)) * 8);
+    }
+    const size_t pl1 = (size_t)p.w3_plane;
+
+    unsigned okmask = 0;
+    f32x4 ra[2 * SA];
+    u32x4 rb0[SB], rb1[SB];
+    // raw loads of k-tile k0: address math + two 16-byte loads per slot, no branch on loaded data
+#define C_LOAD(k0_)                                                                                 \
+    do {                                                                                            \
+        const int tap = (k0_) / p.Cin, c0 = (k0_) - tap * p.Cin + ck8;                              \
+        const int ky = tap / 3, kx = tap - ky * 3;                                                  \
+        _Pragma("unroll") for (int i = 0; i < SA; ++i) {                                            \
+            int sy = a_y[i] + ky - 1, sx = a_x[i] + kx - 1;                                         \
+            bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W_;                                  \
+            sy = ok ? sy : a_y[i];                                                                  \
+            sx = ok ? sx : a_x[i];                                                                  \
+            int hs = p.H, ws = p.W_;                                                                \
+            if (p.up == 1) { sy >>= 1; sx >>= 1; hs >>= 1; ws >>= 1; }                              \
+            if (p.up == 2) {                                                                        \
+                hs = 2 * p.H; ws = 2 * p.W_;                                                        \
+                sy = 2 * a_y[i] + ky; sx = 2 * a_x[i] + kx;                                         \
+                ok = sy < hs && sx < ws;                                                            \
+                sy = ok ? sy : 2 * a_y[i];                                                          \
+                sx = ok ? sx : 2 * a_x[i];                                                          \
+            }                                                                                       \
+            okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));                             \
+            const float* src = p.A + ((size_t)(a_b[i] * hs + sy) * ws + sx) * p.Cin + c0;           \
+            ra[2 * i] = *(const f32x4*)src;                                                         \
+            ra[2 * i + 1] = *(const f32x4*)(src + 4);                                               \
+        }                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < SB; ++j) {                                            \
+            rb0[j] = *(const u32x4*)(b_base[j] + (k0_));                                            \
+            rb1[j] = *(const u32x4*)(b_base[j] + pl1 + (k0_));                                      \
+        }                                                                                           \
+    } while (0)
+    // prologue (GroupNorm affine + swish on the raw activations), zero padding, split, LDS write
+#define C_WRITE(k0_, stage_)                                                                        \
+    do {                                                                                            \
+        _Float16* As_ = smem + (stage_) * STAGE;                                                    \
+        _Float16* Bs_ = As_ + 2 * APL;                                                              \
+        const int ch0 = (k0_) - ((k0_) / p.Cin) * p.Cin + ck8;                                      \
+        _Pragma("unroll") for (int i = 0; i < SA; ++i) {                                            \
+            h8 s0, s1;                                                                              \
+            const bool ok = (okmask >> i) & 1u;                                                     \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                         \
+                f32x4 v = ra[2 * i + q];                                                            \
+                if constexpr (PRO == DS_PRO_AFFINE_SWISH) {                                         \
+                    const f32x4 sc = *(const f32x4*)(p.pro_scale + (size_t)a_b[i] * p.Cin + ch0 + 4 * q); \
+                    const f32x4 sh = *(const f32x4*)(p.pro_shift + (size_t)a_b[i] * p.Cin + ch0 + 4 * q); \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                 \
+                        const float y = v[e] * sc[e] + sh[e];                                       \
+                        v[e] = y / (1.f + expf(-y));                                                \
+                    }                                                                               \
+                }                                                                                   \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
+                    const float a = ok ? v[e] : 0.f;   /* zero padding lives in the activated domain */ \
+                    s0[4 * q + e] = ds_split_hi(a);                                                 \
+                    s1[4 * q + e] = ds_split_lo(a, s0[4 * q + e]);                                  \
+                }                                                                                   \
+            }                                                                                       \
+            *(h8*)(As_ + a_dst[i]) = s0;                                                            \
+            *(h8*)(As_ + APL + a_dst[i]) = s1;                                                      \
+        }                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < SB; ++j) {                                            \
+            *(u32x4*)(Bs_ + b_dst[j]) = rb0[j];                                                     \
+            *(u32x4*)(Bs_ + BPL + b_dst[j]) = rb1[j];                                               \
+        }                                                                                           \
+    } while (0)
+
+    const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / 32;
+    C_LOAD(0);
+    C_WRITE(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) C_LOAD((kt + 1) * 32);
+        {
+            const _Float16* Ac = smem + cur * STAGE + (wm * TM * 32 + l31) * CLD;
+            const _Float16* Bc = smem + cur * STAGE + 2 * APL + (wn * TN * 32 + l31) * CLD;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 fa0[TM], fa1[TM], fb0[TN], fb1[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    fa0[i] = *(const h8*)(Ac + i * 32 * CLD + swz[ks]);
+                    fa1[i] = *(const h8*)(Ac + APL + i * 32 * CLD + swz[ks]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    fb0[j] = *(const h8*)(Bc + j * 32 * CLD + swz[ks]);
+                    fb1[j] = *(const h8*)(Bc + BPL + j * 32 * CLD + swz[ks]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[i], fb0[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[i], fb1[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[i], fb0[j], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+            }
+        }
+        if (more) C_WRITE((kt + 1) * 32, cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: bias, residual, row-major store, staged through LDS for 16-byte accesses (as gemm_f16x2.hip)
+    const float osc = p.out_scale;
+    float* Tf = (float*)smem_raw;     // [BM][BN] floats: the operand stages are free after the last barrier
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = (wn * TN + j) * 32 + l31;
+            const float bv = (p.bias && n0 + cl < p.N) ? p.bias[n0 + cl] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                Tf[rl * BN + cl] = acc[i][j][r] * osc + bv;
+            }
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 4;
+    for (int c = tid; c < BM * CPR; c += 256) {
+        const int cc = c % CPR, rl = c / CPR;
+        const int row = m0 + rl, col = n0 + cc * 4;
+        if (row < p.M && col < p.N) {
+            f32x4 val = *(const f32x4*)(Tf + rl * BN + cc * 4);
+            if (p.R) val += *(const f32x4*)(p.R + (size_t)row * p.ldr + col);
+            *(f32x4*)(p.C + (size_t)row * p.ldc + col) = val;
+        }
+    }
+}
+
+template <int BM, int BN, int PRO>
+static int conv_launch(const GemmParams& p, hipStream_t s) {
+    const size_t stage = (size_t)2 * 2 * (BM + BN) * CLD * sizeof(unsigned short);
+    const size_t tile = (size_t)BM * BN * sizeof(float);
+    const size_t lds = stage > tile ? stage : tile;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_conv2d_f16x2_kernel<BM, BN, PRO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            ds_set_error("conv2d_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL((ds_conv2d_f16x2_kernel<BM, BN, PRO>), dim3(tiles), dim3(256), lds, s, p);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// p.A: channels-last fp32 image; p.W: 2 row-major fp16 planes [N][ldw] of W * 2^s (K = 9 * Cin ordered [tap][c]),
+// w3_plane halves apart; p.out_scale = 2^-s.
+int ds_launch_conv2d_f16x2(const GemmParams& p, hipStream_t stream) {
+    DS_CHECK_ARG(p.M > 0 && p.N > 0 && p.Cin > 0 && p.Cin % 32 == 0 && p.K == 9 * p.Cin, "conv2d: K = 9*Cin, Cin % 32 == 0");
+    DS_CHECK_ARG(p.H > 0 && p.W_ > 0 && p.M % (p.H * p.W_) == 0, "conv2d: M = samples * H * W");
+    DS_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0 &&
+                     ((uintptr_t)p.R & 15) == 0,
+                 "operands must be 16-byte aligned");
+    DS_CHECK_ARG(p.ldw >= p.K && p.ldw % 8 == 0 && p.w3_plane % 8 == 0 && p.w3_plane >= (long long)p.N * p.ldw,
+                 "split-weight strides must be multiples of 8");
+    DS_CHECK_ARG(p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.R || p.ldr % 4 == 0), "N, ldc, ldr must be multiples of 4");
+    DS_CHECK_ARG(p.store == DS_STORE_ROW && p.act == DS_ACT_NONE && p.groups <= 1, "row store, no activation, no groups");
+    DS_CHECK_ARG(p.pro == DS_PRO_NONE || (p.pro == DS_PRO_AFFINE_SWISH && p.pro_scale && p.pro_shift),
+                 "prologue: none or GroupNorm affine + swish");
+    DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (t128 >= 256) {
+        return p.pro == DS_PRO_NONE ? conv_launch<128, 128, DS_PRO_NONE>(p, stream)
+                                    : conv_launch<128, 128, DS_PRO_AFFINE_SWISH>(p, stream);
+    }
+    return p.pro == DS_PRO_NONE ? conv_launch<64, 64, DS_PRO_NONE>(p, stream)
+                                : conv_launch<64, 64, DS_PRO_AFFINE_SWISH>(p, stream);
+}

@@ -11,6 +11,8 @@ Device layout: activations are channels-last [B, H, W, C] fp32.  Every conv is t
 while staging its A tile together with swish; nearest-2x upsampling is index math inside the conv
 loader; the 512-channel spatial attention runs as two batched GEMMs around a row softmax.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -189,9 +191,15 @@ class ColumnMajor(nn.Module):
         return x[:, self.backward_shuffle_idx if reverse else self.forward_shuffle_idx]
 
 
+def _with_split(w, b):
+    """(w [N][K] fp32, bias) + the two fp16 planes of w * 2^s and 2^-s for the 3x3 convs' f16x2 kernel"""
+    w2, sc = _lib.split_f16x2(w)
+    return w, b, w2, sc
+
+
 def _pack_conv3(conv):
     w = conv.weight.detach().float()
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), conv.bias.detach().float().contiguous()
+    return _with_split(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), conv.bias.detach().float().contiguous())
 
 
 def _pack_conv1(conv):
@@ -211,6 +219,9 @@ class VQModel(nn.Module):
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self._pke = None
         self.ddconfig = dict(ddconfig)
+        # arithmetic of the 3x3 convolutions: "f16x2" (default; fp32-class 3-pass fp16 split on the 16-bit matrix
+        # cores, csrc/conv_f16x2.hip) or "fp32" (exact fp32 MFMA, csrc/gemm_f32.hip)
+        self.conv_precision = os.environ.get("DIFFSOUND_CONV", "f16x2")
         self._pk = None
         # samples decoded / encoded at once: bounds the full-resolution workspace (34.7 MB per sample and tensor,
         # ~15 GB live at 64) and the 32-bit element indices inside the kernels ([B][80][848][128] < 2^31 up to B=247);
@@ -288,7 +299,7 @@ class VQModel(nn.Module):
         w = e.conv_in.weight.detach().float()                                   # [ch, 1, 3, 3]
         w_in = torch.zeros(w.shape[0], 9, 32, device=w.device)
         w_in[:, :, 0] = w[:, 0].reshape(w.shape[0], 9)
-        pk = {"conv_in": (w_in.reshape(w.shape[0], -1).contiguous(), e.conv_in.bias.detach().float().contiguous()),
+        pk = {"conv_in": _with_split(w_in.reshape(w.shape[0], -1).contiguous(), e.conv_in.bias.detach().float().contiguous()),
               "down": [], "mid": (res(e.mid.block_1), att(e.mid.attn_1), res(e.mid.block_2)),
               "norm_out": gb(e.norm_out), "conv_out": _pack_conv3(e.conv_out), "quant": _pack_conv1(self.quant_conv)}
         for lvl in range(e.num_resolutions):
@@ -310,16 +321,22 @@ class VQModel(nn.Module):
                                                  _lib.ptr(sh), _lib.stream()))
         return sc, sh
 
-    @staticmethod
-    def _conv3(x, B, H, W, Cin, wb, gn=None, R=None, up=0):
-        """3x3 conv, output H x W (input H/2 x W/2 if up).  gn = (scale, shift) -> GroupNorm+swish prologue."""
-        w, b = wb
+    def _conv3(self, x, B, H, W, Cin, wb, gn=None, R=None, up=0):
+        """3x3 conv, output H x W (input H/2 x W/2 if up == 1, 2H x 2W if up == 2).  gn = (scale, shift) ->
+        GroupNorm + swish prologue."""
+        w, b, w2, sc = wb
         Cout = w.shape[0]
         out = torch.empty(B, H, W, Cout, device=x.device)
-        _lib.gemm(x, w, out, B * H * W, Cout, 9 * Cin, bias=b, R=R, loader=_lib.LOAD_CONV2D,
+        kw = dict(bias=b, R=R, loader=_lib.LOAD_CONV2D,
                   pro=_lib.PRO_AFFINE_SWISH if gn is not None else _lib.PRO_NONE,
                   pro_scale=gn[0] if gn is not None else None, pro_shift=gn[1] if gn is not None else None,
                   Cin=Cin, H=H, Wd=W, up=up)
+        if self.conv_precision == "f16x2" and Cout % 4 == 0:
+            _lib.gemm(x, w2, out, B * H * W, Cout, 9 * Cin, split2=sc, conv_split=True, **kw)
+        elif self.conv_precision in ("f16x2", "fp32"):
+            _lib.gemm(x, w, out, B * H * W, Cout, 9 * Cin, **kw)
+        else:
+            raise ValueError("conv_precision must be 'f16x2' or 'fp32', got %r" % (self.conv_precision,))
         return out
 
     @staticmethod
