@@ -159,10 +159,39 @@ def encoder():
     save("encoder_T10_L2", **arrs)
 
 
+def codebook512():
+    """BASELINE configs[3] runs the 512-entry codebook (configs/caps_512.yaml:12,82 -> 513 classes): logits, one
+    teacher-forced step and the decode of its tokens from the reference built with n_embed = 512."""
+    torch.manual_seed(0)
+    m = rh.build_dalle(n_layer=2, diffusion_step=100, n_embed=512)
+    from sound_synthesis.modeling.transformers.diffusion_transformer import index_to_log_onehot
+    dt = m.transformer
+    keys = state_keys(m, skip=("content_codec.encoder.", "content_codec.quant_conv."))
+    with open(os.path.join(OUT, "state_dict_keys_k512.json"), "w") as f:
+        json.dump({"dalle_k512": keys}, f, indent=0, sort_keys=True)
+    x = synth.synth_tokens(2, 265, 512, mask_frac=0.4, key="k512.x")
+    cond = synth.synth_cond_emb(2, key="k512.c")
+    t = torch.tensor([61, 12])
+    logits = dt.transformer(x, cond, t)
+    log_z = index_to_log_onehot(x, 513)
+    log_pred = dt.predict_start(log_z, cond, t)
+    trunc = m.predict_start_with_truncation(dt.predict_start, "top0.85r")(log_z, cond, t)
+    post = dt.q_posterior(log_x_start=trunc, log_x_t=log_z, t=t)
+    u = synth.synth_uniform((2, 513, 265), key="k512.u")
+    with InjectNoise(lambda shp: u):
+        toks = dt.log_sample_categorical(post).argmax(1)
+    mel = m.decode_to_img(toks.clamp(max=511), (2, 256, 5, 53))
+    s = slice(None, None, POS_STRIDE)
+    save("k512_L2", pos_stride=POS_STRIDE, logits=logits[:, :, s], log_pred=log_pred[:, :, s], trunc=trunc[:, :, s],
+         post=post[:, :, s], tokens=toks, kept=(trunc > -70).sum(1), mel0=mel[0])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--text-only" in sys.argv:
         return text_stage()
+    if "--k512-only" in sys.argv:
+        return codebook512()
     if "--encoder-only" in sys.argv:
         return encoder()
     if "--samplers-only" in sys.argv:
@@ -247,6 +276,7 @@ def main():
     text_stage()
     samplers()
     encoder()
+    codebook512()
     print("done in %.1fs" % (time.time() - t0))
 
 

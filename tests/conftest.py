@@ -26,8 +26,10 @@ def golden(name):
 def key_contract():
     with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
         c = json.load(f)
-    with open(os.path.join(GOLDEN, "state_dict_keys_encoder.json")) as f:   # scope row 8f-2, generated separately
-        c.update(json.load(f))
+    for extra in ("state_dict_keys_encoder.json",      # scope row 8f-2, generated separately
+                  "state_dict_keys_k512.json"):         # the 512-entry codebook build (BASELINE configs[3])
+        with open(os.path.join(GOLDEN, extra)) as f:
+            c.update(json.load(f))
     return c
 
 

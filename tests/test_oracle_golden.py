@@ -151,6 +151,27 @@ def test_vq_encode_and_partial_resample(sd_dalle_l2, sd_encoder):
     assert torch.equal(out, g["partial_tokens"])
 
 
+def test_codebook_512_vs_reference():
+    """BASELINE configs[3]: the 513-class build (caps_512.yaml) -- logits, a teacher-forced step and its decode."""
+    from conftest import synth_sd
+    g = golden("k512_L2")
+    sd = synth_sd("dalle_k512", 2)
+    x = synth.synth_tokens(2, 265, 512, mask_frac=0.4, key="k512.x")
+    cond = synth.synth_cond_emb(2, key="k512.c")
+    t = torch.tensor([61, 12])
+    s = slice(None, None, int(g["pos_stride"]))
+    logits = O.transformer_forward(sd, x, cond, t)
+    assert logits.shape == (2, 512, 265) and (logits[:, :, s] - g["logits"]).abs().max() < 2e-5
+    u = synth.synth_uniform((2, 513, 265), key="k512.u")
+    _, d = O.p_sample_step(sd, O.make_schedule(100, 513), O.log_onehot(x, 513), cond, t, u, trunc_r=0.85, detail=True)
+    assert (d["log_pred"][:, :, s] - g["log_pred"]).abs().max() < 1e-4
+    assert torch.equal((d["trunc"] > -70).sum(1), g["kept"])
+    assert (d["post"][:, :, s] - g["post"]).abs().max() < 1e-4
+    assert torch.equal(d["tokens"], g["tokens"])
+    mel = O.decode_tokens(sd, g["tokens"][:1].clamp(max=511))
+    assert (mel[0] - g["mel0"]).abs().max() < 1e-4
+
+
 def test_decode(sd_dalle_l2):
     tok = synth.synth_tokens(1, mask_frac=0.0, key="dec.tokens")
     mel = O.decode_tokens(sd_dalle_l2, tok)
