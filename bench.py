@@ -109,6 +109,56 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def timed_loop(one_step, warmup, steps, device, world):
+    """W untimed warm-up steps, then EXACTLY K timed steps bracketed by device synchronisation + a barrier on both
+    sides; returns (elapsed seconds = MAX over ranks, last step's output).  Shared by main() and the world-size-2
+    gloo test of the control flow (tests/test_shard_gloo.py)."""
+    import torch.distributed as dist
+
+    def sync_all():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        one_step()
+    sync_all()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = one_step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    return elapsed, out
+
+
+def result_line(args, world, elapsed, n_total):
+    """The driver's one-line JSON contract (whole-job aggregate over all ranks)."""
+    value = n_total * args.steps / elapsed
+    T, B = args.diffusion_steps, args.batch
+    return {
+        "metric": "10s clips/sec whole-node, 100-step Diffsound sample + VQ decode + vocoder",
+        "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": {"fp32": "f32", "bf16x3": "f32 via 3-way bf16 split (6 MFMA passes, fp32 accumulate)",
+                  "f16x2": "f32 via 2-way fp16 split (3 MFMA passes, fp32 accumulate)"}[args.precision],
+        "data": "synthetic caption token ids i64[B,77] + seeded random-init weights of the reference's shapes",
+        "config": {"workload": "BASELINE configs[2]: full pipeline, batch %d per GPU, %d diffusion steps, "
+                               "codebook %d: CLIP text tower -> 19-layer denoiser -> SpecVQGAN decode -> MelGAN "
+                               "22 kHz" % (B, T, args.codes),
+                   "global_batch": n_total, "n_layer": args.n_layer, "parallelism": "caption-sharded x%d" % world,
+                   "denoiser_tflops_effective": round(value * GFLOP_PER_SAMPLE_STEP * T / 1e3, 2)},
+    }
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,24 +212,7 @@ def main():
                 stage[k] += v
         return allw if allw is not None else wave
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        w = one_step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed, w = timed_loop(one_step, args.warmup, args.steps, dev, world)
     assert torch.isfinite(w).all() and w.shape[-1] == 217088
 
     roof = None
@@ -232,27 +265,12 @@ def main():
         if args.precision != "fp32":                   # the exact-fp32 MFMA kernel on the same shapes, for reference
             extra["roofline_fp32_mfma_kernel"] = leg("fp32")
             dt.transformer.precision = args.precision
-    if args.stage_times and rank == 0:
+    if args.stage_times and world == 1:   # (a lone rank calling the collectives of one_step would hang the others)
         one_step(timed_stages=True)
         print("stage seconds (1 step, B=%d): %s" % (B, {k: round(v, 3) for k, v in stage.items()}), file=sys.stderr)
 
     if rank == 0:
-        clips = n_total * args.steps
-        value = clips / elapsed
-        line = {
-            "metric": "10s clips/sec whole-node, 100-step Diffsound sample + VQ decode + vocoder",
-            "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "f32 via 3-way bf16 split (6 MFMA passes, fp32 accumulate)",
-                      "f16x2": "f32 via 2-way fp16 split (3 MFMA passes, fp32 accumulate)"}[args.precision],
-            "data": "synthetic caption token ids i64[B,77] + seeded random-init weights of the reference's shapes",
-            "config": {"workload": "BASELINE configs[2]: full pipeline, batch %d per GPU, %d diffusion steps, "
-                                   "codebook %d: CLIP text tower -> 19-layer denoiser -> SpecVQGAN decode -> MelGAN "
-                                   "22 kHz" % (B, T, args.codes),
-                       "global_batch": n_total, "n_layer": args.n_layer, "parallelism": "caption-sharded x%d" % world,
-                       "denoiser_tflops_effective": round(value * GFLOP_PER_SAMPLE_STEP * T / 1e3, 2)},
-        }
+        line = result_line(args, world, elapsed, n_total)
         if roof is not None:
             line["roofline"] = roof
             line.update(extra)

@@ -68,3 +68,61 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's timed loop and JSON line under a world-size-2 gloo group: caption scatter -> (stand-in) local
+    pipeline whose speed differs per rank -> waveform gather, exactly the control flow main() runs per step."""
+    import importlib.util
+    import time
+    from types import SimpleNamespace
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        dev = torch.device("cpu")
+        B, n_total = 3, 3 * world
+        tok_all = torch.arange(n_total * 77).view(n_total, 77) if rank == 0 else None
+        calls = []
+
+        def one_step():
+            toks = shard.scatter_conditions(tok_all, n_total, (77,), dev, dtype=torch.long)
+            time.sleep(0.05 * (rank + 1))                     # rank 1 is the slow one
+            wave = toks[:, :1].float().expand(-1, 16).contiguous()
+            calls.append(1)
+            return shard.gather_outputs(wave, n_total)
+        elapsed, out = bench.timed_loop(one_step, warmup=1, steps=3, device=dev, world=world)
+        assert len(calls) == 4                                # W + K steps, no more
+        assert elapsed >= 3 * 0.05 * world                    # the MAX over ranks: bounded below by the slowest rank
+        args = SimpleNamespace(steps=3, warmup=1, batch=B, diffusion_steps=100, n_layer=19, codes=256, precision="f16x2")
+        line = bench.result_line(args, world, elapsed, n_total) if rank == 0 else None
+        q.put((rank, elapsed, line, None if out is None else out[:, 0].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_timed_loop_and_json_line_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r[0], r[1:]) for r in (q.get(timeout=180), q.get(timeout=180)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (e0, line, out0), (e1, _, out1) = got[0], got[1]
+    assert e0 == e1                                           # every rank holds the same, all-reduced time
+    assert out1 is None and out0 == [float(i * 77) for i in range(6)]   # gathered in caption order on rank 0
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in line
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert line["config"]["global_batch"] == 6
+    assert abs(line["value"] - 6 * 3 / e0) < 1e-3             # whole-job aggregate: all captions of all ranks / time
+    assert abs(line["ms_per_step"] - e0 / 3 * 1e3) < 1e-2
