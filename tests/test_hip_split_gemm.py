@@ -126,6 +126,29 @@ def test_denoiser_split_steps_and_trajectory_tokens_exact(mode):
     assert (out["content_token"].cpu() != g["tokens"]).sum().item() == 0
 
 
+def test_default_mode_step_is_batch_size_invariant():
+    """Every batch size picks its own GEMM tile configs (64x64 / 128x64 / balanced 128x128 + 64x64 tail, per GEMM
+    shape) and puts the sample boundaries at other places inside the tiles of the attention-ready stores: row 0 of
+    a step over B identical samples must equal the B = 1 step bit for bit, and all rows must agree."""
+    m = build(2, mode="f16x2")
+    dt = m.transformer
+    dt.truncation_r = 0.85
+    x1 = synth.synth_tokens(1, mask_frac=0.5, key="bs.x").cuda()
+    c1 = synth.synth_cond_emb(1, key="bs.c").cuda()
+    u1 = synth.synth_uniform((1, 257, 265), key="bs.u").cuda()
+    ref_tok = ref_logits = None
+    for B in (1, 2, 3, 8, 17, 21, 33, 47, 64):
+        x, c, u = x1.expand(B, -1).contiguous(), c1.expand(B, -1, -1).contiguous(), u1.expand(B, -1, -1).contiguous()
+        t = torch.full((B,), 41, dtype=torch.long, device="cuda")
+        logits = dt.transformer(x, c, t)
+        kv = dt.transformer.condition_kv(c, dt._schedule_table())
+        tok = dt.p_sample_tokens(x, kv, t, u, initial=False)
+        if ref_tok is None:
+            ref_tok, ref_logits = tok.clone(), logits.clone()
+        assert torch.equal(logits, ref_logits.expand(B, -1, -1)), "logits differ at B=%d" % B
+        assert torch.equal(tok, ref_tok.expand(B, -1)), "tokens differ at B=%d" % B
+
+
 @pytest.mark.parametrize("precision", ["f16x2", "fp32"])
 def test_codebook_512_vs_reference(precision):
     """BASELINE configs[3] uses the 512-entry codebook (caps_512.yaml: 513 classes, logits N = 512): logits, one

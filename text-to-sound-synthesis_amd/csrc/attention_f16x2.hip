@@ -129,7 +129,9 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
             }
         }
     }
-    __syncthreads();
+    // (explicit: hipcc does not reliably add the vmcnt(0) an in-flight LDS-DMA needs before a barrier, see gemm_f16x2.hip)
+    if constexpr (READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // K is in LDS
 
     f32x16 s[NKT];
     if (active) {
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
     }
+    if constexpr (READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // V^T is in LDS
 
     f32x16 o0, o1;

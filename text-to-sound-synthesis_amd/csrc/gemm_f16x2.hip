@@ -262,7 +262,12 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
         static_assert(HBK == 32, "two 16-wide k-steps per tile");
         H_DMA(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();   // tile kt has landed (vmcnt(0) precedes the barrier) and stage (kt+1)&1 is free
+            // Tile kt must have landed before anyone crosses the barrier.  The wait is written out: hipcc adds a
+            // vmcnt(0) for an in-flight LDS-DMA on its own in some instantiations of this body but NOT in others
+            // (the 128x128 program inlined into ds_gemm_f16x2_hybrid_kernel got `s_waitcnt lgkmcnt(0)` only -- a
+            // silent race that corrupted large grids; tests/test_hip_split_gemm.py sweeps batch sizes for it).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // ... and stage (kt+1)&1 is free
             if (kt + 1 < nk) H_DMA((kt + 1) & 1, (kt + 1) * 512);
             H_COMPUTE_ALL(kt & 1);
         }
