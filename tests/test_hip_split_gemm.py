@@ -295,6 +295,33 @@ def test_f16x2_balanced_hybrid_launch_bit_identical(M, N, K, slots):
         L.lib().ds_gemm_f16x2_set_balance_slots(512)
 
 
+@pytest.mark.parametrize("M,N,K", [(4240, 4096, 1024), (4240, 2048, 1024), (4240, 1536, 1024)])
+def test_f16x2_large_grids_all_launch_variants(M, N, K):
+    """Grids of several rounds of resident workgroups (where DMA latency exceeds a k-tile's compute): every launch
+    variant of the packed-operand GEMM -- 128x64, 64x64, plain 128x128, balanced hybrid with three balance units --
+    must be bit-identical to the loader-split kernel.  (A dropped s_waitcnt vmcnt(0) made exactly these fail.)"""
+    from text_to_sound_synthesis_amd import _lib as L
+    A, W, b = rnd((M, K), "lg.A", 2.0).cuda(), rnd((N, K), "lg.W", 0.05).cuda(), rnd((N,), "lg.b").cuda()
+    W2, sc = L.split_f16x2(W)
+    W2p, _ = L.split_f16x2(W, packed=True)
+    A2p = L.pack_planes(torch_split(A))
+    M16 = (M + 15) // 16 * 16
+    ref = torch.empty(M, N, device="cuda")
+    L.gemm(A, W2, ref, M, N, K, bias=b, split2=sc)
+    assert relerr(ref.cpu(), (A.double() @ W.double().t() + b.double()).float().cpu()) < 2e-6
+    try:
+        for tile, slots in ((1, 512), (2, 512), (0, 1 << 30), (0, 512), (0, 64), (0, 1)):
+            L.lib().ds_gemm_f16x2_force_tile(tile)
+            L.lib().ds_gemm_f16x2_set_balance_slots(slots)
+            for rep in range(2):
+                out = torch.full((M, N), float("nan"), device="cuda")
+                L.gemm(A2p, W2p, out, M, N, K, bias=b, split2=sc, a_plane=M16 * K)
+                assert torch.equal(out, ref), "tile %d slots %d" % (tile, slots)
+    finally:
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+        L.lib().ds_gemm_f16x2_set_balance_slots(512)
+
+
 def test_split_producers_bit_identical():
     """ds_adaln_split / ds_layernorm_split / ds_attention_f16x2_split == packed split of the fp32-output kernels."""
     from text_to_sound_synthesis_amd import _lib as L

@@ -1,3 +1,6 @@
+"""Correctness sweep of the packed-operand f16x2 GEMM launch variants (plain tiles, balanced hybrid with several
+balance units) against float64 on grids of many rounds -- the configuration in which a missing LDS-DMA wait once
+corrupted results.  python tools/hybrid_check.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
