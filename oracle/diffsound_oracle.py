@@ -301,6 +301,39 @@ def sample_loop_repeat(sd, cond_emb, noise_fn, rate, rng, num_timesteps=100, tru
     return log_z.argmax(1)
 
 
+# --------------------------------------------------------------------------- scope row 8f-3 (oracle only so far)
+def train_loss(sd, x0, cond_emb, t, pt, u, num_timesteps=100, n_head=16, mask_weight=(1.0, 1.0),
+               auxiliary_loss_weight=5.0e-4, adaptive_auxiliary_loss=True):
+    """DiffusionTransformer._train_loss + the normalisation of forward(), diffusion_transformer.py:408-476,571-574:
+    x_t ~ q(x_t | x_0) (uniforms u injected), the network's p(x_0 | x_t), the KL between the true and the modelled
+    posterior (decoder NLL at t = 0), re-weighted by 1/pt, plus the auxiliary KL(x_0 || p(x_0|x_t)) term.
+    x0 i64[B, L] tokens, t i64[B] and pt f32[B] as sample_time() returned them.  No truncation wrapper is installed
+    in training.  Returns (log_model_prob [B, K+1, L], vb_loss [B], loss scalar, Lt2 [B] = kl_loss^2 for Lt_history)."""
+    K = sd["transformer.transformer.to_logits.1.weight"].shape[0]
+    sched = make_schedule(num_timesteps, K + 1)
+    log_x_start = log_onehot(x0, K + 1)
+    log_xt = q_sample(sched, x0, t, u, K + 1)
+    xt = log_xt.argmax(1)
+    log_x0_recon = predict_start(transformer_forward(sd, xt, cond_emb, t, n_head=n_head))
+    log_model_prob = q_posterior(sched, log_x0_recon, log_xt, t)
+    log_true_prob = q_posterior(sched, log_x_start, log_xt, t)
+    kl_of = lambda a, b: (a.exp() * (a - b)).sum(dim=1)                       # multinomial_kl, :237-239
+    mask_region = (xt == K).float()
+    weight = mask_region * mask_weight[0] + (1.0 - mask_region) * mask_weight[1]
+    kl = (kl_of(log_true_prob, log_model_prob) * weight).sum(-1)
+    decoder_nll = -(log_x_start.exp() * log_model_prob).sum(dim=1).sum(-1)    # -log_categorical, :42-43
+    is0 = (t == 0).float()
+    kl_loss = is0 * decoder_nll + (1.0 - is0) * kl
+    vb_loss = kl_loss / pt
+    if auxiliary_loss_weight != 0:
+        kl_aux = (kl_of(log_x_start[:, :-1, :], log_x0_recon[:, :-1, :]) * weight).sum(-1)
+        kl_aux_loss = is0 * decoder_nll + (1.0 - is0) * kl_aux
+        w = t.float() / num_timesteps + 1.0 if adaptive_auxiliary_loss else 1.0
+        vb_loss = vb_loss + w * auxiliary_loss_weight * kl_aux_loss / pt
+    loss = vb_loss.sum() / (x0.shape[0] * x0.shape[1])
+    return log_model_prob, vb_loss, loss, kl_loss.pow(2)
+
+
 # --------------------------------------------------------------------------- A12
 def codebook_gather(sd, tokens, hw=(5, 53), pfx="content_codec."):
     """decode_to_img's first half, dalle_spec.py:80-89: ColumnMajor reverse permutation

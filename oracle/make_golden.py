@@ -186,10 +186,32 @@ def codebook512():
          post=post[:, :, s], tokens=toks, kept=(trunc > -70).sum(1), mel0=mel[0])
 
 
+def train_loss():
+    """SURVEY.md section 8f-3 (oracle groundwork): DiffusionTransformer.forward(return_loss=True) = _train_loss with
+    the sampled timesteps and the q_sample noise injected (2-layer T=100 model, B=3, one sample at t = 0)."""
+    torch.manual_seed(0)
+    m = rh.build_dalle(n_layer=2, diffusion_step=100, n_embed=256)
+    dt = m.transformer
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0")
+    cond = synth.synth_cond_emb(3, key="tl.c")
+    t = torch.tensor([57, 0, 93])
+    pt = torch.ones(3) / 100
+    dt.sample_time = lambda b, device, method="uniform": (t, pt)
+    u = synth.synth_uniform((3, 257, 265), key="tl.u")
+    with torch.enable_grad(), InjectNoise(lambda shp: u):
+        out = dt({"content_token": x0, "condition_embed_token": cond, "condition_token": None}, return_loss=True,
+                 return_logits=True)
+    s = slice(None, None, POS_STRIDE)
+    save("train_loss_L2", pos_stride=POS_STRIDE, loss=out["loss"].detach(), model_prob=out["logits"].detach()[:, :, s],
+         Lt_history=dt.Lt_history.detach(), Lt_count=dt.Lt_count.detach())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--text-only" in sys.argv:
         return text_stage()
+    if "--train-only" in sys.argv:
+        return train_loss()
     if "--k512-only" in sys.argv:
         return codebook512()
     if "--encoder-only" in sys.argv:
@@ -277,6 +299,7 @@ def main():
     samplers()
     encoder()
     codebook512()
+    train_loss()
     print("done in %.1fs" % (time.time() - t0))
 
 

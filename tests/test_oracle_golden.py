@@ -172,6 +172,24 @@ def test_codebook_512_vs_reference():
     assert (mel[0] - g["mel0"]).abs().max() < 1e-4
 
 
+def test_train_loss_vs_reference(sd_dalle_l2):
+    """SURVEY.md 8f-3, oracle groundwork: the variational-bound training loss of DiffusionTransformer.forward
+    (return_loss=True) with the sampled timesteps and the q_sample noise injected -- loss value, the modelled
+    posterior, and the Lt_history update (0.1 * kl_loss^2 into empty slots)."""
+    g = golden("train_loss_L2")
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0")
+    cond = synth.synth_cond_emb(3, key="tl.c")
+    t = torch.tensor([57, 0, 93])
+    u = synth.synth_uniform((3, 257, 265), key="tl.u")
+    log_model_prob, vb, loss, lt2 = O.train_loss(sd_dalle_l2, x0, cond, t, torch.ones(3) / 100, u)
+    assert abs(loss.item() - float(g["loss"])) < 2e-4 * float(g["loss"])
+    s = slice(None, None, int(g["pos_stride"]))
+    assert (log_model_prob.exp()[:, :, s] - g["model_prob"]).abs().max() < 1e-5
+    hist = torch.zeros(100).scatter_(0, t, 0.1 * lt2)             # :455-458 starting from zeros
+    assert torch.allclose(hist, g["Lt_history"], rtol=2e-4, atol=1e-6)
+    assert torch.equal(g["Lt_count"], torch.zeros(100).scatter_add_(0, t, torch.ones(3)))
+
+
 def test_decode(sd_dalle_l2):
     tok = synth.synth_tokens(1, mask_frac=0.0, key="dec.tokens")
     mel = O.decode_tokens(sd_dalle_l2, tok)
