@@ -161,6 +161,14 @@ int ds_sample_tail_ex(const float* logits, const int64_t* xt, const int64_t* t, 
 int ds_q_sample(const int64_t* x0, const int64_t* t, const float* u, const float* sched, int64_t* out_tokens, int B,
                 int L, int K, int T, ds_stream_t stream);
 
+/* forward terms of the training loss (DiffusionTransformer._train_loss, diffusion_transformer.py:408-476), one value
+ * per grid position [B][L]: kl = KL(true posterior || model posterior) (:439-440), nll = the t == 0 decoder term
+ * (:446), kl_aux = KL(x_0 || p(x_0|x_t)) over the K classes (:462); logits [B*L][K] of the network at (x_t, t),
+ * dbg_model_log_prob optional [B][K+1][L].  Forward only: no gradients are produced anywhere in this library. */
+int ds_loss_tail(const float* logits, const int64_t* x0, const int64_t* xt, const int64_t* t, const float* sched,
+                 float* kl, float* nll, float* kl_aux, float* dbg_model_log_prob, int B, int L, int K, int T,
+                 ds_stream_t stream);
+
 /* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
 enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */
     DS_LP_ADALN1 = 0,  /* [T][2D]  ln1 table   */

@@ -189,6 +189,33 @@ def test_vq_encode_get_tokens_and_partial_resample_vs_reference():
     assert (out["content_token"].cpu() != g["partial_tokens"]).sum().item() == 0
 
 
+def test_training_loss_forward_vs_reference():
+    """SURVEY.md 8f-3, forward value only: DiffusionTransformer.forward(return_loss=True) with the reference's
+    timesteps and q_sample noise injected reproduces its loss, modelled posterior and Lt_history update; through
+    DALLE.forward the content comes from the VQ encoder (prepare_input)."""
+    g = golden("train_loss_L2")
+    m = build(2, T=100)
+    dt = m.transformer
+    dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]   # caps_text.yaml
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0").cuda()
+    cond = synth.synth_cond_emb(3, key="tl.c").cuda()
+    t = torch.tensor([57, 0, 93]).cuda()
+    dt.sample_time = lambda b, device, method="uniform": (t, torch.ones(3, device="cuda") / 100)
+    u = synth.synth_uniform((3, 257, 265), key="tl.u")
+    out = dt({"content_token": x0, "condition_embed_token": cond}, return_loss=True, noise=u)
+    print("train loss %.6f vs reference %.6f" % (out["loss"].item(), float(g["loss"])))
+    assert abs(out["loss"].item() - float(g["loss"])) < 2e-4 * float(g["loss"])
+    s = slice(None, None, int(g["pos_stride"]))
+    assert (out["logits"].cpu()[:, :, s] - g["model_prob"]).abs().max() < 2e-5
+    assert torch.allclose(dt.Lt_history.cpu(), g["Lt_history"], rtol=5e-4, atol=1e-6)
+    assert torch.equal(dt.Lt_count.cpu(), g["Lt_count"])
+    # the batch-level entry: mel -> VQ tokens -> loss (finite, right shapes)
+    del dt.sample_time
+    mel = (synth.synth_uniform((2, 1, 80, 848), key="enc.mel") * 2 - 1).cuda()
+    out = m({"image": mel, "condition_embed_token": synth.synth_cond_emb(2, key="tl.c2").cuda()}, return_loss=True)
+    assert out["logits"].shape == (2, 257, 265) and torch.isfinite(out["loss"]) and out["loss"].item() > 0
+
+
 def test_q_sample_matches_oracle():
     import diffsound_oracle as O
     m = build(2, T=100)

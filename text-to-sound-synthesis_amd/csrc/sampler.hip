@@ -227,6 +227,124 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
     if (lane == 0 && live) p.out_tokens[col] = bidx;
 }
 
+// ---- training-loss terms (DiffusionTransformer._train_loss, diffusion_transformer.py:408-476), forward only ----
+// q_posterior (:293-339) of a per-column distribution lx0[] over the K classes (+ its [MASK] row lx0_m) given
+// x_t and t: the same arithmetic as the sampling tail above, factored out for the two posteriors of the loss.
+template <int NPL>
+__device__ __forceinline__ void ds_posterior(const float (&lx0)[NPL], float lx0_m, int xt, int K, int lane,
+                                             const float* __restrict__ S, int T1, int t, float (&post)[NPL],
+                                             float& post_m) {
+    const int tm1 = (t - 1 + T1) % T1;
+    const float lat = S[0 * T1 + t], lbt = S[1 * T1 + t], lct = S[2 * T1 + t];
+    const float lcat = S[4 * T1 + t], lcbt = S[5 * T1 + t], lcct = S[6 * T1 + t];
+    const float lcat1 = S[4 * T1 + tm1], lcbt1 = S[5 * T1 + tm1], lcct1 = S[6 * T1 + tm1], l1mcct1 = S[7 * T1 + tm1];
+    const bool is_mask = xt == K;
+    const float qt_hit = is_mask ? lcct : lae(0.f + lcat, lcbt), qt_off = is_mask ? lcct : lae(LOG_ZERO_F + lcat, lcbt);
+    const float q1_hit = is_mask ? lct : lae(0.f + lat, lbt), q1_off = is_mask ? lct : lae(LOG_ZERO_F + lat, lbt);
+    const float qt_m = is_mask ? 0.f : LOG_ZERO_F, q1_m = qt_m;
+    float q[NPL];
+    float qmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int c = j * 64 + lane;
+        q[j] = lx0[j] - (c == xt ? qt_hit : qt_off);
+        qmax = fmaxf(qmax, q[j]);
+    }
+    const float q_m = lx0_m - qt_m;
+    qmax = fmaxf(wmaxf(qmax), q_m);
+    float es = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) es += expf(q[j] - qmax);
+    es = wsumf(es) + expf(q_m - qmax);
+    const float lse = logf(es) + qmax;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int c = j * 64 + lane;
+        const float ev = lae((q[j] - lse) + lcat1, lcbt1);
+        post[j] = fminf(fmaxf(ev + (c == xt ? q1_hit : q1_off) + lse, -70.f), 0.f);
+    }
+    const float evm = lae((q_m - lse) + l1mcct1, lcct1);
+    post_m = fminf(fmaxf(evm + q1_m + lse, -70.f), 0.f);
+}
+
+// Per grid position: kl = KL(q(x_{t-1}|x_t,x_0) || p_theta(x_{t-1}|x_t)) (:439-440), decoder_nll =
+// -log p_theta(x_0|...) (:446), kl_aux = KL(x_0 || p_theta(x_0|x_t)) over the K real classes (:462).  The mask
+// weights, the t == 0 switch, 1/pt and the sums over positions are a few tiny torch ops on the [B][L] outputs.
+template <int NPL>
+__global__ __launch_bounds__(256) void ds_loss_tail_kernel(const float* __restrict__ logits,
+                                                           const int64_t* __restrict__ x0, const int64_t* __restrict__ xt,
+                                                           const int64_t* __restrict__ t, const float* __restrict__ sched,
+                                                           float* __restrict__ kl, float* __restrict__ nll,
+                                                           float* __restrict__ kl_aux, float* __restrict__ dbg_model,
+                                                           int B, int L, int T) {
+    constexpr int K = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= B * L) return;
+    const int b = col / L, pos = col - b * L;
+    float v[NPL];
+    const float* lg = logits + (size_t)col * K;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) v[j] = lg[j * 64 + lane];
+    float mx = v[0];
+#pragma unroll
+    for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, v[j]);
+    mx = wmaxf(mx);
+    double se = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) se += exp((double)v[j] - (double)mx);
+    const double lse64 = log(wsumd(se));
+    float lp[NPL], ls[NPL];
+    const int x0c = (int)x0[col], xtc = (int)xt[col], tt = (int)t[b];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        lp[j] = fminf(fmaxf((float)(((double)v[j] - (double)mx) - lse64), -70.f), 0.f);   // log p_theta(x_0 | x_t)
+        ls[j] = (j * 64 + lane) == x0c ? 0.f : LOG_ZERO_F;                                 // log one-hot of x_0
+    }
+    const float ls_m = x0c == K ? 0.f : LOG_ZERO_F;
+    float pm[NPL], pr[NPL], pm_m, pr_m;
+    ds_posterior<NPL>(lp, -70.f, xtc, K, lane, sched, T + 1, tt, pm, pm_m);    // model posterior
+    ds_posterior<NPL>(ls, ls_m, xtc, K, lane, sched, T + 1, tt, pr, pr_m);     // true posterior
+    float a = 0.f, n = 0.f, x = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        a += expf(pr[j]) * (pr[j] - pm[j]);
+        n += expf(ls[j]) * pm[j];
+        x += expf(ls[j]) * (ls[j] - lp[j]);
+    }
+    a = wsumf(a) + expf(pr_m) * (pr_m - pm_m);
+    n = wsumf(n) + expf(ls_m) * pm_m;
+    x = wsumf(x);
+    if (lane == 0) {
+        kl[col] = a;
+        nll[col] = -n;
+        kl_aux[col] = x;
+    }
+    if (dbg_model) {
+        const size_t base = (size_t)b * (K + 1) * L + pos;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) dbg_model[base + (size_t)(j * 64 + lane) * L] = pm[j];
+        if (lane == 0) dbg_model[base + (size_t)K * L] = pm_m;
+    }
+}
+
+extern "C" int ds_loss_tail(const float* logits, const int64_t* x0, const int64_t* xt, const int64_t* t,
+                            const float* sched, float* kl, float* nll, float* kl_aux, float* dbg_model_log_prob, int B,
+                            int L, int K, int T, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(logits && x0 && xt && t && sched && kl && nll && kl_aux && B > 0 && L > 0 && T > 0, "bad arguments");
+    DS_CHECK_ARG(K == 256 || K == 512, "codebook size must be 256 or 512");
+    const int cols = B * L;
+    if (K == 256)
+        hipLaunchKernelGGL((ds_loss_tail_kernel<4>), dim3((cols + 3) / 4), dim3(256), 0, stream, logits, x0, xt, t, sched,
+                           kl, nll, kl_aux, dbg_model_log_prob, B, L, T);
+    else
+        hipLaunchKernelGGL((ds_loss_tail_kernel<8>), dim3((cols + 3) / 4), dim3(256), 0, stream, logits, x0, xt, t, sched,
+                           kl, nll, kl_aux, dbg_model_log_prob, B, L, T);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- q_sample (diffusion_transformer.py:370-377): x_t ~ q(x_t | x_0) for token ids, Gumbel-argmax ----------
 // log q(x_t = c | x_0) = log_add_exp(log_onehot(x_0)[c] + log_cumprod_at[t], log_cumprod_bt[t]) for the K classes,
 // log_add_exp(log_onehot(x_0)[K] + log_1_min_cumprod_ct[t], log_cumprod_ct[t]) for [MASK]  (q_pred, :253-267)

@@ -52,6 +52,19 @@ class DALLE(nn.Module):
         quant_z, indices = self.get_tokens(cont)
         return {"content_token": indices, "content_quant": quant_z}
 
+    @torch.no_grad()
+    def prepare_input(self, batch):
+        """condition + content of a training batch (dalle_spec.py:128-133)"""
+        inp = self.prepare_condition(batch)
+        inp.update(self.prepare_content(batch))
+        return inp
+
+    @torch.no_grad()
+    def forward(self, batch, name="none", **kwargs):
+        """batch {'image': mel f32[B,1,80,848], 'text' | 'condition_embed_token': ...} -> the transformer's
+        {'logits', 'loss'} (dalle_spec.py:389-400).  Forward value only (no autograd through the HIP path)."""
+        return self.transformer(self.prepare_input(batch), **kwargs)
+
     def decode_to_img(self, index, zshape, stage="first"):
         """tokens (sequence order) -> mel image [B, 1, 80, 848] (:80-91)."""
         assert stage == "first"

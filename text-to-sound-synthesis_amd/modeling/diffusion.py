@@ -169,6 +169,78 @@ class DiffusionTransformer(nn.Module):
             raise ValueError("pass condition_token (with a condition_emb module) or condition_embed [B,77,512]")
         return condition_embed.float()
 
+    # ---- training loss, FORWARD VALUE only (no backward kernels exist yet) ----------------
+    def sample_time(self, b, device, method="uniform"):
+        """Timesteps for a batch and their sampling probabilities (:379-406): importance sampling by sqrt(Lt_history)
+        once every timestep has been seen more than 10 times, uniform before."""
+        if method == "importance":
+            if not (self.Lt_count > 10).all():
+                return self.sample_time(b, device, method="uniform")
+            lt_sqrt = torch.sqrt(self.Lt_history + 1e-10) + 0.0001
+            lt_sqrt[0] = lt_sqrt[1]
+            pt_all = lt_sqrt / lt_sqrt.sum()
+            t = torch.multinomial(pt_all, num_samples=b, replacement=True)
+            return t, pt_all.gather(dim=0, index=t)
+        if method == "uniform":
+            t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+            return t, torch.ones_like(t).float() / self.num_timesteps
+        raise ValueError(method)
+
+    @torch.no_grad()
+    def _train_loss(self, x, cond_emb, is_train=True, noise=None):
+        """(log_model_prob [B, K+1, L], vb_loss [B]) of :408-476, computed forward-only on the HIP path: ds_q_sample,
+        the denoiser, and ds_loss_tail for the per-position KL / NLL / auxiliary-KL terms.  Updates Lt_history /
+        Lt_count like the reference (the accuracy bookkeeping lists :425-436 are logging only and not kept).
+        noise: optional f32[B, K+1, L] uniforms for q_sample (tests)."""
+        B, L, K1, T = x.shape[0], self.content_seq_len, self.num_classes, self.num_timesteps
+        dev = x.device
+        t, pt = self.sample_time(B, dev, "importance")
+        t, pt = t.to(dev), pt.to(dev)
+        u = torch.rand((B, K1, L), device=dev) if noise is None else noise.to(dev)
+        xt = self.q_sample_tokens(x.contiguous(), t, u)
+        tr = self.transformer
+        sched = self._schedule_table()
+        p = tr.packed(sched)
+        kv = tr.condition_kv(cond_emb, sched)
+        logits = torch.empty(B * L, K1 - 1, device=dev)
+        _lib.check(_lib.lib().ds_denoiser_forward(p["handle"], _lib.ptr(xt), _lib.ptr(t), _lib.ptr(kv), B,
+                                                  _lib.ptr(tr.workspace(B, sched)), _lib.ptr(logits), 0, _lib.stream()))
+        kl, nll, kl_aux = (torch.empty(B, L, device=dev) for _ in range(3))
+        log_model_prob = torch.empty(B, K1, L, device=dev)
+        _lib.check(_lib.lib().ds_loss_tail(_lib.ptr(logits), _lib.ptr(x.contiguous()), _lib.ptr(xt), _lib.ptr(t),
+                                           _lib.ptr(sched), _lib.ptr(kl), _lib.ptr(nll), _lib.ptr(kl_aux),
+                                           _lib.ptr(log_model_prob), B, L, K1 - 1, T, _lib.stream()))
+        mask_region = (xt == K1 - 1).float()
+        weight = mask_region * self.mask_weight[0] + (1.0 - mask_region) * self.mask_weight[1]
+        is0 = (t == 0).float()
+        decoder_nll = nll.sum(-1)
+        kl_loss = is0 * decoder_nll + (1.0 - is0) * (kl * weight).sum(-1)
+        lt2 = kl_loss.pow(2)
+        self.Lt_history.scatter_(dim=0, index=t, src=(0.1 * lt2 + 0.9 * self.Lt_history.gather(dim=0, index=t)))
+        self.Lt_count.scatter_add_(dim=0, index=t, src=torch.ones_like(lt2))
+        vb_loss = kl_loss / pt
+        if self.auxiliary_loss_weight != 0 and is_train:
+            kl_aux_loss = is0 * decoder_nll + (1.0 - is0) * (kl_aux * weight).sum(-1)
+            w = t.float() / T + 1.0 if self.adaptive_auxiliary_loss else 1.0
+            vb_loss = vb_loss + w * self.auxiliary_loss_weight * kl_aux_loss / pt
+        return log_model_prob, vb_loss
+
+    @torch.no_grad()
+    def forward(self, input, return_loss=False, return_logits=True, return_att_weight=False, is_train=True, **kwargs):
+        """{'logits': exp(log_model_prob), 'loss': scalar} as :539-577.  The loss is a forward value: this package
+        has no backward pass, so it serves evaluation / loss parity, not optimisation."""
+        x = input["content_token"]
+        cond_emb = self._cond(input.get("condition_token"), input.get("condition_embed_token")).to(x.device)
+        out = {}
+        if is_train:
+            log_model_prob, loss = self._train_loss(x, cond_emb, noise=kwargs.get("noise"))
+            loss = loss.sum() / (x.shape[0] * x.shape[1])
+            if return_logits:
+                out["logits"] = torch.exp(log_model_prob)
+            if return_loss:
+                out["loss"] = loss
+        return out
+
     @torch.no_grad()
     def q_sample_tokens(self, x0, t, u):
         """x_t ~ q(x_t | x_0) on token ids (q_sample, :370-377); u f32[B, K+1, L] uniforms."""
