@@ -186,6 +186,13 @@ def codebook512():
          post=post[:, :, s], tokens=toks, kept=(trunc > -70).sum(1), mel0=mel[0])
 
 
+GRAD_PROBES = ("transformer.to_logits.1.weight", "transformer.to_logits.0.weight", "transformer.blocks.1.mlp.2.weight",
+               "transformer.blocks.1.mlp.0.bias", "transformer.blocks.0.attn1.query.weight",
+               "transformer.blocks.0.attn2.key.weight", "transformer.blocks.0.ln1.linear.weight",
+               "transformer.blocks.0.ln1.emb.weight", "transformer.blocks.1.ln2.weight",
+               "transformer.content_emb.emb.weight", "transformer.content_emb.width_emb.weight")
+
+
 def train_loss():
     """SURVEY.md section 8f-3 (oracle groundwork): DiffusionTransformer.forward(return_loss=True) = _train_loss with
     the sampled timesteps and the q_sample noise injected (2-layer T=100 model, B=3, one sample at t = 0)."""
@@ -201,9 +208,25 @@ def train_loss():
     with torch.enable_grad(), InjectNoise(lambda shp: u):
         out = dt({"content_token": x0, "condition_embed_token": cond, "condition_token": None}, return_loss=True,
                  return_logits=True)
+    # gradients of that loss (what Solver.step back-propagates, engine/solver_spec.py): norms of a few parameters
+    # spread over the network + the global norm
+    params = dict(dt.named_parameters())
+    for p_ in params.values():
+        p_.requires_grad_(True)
+        p_.grad = None
+    Lt_h, Lt_c = dt.Lt_history.clone(), dt.Lt_count.clone()
+    dt.Lt_history.zero_(); dt.Lt_count.zero_()
+    with torch.enable_grad(), InjectNoise(lambda shp: u):
+        out2 = dt({"content_token": x0, "condition_embed_token": cond, "condition_token": None}, return_loss=True)
+        out2["loss"].backward()
+    names = GRAD_PROBES
+    gn = {n: params[n].grad.norm() for n in names}
+    total = torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in params.values() if p_.grad is not None)).float()
     s = slice(None, None, POS_STRIDE)
     save("train_loss_L2", pos_stride=POS_STRIDE, loss=out["loss"].detach(), model_prob=out["logits"].detach()[:, :, s],
-         Lt_history=dt.Lt_history.detach(), Lt_count=dt.Lt_count.detach())
+         Lt_history=Lt_h.detach(), Lt_count=Lt_c.detach(), grad_total=total,
+         grad_logits_w_sample=params["transformer.to_logits.1.weight"].grad[::37, ::53].clone(),
+         **{"gradnorm_" + n.replace(".", "_"): v for n, v in gn.items()})
 
 
 def main():

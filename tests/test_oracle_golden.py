@@ -190,6 +190,32 @@ def test_train_loss_vs_reference(sd_dalle_l2):
     assert torch.equal(g["Lt_count"], torch.zeros(100).scatter_add_(0, t, torch.ones(3)))
 
 
+def test_train_loss_gradients_vs_reference(sd_dalle_l2):
+    """The oracle's loss is differentiable torch code: its autograd gradients must match what the reference
+    back-propagates (parameter-gradient norms spread over the network, a strided sample of d loss / d to_logits
+    weight, the global norm) -- the yardstick for the backward kernels of scope row 8f-3."""
+    g = golden("train_loss_L2")
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd_dalle_l2.items()}
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0")
+    cond = synth.synth_cond_emb(3, key="tl.c")
+    t = torch.tensor([57, 0, 93])
+    u = synth.synth_uniform((3, 257, 265), key="tl.u")
+    with torch.enable_grad():
+        _, _, loss, _ = O.train_loss(sd, x0, cond, t, torch.ones(3) / 100, u)
+        loss.backward()
+    probes = [k[len("gradnorm_"):] for k in g if k.startswith("gradnorm_")]
+    assert len(probes) >= 10
+    by_flat = {k[len("transformer."):].replace(".", "_"): k for k in sd if k.startswith("transformer.")}
+    for pr in probes:
+        got, want = sd[by_flat[pr]].grad.norm().item(), float(g["gradnorm_" + pr])
+        assert abs(got - want) < 2e-3 * want + 1e-7, (pr, got, want)
+    gw = sd["transformer.transformer.to_logits.1.weight"].grad[::37, ::53]
+    assert (gw - g["grad_logits_w_sample"]).abs().max() < 2e-3 * g["grad_logits_w_sample"].abs().max()
+    total = torch.sqrt(sum((v.grad.double() ** 2).sum() for k, v in sd.items()
+                           if v.is_floating_point() and v.grad is not None and k.startswith("transformer.")))
+    assert abs(total.item() - float(g["grad_total"])) < 2e-3 * float(g["grad_total"])
+
+
 def test_decode(sd_dalle_l2):
     tok = synth.synth_tokens(1, mask_frac=0.0, key="dec.tokens")
     mel = O.decode_tokens(sd_dalle_l2, tok)
