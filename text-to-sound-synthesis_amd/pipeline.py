@@ -41,10 +41,11 @@ class Diffsound:
             p.requires_grad = False
 
     @torch.no_grad()
-    def generate_sample_with_condition(self, cond, truncation_rate=0.85, replicate=1):
+    def generate_sample_with_condition(self, cond, truncation_rate=0.85, replicate=1, fast=False):
         """Captions -> (mel01 f32[B,80,848], wave f32[B,1,217088], tokens), everything left on the GPU.
         `cond` is a list of caption strings (needs the text stage: tokenizer + CLIP in the config),
-        token ids i64[B,77], or caption embeddings f32[B,77,512]."""
+        token ids i64[B,77], or caption embeddings f32[B,77,512].  fast=n selects the skip-step sampler with
+        skip_step n-1, spelled like the reference's drivers (generate_samples_batch.py:100-103,148-151)."""
         if isinstance(cond, (list, tuple, str)):
             batch = {"text": [cond] if isinstance(cond, str) else list(cond)}
         elif cond.dtype == torch.long:
@@ -52,7 +53,8 @@ class Diffsound:
         else:
             batch = {"condition_embed_token": cond}
         out = self.model.generate_content(batch=batch, filter_ratio=0, replicate=replicate, content_ratio=1,
-                                          return_att_weight=False, sample_type="top" + str(truncation_rate) + "r")
+                                          return_att_weight=False,
+                                          sample_type="top" + str(truncation_rate) + ("r,fast" + str(fast - 1) if fast else "r"))
         mel = out["content"]                                   # [B,1,80,848] in ~[-1,1]
         wave = self.vocoder(mel[:, 0], scale=0.5, shift=0.5)   # spec = (x+1)/2, :182
         return (mel[:, 0] + 1) / 2, wave, out["content_token"]
@@ -75,14 +77,12 @@ class Diffsound:
         its captions x `replicate` are sampled in one batch; every sample is written as
         `{base}_mel_sample_{i}.npy` (mel in [0,1], f32[80,848]) and `{base}_mel_sample_{i}.wav`
         (22 050 Hz, PCM_24).  Unlike the reference the vocoder runs on the whole batch at once."""
-        if fast:
-            raise NotImplementedError("'fast' skip-step sampling: SURVEY.md section 8f-4")
         import numpy as np
         os.makedirs(save_root, exist_ok=True)
         written = []
         for key, captions in self.read_tsv(val_path).items():
             base = key.split(".")[0] + "_mel_sample_"
-            mel01, wave, _ = self.generate_sample_with_condition(list(captions), truncation_rate, replicate)
+            mel01, wave, _ = self.generate_sample_with_condition(list(captions), truncation_rate, replicate, fast=fast)
             mel01, wave = mel01.cpu().numpy(), wave[:, 0].cpu().numpy()
             for i in range(mel01.shape[0]):
                 path = os.path.join(save_root, base + str(i))
