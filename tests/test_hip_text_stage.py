@@ -103,3 +103,35 @@ def test_generate_content_from_tokens_end_to_end(model):
                                  content_ratio=1, sample_type="top0.85r")
     assert out["content"].shape == (4, 1, 80, 848) and torch.isfinite(out["content"]).all()
     assert int(out["content_token"].max()) <= 255
+
+
+def test_file_writing_driver_end_to_end(tmp_path, monkeypatch):
+    """Diffsound.generate_sample (generate_samples_batch.py:143-187): captions file -> tokenizer -> CLIP -> sampling
+    -> decode -> batched vocoder -> `{base}_mel_sample_{i}.npy` / `.wav` (22 050 Hz PCM_24), also with the drivers'
+    fast=n flag.  A toy merge table stands in for the reference's BPE vocabulary (not shipped to the GPU box)."""
+    import gzip
+
+    import numpy as np
+    vocab = tmp_path / "toy_bpe.txt.gz"
+    merges = ["d o", "do g</w>", "b a", "ba r", "bar k", "bark s</w>", "r a", "ra i", "rai n</w>"]
+    with gzip.open(vocab, "wb") as f:
+        f.write(("#version: toy\n" + "\n".join(merges) + "\n").encode())
+    monkeypatch.setenv("DIFFSOUND_BPE_PATH", str(vocab))
+    from text_to_sound_synthesis_amd.config import default_config
+    from text_to_sound_synthesis_amd.pipeline import Diffsound
+    torch.manual_seed(0)
+    d = Diffsound(config=default_config(n_layer=1, diffusion_step=4, with_clip=True))
+    tsv = tmp_path / "val.csv"
+    tsv.write_text("file_name,caption\nabc.wav,a dog barks\nabc.wav,rain falls\nxyz.wav,a dog barks in the rain\n")
+    for fast, sub in ((False, "plain"), (2, "fast")):
+        root = tmp_path / sub
+        written = d.generate_sample(str(tsv), 0.85, str(root), fast=fast)
+        assert [os.path.basename(w) for w in written] == ["abc_mel_sample_%d" % i for i in range(4)] + \
+            ["xyz_mel_sample_%d" % i for i in range(2)]
+        for w in written:
+            mel = np.load(w + ".npy")
+            assert mel.shape == (80, 848) and mel.dtype == np.float32 and np.isfinite(mel).all()
+            assert os.path.getsize(w + ".wav") == 44 + 217088 * 3
+            with open(w + ".wav", "rb") as f:
+                head = f.read(44)
+            assert head[:4] == b"RIFF" and head[8:12] == b"WAVE" and int.from_bytes(head[24:28], "little") == 22050
