@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--codes", type=int, default=256)
     ap.add_argument("--precision", default=os.environ.get("DIFFSOUND_GEMM", "f16x2"), choices=("fp32", "bf16x3", "f16x2"),
                     help="denoiser GEMM arithmetic: fp32 MFMA, or the fp32-accurate 3-way bf16 split")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFSOUND_STREAMS", "1")), choices=(1, 2),
+                    help="2: the sampling loop runs the batch as two half-batches on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
@@ -184,6 +186,7 @@ def main():
     dt = model.transformer
     dt.truncation_r = 0.85
     dt.transformer.precision = args.precision
+    dt.sample_streams = args.streams
     n_total = B * world
     # rank 0 owns the captions (token ids i64[n,77]: <SOT> word pieces <EOT>, as clip.tokenize emits); every
     # rank gets a slice and runs the CLIP text tower on it

@@ -149,6 +149,24 @@ def test_default_mode_step_is_batch_size_invariant():
         assert torch.equal(tok, ref_tok.expand(B, -1)), "tokens differ at B=%d" % B
 
 
+def test_two_stream_sampling_gives_the_same_tokens():
+    """sample_streams = 2 (two half-batches on two HIP streams, separate workspaces) vs the single-stream loop:
+    identical tokens for the same noise, odd and even batch sizes."""
+    m = build(2, T=10, mode="f16x2")
+    dt = m.transformer
+    dt.truncation_r = 0.85
+    for B in (2, 5):
+        cond = synth.synth_cond_emb(B, key="ts.c%d" % B).cuda()
+        nf = lambda t, shp: synth.synth_uniform(shp, key="ts.u%d" % t)
+        dt.sample_streams = 1
+        one = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, noise_fn=nf)
+        dt.sample_streams = 2
+        two = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, noise_fn=nf)
+        torch.cuda.synchronize()
+        assert torch.equal(one["content_token"], two["content_token"])
+    dt.sample_streams = 1
+
+
 @pytest.mark.parametrize("precision", ["f16x2", "fp32"])
 def test_codebook_512_vs_reference(precision):
     """BASELINE configs[3] uses the 512-entry codebook (caps_512.yaml: 513 classes, logits N = 512): logits, one

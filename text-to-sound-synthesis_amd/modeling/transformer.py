@@ -244,12 +244,13 @@ class Text2ImageTransformer(nn.Module):
                         "precision": self.precision}
         return self._packed
 
-    def workspace(self, B, sched=None):
+    def workspace(self, B, sched=None, slot=0):
+        """One workspace per (batch size, slot); concurrent sub-batches on different streams take different slots."""
         p = self.packed(sched)
-        if B not in p["ws"]:
+        if (B, slot) not in p["ws"]:
             n = _lib.lib().ds_denoiser_workspace_bytes(p["handle"], B)
-            p["ws"][B] = torch.empty(n // 4, device=p["device"], dtype=torch.float32)
-        return p["ws"][B]
+            p["ws"][(B, slot)] = torch.empty(n // 4, device=p["device"], dtype=torch.float32)
+        return p["ws"][(B, slot)]
 
     @torch.no_grad()
     def condition_kv(self, cond_emb, sched=None):
