@@ -334,6 +334,59 @@ def train_loss(sd, x0, cond_emb, t, pt, u, num_timesteps=100, n_head=16, mask_we
     return log_model_prob, vb_loss, loss, kl_loss.pow(2)
 
 
+def loss_tail_backward(sched, logits, x0, xt, t, pt, num_timesteps=100, mask_weight=(1.0, 1.0),
+                       auxiliary_loss_weight=5.0e-4, adaptive_auxiliary_loss=True):
+    """Closed-form d(sum_b vb_loss_b) / d logits of train_loss() -- the formula a HIP loss-tail backward kernel will
+    implement (plan for row 8f-3); tests compare it with autograd through the forward restatement.
+    logits f32[B, K, L] (the network output at (x_t, t)); returns the gradient, same shape."""
+    B, K, L = logits.shape
+    T = num_timesteps
+    tt = (t + (T + 1)) % (T + 1)
+    tm1 = (t - 1 + (T + 1)) % (T + 1)
+    g = lambda n, idx: sched[n][idx].view(-1, 1, 1)
+    lsm = torch.log_softmax(logits.double(), dim=1).float()
+    lp = lsm.clamp(-70.0, 0.0)
+    lp_live = (lsm > -70.0) & (lsm < 0.0)                                    # where the clamp passes gradient
+    log_xt, log_x0 = log_onehot(xt, K + 1), log_onehot(x0, K + 1)
+    is_mask = (xt == K).unsqueeze(1)
+    # log q(x_t | x_0 = c) per row c (the `fix`ed q_pred of q_posterior) and the one-step version
+    qt_cls = torch.where(is_mask, g("log_cumprod_ct", tt).expand(B, K, L),
+                         _lae(log_xt[:, :-1] + g("log_cumprod_at", tt), g("log_cumprod_bt", tt)))
+    qt_m = torch.where(is_mask, torch.zeros(B, 1, L), torch.full((B, 1, L), LOG_ZERO))
+    q1_cls = torch.where(is_mask, g("log_ct", t).expand(B, K, L), _lae(log_xt[:, :-1] + g("log_at", t), g("log_bt", t)))
+    q1_m = qt_m
+
+    def posterior(lx0_cls, lx0_m):
+        q = torch.cat((lx0_cls - qt_cls, lx0_m - qt_m), dim=1)
+        lse = torch.logsumexp(q, dim=1, keepdim=True)
+        a = torch.cat((g("log_cumprod_at", tm1).expand(B, K, 1), g("log_1_min_cumprod_ct", tm1)), dim=1)
+        b = torch.cat((g("log_cumprod_bt", tm1).expand(B, K, 1), g("log_cumprod_ct", tm1)), dim=1)
+        A = _lae(q - lse + a, b)
+        raw = A + torch.cat((q1_cls, q1_m), dim=1) + lse
+        sigma = torch.exp(q - lse + a - A)
+        return raw.clamp(-70.0, 0.0), (raw > -70.0) & (raw < 0.0), sigma, torch.exp(q - lse)
+
+    pm, pm_live, sigma, p = posterior(lp, torch.full((B, 1, L), -70.0))
+    pr, _, _, _ = posterior(log_x0[:, :-1], log_x0[:, -1:])
+    mask_region = (xt == K).float().unsqueeze(1)
+    weight = mask_region * mask_weight[0] + (1.0 - mask_region) * mask_weight[1]         # [B,1,L]
+    is0 = (t == 0).float().view(-1, 1, 1)
+    ipt = (1.0 / pt).view(-1, 1, 1)
+    # upstream weights on the model posterior rows: KL term (t > 0) and decoder NLL (t == 0, in both loss terms)
+    nll_scale = ipt
+    if auxiliary_loss_weight != 0:
+        wa = (t.float() / T + 1.0 if adaptive_auxiliary_loss else torch.ones_like(t, dtype=torch.float32)).view(-1, 1, 1)
+        nll_scale = ipt + wa * auxiliary_loss_weight * ipt
+    w = (-(1.0 - is0) * torch.exp(pr) * weight * ipt - is0 * torch.exp(log_x0) * nll_scale) * pm_live
+    s = (w * (1.0 - sigma)).sum(dim=1, keepdim=True)
+    g_q = w * sigma + p * s                                                   # over the K+1 rows
+    g_lp = g_q[:, :-1]                                                        # the [MASK] row of lp is a constant
+    if auxiliary_loss_weight != 0:
+        g_lp = g_lp - (1.0 - is0) * wa * auxiliary_loss_weight * ipt * weight * torch.exp(log_x0[:, :-1])
+    g_lp = g_lp * lp_live
+    return g_lp - torch.softmax(logits.double(), dim=1).float() * g_lp.sum(dim=1, keepdim=True)
+
+
 # --------------------------------------------------------------------------- A12
 def codebook_gather(sd, tokens, hw=(5, 53), pfx="content_codec."):
     """decode_to_img's first half, dalle_spec.py:80-89: ColumnMajor reverse permutation

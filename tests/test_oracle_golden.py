@@ -216,6 +216,35 @@ def test_train_loss_gradients_vs_reference(sd_dalle_l2):
     assert abs(total.item() - float(g["grad_total"])) < 2e-3 * float(g["grad_total"])
 
 
+def test_loss_tail_backward_formula_vs_autograd(sd_dalle_l2):
+    """The closed-form d loss / d logits (oracle.loss_tail_backward, the spec of the future HIP backward tail) equals
+    autograd through the forward restatement, for masked and unmasked x_t, t = 0 and t > 0, with the aux term."""
+    T, K = 100, 256
+    sched = O.make_schedule(T, K + 1)
+    x0 = synth.synth_tokens(4, mask_frac=0.0, key="ltb.x0")
+    t = torch.tensor([57, 0, 93, 1])
+    pt = torch.tensor([0.01, 0.02, 0.005, 0.01])
+    u = synth.synth_uniform((4, K + 1, 265), key="ltb.u")
+    xt = O.q_sample(sched, x0, t, u, K + 1).argmax(1)
+    logits = (synth.synth_uniform((4, K, 265), key="ltb.z") * 8 - 4).requires_grad_(True)
+    with torch.enable_grad():
+        log_x0, log_xt = O.log_onehot(x0, K + 1), O.log_onehot(xt, K + 1)
+        lrec = O.predict_start(logits)
+        pm = O.q_posterior(sched, lrec, log_xt, t)
+        pr = O.q_posterior(sched, log_x0, log_xt, t)
+        kl_of = lambda a, b: (a.exp() * (a - b)).sum(dim=1)
+        kl = kl_of(pr, pm).sum(-1)
+        nll = -(log_x0.exp() * pm).sum(dim=1).sum(-1)
+        is0 = (t == 0).float()
+        kl_loss = is0 * nll + (1 - is0) * kl
+        aux = is0 * nll + (1 - is0) * kl_of(log_x0[:, :-1], lrec[:, :-1]).sum(-1)
+        vb = kl_loss / pt + (t.float() / T + 1.0) * 5.0e-4 * aux / pt
+        vb.sum().backward()
+    got = O.loss_tail_backward(sched, logits.detach(), x0, xt, t, pt)
+    ref = logits.grad
+    assert (got - ref).abs().max() < 2e-4 * ref.abs().max(), ((got - ref).abs().max().item(), ref.abs().max().item())
+
+
 def test_decode(sd_dalle_l2):
     tok = synth.synth_tokens(1, mask_frac=0.0, key="dec.tokens")
     mel = O.decode_tokens(sd_dalle_l2, tok)
