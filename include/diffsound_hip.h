@@ -169,6 +169,13 @@ int ds_loss_tail(const float* logits, const int64_t* x0, const int64_t* xt, cons
                  float* kl, float* nll, float* kl_aux, float* dbg_model_log_prob, int B, int L, int K, int T,
                  ds_stream_t stream);
 
+/* d(sum over samples of vb_loss) / d logits for the loss above (pt [B] = the sampling probabilities of t; mask
+ * weights for masked / unmasked x_t positions; auxiliary loss weight and its adaptive flag): dlogits [B*L][K].  The
+ * first backward kernel of the training step; the rest of the backward does not exist yet. */
+int ds_loss_tail_bwd(const float* logits, const int64_t* x0, const int64_t* xt, const int64_t* t, const float* pt,
+                     const float* sched, float* dlogits, int B, int L, int K, int T, float mask_weight_masked,
+                     float mask_weight_other, float aux_weight, int adaptive, ds_stream_t stream);
+
 /* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
 enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */
     DS_LP_ADALN1 = 0,  /* [T][2D]  ln1 table   */

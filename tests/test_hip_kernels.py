@@ -340,3 +340,32 @@ def test_softmax_rows_and_stencils(L):
     t7c = t7.cuda()
     L.check(L.lib().ds_stencil7_tanh(L.ptr(t7c), 8, -0.1, L.ptr(out), B, N, L.stream()))
     assert (out.cpu() - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("K", [256, 512])
+def test_loss_tail_backward_vs_oracle(L, K):
+    """ds_loss_tail_bwd (d loss / d logits of the training loss) against the oracle's closed form, which the CPU
+    suite checks against autograd: masked and unmasked x_t, t = 0 and t > 0, auxiliary term on."""
+    import diffsound_oracle as O
+    T, B = 100, 4
+    sched = O.make_schedule(T, K + 1)
+    x0 = synth.synth_tokens(B, 265, K, mask_frac=0.0, key="ltb.x0")
+    t = torch.tensor([57, 0, 93, 1])
+    pt = torch.tensor([0.01, 0.02, 0.005, 0.01])
+    u = synth.synth_uniform((B, K + 1, 265), key="ltb.u")
+    xt = O.q_sample(sched, x0, t, u, K + 1).argmax(1)
+    logits = synth.synth_uniform((B, K, 265), key="ltb.z") * 8 - 4
+    ref = O.loss_tail_backward(sched, logits, x0, xt, t, pt)                       # [B, K, L]
+    names = ("log_at", "log_bt", "log_ct", "log_1_min_ct", "log_cumprod_at", "log_cumprod_bt", "log_cumprod_ct",
+             "log_1_min_cumprod_ct")
+    tab = torch.zeros(8, T + 1)
+    for i, n in enumerate(names):
+        tab[i, :sched[n].numel()] = sched[n]
+    rows = logits.permute(0, 2, 1).reshape(B * 265, K).contiguous().cuda()
+    out = torch.full((B * 265, K), float("nan"), device="cuda")
+    x0c, xtc, tc, ptc, tabc = x0.cuda(), xt.cuda(), t.cuda(), pt.cuda(), tab.cuda()
+    L.check(L.lib().ds_loss_tail_bwd(L.ptr(rows), L.ptr(x0c), L.ptr(xtc), L.ptr(tc), L.ptr(ptc), L.ptr(tabc), L.ptr(out),
+                                     B, 265, K, T, 1.0, 1.0, 5.0e-4, 1, L.stream()))
+    got = out.view(B, 265, K).permute(0, 2, 1).cpu()
+    assert (got - ref).abs().max() < 5e-4 * ref.abs().max()
+

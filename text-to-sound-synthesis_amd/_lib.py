@@ -81,6 +81,8 @@ _PROTOS = {
     "ds_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_vq_argmin": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_loss_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f,
+                                   C.c_int, _vp]),
     "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),
     "ds_denoiser_destroy": (None, [_vp]),
     "ds_denoiser_workspace_bytes": (_i64, [_vp, C.c_int]),

@@ -328,6 +328,128 @@ __global__ __launch_bounds__(256) void ds_loss_tail_kernel(const float* __restri
     }
 }
 
+// d(sum_b vb_loss_b) / d logits of the training loss: the first backward kernel of scope row 8f-3 (closed form and
+// derivation: oracle/diffsound_oracle.py loss_tail_backward).  Same thread mapping as the forward tail.
+template <int NPL>
+__global__ __launch_bounds__(256) void ds_loss_tail_bwd_kernel(const float* __restrict__ logits,
+                                                               const int64_t* __restrict__ x0, const int64_t* __restrict__ xt,
+                                                               const int64_t* __restrict__ t, const float* __restrict__ pt,
+                                                               const float* __restrict__ sched, float* __restrict__ dlogits,
+                                                               int B, int L, int T, float mw_mask, float mw_other,
+                                                               float aux_weight, int adaptive) {
+    constexpr int K = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= B * L) return;
+    const int b = col / L;
+    float v[NPL];
+    const float* lg = logits + (size_t)col * K;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) v[j] = lg[j * 64 + lane];
+    float mx = v[0];
+#pragma unroll
+    for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, v[j]);
+    mx = wmaxf(mx);
+    double se = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) se += exp((double)v[j] - (double)mx);
+    const double lse64 = log(wsumd(se));
+    const int x0c = (int)x0[col], xtc = (int)xt[col], tt = (int)t[b];
+    const int T1 = T + 1, tm1 = (tt - 1 + T1) % T1;
+    const float* S = sched;
+    float lp[NPL], ls[NPL], sm[NPL];
+    bool lp_live[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const float l = (float)(((double)v[j] - (double)mx) - lse64);
+        sm[j] = expf(l);
+        lp_live[j] = l > -70.f && l < 0.f;
+        lp[j] = fminf(fmaxf(l, -70.f), 0.f);
+        ls[j] = (j * 64 + lane) == x0c ? 0.f : LOG_ZERO_F;
+    }
+    const float ls_m = x0c == K ? 0.f : LOG_ZERO_F;
+    // true posterior (forward code)
+    float pr[NPL], pr_m;
+    ds_posterior<NPL>(ls, ls_m, xtc, K, lane, S, T1, tt, pr, pr_m);
+    // model posterior with the quantities its derivative needs
+    const float lat = S[0 * T1 + tt], lbt = S[1 * T1 + tt], lct = S[2 * T1 + tt];
+    const float lcat = S[4 * T1 + tt], lcbt = S[5 * T1 + tt], lcct = S[6 * T1 + tt];
+    const float lcat1 = S[4 * T1 + tm1], lcbt1 = S[5 * T1 + tm1], lcct1 = S[6 * T1 + tm1], l1mcct1 = S[7 * T1 + tm1];
+    const bool is_mask = xtc == K;
+    const float qt_hit = is_mask ? lcct : lae(0.f + lcat, lcbt), qt_off = is_mask ? lcct : lae(LOG_ZERO_F + lcat, lcbt);
+    const float q1_hit = is_mask ? lct : lae(0.f + lat, lbt), q1_off = is_mask ? lct : lae(LOG_ZERO_F + lat, lbt);
+    const float qt_m = is_mask ? 0.f : LOG_ZERO_F, q1_m = qt_m;
+    float q[NPL];
+    float qmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        q[j] = lp[j] - ((j * 64 + lane) == xtc ? qt_hit : qt_off);
+        qmax = fmaxf(qmax, q[j]);
+    }
+    const float q_m = -70.f - qt_m;
+    qmax = fmaxf(wmaxf(qmax), q_m);
+    float es = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) es += expf(q[j] - qmax);
+    es = wsumf(es) + expf(q_m - qmax);
+    const float lse = logf(es) + qmax;
+    const float is0 = tt == 0 ? 1.f : 0.f, ipt = 1.f / pt[b];
+    const float wgt = is_mask ? mw_mask : mw_other;
+    const float wa = adaptive ? (float)tt / (float)T + 1.f : 1.f;
+    const float nll_scale = ipt + (aux_weight != 0.f ? wa * aux_weight * ipt : 0.f);
+    float w[NPL], sg[NPL], pp[NPL];
+    float ssum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const float A = lae((q[j] - lse) + lcat1, lcbt1);
+        const float raw = A + ((j * 64 + lane) == xtc ? q1_hit : q1_off) + lse;
+        sg[j] = expf((q[j] - lse) + lcat1 - A);
+        pp[j] = expf(q[j] - lse);
+        const bool live = raw > -70.f && raw < 0.f;
+        w[j] = live ? -(1.f - is0) * expf(pr[j]) * wgt * ipt - is0 * expf(ls[j]) * nll_scale : 0.f;
+        ssum += w[j] * (1.f - sg[j]);
+    }
+    {   // [MASK] row
+        const float A = lae((q_m - lse) + l1mcct1, lcct1);
+        const float raw = A + q1_m + lse;
+        const float sgm = expf((q_m - lse) + l1mcct1 - A);
+        const bool live = raw > -70.f && raw < 0.f;
+        const float wm = live ? -(1.f - is0) * expf(pr_m) * wgt * ipt - is0 * expf(ls_m) * nll_scale : 0.f;
+        ssum = wsumf(ssum) + wm * (1.f - sgm);
+    }
+    float glp[NPL];
+    float G = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        float gq = w[j] * sg[j] + pp[j] * ssum;
+        if (aux_weight != 0.f) gq -= (1.f - is0) * wa * aux_weight * ipt * wgt * expf(ls[j]);
+        glp[j] = lp_live[j] ? gq : 0.f;
+        G += glp[j];
+    }
+    G = wsumf(G);
+    float* dz = dlogits + (size_t)col * K;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) dz[j * 64 + lane] = glp[j] - sm[j] * G;
+}
+
+extern "C" int ds_loss_tail_bwd(const float* logits, const int64_t* x0, const int64_t* xt, const int64_t* t,
+                                const float* pt, const float* sched, float* dlogits, int B, int L, int K, int T,
+                                float mask_weight_masked, float mask_weight_other, float aux_weight, int adaptive,
+                                ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(logits && x0 && xt && t && pt && sched && dlogits && B > 0 && L > 0 && T > 0, "bad arguments");
+    DS_CHECK_ARG(K == 256 || K == 512, "codebook size must be 256 or 512");
+    const int cols = B * L;
+    if (K == 256)
+        hipLaunchKernelGGL((ds_loss_tail_bwd_kernel<4>), dim3((cols + 3) / 4), dim3(256), 0, stream, logits, x0, xt, t, pt,
+                           sched, dlogits, B, L, T, mask_weight_masked, mask_weight_other, aux_weight, adaptive);
+    else
+        hipLaunchKernelGGL((ds_loss_tail_bwd_kernel<8>), dim3((cols + 3) / 4), dim3(256), 0, stream, logits, x0, xt, t, pt,
+                           sched, dlogits, B, L, T, mask_weight_masked, mask_weight_other, aux_weight, adaptive);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ds_loss_tail(const float* logits, const int64_t* x0, const int64_t* xt, const int64_t* t,
                             const float* sched, float* kl, float* nll, float* kl_aux, float* dbg_model_log_prob, int B,
                             int L, int K, int T, ds_stream_t stream_) {
