@@ -176,6 +176,24 @@ int ds_loss_tail_bwd(const float* logits, const int64_t* x0, const int64_t* xt, 
                      const float* sched, float* dlogits, int B, int L, int K, int T, float mask_weight_masked,
                      float mask_weight_other, float aux_weight, int adaptive, ds_stream_t stream);
 
+/* ---- row / elementwise kernels of the training step (csrc/train.hip; scope row 8f-3, building blocks) --------
+ * AdaLN (mode 0: table [T][2D], t [M/L]) / LayerNorm (mode 1: gamma) backward: dx, and dyxn = dy * xn for the scale
+ * gradient (NULL to skip); D = 1024 */
+int ds_layernorm_bwd(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
+                     const float* table, const int64_t* t, const float* gamma, ds_stream_t stream);
+/* out[g][c] (+)= sum over R rows of x[(g*gstride) + r*ld + c]: bias / scale / per-sample AdaLN gradients */
+int ds_colsum(const float* x, float* out, int G, int R, int C, long long ld, long long gstride, int accumulate,
+              ds_stream_t stream);
+/* GELU2: dy == NULL -> out = x * sigmoid(1.702 x); else out = dy * d/dx of that */
+int ds_gelu2(const float* x, const float* dy, float* out, long long n, ds_stream_t stream);
+/* in place dS = scale * P * (dP - rowsum(dP * P)) over the first n columns of each row (attention backward) */
+int ds_softmax_bwd_rows(const float* P, float* dP, int rows, int n, int ld, float scale, ds_stream_t stream);
+/* d emb[tokens[m]] += dx[m] (atomic) */
+int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
+/* fused AdamW update (torch.optim.AdamW semantics), step >= 1 */
+int ds_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int step, ds_stream_t stream);
+
 /* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
 enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */
     DS_LP_ADALN1 = 0,  /* [T][2D]  ln1 table   */

@@ -83,6 +83,12 @@ _PROTOS = {
     "ds_loss_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f,
                                    C.c_int, _vp]),
+    "ds_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "ds_colsum": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _i64, C.c_int, _vp]),
+    "ds_gelu2": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "ds_softmax_bwd_rows": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_embed_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, C.c_int, _vp]),
     "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),
     "ds_denoiser_destroy": (None, [_vp]),
     "ds_denoiser_workspace_bytes": (_i64, [_vp, C.c_int]),

@@ -1,0 +1,207 @@
+// Row / elementwise kernels of the training step (scope row 8f-3): the backward of AdaLN / LayerNorm, GELU2,
+// row softmax, the embedding, column sums for bias / scale gradients, and the fused AdamW update.  All HBM-bound,
+// one wave per 1024-wide row where rows are reduced.  The GEMM-shaped parts of the backward run on the GEMM kernels.
+// Reference ops: AdaLayerNorm / nn.LayerNorm / GELU2 (transformer_utils.py:111-149), DalleMaskImageEmbedding
+// (dalle_mask_image_embedding.py:36-58), torch.optim.AdamW as configured by configs/caps.yaml:111-115.
+#include "common.h"
+
+__device__ __forceinline__ float tr_wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- LayerNorm / AdaLN backward ---------------------------------------------------------------------------
+// forward  xn = (x - mean) * rstd;  y = xn * s + b  with  s = 1 + tab[t][c] (AdaLN, mode 0) or gamma[c] (mode 1)
+// backward g = dy * s;  dx = rstd * (g - mean(g) - xn * mean(g * xn));  dyxn = dy * xn  (for d scale, via ds_colsum)
+template <int D>
+__global__ __launch_bounds__(256) void ds_layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, float* __restrict__ dyxn, int M,
+                                                               int L, int mode, const float* __restrict__ tab,
+                                                               const int64_t* __restrict__ t,
+                                                               const float* __restrict__ gamma, float eps) {
+    constexpr int NV = D / 256;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    f32x4 v[NV], g[NV];
+    const float* xr = x + (size_t)row * D;
+    const float* dr = dy + (size_t)row * D;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        v[j] = *(const f32x4*)(xr + (j * 64 + lane) * 4);
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = tr_wsum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = v[j][k] - mean;
+            q += d * d;
+        }
+    const float rstd = 1.f / sqrtf(tr_wsum(q) * (1.f / D) + eps);
+    const float* sc = mode == 0 ? tab + (size_t)t[row / L] * 2 * D : gamma;
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        const f32x4 a = *(const f32x4*)(sc + c), d4 = *(const f32x4*)(dr + c);
+        f32x4 px;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xn = (v[j][k] - mean) * rstd;
+            v[j][k] = xn;
+            g[j][k] = d4[k] * (mode == 0 ? 1.f + a[k] : a[k]);
+            px[k] = d4[k] * xn;
+            sg += g[j][k];
+            sgx += g[j][k] * xn;
+        }
+        if (dyxn) *(f32x4*)(dyxn + (size_t)row * D + c) = px;
+    }
+    const float mg = tr_wsum(sg) * (1.f / D), mgx = tr_wsum(sgx) * (1.f / D);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = rstd * (g[j][k] - mg - v[j][k] * mgx);
+        *(f32x4*)(dx + (size_t)row * D + c) = o;
+    }
+}
+
+extern "C" int ds_layernorm_bwd(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
+                                const float* table, const int64_t* t, const float* gamma, ds_stream_t stream) {
+    DS_CHECK_ARG(x && dy && dx && M > 0 && D == 1024, "bad arguments (D = 1024 is built)");
+    DS_CHECK_ARG(mode == 0 ? (table && t && L > 0) : (mode == 1 && gamma), "mode 0 needs table / t / L, mode 1 gamma");
+    hipLaunchKernelGGL((ds_layernorm_bwd_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, dyxn,
+                       M, mode == 0 ? L : 1, mode, table, t, gamma, 1e-5f);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- column sums:  out[g][c] (+)= sum_{r < R} x[(g * R + r) * ld + c]   (bias / scale / embedding gradients) ----------
+// grid (ceil(C/256), G); each thread owns one column and walks the rows: coalesced, deterministic order
+__global__ __launch_bounds__(256) void ds_colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C,
+                                                        long long ld, long long gstride, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* p = x + (size_t)blockIdx.y * gstride + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < R; r += 4) {
+        s0 += p[(size_t)r * ld];
+        s1 += p[(size_t)(r + 1) * ld];
+        s2 += p[(size_t)(r + 2) * ld];
+        s3 += p[(size_t)(r + 3) * ld];
+    }
+    for (; r < R; ++r) s0 += p[(size_t)r * ld];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* o = out + (size_t)blockIdx.y * C + c;
+    *o = accumulate ? *o + s : s;
+}
+
+extern "C" int ds_colsum(const float* x, float* out, int G, int R, int C, long long ld, long long gstride, int accumulate,
+                         ds_stream_t stream) {
+    DS_CHECK_ARG(x && out && G > 0 && R > 0 && C > 0 && ld >= C, "bad arguments");
+    hipLaunchKernelGGL(ds_colsum_kernel, dim3((C + 255) / 256, G), dim3(256), 0, (hipStream_t)stream, x, out, R, C, ld, gstride,
+                       accumulate);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- GELU2 (x * sigmoid(1.702 x), transformer_utils.py:111-115) forward and backward, elementwise ---------------------
+__global__ __launch_bounds__(256) void ds_gelu2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ out, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 v = *(const f32x4*)(x + i);
+    f32x4 o;
+    if (dy) {
+        const f32x4 d = *(const f32x4*)(dy + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sg = 1.f / (1.f + expf(-1.702f * v[k]));
+            o[k] = d[k] * (sg + 1.702f * v[k] * sg * (1.f - sg));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = v[k] / (1.f + expf(-1.702f * v[k]));
+    }
+    *(f32x4*)(out + i) = o;
+}
+
+// dy == NULL: out = gelu2(x);  else out = dy * gelu2'(x).  n % 4 == 0.
+extern "C" int ds_gelu2(const float* x, const float* dy, float* out, long long n, ds_stream_t stream) {
+    DS_CHECK_ARG(x && out && n > 0 && n % 4 == 0, "bad arguments (n % 4 == 0)");
+    hipLaunchKernelGGL(ds_gelu2_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, out, n);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- row softmax backward, in place:  dS = scale * P * (dP - sum_j dP_j P_j)  over the first n columns of a row -------
+__global__ __launch_bounds__(256) void ds_softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP,
+                                                                  int rows, int n, int ld, float scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* pr = P + (size_t)row * ld;
+    float* dr = dP + (size_t)row * ld;
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += dr[c] * pr[c];
+    s = tr_wsum(s);
+    for (int c = lane; c < ld; c += 64) dr[c] = c < n ? scale * pr[c] * (dr[c] - s) : 0.f;
+}
+
+extern "C" int ds_softmax_bwd_rows(const float* P, float* dP, int rows, int n, int ld, float scale, ds_stream_t stream) {
+    DS_CHECK_ARG(P && dP && rows > 0 && n > 0 && ld >= n, "bad arguments");
+    hipLaunchKernelGGL(ds_softmax_bwd_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, P, dP, rows, n, ld,
+                       scale);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- embedding backward: d emb[token[m]][:] += dx[m][:]  (fp32 atomics; the content embedding has 257 rows) ------------
+__global__ __launch_bounds__(256) void ds_embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tok,
+                                                           float* __restrict__ demb, int M, int D, int rows) {
+    const int m = blockIdx.x;
+    long long tk = tok[m];
+    if (tk < 0 || tk >= rows) return;
+    for (int c = threadIdx.x; c < D; c += 256) atomicAdd(demb + (size_t)tk * D + c, dx[(size_t)m * D + c]);
+}
+
+extern "C" int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream) {
+    DS_CHECK_ARG(dx && tokens && demb && M > 0 && D > 0 && rows > 0, "bad arguments");
+    hipLaunchKernelGGL(ds_embed_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, dx, tokens, demb, M, D, rows);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias-corrected moments), one fused pass ----------------
+__global__ __launch_bounds__(256) void ds_adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                       float b1, float b2, float eps, float wd, float bc1, float bc2s) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float pi = p[i] * (1.f - lr * wd);
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+    p[i] = pi;
+}
+
+// step >= 1: the number of this update (bias corrections 1 - beta^step)
+extern "C" int ds_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step, ds_stream_t stream) {
+    DS_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(ds_adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2s);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
