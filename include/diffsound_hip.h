@@ -190,6 +190,8 @@ int ds_gelu2(const float* x, const float* dy, float* out, long long n, ds_stream
 int ds_softmax_bwd_rows(const float* P, float* dP, int rows, int n, int ld, float scale, ds_stream_t stream);
 /* d emb[tokens[m]] += dx[m] (atomic) */
 int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
+/* y += a * x, n % 4 == 0 */
+int ds_axpy(float* y, const float* x, float a, long long n, ds_stream_t stream);
 /* fused AdamW update (torch.optim.AdamW semantics), step >= 1 */
 int ds_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int step, ds_stream_t stream);

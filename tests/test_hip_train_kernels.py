@@ -116,3 +116,67 @@ def test_adamw_matches_torch(L):
         gc = g.cuda()
         L.check(L.lib().ds_adamw(L.ptr(p), L.ptr(gc), L.ptr(m), L.ptr(v), n, 3e-3, 0.9, 0.96, 1e-8, 4.5e-2, step, L.stream()))
     assert close(p.cpu(), ref.detach(), 2e-6)
+
+
+def test_training_step_gradients_vs_oracle_autograd():
+    """The whole backward of the denoiser on the HIP kernels (modeling/train.py, exact-fp32 first version): loss and
+    EVERY parameter gradient of the 2-layer model against autograd through the oracle (which the CPU suite pins to
+    the reference's loss.backward()), then one AdamW update against torch.optim.AdamW."""
+    import diffsound_oracle as O
+    from conftest import golden, synth_sd
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    g = golden("train_loss_L2")
+    m = build_model(default_config(n_layer=2, diffusion_step=100))
+    sd_cpu = dict(synth_sd("dalle", 2))
+    m.load_state_dict({**sd_cpu, **synth_sd("encoder")}, strict=False)
+    m = m.cuda().eval()
+    dt = m.transformer
+    dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0")
+    cond = synth.synth_cond_emb(3, key="tl.c")
+    t = torch.tensor([57, 0, 93])
+    pt = torch.ones(3) / 100
+    u = synth.synth_uniform((3, 257, 265), key="tl.u")
+    # oracle: loss + autograd gradients on the CPU
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd_cpu.items()}
+    with torch.enable_grad():
+        _, _, loss_ref, _ = O.train_loss(sd, x0, cond, t, pt, u)
+        loss_ref.backward()
+    step = TrainStep(dt)
+    loss, grads = step.loss_and_grads(x0.cuda(), cond.cuda(), t.cuda(), pt.cuda(), u.cuda())
+    print("loss %.6f (oracle %.6f, reference %.6f)" % (loss.item(), loss_ref.item(), float(g["loss"])))
+    assert abs(loss.item() - float(g["loss"])) < 2e-4 * float(g["loss"])
+    worst, missing = [], []
+    for k, v in sd.items():
+        if not (k.startswith("transformer.transformer.") and v.is_floating_point() and v.grad is not None):
+            continue
+        name = k[len("transformer."):]
+        if name not in grads:
+            if v.grad.abs().max() > 0:
+                missing.append(name)
+            continue
+        got, want = grads[name].cpu().double(), v.grad.double()
+        if want.abs().max().item() < 1e-7:
+            # the key biases have an analytically ZERO gradient (softmax is invariant to them): both sides hold
+            # ~1e-9 rounding noise there, which a relative measure cannot compare
+            assert got.abs().max().item() < 1e-6, name
+            continue
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        worst.append((err, name, want.abs().max().item()))
+    worst.sort(reverse=True)
+    for err, name, mag in worst[:12]:
+        print("  grad rel err %.2e  |g|max %.2e  %s" % (err, mag, name))
+    assert not missing, missing
+    assert len(worst) >= 50 and worst[0][0] < 2e-3, worst[:5]
+    # one optimizer step on a few tensors vs torch.optim.AdamW
+    names = ["transformer.to_logits.1.weight", "transformer.blocks.0.attn1.query.weight", "transformer.blocks.1.ln2.weight"]
+    params = dict(dt.named_parameters())
+    before = {n: params[n].detach().cpu().double().clone() for n in names}
+    step.adamw_step({n: grads[n] for n in names}, {}, 1, lr=1e-3)
+    for n in names:
+        ref = before[n].clone().requires_grad_(True)
+        opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2)
+        ref.grad = grads[n].cpu().double()
+        opt.step()
+        assert close(params[n].detach().cpu(), ref.detach(), 2e-6), n

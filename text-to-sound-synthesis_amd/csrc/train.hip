@@ -205,3 +205,22 @@ extern "C" int ds_adamw(float* p, const float* g, float* m, float* v, long long 
     DS_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- y += a * x (residual-stream gradient accumulation), n % 4 == 0 ----------------------------------------------------
+__global__ __launch_bounds__(256) void ds_axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 yy = *(const f32x4*)(y + i);
+    const f32x4 xx = *(const f32x4*)(x + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) yy[k] += a * xx[k];
+    *(f32x4*)(y + i) = yy;
+}
+
+extern "C" int ds_axpy(float* y, const float* x, float a, long long n, ds_stream_t stream) {
+    DS_CHECK_ARG(y && x && n > 0 && n % 4 == 0, "bad arguments (n % 4 == 0)");
+    hipLaunchKernelGGL(ds_axpy_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
