@@ -229,8 +229,51 @@ def train_loss():
          **{"gradnorm_" + n.replace(".", "_"): v for n, v in gn.items()})
 
 
+def solver_schedule():
+    """SURVEY.md section 8f-3, the host logic around the training step (engine/solver_spec.py:308-331): the reference's
+    own ReduceLROnPlateauWithWarmup, ClipGradNorm and EMA classes driven over a short deterministic run."""
+    import types
+    if "torch._six" not in sys.modules:          # removed from current torch; the reference imports `inf` from it
+        m_ = types.ModuleType("torch._six"); m_.inf = float("inf"); sys.modules["torch._six"] = m_
+    rh.install()
+    from sound_synthesis.engine.lr_scheduler import ReduceLROnPlateauWithWarmup
+    from sound_synthesis.engine.clip_grad_norm import ClipGradNorm
+    from sound_synthesis.engine.ema import EMA
+    torch.manual_seed(0)
+    net = torch.nn.Linear(6, 4)
+    with torch.no_grad():
+        net.weight.copy_(synth.synth_uniform((4, 6), key="sv.w") - 0.5); net.bias.copy_(synth.synth_uniform((4,), key="sv.b") - 0.5)
+    w0, b0 = net.weight.detach().clone(), net.bias.detach().clone()
+    opt = torch.optim.AdamW(net.parameters(), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2)
+    sch = ReduceLROnPlateauWithWarmup(opt, factor=0.5, patience=4, min_lr=1.0e-6, threshold=1.0e-1, threshold_mode="rel",
+                                      warmup_lr=4.5e-4, warmup=10)
+    clip = ClipGradNorm(start_iteration=0, end_iteration=5, max_norm=0.5)
+    ema = EMA(net, decay=0.99, update_interval=3)
+    n = 40
+    losses = synth.synth_uniform((n,), key="sv.loss") * 0.05 + torch.cat([torch.linspace(5, 1, 12), torch.ones(n - 12)])
+    xs = synth.synth_uniform((n, 5, 6), key="sv.x") * 2 - 1
+    lrs, gnorm_pre, gnorm_post = [], [], []
+    for it in range(n):
+        opt.zero_grad()
+        out = (net(xs[it]) ** 2).sum() * 3.0
+        out.backward()
+        gnorm_pre.append(torch.sqrt(sum((p_.grad ** 2).sum() for p_ in net.parameters())))
+        clip(net.parameters())
+        gnorm_post.append(torch.sqrt(sum((p_.grad ** 2).sum() for p_ in net.parameters())))
+        opt.step()
+        sch.step(losses[it])
+        ema.update(iteration=it)
+        lrs.append(opt.param_groups[0]["lr"])
+    es = ema.state_dict()
+    save("solver_schedule", w0=w0, b0=b0, losses=losses, xs=xs, lrs=torch.tensor(lrs, dtype=torch.float64),
+         gnorm_pre=torch.stack(gnorm_pre), gnorm_post=torch.stack(gnorm_post), w_final=net.weight.detach(),
+         b_final=net.bias.detach(), ema_w=es["weight"], ema_b=es["bias"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--solver-only" in sys.argv:
+        return solver_schedule()
     if "--text-only" in sys.argv:
         return text_stage()
     if "--train-only" in sys.argv:
@@ -323,6 +366,7 @@ def main():
     encoder()
     codebook512()
     train_loss()
+    solver_schedule()
     print("done in %.1fs" % (time.time() - t0))
 
 

@@ -180,3 +180,58 @@ def test_training_step_gradients_vs_oracle_autograd():
         ref.grad = grads[n].cpu().double()
         opt.step()
         assert close(params[n].detach().cpu(), ref.detach(), 2e-6), n
+
+
+def test_solver_three_iterations_vs_cpu_autograd():
+    """The training iteration in the reference's order (modeling/solver.py: gradients -> global-norm clip -> AdamW ->
+    EMA) on the HIP training step, three iterations on one batch: every loss and the pre-clip gradient norm against
+    the same loop run on the CPU with autograd through the oracle, torch's clip_grad_norm_ and torch.optim.AdamW.  The
+    second and third losses depend on the updated weights, so this covers the update path end to end."""
+    import diffsound_oracle as O
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.solver import EMA, GradClipWindow, Solver
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    m = build_model(default_config(n_layer=2, diffusion_step=100))
+    sd_cpu = dict(synth_sd("dalle", 2))
+    m.load_state_dict({**sd_cpu, **synth_sd("encoder")}, strict=False)
+    m = m.cuda().eval()
+    dt = m.transformer
+    dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0")
+    cond = synth.synth_cond_emb(3, key="tl.c")
+    t = torch.tensor([57, 0, 93])
+    pt = torch.ones(3) / 100
+    u = synth.synth_uniform((3, 257, 265), key="tl.u")
+    # CPU loop
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k.startswith("transformer.transformer.") else v)
+          for k, v in sd_cpu.items()}
+    leaves = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.AdamW(leaves, lr=1e-3, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2)
+    want = []
+    for _ in range(3):
+        opt.zero_grad()
+        with torch.enable_grad():
+            _, _, loss_ref, _ = O.train_loss(sd, x0, cond, t, pt, u)
+            loss_ref.backward()
+        norm_ref = torch.nn.utils.clip_grad_norm_([p for p in leaves if p.grad is not None], 0.5)
+        opt.step()
+        want.append((loss_ref.item(), norm_ref.item()))
+    # HIP loop
+    key = "transformer.to_logits.1.weight"
+    w_start = dict(dt.named_parameters())[key].detach().clone()
+    solver = Solver(TrainStep(dt), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5),
+                    ema=EMA(dt, decay=0.5, update_interval=1, device="cuda"))
+    batch = (x0.cuda(), cond.cuda(), t.cuda(), pt.cuda(), u.cuda())
+    ema_want = w_start.clone()
+    for it in range(3):
+        out = solver.step(*batch)
+        loss, norm = float(out["loss"]), float(out["grad_norm"])
+        print("iter %d: loss %.5f (cpu %.5f)  |g| %.4f (cpu %.4f)" % (it, loss, want[it][0], norm, want[it][1]))
+        assert abs(loss - want[it][0]) < 2e-3 * want[it][0]
+        assert abs(norm - want[it][1]) < 5e-3 * want[it][1]
+        ema_want = ema_want * 0.5 + dict(dt.named_parameters())[key].detach() * 0.5
+    assert abs(want[1][0] - want[0][0]) > 0.02 * want[0][0]          # the update visibly moved the loss
+    w_end = dict(dt.named_parameters())[key].detach()
+    assert not torch.equal(w_end, w_start)
+    assert close(solver.ema.state_dict()[key].cpu(), ema_want.cpu(), 1e-6)

@@ -126,3 +126,41 @@ def test_bench_timed_loop_and_json_line_world2():
     assert line["config"]["global_batch"] == 6
     assert abs(line["value"] - 6 * 3 / e0) < 1e-3             # whole-job aggregate: all captions of all ranks / time
     assert abs(line["ms_per_step"] - e0 / 3 * 1e3) < 1e-2
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = {"b.weight": torch.randn(300, 7, generator=g), "a.bias": torch.randn(11, generator=g),
+                 "c.emb": torch.randn(64, 33, generator=g)}
+        shard.allreduce_gradients(grads, bucket_bytes=4096)        # small buckets: several flushes
+        q.put((rank, {k: v.clone() for k, v in grads.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    """The data-parallel gradient reduction of the training step: bucketed all-reduce + average, every rank ends up
+    with the mean of the per-rank gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per_rank = []
+    for rank in range(2):
+        g = torch.Generator().manual_seed(100 + rank)
+        per_rank.append({"b.weight": torch.randn(300, 7, generator=g), "a.bias": torch.randn(11, generator=g),
+                         "c.emb": torch.randn(64, 33, generator=g)})
+    for k in per_rank[0]:
+        mean = (per_rank[0][k] + per_rank[1][k]) / 2
+        assert torch.allclose(got[0][k], mean, atol=1e-6) and torch.equal(got[0][k], got[1][k])
+

@@ -1,0 +1,225 @@
+"""Host logic around the training step (scope row 8f-3): what engine/solver_spec.py:308-331 does per iteration --
+
+    loss.backward() -> clip_grad_norm -> optimizer.step() -> scheduler.step(loss) -> ema.update(iteration)
+
+-- restated over gradient *dicts* (name -> tensor) instead of torch.optim objects, because the gradients here come from
+`modeling.train.TrainStep` (HIP kernels, no autograd graph) and the update is the `ds_adamw` kernel.  The classes keep
+the reference's names for their knobs (configs/caps.yaml:88-131) and its quirks:
+
+  * PlateauWarmupLR   = engine/lr_scheduler.py:14-209  ReduceLROnPlateauWithWarmup
+  * GradClipWindow    = engine/clip_grad_norm.py:8-29   ClipGradNorm (+ torch.nn.utils.clip_grad_norm_)
+  * EMA               = engine/ema.py:8-72
+
+Nothing here needs the GPU library, so the CPU test suite drives the whole iteration order against a golden run of the
+reference's own classes (tests/golden/solver_schedule.npz).
+"""
+import math
+
+import torch
+
+
+class PlateauWarmupLR:
+    """Linear warm-up from the initial lr to `warmup_lr` over `warmup` steps (one equal increment per step, computed
+    once from the lr at construction), then reduce-on-plateau: the lr is multiplied by `factor` (floored at `min_lr`)
+    when the metric has not improved on `best` (relative/absolute `threshold`) for more than `patience` steps.  The
+    metric seen during warm-up is ignored, as in the reference (lr_scheduler.py:124-147)."""
+
+    def __init__(self, lr, mode="min", factor=0.1, patience=10, threshold=1e-4, threshold_mode="rel", cooldown=0,
+                 min_lr=0.0, eps=1e-8, warmup_lr=None, warmup=0):
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        if mode not in ("min", "max"):
+            raise ValueError("mode " + mode + " is unknown!")
+        if threshold_mode not in ("rel", "abs"):
+            raise ValueError("threshold mode " + threshold_mode + " is unknown!")
+        self.lr = float(lr)
+        self.mode, self.factor, self.patience = mode, factor, patience
+        self.threshold, self.threshold_mode = threshold, threshold_mode
+        self.cooldown, self.min_lr, self.eps = cooldown, float(min_lr), eps
+        self.warmup_lr, self.warmup = warmup_lr, warmup
+        self.best = math.inf if mode == "min" else -math.inf
+        self.num_bad_epochs = 0
+        self.cooldown_counter = 0
+        self.last_epoch = 0
+        self.warmup_lr_step = None
+        if warmup > 0 and warmup_lr is not None:
+            self.warmup_lr_step = max(0.0, (float(warmup_lr) - self.lr) / float(warmup))
+
+    def is_better(self, a, best):
+        if self.mode == "min":
+            return a < best * (1.0 - self.threshold) if self.threshold_mode == "rel" else a < best - self.threshold
+        return a > best * (1.0 + self.threshold) if self.threshold_mode == "rel" else a > best + self.threshold
+
+    def step(self, metric):
+        """One scheduler step with this iteration's loss; returns the lr for the next iteration."""
+        current = float(metric)
+        self.last_epoch += 1
+        if self.last_epoch <= self.warmup:
+            if self.warmup_lr_step is None:
+                raise RuntimeError("warmup > 0 needs warmup_lr")      # the reference fails here too (None in a sum)
+            self.lr = max(self.lr + self.warmup_lr_step, self.min_lr)
+            return self.lr
+        if self.is_better(current, self.best):
+            self.best = current
+            self.num_bad_epochs = 0
+        else:
+            self.num_bad_epochs += 1
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.num_bad_epochs = 0
+        if self.num_bad_epochs > self.patience:
+            new_lr = max(self.lr * self.factor, self.min_lr)
+            if self.lr - new_lr > self.eps:
+                self.lr = new_lr
+            self.cooldown_counter = self.cooldown
+            self.num_bad_epochs = 0
+        return self.lr
+
+    def state_dict(self):
+        return dict(self.__dict__)
+
+    def load_state_dict(self, state):
+        self.__dict__.update(state)
+
+
+class GradClipWindow:
+    """Global-L2-norm clipping of a gradient dict to `max_norm`.  The reference's window test
+    (clip_grad_norm.py:21-28) clips when `it >= start_iteration` OR (`end_iteration > 0` and `it < end_iteration`),
+    which with the shipped start_iteration = 0 means every iteration; reproduced as written.  The scale is torch's:
+    coef = max_norm / (total_norm + 1e-6), applied only when < 1."""
+
+    def __init__(self, start_iteration=0, end_iteration=-1, max_norm=0.5):
+        self.start_iteration, self.end_iteration, self.max_norm = start_iteration, end_iteration, max_norm
+        self.last_epoch = -1
+
+    def __call__(self, grads):
+        """In place; returns the pre-clip total norm (0-dim tensor) or None when this iteration is outside the window."""
+        self.last_epoch += 1
+        clip = self.last_epoch >= self.start_iteration
+        if self.end_iteration > 0 and self.last_epoch < self.end_iteration:
+            clip = True
+        if not clip or not grads:
+            return None
+        tensors = list(grads.values())
+        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)))
+        coef = torch.clamp(self.max_norm / (total + 1e-6), max=1.0)
+        torch._foreach_mul_(tensors, coef)
+        return total
+
+    def state_dict(self):
+        return dict(self.__dict__)
+
+    def load_state_dict(self, state):
+        self.__dict__.update(state)
+
+
+class EMA:
+    """Exponential moving average of `model.get_ema_model().state_dict()` (parameters *and* buffers, as the reference's
+    state-dict loop does), refreshed every `update_interval` iterations: ema = ema * decay + current * (1 - decay).
+    The shipped config keeps the average on the CPU (configs/caps.yaml:98-101); `device` may equally be the GPU."""
+
+    def __init__(self, model, decay=0.99, update_interval=1, device=torch.device("cpu")):
+        self.decay, self.update_interval, self.device = decay, update_interval, torch.device(device)
+        self.model = model
+        self.ema = {k: v.detach().clone().to(self.device) for k, v in self._target().state_dict().items()}
+        self.cur = None
+
+    def _target(self):
+        m = self.model
+        return m.get_ema_model() if callable(getattr(m, "get_ema_model", None)) else m
+
+    @torch.no_grad()
+    def update(self, iteration):
+        if (iteration + 1) % self.update_interval != 0:
+            return
+        cur = self._target().state_dict()
+        for k, e in self.ema.items():
+            e.copy_(e * self.decay + cur[k].detach().to(self.device) * (1 - self.decay))
+
+    def state_dict(self):
+        return self.ema
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing = [k for k in self.ema if k not in state_dict]
+        extra = [k for k in state_dict if k not in self.ema]
+        if strict and (missing or extra):
+            raise RuntimeError("EMA.load_state_dict: missing %s, unexpected %s" % (missing, extra))
+        for k, v in state_dict.items():
+            if k in self.ema:
+                self.ema[k].copy_(v.to(self.device))
+
+    @torch.no_grad()
+    def modify_to_inference(self):
+        """Put the averaged weights into the live model (keeping a copy of the live ones for modify_to_train)."""
+        tgt = self._target()
+        self.cur = {k: v.detach().clone().to(self.device) for k, v in tgt.state_dict().items()}
+        tgt.load_state_dict({k: v.to(_model_device(tgt)) for k, v in self.ema.items()})
+        _invalidate(tgt)
+
+    @torch.no_grad()
+    def modify_to_train(self):
+        tgt = self._target()
+        tgt.load_state_dict({k: v.to(_model_device(tgt)) for k, v in self.cur.items()})
+        _invalidate(tgt)
+
+
+def _model_device(m):
+    d = getattr(m, "device", None)
+    if isinstance(d, torch.device):
+        return d
+    return next(iter(m.state_dict().values())).device
+
+
+def _invalidate(m):
+    """Weight packs cached by the HIP modules (split fp16 planes, AdaLN tables) are stale after a weight swap."""
+    for sub in m.modules():
+        if hasattr(sub, "_packed"):
+            sub._packed = None
+
+
+class Solver:
+    """One training iteration in the reference's order (engine/solver_spec.py:308-331).  `train_step` supplies
+    `loss_and_grads(*batch) -> (loss, {name: grad})` and `adamw_step(grads, state, step, lr, betas, eps, weight_decay)`
+    -- `modeling.train.TrainStep` on the GPU; the gradients are averaged over the data-parallel ranks (bucketed RCCL
+    all-reduce, shard.allreduce_gradients) before clipping, which is where DDP's reduction lands too."""
+
+    def __init__(self, train_step, lr=3.0e-6, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, scheduler=None,
+                 clip_grad_norm=None, ema=None, allreduce=None):
+        self.train_step, self.lr = train_step, float(lr)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.scheduler, self.clip_grad_norm, self.ema, self.allreduce = scheduler, clip_grad_norm, ema, allreduce
+        self.opt_state = {}
+        self.last_iter = -1
+
+    def step(self, *batch):
+        loss, grads = self.train_step.loss_and_grads(*batch)
+        if self.allreduce is not None:
+            self.allreduce(grads)
+        total = self.clip_grad_norm(grads) if self.clip_grad_norm is not None else None
+        self.last_iter += 1
+        self.train_step.adamw_step(grads, self.opt_state, self.last_iter + 1, self.lr, betas=self.betas, eps=self.eps,
+                                   weight_decay=self.weight_decay)
+        if self.scheduler is not None:
+            self.lr = self.scheduler.step(loss)
+        if self.ema is not None:
+            self.ema.update(iteration=self.last_iter)
+        return {"loss": loss, "lr": self.lr, "grad_norm": total}
+
+    def state_dict(self):
+        out = {"last_iter": self.last_iter, "lr": self.lr, "optimizer": self.opt_state}
+        if self.scheduler is not None:
+            out["scheduler"] = self.scheduler.state_dict()
+        if self.clip_grad_norm is not None:
+            out["clip_grad_norm"] = self.clip_grad_norm.state_dict()
+        if self.ema is not None:
+            out["ema"] = self.ema.state_dict()
+        return out
+
+    def load_state_dict(self, state):
+        self.last_iter, self.lr, self.opt_state = state["last_iter"], state["lr"], state["optimizer"]
+        if self.scheduler is not None and "scheduler" in state:
+            self.scheduler.load_state_dict(state["scheduler"])
+        if self.clip_grad_norm is not None and "clip_grad_norm" in state:
+            self.clip_grad_norm.load_state_dict(state["clip_grad_norm"])
+        if self.ema is not None and "ema" in state:
+            self.ema.load_state_dict(state["ema"])
