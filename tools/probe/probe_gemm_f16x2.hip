@@ -314,6 +314,176 @@ __global__ __launch_bounds__(256, 1) void sp_kernel(const _Float16* A, long long
     }
 }
 
+
+// ---- big-tile variant (round-2 candidate): ONE workgroup per CU of WGM x WGN waves, BM x BN tile, ring of NS stages,
+// LDS-DMA issued NS-1 tiles ahead with a counted vmcnt.  Motivation (profiles/README.md, limiter analysis): at 128x128
+// the loop moves 341 B L2->LDS and 683 B LDS->VGPR per MFMA; MFMA-only and DMA-only loops each take ~2/3 of the full
+// loop's time and overlap poorly.  256x256 (8 waves of 128x64) halves the DMA bytes and cuts the fragment reads by a
+// quarter per MFMA, and a k-tile's MFMAs (1536 cycles per wave) outlast the DMA latency; 256x128 with three stages keeps
+// two tiles in flight.  Same packed operands, same MFMA order per accumulator -> results are bit-identical to probe_kernel.
+template <int BM, int BN, int WGM, int WGN, int NS, int GM, int SCHED = 0>
+__global__ __launch_bounds__(WGM * WGN * 64, 1) void big_kernel(const _Float16* A, long long a_plane, const _Float16* W,
+                                                                 long long w_plane, float* C, int M, int N, int K,
+                                                                 unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NW = WGM * WGN;
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+    constexpr int APL = BM * HLD, BPL = BN * HLD, STAGE = 2 * (APL + BPL);   // halves
+    constexpr int G = 2 * (BM + BN) / 16 / NW;                                // DMA instructions per wave per k-tile
+    static_assert(G * NW * 16 == 2 * (BM + BN), "16-row groups must divide over the waves");
+    static_assert(BM % (WGM * 32) == 0 && BN % (WGN * 32) == 0, "wave tiles of 32x32 blocks");
+    _Float16* smem = (_Float16*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tiles_n = (N + BN - 1) / BN, nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm_, tn_;
+    {
+        const int tiles_m = (M + BM - 1) / BM;
+        const int per = GM * tiles_n, grp = bid / per, first = grp * GM;
+        const int gsz = tiles_m - first < GM ? tiles_m - first : GM;
+        const int in = bid - grp * per;
+        tm_ = first + in % gsz;
+        tn_ = in / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    const int nk = K / HBK;
+    const _Float16* src[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        int r = 16 * (wave + NW * i);
+        const _Float16* base;
+        int rg, rgs;
+        if (r < 2 * BM) { base = A; if (r >= BM) { r -= BM; base += a_plane; } rg = (m0 + r) >> 4; rgs = (M + 15) >> 4; }
+        else { r -= 2 * BM; base = W; if (r >= BN) { r -= BN; base += w_plane; } rg = (n0 + r) >> 4; rgs = (N + 15) >> 4; }
+        if (rg >= rgs) rg = rgs - 1;
+        src[i] = base + (size_t)rg * nk * 512 + lane * 8;
+    }
+#define BG_DMA(stage_, tile_)                                                                         \
+    do {                                                                                              \
+        unsigned char* d_ = smem_raw + (stage_) * (STAGE * 2) + wave * 1024;                          \
+        _Pragma("unroll") for (int i = 0; i < G; ++i)                                                 \
+            __builtin_amdgcn_global_load_lds((gptr)(src[i] + (size_t)(tile_) * 512), (lptr)(d_ + i * NW * 1024), 16, 0, 0); \
+    } while (0)
+    const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // prologue: tiles 0 .. NS-2 in flight
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) BG_DMA(t, t);
+    int cur = 0, nxt = NS - 1;       // stage of tile kt, stage that receives tile kt + NS - 1
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt landed: at most the G (NS-2) younger instructions of this wave may still be in flight
+        if (kt + NS - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();             // ... for every wave, and stage `nxt` (tile kt-1) is free
+        if (kt + NS - 1 < nk) BG_DMA(nxt, kt + NS - 1);
+        const _Float16* Ac = smem + cur * STAGE + (wm * TM * 32 + l31) * HLD;
+        const _Float16* Bc = smem + cur * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD;
+        h8 fa0[2][TM], fa1[2][TM], fb0[2][TN], fb1[2][TN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fa0[ks][i] = *(const h8*)(Ac + i * 32 * HLD + swz[ks]);
+                fa1[ks][i] = *(const h8*)(Ac + APL + i * 32 * HLD + swz[ks]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fb0[ks][j] = *(const h8*)(Bc + j * 32 * HLD + swz[ks]);
+                fb1[ks][j] = *(const h8*)(Bc + BPL + j * 32 * HLD + swz[ks]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[ks][i], fb0[ks][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb1[ks][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb0[ks][j], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        if (SCHED == 0) {            // k-step 0 fragments, its MFMAs, k-step 1 fragments (same registers), its MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM * TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM * TN, 0);
+        } else if (SCHED == 1) {     // all fragments first (two register sets), like the product kernel
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);
+        } else {                     // k-step 1 fragments issued one third into k-step 0's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 5 * TM * TN, 0);
+        }
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    if (tid == 0 && clk) {
+        clk[2 * blockIdx.x] = __builtin_readcyclecounter() - t0;
+        clk[2 * blockIdx.x + 1] = wall_clock64() - w0;
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NS, int GM, int SCHED = 0>
+static void run_big(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
+                    unsigned long long* clk) {
+    const size_t lds = (size_t)NS * 2 * (BM + BN) * HLD * 2;
+    hipFuncSetAttribute((const void*)big_kernel<BM, BN, WGM, WGN, NS, GM, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nt = WGM * WGN * 64;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i)
+        hipLaunchKernelGGL((big_kernel<BM, BN, WGM, WGN, NS, GM, SCHED>), dim3(tiles), dim3(nt), lds, 0, A, (long long)M * K, W,
+                           (long long)N * K, C, M, N, K, clk);
+    const int reps = 30;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL((big_kernel<BM, BN, WGM, WGN, NS, GM, SCHED>), dim3(tiles), dim3(nt), lds, 0, A, (long long)M * K, W,
+                           (long long)N * K, C, M, N, K, clk);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) printf("  launch error: %s\n", hipGetErrorString(err));
+    std::vector<unsigned long long> h(2 * tiles);
+    hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, wall = 0;
+    for (int i = 0; i < tiles; ++i) { cyc += h[2 * i]; wall += h[2 * i + 1]; }
+    const double us = ms * 1e3 / reps;
+    printf("%-26s NS%d GM%-2d %dx%d %dw  M=%d N=%d K=%d: %8.1f us  %6.1f TF-eq  clock %.2f GHz  block life %.0f cyc  (%d tiles = %.2f rounds)\n",
+           name, NS, GM, BM, BN, WGM * WGN, M, N, K, us, 2.0 * M * N * K / us / 1e6, cyc / wall * 0.1, cyc / tiles, tiles,
+           tiles / 256.0);
+    fflush(stdout);
+}
+
 template <int NS, int GM>
 static void run_sp(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
                    unsigned long long* clk) {
@@ -403,13 +573,34 @@ int main() {
     hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     float* C2; hipMalloc(&C2, (size_t)M * Nmax * 4);
     std::vector<float> c1((size_t)M * 1024), c2((size_t)M * 1024);
-#define QCASE(MM, N, K) run<128, 128, 16, 2, 8>("packed 2-stage occ2", A, W, C, MM, N, K, clk);
-    QCASE(16960, 1024, 1024)
+    auto differ = [&](float* X, float* Y, int MM, int N) {
+        hipDeviceSynchronize();
+        const size_t n = (size_t)MM * N;
+        std::vector<float> x(n), y(n);
+        hipMemcpy(x.data(), X, n * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(y.data(), Y, n * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (size_t i = 0; i < n; ++i) bad += (x[i] != y[i]);
+        if (bad) printf("  outputs differ at %zu of %zu elements\n", bad, n);
+    };
+#define QCASE(MM, N, K)                                                                             \
+    run<128, 128, 16, 2, 8>("packed 2-stage occ2", A, W, C, MM, N, K, clk);                         \
+    run_big<256, 256, 2, 4, 2, 4>("big 256x256 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<256, 256, 4, 2, 2, 4>("big 256x256 8w (4x2)", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<256, 256, 2, 4, 2, 4, 1>("big 256x256 8w sched1", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<256, 256, 2, 4, 2, 4, 2>("big 256x256 8w sched2", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<256, 128, 4, 2, 3, 8, 1>("big 256x128 8w sched1", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<256, 128, 4, 2, 3, 8>("big 256x128 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<256, 128, 4, 2, 2, 8>("big 256x128 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<128, 256, 2, 4, 3, 8>("big 128x256 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<256, 128, 2, 2, 3, 8>("big 256x128 4w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_big<128, 128, 2, 2, 4, 8>("big 128x128 4w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);
+    // M = 16384 = whole rounds for every tile (what a balanced launch would give the big tiles), 16960 = the real shape
     QCASE(16384, 1024, 1024)
-    QCASE(16960, 1024, 4096)
-    QCASE(16384, 1024, 4096)
-    QCASE(16960, 3072, 1024)
     QCASE(16384, 3072, 1024)
-    QCASE(32768, 1024, 1024)
+    QCASE(16384, 4096, 1024)
+    QCASE(16384, 1024, 4096)
+    QCASE(16960, 1024, 1024)
+    QCASE(16960, 3072, 1024)
     return 0;
 }
