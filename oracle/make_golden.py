@@ -270,8 +270,32 @@ def solver_schedule():
          b_final=net.bias.detach(), ema_w=es["weight"], ema_b=es["bias"])
 
 
+def dalle_sample():
+    """DALLE.sample (the trainer's logging sampler, dalle_spec.py:264-343) on the T=10 two-layer model with the VQ
+    encoder: reconstruction + re-sampling at filter_ratio 0 / 0.5 / 1.0 from the batch's own tokens.  The caption
+    conditioning is injected as an embedding (prepare_condition stubbed: CLIP is pinned separately)."""
+    torch.manual_seed(0)
+    m = rh.build_dalle(n_layer=2, diffusion_step=10, n_embed=256, with_encoder=True)
+    mel = synth.synth_uniform((2, 1, 80, 848), key="enc.mel") * 2 - 1
+    cond = synth.synth_cond_emb(2, key="traj.cond")
+    m.prepare_condition = lambda batch, condition=None: {"condition_token": None, "condition_embed_token": cond}
+    n = [0]
+
+    def noise(shp):
+        n[0] += 1
+        return synth.synth_uniform(shp, key="ds.u%d" % (n[0] - 1))
+    with InjectNoise(noise):
+        out = m.sample({"image": mel, "text": ["a", "b"]}, filter_ratio=[0, 0.5, 1.0], content_ratio=[1], batch_size=2)
+    s = slice(None, None, 7)
+    save("dalle_sample_T10_L2", calls=torch.tensor(n[0]), time_stride=torch.tensor(7),
+         reconstruction=out["reconstruction_image"][..., s], fr0=out["cond1_cont1_fr0_image"][..., s],
+         fr05=out["cond1_cont1_fr0.5_image"][..., s], fr1=out["cond1_cont1_fr1.0_image"][..., s])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--dsample-only" in sys.argv:
+        return dalle_sample()
     if "--solver-only" in sys.argv:
         return solver_schedule()
     if "--text-only" in sys.argv:
@@ -367,6 +391,7 @@ def main():
     codebook512()
     train_loss()
     solver_schedule()
+    dalle_sample()
     print("done in %.1fs" % (time.time() - t0))
 
 

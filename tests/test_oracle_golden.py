@@ -259,3 +259,31 @@ def test_vocoder(sd_vocoder):
     ref = golden("vocoder")["wave"]
     assert wave.shape == ref.shape == (1, 1, 217088)
     assert (wave - ref).abs().max() < 1e-5
+
+
+def test_dalle_sample_logging_sampler_vs_reference(sd_dalle_l2, sd_encoder):
+    """DALLE.sample (dalle_spec.py:264-343): reconstruction and re-sampling at filter_ratio 0 / 0.5 / 1.0, composed from
+    the oracle's pieces and compared with the reference's images.  The re-sampling starts from the reference's own
+    tokens (the synthetic codebook has rounding-level ties in the nearest-code search, tested separately above); no
+    truncation wrapper is installed in this entry point."""
+    g, ge = golden("dalle_sample_T10_L2"), golden("encoder_T10_L2")
+    sd = dict(sd_dalle_l2)
+    sd.update(sd_encoder)
+    cond = synth.synth_cond_emb(2, key="traj.cond")
+    tokens = ge["tokens"]
+    n = [0]
+
+    def noise(_, shp):
+        n[0] += 1
+        return synth.synth_uniform(shp, key="ds.u%d" % (n[0] - 1))
+    s = slice(None, None, int(g["time_stride"]))
+    outs = {"reconstruction": tokens,
+            "fr0": O.sample_loop(sd_dalle_l2, cond, noise, num_timesteps=10, trunc_r=None),
+            "fr05": O.sample_loop_partial(sd_dalle_l2, cond, tokens, 0.5, noise, num_timesteps=10, trunc_r=None),
+            "fr1": O.sample_loop_partial(sd_dalle_l2, cond, tokens, 1.0, noise, num_timesteps=10, trunc_r=None)}
+    assert n[0] == int(g["calls"]) == 27
+    for name, tok in outs.items():
+        img = O.decode_tokens(sd, tok)
+        assert img.shape == (2, 1, 80, 848)
+        assert (img[..., s] - g[name]).abs().max() < 1e-4, name
+

@@ -2,10 +2,10 @@
 
 generate_content() keeps the reference's keyword signature and `sample_type` mini-language
 (:179-247): "top{r}r" installs top-r truncation -- natively, as a kernel argument, instead of the
-reference's monkey-patched predict_start wrapper (:208-210).  Text tokenisation + the CLIP text
-encoder are the next scope row; until then the caption conditioning enters as
-`condition_embed_token` f32[B, 77, 512] (what CLIPTextEmbedding.forward returns), either in `batch`
-or as `condition=`.
+reference's monkey-patched predict_start wrapper (:208-210).  The caption conditioning is either text
+(`batch['text']`: BPE tokenizer + the HIP CLIP text tower, when the config builds them), already tokenised
+captions (`condition_token` i64[B, 77]) or the embedding itself (`condition_embed_token` f32[B, 77, 512], what
+CLIPTextEmbedding.forward returns), in `batch` or as `condition=`.
 """
 import torch
 from torch import nn
@@ -32,7 +32,6 @@ class DALLE(nn.Module):
     def get_ema_model(self):
         return self.transformer
 
-    @torch.no_grad()
     @torch.no_grad()
     def get_tokens(self, spec):
         """mel image [B, 1, 80, 848] -> (quant_z, token ids [B, 265] in sequence order) (dalle_spec.py:70-77)."""
@@ -88,8 +87,8 @@ class DALLE(nn.Module):
                 cond["condition_" + k] = v.to(self.device) if torch.is_tensor(v) else v
         else:
             raise NotImplementedError(
-                "text -> CLIP embedding is the next scope row (SURVEY.md section 8f-1); pass "
-                "batch={'condition_embed_token': f32[B,77,512]}")
+                "this model was built without a text codec (condition_codec_config = None): pass "
+                "batch={'condition_embed_token': f32[B,77,512]} or {'condition_token': i64[B,77]}")
         return cond
 
     @torch.no_grad()
@@ -127,3 +126,43 @@ class DALLE(nn.Module):
         content = self.decode_to_img(tokens, zshape)
         self.train()
         return {"content": content, "content_token": tokens}
+
+    @torch.no_grad()
+    def sample(self, batch, clip=None, temperature=1., return_rec=True, filter_ratio=[0, 0.5, 1.0], content_ratio=[1],
+               return_att_weight=False, return_logits=False, sample_type="normal", **kwargs):
+        """The trainer's logging sampler (dalle_spec.py:264-343): encode the batch's mel to tokens, optionally decode
+        them back ('reconstruction_image'), and for every filter_ratio fr re-sample from those tokens diffused to
+        t = int(T * fr) - 1 (fr = 0: from the all-[MASK] state) -> 'cond1_cont{cr}_fr{fr}_image'.  Only
+        content_ratio = 1 is meaningful for the fixed 265-token grid (the reference slices the token sequence, which
+        its own q_sample cannot take either)."""
+        if return_att_weight:
+            raise NotImplementedError("attention weights are never materialised on the HIP path")
+        if sample_type == "debug":
+            raise NotImplementedError("sample_debug is not part of the sound pipeline")
+        self.eval()
+        condition = self.prepare_condition(batch)
+        content = self.prepare_content(batch)
+        out = {"input_image": batch[self.content_info["key"]]}
+        zshape = content["content_quant"].shape
+        if return_rec:
+            out["reconstruction_image"] = self.decode_to_img(content["content_token"], zshape)
+        for fr in filter_ratio:
+            for cr in content_ratio:
+                n_tok = int(content["content_token"].shape[1] * cr)
+                if n_tok < 0:
+                    continue
+                if n_tok != content["content_token"].shape[1] and int(self.transformer.num_timesteps * fr) > 0:
+                    raise ValueError("content_ratio < 1 cannot be re-sampled: q_sample needs the whole token grid")
+                trans_out = self.transformer.sample(
+                    condition_token=condition.get("condition_token"), condition_mask=condition.get("condition_mask"),
+                    condition_embed=condition.get("condition_embed_token"), content_token=content["content_token"][:, :n_tok],
+                    filter_ratio=fr, temperature=temperature, return_att_weight=False, return_logits=return_logits,
+                    content_logits=None, sample_type=sample_type, **kwargs)
+                out["cond1_cont{}_fr{}_image".format(cr, fr)] = self.decode_to_img(trans_out["content_token"], zshape)
+                if return_logits:
+                    out["logits"] = trans_out["logits"]
+        self.train()
+        res = {"condition": batch.get(self.condition_info["key"])}
+        res.update(out)
+        return res
+

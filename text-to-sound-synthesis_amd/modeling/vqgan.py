@@ -462,6 +462,20 @@ class VQModel(nn.Module):
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
     @torch.no_grad()
+    def forward(self, input):
+        """mel -> (reconstruction, codebook loss) (spec_codec/vqgan.py:72-75)"""
+        quant, diff, _ = self.encode(input)
+        return self.decode(quant), diff
+
+    @staticmethod
+    def get_input(batch, k):
+        """batch[k] [B, H, W] or [B, H, W, C] -> f32[B, C, H, W] (spec_codec/vqgan.py:77-82)"""
+        x = batch[k]
+        if x.dim() == 3:
+            x = x[..., None]
+        return x.permute(0, 3, 1, 2).contiguous().float()
+
+    @torch.no_grad()
     def decode_tokens(self, tokens, H=5, W=53):
         """tokens i64[B, H*W] in sequence (column-major) order -> mel; fuses DALLE.decode_to_img's
         permuter + codebook lookup (dalle_spec.py:80-91) with decode()."""
