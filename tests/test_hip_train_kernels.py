@@ -147,6 +147,8 @@ def test_training_step_gradients_vs_oracle_autograd():
     loss, grads = step.loss_and_grads(x0.cuda(), cond.cuda(), t.cuda(), pt.cuda(), u.cuda())
     print("loss %.6f (oracle %.6f, reference %.6f)" % (loss.item(), loss_ref.item(), float(g["loss"])))
     assert abs(loss.item() - float(g["loss"])) < 2e-4 * float(g["loss"])
+    assert torch.allclose(dt.Lt_history.cpu(), g["Lt_history"], rtol=5e-4, atol=1e-6)     # importance-sampling statistics
+    assert torch.equal(dt.Lt_count.cpu(), g["Lt_count"])
     worst, missing = [], []
     for k, v in sd.items():
         if not (k.startswith("transformer.transformer.") and v.is_floating_point() and v.grad is not None):

@@ -198,6 +198,9 @@ class TrainStep:
         weight = mask_region * dt.mask_weight[0] + (1.0 - mask_region) * dt.mask_weight[1]
         is0 = (t == 0).float()
         kl_loss = is0 * nll.sum(-1) + (1.0 - is0) * (kl * weight).sum(-1)
+        lt2 = kl_loss.pow(2)                         # importance-sampling statistics of sample_time (:452-455)
+        dt.Lt_history.scatter_(dim=0, index=t, src=(0.1 * lt2 + 0.9 * dt.Lt_history.gather(dim=0, index=t)))
+        dt.Lt_count.scatter_add_(dim=0, index=t, src=torch.ones_like(lt2))
         vb = kl_loss / pt
         if dt.auxiliary_loss_weight != 0:
             wa = t.float() / T + 1.0 if dt.adaptive_auxiliary_loss else 1.0

@@ -1,0 +1,124 @@
+"""Training-iteration timer for BASELINE.json configs[4] / SURVEY.md section 8d row 5 (NOT the driver's bench: that is
+bench.py at the repo root).  One iteration = DALLE-side training step of the denoiser on an AudioCaps-shaped synthetic
+batch: q_sample -> 19-layer forward keeping activations -> loss -> hand-written backward -> (bucketed RCCL all-reduce)
+-> global-norm clip -> AdamW -> LR schedule -> EMA, i.e. modeling/solver.py: Solver.step on modeling/train.py: TrainStep.
+
+  python tools/bench_train.py --batch 20 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py ...
+
+Prints one JSON line on rank 0: iterations/s, samples/s (whole job), ms per phase (loss+gradients / all-reduce / update).
+The training step is the exact-fp32, untuned first version: this tool exists to measure it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=20, help="samples per GPU (configs/caps.yaml:136)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-layer", type=int, default=19)
+    ap.add_argument("--codes", type=int, default=256)
+    ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from text_to_sound_synthesis_amd import shard, synth
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.solver import EMA, GradClipWindow, PlateauWarmupLR, Solver
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+
+    m = build_model(default_config(n_layer=args.n_layer, diffusion_step=100, n_embed=args.codes))
+    synth.synth_init_(m, seed=0)
+    m = m.to(dev).eval()
+    dt = m.transformer
+    dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]   # configs/caps.yaml
+    B, K1, L = args.batch, args.codes + 1, 265
+    x0 = synth.synth_tokens(B, L, args.codes, mask_frac=0.0, key="bt.x0.%d" % rank).to(dev)
+    cond = synth.synth_cond_emb(B, key="bt.c.%d" % rank).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    times = {"grads": 0.0, "allreduce": 0.0, "update": 0.0}
+    timing = [False]
+
+    def timed_allreduce(grads):
+        if timing[0]:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        shard.allreduce_gradients(grads)
+        if timing[0]:
+            torch.cuda.synchronize()
+            times["allreduce"] += time.perf_counter() - t0
+
+    class Timed(TrainStep):
+        def loss_and_grads(self, *a):
+            if timing[0]:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            out = super().loss_and_grads(*a)
+            if timing[0]:
+                torch.cuda.synchronize()
+                times["grads"] += time.perf_counter() - t0
+            return out
+
+    solver = Solver(Timed(dt), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+                    scheduler=PlateauWarmupLR(3.0e-6, factor=0.5, patience=25000, min_lr=1.0e-6, threshold=1.0e-1,
+                                              warmup_lr=4.5e-4, warmup=1000),
+                    clip_grad_norm=GradClipWindow(0, 5000, 0.5),
+                    ema=EMA(dt, decay=0.99, update_interval=25, device=args.ema_device),
+                    allreduce=timed_allreduce if world > 1 else None)
+
+    def one():
+        t, pt = dt.sample_time(B, dev, "importance")
+        u = torch.rand((B, K1, L), device=dev, generator=gen)
+        return solver.step(x0, cond, t, pt, u)
+
+    for _ in range(args.warmup):
+        out = one()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timing[0] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = el.item()
+    times["update"] = el - times["grads"] - times["allreduce"]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training iterations/s (denoiser step: loss + backward + clip + AdamW + EMA)", "value": args.steps / el,
+            "unit": "it/s", "samples_per_s": args.steps * B * world / el, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "dtype": "f32", "data": "synthetic",
+            "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
+            "ms": {k: 1e3 * v / args.steps for k, v in times.items()},
+            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "config": {"workload": "BASELINE configs[4]: training step, B=%d per GPU, %d layers, K=%d" % (B, args.n_layer, args.codes),
+                       "parallelism": "dp%d" % world}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
