@@ -87,10 +87,16 @@ int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
    affine + swish; bias, residual, row store) in the same fp32-class 3-pass formulation: A fp32, W = the two fp16
    planes [N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart), out_scale = 2^-s */
 int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
+/* cfg: -1 automatic (default); 0 = 128x128 (balanced launch for packed operands), 1 = 128x64, 2 = 64x64 tiles of one
+   4-wave workgroup; 3 = 256x256, 4 = 256x128 (3-stage ring), 6 = 128x256 (3-stage ring) tiles of one 8-wave workgroup
+   per CU -- the big-tile candidates, packed operands only (others fall back to 0), same bits as every other cfg. */
 void ds_gemm_f16x2_force_tile(int cfg);
 /* packed-operand launches that pick the 128x128 tile are balanced: 128x128 tiles over the leading rows that fill
    whole rounds of `slots` resident workgroups (default 512 = 256 CUs x 2), 64x64 tiles over the rest.  Test hook. */
 void ds_gemm_f16x2_set_balance_slots(int slots);
+/* the same balance unit for the big-tile launches (default 256 = one workgroup per CU); rows past the last whole
+   round go to 8-wave 128x128 tiles in the same grid.  Test hook. */
+void ds_gemm_f16x2_set_big_slots(int slots);
 
 /* ---- row kernels of the denoiser -------------------------------------------------------------- */
 /* DalleMaskImageEmbedding.forward, sound_synthesis/modeling/embeddings/dalle_mask_image_embedding.py:36-58

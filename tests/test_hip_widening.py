@@ -66,3 +66,103 @@ def test_vqmodel_forward_is_decode_of_encode():
     assert dec.shape == (2, 1, 80, 848) and torch.equal(dec, codec.decode(quant)) and torch.equal(diff, loss)
     x = codec.get_input({"image": mel[:, 0]}, "image")
     assert x.shape == (2, 1, 80, 848) and torch.equal(x, mel)
+
+
+# ---- big-tile candidates of the split GEMM (8-wave workgroups, ds_gemm_f16x2_force_tile 3 / 4 / 6) ------------------
+BIG_TILES = (3, 4, 6)
+
+
+@pytest.mark.parametrize("M,N,K", [(4240, 4096, 1024), (4240, 1024, 4096), (2100, 1024, 1024), (700, 256, 1024),
+                                   (300, 96, 64)])
+def test_f16x2_big_tiles_bit_identical(M, N, K):
+    """256x256 / 256x128 / 128x256 tiles of one 8-wave workgroup (slab-staged epilogues, three-stage DMA ring) and their
+    balanced launch with an 8-wave 128x128 tail program: same bits as the loader-split 4-wave GEMM, for row-major
+    output with residual and for packed split output with GELU2; several balance units so that every shape runs with
+    and without a tail program."""
+    from test_hip_split_gemm import relerr, rnd, torch_split
+    from text_to_sound_synthesis_amd import _lib as L
+    A, W, b, R = rnd((M, K), "bg.A", 2.0).cuda(), rnd((N, K), "bg.W", 0.05).cuda(), rnd((N,), "bg.b").cuda(), \
+        rnd((M, N), "bg.R").cuda()
+    W2, sc = L.split_f16x2(W)
+    W2p, _ = L.split_f16x2(W, packed=True)
+    A2p = L.pack_planes(torch_split(A))
+    M16 = (M + 15) // 16 * 16
+    ref = torch.empty(M, N, device="cuda")
+    L.gemm(A, W2, ref, M, N, K, bias=b, R=R, split2=sc)
+    assert relerr((ref - R).cpu(), (A.double() @ W.double().t() + b.double()).float().cpu()) < 2e-6
+    refg = torch.empty(M, N, device="cuda")
+    L.gemm(A, W2, refg, M, N, K, bias=b, act=L.ACT_GELU2, split2=sc)
+    try:
+        for tile in BIG_TILES:
+            for slots in (256, 8, 1):
+                L.lib().ds_gemm_f16x2_force_tile(tile)
+                L.lib().ds_gemm_f16x2_set_big_slots(slots)
+                for rep in range(2):
+                    out = torch.full((M, N), float("nan"), device="cuda")
+                    L.gemm(A2p, W2p, out, M, N, K, bias=b, R=R, split2=sc, a_plane=M16 * K)
+                    assert torch.equal(out, ref), "tile %d slots %d" % (tile, slots)
+                if N % 32 == 0:
+                    outs = torch.zeros(2, M16 * N, device="cuda", dtype=torch.float16)
+                    L.gemm(A2p, W2p, outs, M, N, K, bias=b, act=L.ACT_GELU2, split2=sc, a_plane=M16 * K, c_plane=M16 * N)
+                    assert torch.equal(L.unpack_planes(outs, M, N), torch_split(refg)), "packed, tile %d slots %d" % (tile, slots)
+    finally:
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+        L.lib().ds_gemm_f16x2_set_big_slots(256)
+
+
+@pytest.mark.parametrize("B", [3, 8])
+def test_f16x2_big_tiles_attention_store_bit_identical(B):
+    """The attention-ready QKV store (Q planes, K image, V^T image) through the big tiles: slabs of 128 or 256 rows
+    crossing sample boundaries, with and without the tail program."""
+    from test_hip_split_gemm import rnd, torch_split
+    from text_to_sound_synthesis_amd import _lib as L
+    Lq, H, D = 265, 16, 1024
+    M, N, K = B * Lq, 3 * D, D
+    A, W, b = rnd((M, K), "ba.A", 2.0).cuda(), rnd((N, K), "ba.W", 0.05).cuda(), rnd((N,), "ba.b").cuda()
+    W2p, sc = L.split_f16x2(W, packed=True)
+    A2p = L.pack_planes(torch_split(A))
+    M16 = (M + 15) // 16 * 16
+
+    def run():
+        qh = torch.full((2, B, H, Lq, 64), float("nan"), device="cuda", dtype=torch.float16)
+        img = torch.zeros(B, H, 4, 288 * 64, device="cuda", dtype=torch.float16)
+        L.gemm(A2p, W2p, qh, M, N, K, bias=b, split2=sc, a_plane=M16 * K, store=L.STORE_ATTN, rows_per_sample=Lq,
+               attn=(img, H, 288, B * H * Lq * 64))
+        return qh, img
+    q_ref, img_ref = run()                                   # default launch (tested against the host packing elsewhere)
+    try:
+        for tile in BIG_TILES:
+            for slots in (256, 4, 1):
+                L.lib().ds_gemm_f16x2_force_tile(tile)
+                L.lib().ds_gemm_f16x2_set_big_slots(slots)
+                qh, img = run()
+                assert torch.equal(qh, q_ref) and torch.equal(img, img_ref), "tile %d slots %d" % (tile, slots)
+    finally:
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+        L.lib().ds_gemm_f16x2_set_big_slots(256)
+
+
+def test_denoiser_step_with_big_tiles_gives_the_same_tokens():
+    """A whole sampling step of the 19-layer denoiser at B = 8 with every GEMM forced onto a big tile: tokens equal the
+    default launch's."""
+    from test_hip_split_gemm import build
+    from text_to_sound_synthesis_amd import _lib as L
+    m = build(19, mode="f16x2")
+    dt = m.transformer
+    dt.truncation_r = 0.85
+    B = 8
+    cond = synth.synth_cond_emb(B, key="bt.cond").cuda()
+    x = synth.synth_tokens(B, mask_frac=0.6, key="bt.x").cuda()
+    t = torch.full((B,), 41, device="cuda", dtype=torch.long)
+    u = synth.synth_uniform((B, 257, 265), key="bt.u").cuda()
+    kv = dt.transformer.condition_kv(cond, dt._schedule_table())
+    want = dt.p_sample_tokens(x, kv, t, u, False).clone()
+    try:
+        for tile in BIG_TILES:
+            L.lib().ds_gemm_f16x2_force_tile(tile)
+            L.lib().ds_gemm_f16x2_set_big_slots(4)
+            got = dt.p_sample_tokens(x, kv, t, u, False)
+            assert torch.equal(got, want), "tile %d" % tile
+    finally:
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+        L.lib().ds_gemm_f16x2_set_big_slots(256)

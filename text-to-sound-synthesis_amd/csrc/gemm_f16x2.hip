@@ -41,11 +41,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* ds_gptr;
 typedef __attribute__((address_space(3))) void* ds_lptr;
 
-// the whole workgroup program for output tile `bid` of `nblk` (both as launched; remapped below)
-template <int BM, int BN, int AMODE>
+// the whole workgroup program for output tile `bid` of `nblk` (both as launched; remapped below).
+// WGM x WGN waves (default 2 x 2 = 256 threads); NS = LDS stages of the AMODE 2 ring (2: one tile in flight;
+// 3: two tiles in flight, counted vmcnt).  The 8-wave instantiations are the big-tile candidates of DESIGN.md
+// section 3 (opt-in through ds_gemm_f16x2_force_tile until measured).
+template <int BM, int BN, int AMODE, int WGM = 2, int WGN = 2, int NS = 2>
 __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid, const int nblk,
                                                    unsigned char* smem_raw) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int NW = WGM * WGN, NT = NW * 64;
+    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+    static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave tiles are made of 32x32 blocks");
+    static_assert(AMODE == 2 || (NT == 256 && NS == 2), "register staging is written for 256 threads, two stages");
     constexpr int SA = BM / 64;   // 8-element (2 x float4) staging chunks per thread (A)
     constexpr int SB = BN / 64;   // 16-byte staging chunks per thread per plane (B)
     constexpr int APL = BM * HLD, BPL = BN * HLD;       // plane strides (halves)
@@ -55,7 +61,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     const int tiles_n = (p.N + BN - 1) / BN;
     {
@@ -203,12 +209,13 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     if constexpr (AMODE == 2) {
         // LDS image of a stage = 2*(BM+BN) rows of 64 B: A hi rows, A lo rows, B hi rows, B lo rows.  One DMA
         // instruction of a wave fills 16 consecutive rows = one packed 16-row x 32-k tile (lane l -> bytes 16 l);
-        // the wave owns the 16-row groups g = wave + 4 i.
-        constexpr int G = (BM + BN) / 32;
+        // the wave owns the 16-row groups g = wave + NW i.
+        constexpr int G = 2 * (BM + BN) / 16 / NW;
+        static_assert(G * NW * 16 == 2 * (BM + BN), "16-row groups must divide over the waves");
         const _Float16* src[G];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            int r = 16 * (wave + 4 * i);                     // first row of the group within the stage image
+            int r = 16 * (wave + NW * i);                    // first row of the group within the stage image
             const _Float16* base;
             int rg, rgs;
             if (r < 2 * BM) {
@@ -228,7 +235,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     do {                                                                                            \
         unsigned char* d_ = smem_raw + (stage_) * (STAGE * 2) + wave * 1024;                        \
         _Pragma("unroll") for (int i = 0; i < G; ++i)                                               \
-            __builtin_amdgcn_global_load_lds((ds_gptr)(src[i] + (k0_)), (ds_lptr)(d_ + i * 4096), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((ds_gptr)(src[i] + (k0_)), (ds_lptr)(d_ + i * (NW * 1024)), 16, 0, 0); \
     } while (0)
         // all 4 (TM + TN) fragment reads of the k-tile are issued back to back, then its 6 TM TN MFMAs: the LDS
         // latency is paid once per tile and the other resident workgroups' MFMAs fill it
@@ -256,10 +263,34 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb0[ks][j], c, 0, 0, 0); \
                     acc[i][j] = c;                                                                  \
                 }                                                                                   \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0); /* DS reads */               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);   /* MFMA */                   \
+        if (TM * TN <= 4) {                                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0); /* DS reads */           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);   /* MFMA */               \
+        } else { /* big wave tiles: one fragment register set, k-step by k-step (VGPR budget) */    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM * TN, 0);                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM * TN, 0);                            \
+        }                                                                                           \
     } while (0)
         static_assert(HBK == 32, "two 16-wide k-steps per tile");
+        if constexpr (NS > 2) {
+            // ring of NS stages, NS-1 tiles in flight: tile kt has landed once at most the G (NS-2) younger DMA
+            // instructions of this wave are outstanding (vmcnt counts in issue order)
+#pragma unroll
+            for (int t = 0; t < NS - 1; ++t)
+                if (t < nk) H_DMA(t, t * 512);
+            int cur = 0, nxt = NS - 1;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + NS - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();   // tile kt visible to every wave, and stage `nxt` (tile kt-1) is free
+                if (kt + NS - 1 < nk) H_DMA(nxt, (kt + NS - 1) * 512);
+                H_COMPUTE_ALL(cur);
+                cur = cur + 1 == NS ? 0 : cur + 1;
+                nxt = nxt + 1 == NS ? 0 : nxt + 1;
+            }
+        } else {
         H_DMA(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             // Tile kt must have landed before anyone crosses the barrier.  The wait is written out: hipcc adds a
@@ -270,6 +301,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
             __syncthreads();   // ... and stage (kt+1)&1 is free
             if (kt + 1 < nk) H_DMA((kt + 1) & 1, (kt + 1) * 512);
             H_COMPUTE_ALL(kt & 1);
+        }
         }
     } else {
         const int nk = p.K / HBK;
@@ -307,28 +339,40 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
             }                                                                                       \
         }                                                                                           \
     }
+    // The staged epilogues reuse the operand stages (NS * STAGE halves) as the tile buffer.  A tile that does not fit
+    // (256x256: 256 KB of fp32 against 128 KB of stages) goes through in SLABS row slabs of SR rows, each filled by
+    // the waves whose rows lie in it; SLABS = 1 for every 4-wave instantiation.
+    constexpr int LDS_BYTES = AMODE == 2 ? NS * STAGE * 2 : 2 * STAGE * 2;
+    constexpr int SLABS = (BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES;
+    static_assert(WGM % SLABS == 0, "a wave's rows must lie in one slab");
+    constexpr int SR = BM / SLABS;
+    const int my_slab = SLABS == 1 ? 0 : wm / (WGM / SLABS);
     if (p.store == DS_STORE_ATTN || p.c_split) {
         // fp16 split outputs (packed planes for the next GEMM, or attention-ready Q / K / V^T): the tile is split,
-        // staged in LDS as T[plane][BM][BN] halves and leaves as 16-byte stores -- 2-byte stores straight from the
+        // staged in LDS as T[plane][SR][BN] halves and leaves as 16-byte stores -- 2-byte stores straight from the
         // accumulator layout cost +3..+25 % of the GEMM (one L2 write request per few bytes)
-        __syncthreads();                                  // every wave is done with the operand stages
+      for (int sl = 0; sl < SLABS; ++sl) {
+        const int ms = m0 + sl * SR;                      // first row of this slab
+        __syncthreads();                                  // every wave is done with the operand stages / the last slab
         _Float16* T = smem;
-        H_EPILOGUE({
-            const _Float16 hi = ds_split_hi(v);
-            const int tl = (row - m0) * BN + (col - n0);
-            T[tl] = hi;
-            T[BM * BN + tl] = ds_split_lo(v, hi);
-        })
+        if (my_slab == sl) {
+            H_EPILOGUE({
+                const _Float16 hi = ds_split_hi(v);
+                const int tl = (row - ms) * BN + (col - n0);
+                T[tl] = hi;
+                T[SR * BN + tl] = ds_split_lo(v, hi);
+            })
+        }
         __syncthreads();
         const int hw = p.attn_heads * 64;
         const int which = p.c_split ? 0 : n0 / hw;        // block-uniform: Q, K or V columns
         if (p.c_split || which < 2) {                     // 8 consecutive columns of a row per store
             constexpr int CPR = BN / 8;
-            for (int c = tid; c < 2 * BM * CPR; c += 256) {
-                const int cc = c % CPR, rl = (c / CPR) % BM, pl = c / (CPR * BM);
-                const int row = m0 + rl, col = n0 + cc * 8;
+            for (int c = tid; c < 2 * SR * CPR; c += NT) {
+                const int cc = c % CPR, rl = (c / CPR) % SR, pl = c / (CPR * SR);
+                const int row = ms + rl, col = n0 + cc * 8;
                 if (row < p.M && col < p.N) {
-                    const u32x4 val = *(const u32x4*)(T + (pl * BM + rl) * BN + cc * 8);
+                    const u32x4 val = *(const u32x4*)(T + (pl * SR + rl) * BN + cc * 8);
                     _Float16* dst;
                     if (p.c_split) {
                         dst = (_Float16*)p.C + (size_t)pl * p.c_plane + ds_packed_off(row, col, p.ldc >> 5);
@@ -348,15 +392,15 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
         } else {                                           // V^T: 8 consecutive keys of one d per store
             // The tile's rows belong to at most two samples; units of 8 keys are aligned in a sample's own key
             // index, so the first / last unit of each sample segment can be partial (2-byte stores for those).
-            const int L = p.rows_per_sample, g0 = m0 + p.row_off;        // absolute first row
+            const int L = p.rows_per_sample, g0 = ms + p.row_off;        // absolute first row
             const int b0 = g0 / L, pos0 = g0 - b0 * L;
-            const int rows_here = (p.M - m0 < BM ? p.M - m0 : BM);       // valid rows of this tile
+            const int rows_here = (p.M - ms < SR ? p.M - ms : SR);       // valid rows of this slab (may be <= 0)
             const int seg0 = (L - pos0 < rows_here ? L - pos0 : rows_here);   // rows in sample b0
             const int u0 = ((pos0 + seg0 + 7) >> 3) - (pos0 >> 3);       // units touching sample b0
             const int seg1 = rows_here - seg0;                           // rows in sample b0 + 1 (from key 0)
-            const int units = u0 + ((seg1 + 7) >> 3);
+            const int units = (SLABS > 1 && rows_here <= 0) ? 0 : u0 + ((seg1 + 7) >> 3);   // slab past the last row
             const int pln = p.attn_nkey * 64;
-            for (int c = tid; c < 2 * BN * units; c += 256) {
+            for (int c = tid; c < 2 * BN * units; c += NT) {
                 const int cl = c % BN, u = (c / BN) % units, pl = c / (BN * units);
                 const int col = n0 + cl;
                 if (col < p.N) {
@@ -368,7 +412,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
                     const int hc = col - 2 * hw, head = hc >> 6, d = hc & 63;
                     _Float16* dst = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2 + pl) * (size_t)pln +
                                     ds_attn_vt_off(k0, d, p.attn_nkey);
-                    const _Float16* src = T + (pl * BM) * BN + cl;
+                    const _Float16* src = T + (pl * SR) * BN + cl;
                     if (rl0 >= lo_ok && rl0 + 8 <= hi_ok) {
                         h8 val;
 #pragma unroll
@@ -382,23 +426,29 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
                 }
             }
         }
+      }
     } else if (p.store == DS_STORE_ROW && ((p.N | p.ldc | p.ldr) & 3) == 0 &&
                (((uintptr_t)p.C | (uintptr_t)p.R) & 15) == 0) {
-        // row-major fp32 (+ residual): the same staging, T[BM][BN] floats, 16-byte residual loads and stores
+        // row-major fp32 (+ residual): the same staging, T[SR][BN] floats, 16-byte residual loads and stores
+      for (int sl = 0; sl < SLABS; ++sl) {
+        const int ms = m0 + sl * SR;
         __syncthreads();
         float* Tf = (float*)smem;
-        H_EPILOGUE({ Tf[(row - m0) * BN + (col - n0)] = v; })
+        if (my_slab == sl) {
+            H_EPILOGUE({ Tf[(row - ms) * BN + (col - n0)] = v; })
+        }
         __syncthreads();
         constexpr int CPR = BN / 4;
-        for (int c = tid; c < BM * CPR; c += 256) {
+        for (int c = tid; c < SR * CPR; c += NT) {
             const int cc = c % CPR, rl = c / CPR;
-            const int row = m0 + rl, col = n0 + cc * 4;
+            const int row = ms + rl, col = n0 + cc * 4;
             if (row < p.M && col < p.N) {
                 f32x4 val = *(const f32x4*)(Tf + rl * BN + cc * 4);
                 if (p.R) val += *(const f32x4*)(p.R + (size_t)row * p.ldr + col);
                 *(f32x4*)(p.C + (size_t)row * p.ldc + col) = val;
             }
         }
+      }
     } else if (p.store == DS_STORE_ROW) {
         H_EPILOGUE({
             if (p.R) v += p.R[(size_t)row * p.ldr + col];
@@ -429,6 +479,62 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_hybrid_kernel(const Gemm
     const int bid = blockIdx.x;   // uniform branch: a workgroup runs one of the two programs
     if (bid < nbig) ds_gemm_f16x2_body<128, 128, 2>(pb, bid, nbig, smem_dyn);
     else ds_gemm_f16x2_body<64, 64, 2>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
+}
+
+// ---- big-tile candidates (opt-in: ds_gemm_f16x2_force_tile(3 / 4 / 6), packed operands only) -------------------------
+// One 8-wave workgroup per CU.  256x256 (waves of 128x64): half the L2->LDS bytes and three quarters of the LDS->VGPR
+// bytes per MFMA of the 128x128 program; 256x128 / 128x256 with a three-stage ring keep two k-tiles in flight.  The
+// balanced launch gives the big tiles the rows that fill whole rounds of 256 CUs and the rows after them to 8-wave
+// 128x128 tiles (waves of 64x32) in the same grid.  Results are bit-identical to the 4-wave programs (same MFMA order
+// per accumulator).  tools/probe/probe_gemm_f16x2.hip holds the bare main loops; see DESIGN.md section 3.
+template <int BM, int BN, int WGM, int WGN, int NS>
+__global__ __launch_bounds__(WGM * WGN * 64, 1) void ds_gemm_f16x2_big_kernel(const GemmParams pb, const GemmParams ps,
+                                                                              const int nbig) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    static_assert(WGM * WGN == 8, "the tail program below is written for 8 waves");
+    const int bid = blockIdx.x;   // uniform branch: a workgroup runs one of the two programs
+    if (bid < nbig) ds_gemm_f16x2_body<BM, BN, 2, WGM, WGN, NS>(pb, bid, nbig, smem_dyn);
+    else ds_gemm_f16x2_body<128, 128, 2, 2, 4, 2>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
+}
+
+static int g_big_slots = 256;   // one big workgroup per CU; a test hook shrinks it so small shapes get a tail program
+extern "C" void ds_gemm_f16x2_set_big_slots(int n) { g_big_slots = n > 0 ? n : 256; }
+template <int BM, int BN, int WGM, int WGN, int NS>
+static int launch_big(const GemmParams& p, hipStream_t s) {
+    const int tn = (p.N + BN - 1) / BN;
+    int rb = p.M / BM;                               // full BM-row tiles available
+    while (rb > 0 && ((long)rb * tn) % g_big_slots != 0) --rb;
+    if (rb == 0 || (p.store != DS_STORE_ROW && p.store != DS_STORE_ATTN)) rb = (p.M + BM - 1) / BM;   // no tail program
+    const int m_off = rb * BM < p.M ? rb * BM : p.M;
+    GemmParams pb = p, ps = p;
+    pb.M = m_off;
+    ps.M = p.M - m_off;
+    int nsmall = 0;
+    if (ps.M > 0) {
+        const size_t rg = (size_t)m_off / 16;
+        ps.A = (const float*)((const _Float16*)p.A + rg * (p.K / HBK) * 512);       // packed planes: row-group offset
+        if (p.store == DS_STORE_ATTN) ps.row_off = p.row_off + m_off;   // destinations are computed from absolute rows
+        else if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
+        else ps.C = p.C + (size_t)m_off * p.ldc;
+        if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
+        nsmall = ((ps.M + 127) / 128) * ((p.N + 127) / 128);
+    }
+    const int nbig = ((m_off + BM - 1) / BM) * tn;
+    const size_t lds = (size_t)NS * 2 * (BM + BN) * HLD * sizeof(unsigned short);   // >= the tail program's 64 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS>), dim3(nbig + nsmall), dim3(WGM * WGN * 64), lds, s,
+                       pb, ps, nbig);
+    DS_CHECK_LAUNCH();
+    return 0;
 }
 
 template <int BM, int BN, int AMODE>
@@ -531,10 +637,14 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
         // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups
         best = t128 >= (p.a_split ? 1000 : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
     }
+    if (best >= 3 && (!p.a_split || (p.store == DS_STORE_ATTN && p.rows_per_sample < 256))) best = 0;   // big tiles: packed only
     g_last_tile = best;
     switch (best) {
         case 0: return p.a_split ? launch_hybrid(p, stream) : launch_h<128, 128>(p, stream);
         case 1: return launch_h<128, 64>(p, stream);
+        case 3: return launch_big<256, 256, 2, 4, 2>(p, stream);
+        case 4: return launch_big<256, 128, 4, 2, 3>(p, stream);
+        case 6: return launch_big<128, 256, 2, 4, 3>(p, stream);
         default: return launch_h<64, 64>(p, stream);
     }
 }
