@@ -4,6 +4,8 @@ CPU-verified oracle, first executed by the round-end run).  Sorted after the oth
   * DALLE.sample -- the trainer's logging sampler (dalle_spec.py:264-343) vs the reference's images
   * VQModel.forward / get_input (spec_codec/vqgan.py:72-82)
 """
+import os
+
 import pytest
 import torch
 
@@ -70,8 +72,13 @@ def test_vqmodel_forward_is_decode_of_encode():
 
 # ---- big-tile candidates of the split GEMM (8-wave workgroups, ds_gemm_f16x2_force_tile 3 / 4 / 6) ------------------
 BIG_TILES = (3, 4, 6)
+# These kernels were written after the round's GPU budget was spent and have never run on hardware; a defect in a new
+# main loop could hang the device, so they stay out of the default GPU run until their first supervised execution.
+big = pytest.mark.skipif(os.environ.get("DIFFSOUND_TEST_BIG_TILES") != "1",
+                         reason="opt-in big-tile GEMM programs, not yet executed on a GPU: set DIFFSOUND_TEST_BIG_TILES=1")
 
 
+@big
 @pytest.mark.parametrize("M,N,K", [(4240, 4096, 1024), (4240, 1024, 4096), (2100, 1024, 1024), (700, 256, 1024),
                                    (300, 96, 64)])
 def test_f16x2_big_tiles_bit_identical(M, N, K):
@@ -110,6 +117,7 @@ def test_f16x2_big_tiles_bit_identical(M, N, K):
         L.lib().ds_gemm_f16x2_set_big_slots(256)
 
 
+@big
 @pytest.mark.parametrize("B", [3, 8])
 def test_f16x2_big_tiles_attention_store_bit_identical(B):
     """The attention-ready QKV store (Q planes, K image, V^T image) through the big tiles: slabs of 128 or 256 rows
@@ -142,6 +150,7 @@ def test_f16x2_big_tiles_attention_store_bit_identical(B):
         L.lib().ds_gemm_f16x2_set_big_slots(256)
 
 
+@big
 def test_denoiser_step_with_big_tiles_gives_the_same_tokens():
     """A whole sampling step of the 19-layer denoiser at B = 8 with every GEMM forced onto a big tile: tokens equal the
     default launch's."""
