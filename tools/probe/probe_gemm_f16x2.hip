@@ -484,6 +484,168 @@ static void run_big(const char* name, const _Float16* A, const _Float16* W, floa
     fflush(stdout);
 }
 
+
+// ---- register-staged variant on PACKED planes (round-2 candidate): the 128x128 4-wave program at two workgroups per
+// CU, but the tile bytes travel global -> VGPR -> ds_write_b128 instead of LDS-DMA, with two register sets so that the
+// loads of tile kt+2 are issued before tile kt is computed: twice the latency tolerance of the two-stage DMA ring at
+// the same LDS footprint (the third stage lives in 64 VGPRs).  Same lane -> byte mapping as the DMA (1 KB per wave
+// instruction, linear LDS writes).  Never measured with packed planes: the register-staged kernel of the early round
+// read row-major planes (half-cacheline requests).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int BM, int BN, int OCC, int GM>
+__global__ __launch_bounds__(256, OCC) void reg_kernel(const _Float16* A, long long a_plane, const _Float16* W,
+                                                       long long w_plane, float* C, int M, int N, int K,
+                                                       unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int APL = BM * HLD, BPL = BN * HLD, STAGE = 2 * (APL + BPL);
+    _Float16* smem = (_Float16*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (N + BN - 1) / BN, nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm_, tn_;
+    {
+        const int tiles_m = (M + BM - 1) / BM;
+        const int per = GM * tiles_n, grp = bid / per, first = grp * GM;
+        const int gsz = tiles_m - first < GM ? tiles_m - first : GM;
+        const int in = bid - grp * per;
+        tm_ = first + in % gsz;
+        tn_ = in / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    const int nk = K / HBK;
+    constexpr int G = (BM + BN) / 32;
+    const _Float16* src[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        int r = 16 * (wave + 4 * i);
+        const _Float16* base;
+        int rg, rgs;
+        if (r < 2 * BM) { base = A; if (r >= BM) { r -= BM; base += a_plane; } rg = (m0 + r) >> 4; rgs = (M + 15) >> 4; }
+        else { r -= 2 * BM; base = W; if (r >= BN) { r -= BN; base += w_plane; } rg = (n0 + r) >> 4; rgs = (N + 15) >> 4; }
+        if (rg >= rgs) rg = rgs - 1;
+        src[i] = base + (size_t)rg * nk * 512 + lane * 8;
+    }
+    const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4 rX[G], rY[G];
+#define RG_LOAD(R, tile_)                                                                             \
+    do {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < G; ++i) R[i] = *(const u32x4*)(src[i] + (size_t)(tile_) * 512); \
+    } while (0)
+#define RG_WRITE(R, stage_)                                                                           \
+    do {                                                                                              \
+        unsigned char* d_ = smem_raw + (stage_) * (STAGE * 2) + wave * 1024 + lane * 16;              \
+        _Pragma("unroll") for (int i = 0; i < G; ++i) *(u32x4*)(d_ + i * 4096) = R[i];                \
+    } while (0)
+#define RG_COMPUTE(cur_)                                                                              \
+    do {                                                                                              \
+        const _Float16* Ac = smem + (cur_) * STAGE + (wm * TM * 32 + l31) * HLD;                      \
+        const _Float16* Bc = smem + (cur_) * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD;            \
+        h8 fa0[2][TM], fa1[2][TM], fb0[2][TN], fb1[2][TN];                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                          \
+                fa0[ks][i] = *(const h8*)(Ac + i * 32 * HLD + swz[ks]);                               \
+                fa1[ks][i] = *(const h8*)(Ac + APL + i * 32 * HLD + swz[ks]);                         \
+            }                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                          \
+                fb0[ks][j] = *(const h8*)(Bc + j * 32 * HLD + swz[ks]);                               \
+                fb1[ks][j] = *(const h8*)(Bc + BPL + j * 32 * HLD + swz[ks]);                         \
+            }                                                                                         \
+        }                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                      \
+                    f32x16 c = acc[i][j];                                                             \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[ks][i], fb0[ks][j], c, 0, 0, 0);   \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb1[ks][j], c, 0, 0, 0);   \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb0[ks][j], c, 0, 0, 0);   \
+                    acc[i][j] = c;                                                                    \
+                }                                                                                     \
+    } while (0)
+    // X holds tile kt+1 (landed or landing), Y receives tile kt+2; tile kt is in stage cur
+#define RG_BODY(RX, RY)                                                                               \
+    do {                                                                                              \
+        RG_LOAD(RY, kt + 2 < nk ? kt + 2 : nk - 1);                                                   \
+        RG_COMPUTE(cur);                                                                              \
+        RG_WRITE(RX, cur ^ 1);                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x020, G, 0);           /* the VMEM loads first */        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0); /* fragment reads */           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);   /* MFMAs */                    \
+        __builtin_amdgcn_sched_group_barrier(0x200, G, 0);           /* then the staging writes */    \
+        __syncthreads();                                                                              \
+        cur ^= 1;                                                                                     \
+        ++kt;                                                                                         \
+    } while (0)
+    RG_LOAD(rX, 0);
+    RG_WRITE(rX, 0);
+    RG_LOAD(rX, nk > 1 ? 1 : 0);
+    __syncthreads();
+    int cur = 0, kt = 0;
+    while (kt + 1 < nk) {
+        RG_BODY(rX, rY);
+        RG_BODY(rY, rX);
+    }
+    if (kt < nk) RG_BODY(rX, rY);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    if (tid == 0 && clk) {
+        clk[2 * blockIdx.x] = __builtin_readcyclecounter() - t0;
+        clk[2 * blockIdx.x + 1] = wall_clock64() - w0;
+    }
+}
+
+template <int BM, int BN, int OCC, int GM>
+static void run_reg(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
+                    unsigned long long* clk) {
+    const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * 2;
+    hipFuncSetAttribute((const void*)reg_kernel<BM, BN, OCC, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i)
+        hipLaunchKernelGGL((reg_kernel<BM, BN, OCC, GM>), dim3(tiles), dim3(256), lds, 0, A, (long long)M * K, W,
+                           (long long)N * K, C, M, N, K, clk);
+    const int reps = 30;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL((reg_kernel<BM, BN, OCC, GM>), dim3(tiles), dim3(256), lds, 0, A, (long long)M * K, W,
+                           (long long)N * K, C, M, N, K, clk);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(2 * tiles);
+    hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, wall = 0;
+    for (int i = 0; i < tiles; ++i) { cyc += h[2 * i]; wall += h[2 * i + 1]; }
+    const double us = ms * 1e3 / reps;
+    printf("%-26s GM%-2d %dx%d occ%d M=%d N=%d K=%d: %8.1f us  %6.1f TF-eq  clock %.2f GHz  block life %.0f cyc\n", name, GM, BM, BN, OCC,
+           M, N, K, us, 2.0 * M * N * K / us / 1e6, cyc / wall * 0.1, cyc / tiles);
+    fflush(stdout);
+}
+
 template <int NS, int GM>
 static void run_sp(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
                    unsigned long long* clk) {
@@ -585,6 +747,8 @@ int main() {
     };
 #define QCASE(MM, N, K)                                                                             \
     run<128, 128, 16, 2, 8>("packed 2-stage occ2", A, W, C, MM, N, K, clk);                         \
+    run_reg<128, 128, 2, 8>("packed reg-staged 2-ahead", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_reg<128, 64, 3, 8>("packed reg-staged 2-ahead", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 2, 4, 2, 4>("big 256x256 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 4, 2, 2, 4>("big 256x256 8w (4x2)", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 2, 4, 2, 4, 1>("big 256x256 8w sched1", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
