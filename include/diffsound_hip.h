@@ -89,7 +89,9 @@ int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 /* cfg: -1 automatic (default); 0 = 128x128 (balanced launch for packed operands), 1 = 128x64, 2 = 64x64 tiles of one
    4-wave workgroup; 3 = 256x256, 4 = 256x128 (3-stage ring), 6 = 128x256 (3-stage ring) tiles of one 8-wave workgroup
-   per CU -- the big-tile candidates, packed operands only (others fall back to 0), same bits as every other cfg. */
+   per CU -- the big-tile candidates; 7 = cfg 0 with the packed tiles staged through registers two k-tiles ahead
+   instead of LDS-DMA.  3 / 4 / 6 / 7 are unmeasured candidates for packed operands only (others fall back to 0);
+   every cfg produces the same bits. */
 void ds_gemm_f16x2_force_tile(int cfg);
 /* packed-operand launches that pick the 128x128 tile are balanced: 128x128 tiles over the leading rows that fill
    whole rounds of `slots` resident workgroups (default 512 = 256 CUs x 2), 64x64 tiles over the rest.  Test hook. */

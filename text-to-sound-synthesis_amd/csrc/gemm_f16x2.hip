@@ -206,7 +206,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     } while (0)
 
     const int nk = p.K / HBK;
-    if constexpr (AMODE == 2) {
+    if constexpr (AMODE >= 2) {
         // LDS image of a stage = 2*(BM+BN) rows of 64 B: A hi rows, A lo rows, B hi rows, B lo rows.  One DMA
         // instruction of a wave fills 16 consecutive rows = one packed 16-row x 32-k tile (lane l -> bytes 16 l);
         // the wave owns the 16-row groups g = wave + NW i.
@@ -274,7 +274,72 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
         }                                                                                           \
     } while (0)
         static_assert(HBK == 32, "two 16-wide k-steps per tile");
-        if constexpr (NS > 2) {
+        if constexpr (AMODE == 3) {
+            // Register staging of the PACKED tiles (opt-in candidate, force_tile 7): the same lane -> byte mapping as
+            // the DMA, but global -> VGPR -> ds_write_b128 with two register sets, so the loads of tile kt+2 are in
+            // flight while tile kt is computed -- twice the latency tolerance of the two-stage DMA ring at the same
+            // LDS footprint (the third stage is 8 G VGPRs).  Ordinary loads: the compiler places the vmcnt waits.
+            static_assert(NW == 4 && NS == 2, "written for the 4-wave programs");
+            u32x4 rX[G], rY[G];
+#define H_RLOAD(R, tile_)                                                                           \
+    do {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < G; ++i) R[i] = *(const u32x4*)(src[i] + (size_t)(tile_) * 512); \
+    } while (0)
+#define H_RWRITE(R, stage_)                                                                         \
+    do {                                                                                            \
+        unsigned char* d_ = smem_raw + (stage_) * (STAGE * 2) + wave * 1024 + lane * 16;            \
+        _Pragma("unroll") for (int i = 0; i < G; ++i) *(u32x4*)(d_ + i * (NW * 1024)) = R[i];       \
+    } while (0)
+#define H_RCOMPUTE(cur_)                                                                            \
+    do {                                                                                            \
+        const _Float16* Ac = smem + (cur_) * STAGE + (wm * TM * 32 + l31) * HLD;                    \
+        const _Float16* Bc = smem + (cur_) * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD;          \
+        h8 fa0[2][TM], fa1[2][TM], fb0[2][TN], fb1[2][TN];                                          \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+                fa0[ks][i] = *(const h8*)(Ac + i * 32 * HLD + swz[ks]);                             \
+                fa1[ks][i] = *(const h8*)(Ac + APL + i * 32 * HLD + swz[ks]);                       \
+            }                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
+                fb0[ks][j] = *(const h8*)(Bc + j * 32 * HLD + swz[ks]);                             \
+                fb1[ks][j] = *(const h8*)(Bc + BPL + j * 32 * HLD + swz[ks]);                       \
+            }                                                                                       \
+        }                                                                                           \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                    \
+                    f32x16 c = acc[i][j];                                                           \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[ks][i], fb0[ks][j], c, 0, 0, 0); \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb1[ks][j], c, 0, 0, 0); \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb0[ks][j], c, 0, 0, 0); \
+                    acc[i][j] = c;                                                                  \
+                }                                                                                   \
+    } while (0)
+            // RX holds tile kt+1 (landed or landing), RY receives tile kt+2; tile kt is in stage cur
+#define H_RBODY(RX, RY)                                                                             \
+    do {                                                                                            \
+        H_RLOAD(RY, kt + 2 < nk ? kt + 2 : nk - 1);                                                 \
+        H_RCOMPUTE(cur);                                                                            \
+        H_RWRITE(RX, cur ^ 1);                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x020, G, 0);             /* VMEM loads first */        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0); /* fragment reads */         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);   /* MFMAs */                  \
+        __builtin_amdgcn_sched_group_barrier(0x200, G, 0);             /* staging writes last */    \
+        __syncthreads();                                                                            \
+        cur ^= 1;                                                                                   \
+        ++kt;                                                                                       \
+    } while (0)
+            H_RLOAD(rX, 0);
+            H_RWRITE(rX, 0);
+            H_RLOAD(rX, nk > 1 ? 1 : 0);
+            __syncthreads();
+            int cur = 0, kt = 0;
+            while (kt + 1 < nk) {
+                H_RBODY(rX, rY);
+                H_RBODY(rY, rX);
+            }
+            if (kt < nk) H_RBODY(rX, rY);
+        } else if constexpr (NS > 2) {
             // ring of NS stages, NS-1 tiles in flight: tile kt has landed once at most the G (NS-2) younger DMA
             // instructions of this wave are outstanding (vmcnt counts in issue order)
 #pragma unroll
@@ -537,6 +602,15 @@ static int launch_big(const GemmParams& p, hipStream_t s) {
     return 0;
 }
 
+// the balanced launch of ds_gemm_f16x2_hybrid_kernel with the register-staged programs (opt-in candidate, force_tile 7)
+__global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_hybrid_reg_kernel(const GemmParams pb, const GemmParams ps,
+                                                                         const int nbig) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    const int bid = blockIdx.x;
+    if (bid < nbig) ds_gemm_f16x2_body<128, 128, 3>(pb, bid, nbig, smem_dyn);
+    else ds_gemm_f16x2_body<64, 64, 3>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
+}
+
 template <int BM, int BN, int AMODE>
 static int launch_h2(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * sizeof(unsigned short);
@@ -569,13 +643,14 @@ static int g_balance_slots = 512;
 extern "C" void ds_gemm_f16x2_set_balance_slots(int n) { g_balance_slots = n > 0 ? n : 512; }
 
 // 128x128 tiles for the largest row range that fills whole rounds of slots, 64x64 tiles for the rows after it
+template <bool REG = false>   // REG: the register-staged programs (force_tile 7)
 static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     const int tn = (p.N + 127) / 128;
     int rb = p.M / 128;                              // full 128-row tiles available
     while (rb > 0 && ((long)rb * tn) % g_balance_slots != 0) --rb;
     const int m_off = rb * 128;
     if (rb == 0 || m_off == p.M || (p.store != DS_STORE_ROW && p.store != DS_STORE_ATTN))
-        return launch_h2<128, 128, 2>(p, s);
+        return launch_h2<128, 128, REG ? 3 : 2>(p, s);
     GemmParams pb = p, ps = p;
     pb.M = m_off;
     ps.M = p.M - m_off;
@@ -588,17 +663,18 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     const int nbig = rb * tn;
     const int nsmall = ((ps.M + 63) / 64) * ((p.N + 63) / 64);
     const size_t lds = (size_t)2 * 2 * (128 + 128) * HLD * sizeof(unsigned short);
+    const void* kern = REG ? (const void*)ds_gemm_f16x2_hybrid_reg_kernel : (const void*)ds_gemm_f16x2_hybrid_kernel;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_hybrid_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
+    if (REG) hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_reg_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
+    else hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -637,10 +713,12 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
         // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups
         best = t128 >= (p.a_split ? 1000 : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
     }
-    if (best >= 3 && (!p.a_split || (p.store == DS_STORE_ATTN && p.rows_per_sample < 256))) best = 0;   // big tiles: packed only
+    if (best >= 3 && (!p.a_split || (best != 7 && p.store == DS_STORE_ATTN && p.rows_per_sample < 256)))
+        best = 0;   // the candidates take packed operands only; big slabs must not span more than two samples
     g_last_tile = best;
     switch (best) {
-        case 0: return p.a_split ? launch_hybrid(p, stream) : launch_h<128, 128>(p, stream);
+        case 0: return p.a_split ? launch_hybrid<false>(p, stream) : launch_h<128, 128>(p, stream);
+        case 7: return launch_hybrid<true>(p, stream);
         case 1: return launch_h<128, 64>(p, stream);
         case 3: return launch_big<256, 256, 2, 4, 2>(p, stream);
         case 4: return launch_big<256, 128, 4, 2, 3>(p, stream);

@@ -1,5 +1,6 @@
 """A/B timing of the packed-operand f16x2 GEMM on the denoiser's shapes (B=64): default launch (balanced 128x128 +
-64x64 tail) against the opt-in big-tile programs (force_tile 3 = 256x256, 4 = 256x128, 6 = 128x256; 8-wave workgroups),
+64x64 tail) against the opt-in candidates (force_tile 3 = 256x256, 4 = 256x128, 6 = 128x256: 8-wave workgroups;
+7 = the default tiles with register-staged packed operands),
 with a bit-compare of the outputs.  Run on the GPU box:  python tools/gemm_big_ab.py [--batch 64]"""
 import argparse
 import os
@@ -14,7 +15,7 @@ ap.add_argument("--batch", type=int, default=64)
 args = ap.parse_args()
 M = args.batch * 265
 SHAPES = [("qkv", 3072, 1024), ("proj/q2", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
-NAMES = {-1: "default", 3: "256x256", 4: "256x128/3", 6: "128x256/3"}
+NAMES = {-1: "default", 3: "256x256", 4: "256x128/3", 6: "128x256/3", 7: "128x128 reg-staged"}
 
 
 def split(a):
