@@ -126,6 +126,9 @@ def lib():
             fn = getattr(L, name)   # AttributeError here == header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        tile = os.environ.get("DIFFSOUND_F16X2_TILE")        # A/B hook: force a tile / staging candidate of the split GEMM
+        if tile:
+            L.ds_gemm_f16x2_force_tile(int(tile))
         _lib = L
     return _lib
 
