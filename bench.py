@@ -248,6 +248,8 @@ def main():
             names = [fmt % bb for bb in ((128, 128), (128, 64), (64, 64))]
             if precision == "f16x2":   # packed-operand launches of the 128x128 config go through the balanced kernel
                 names[0] = "ds_gemm_f16x2_hybrid_kernel (128x128 tiles + 64x64 tail tiles)"
+                if os.environ.get("DIFFSOUND_F16X2_TILE"):   # A/B run of an opt-in candidate (include/diffsound_hip.h)
+                    names[0] = "split-GEMM candidate cfg %s (DIFFSOUND_F16X2_TILE)" % os.environ["DIFFSOUND_F16X2_TILE"]
             dom = max(range(3), key=lambda c: ms[c])   # the kernel symbol with the largest total time
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             peak = mfma_peak / passes                  # ceiling in algorithmic (2MNK) flops of this formulation

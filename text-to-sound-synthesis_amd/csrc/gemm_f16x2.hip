@@ -715,7 +715,7 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     }
     if (best >= 3 && (!p.a_split || (best != 7 && p.store == DS_STORE_ATTN && p.rows_per_sample < 256)))
         best = 0;   // the candidates take packed operands only; big slabs must not span more than two samples
-    g_last_tile = best;
+    g_last_tile = best >= 3 ? 0 : best;   // the profiler has three classes; the candidates stand in for class 0
     switch (best) {
         case 0: return p.a_split ? launch_hybrid<false>(p, stream) : launch_h<128, 128>(p, stream);
         case 7: return launch_hybrid<true>(p, stream);
