@@ -46,6 +46,8 @@ def parse():
                     help="denoiser GEMM arithmetic: fp32 MFMA, or the fp32-accurate 3-way bf16 split")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFSOUND_STREAMS", "1")), choices=(1, 2),
                     help="2: the sampling loop runs the batch as two half-batches on two HIP streams")
+    ap.add_argument("--transformer-only", action="store_true",
+                    help="BASELINE configs[1]: CLIP + sampling loop only (no decode / vocoder); not the default metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
@@ -153,9 +155,12 @@ def result_line(args, world, elapsed, n_total):
         "dtype": {"fp32": "f32", "bf16x3": "f32 via 3-way bf16 split (6 MFMA passes, fp32 accumulate)",
                   "f16x2": "f32 via 2-way fp16 split (3 MFMA passes, fp32 accumulate)"}[args.precision],
         "data": "synthetic caption token ids i64[B,77] + seeded random-init weights of the reference's shapes",
-        "config": {"workload": "BASELINE configs[2]: full pipeline, batch %d per GPU, %d diffusion steps, "
-                               "codebook %d: CLIP text tower -> 19-layer denoiser -> SpecVQGAN decode -> MelGAN "
-                               "22 kHz" % (B, T, args.codes),
+        "config": {"workload": ("BASELINE configs[1]: transformer only, batch %d per GPU, %d diffusion steps, codebook %d: "
+                                "CLIP text tower -> 19-layer denoiser + sampler (tokens; no decode / vocoder)"
+                                if getattr(args, "transformer_only", False) else
+                                "BASELINE configs[2]: full pipeline, batch %d per GPU, %d diffusion steps, "
+                                "codebook %d: CLIP text tower -> 19-layer denoiser -> SpecVQGAN decode -> MelGAN "
+                                "22 kHz") % (B, T, args.codes),
                    "global_batch": n_total, "n_layer": args.n_layer, "parallelism": "caption-sharded x%d" % world,
                    "denoiser_tflops_effective": round(value * GFLOP_PER_SAMPLE_STEP * T / 1e3, 2)},
     }
@@ -204,6 +209,10 @@ def main():
         t1 = mark()
         out = dt.sample(condition_token=toks, condition_mask=None, condition_embed=None, filter_ratio=0)
         t2 = mark()
+        if args.transformer_only:
+            tok = out["content_token"]
+            allt = shard.gather_outputs(tok, n_total)
+            return allt if allt is not None else tok
         mel = model.decode_to_img(out["content_token"], (B, 256, 5, 53))
         t3 = mark()
         wave = voc(mel[:, 0], scale=0.5, shift=0.5)
@@ -216,7 +225,10 @@ def main():
         return allw if allw is not None else wave
 
     elapsed, w = timed_loop(one_step, args.warmup, args.steps, dev, world)
-    assert torch.isfinite(w).all() and w.shape[-1] == 217088
+    if args.transformer_only:
+        assert w.shape[-1] == 265 and int(w.max()) < args.codes       # no [MASK] left at t = 0
+    else:
+        assert torch.isfinite(w).all() and w.shape[-1] == 217088
 
     roof = None
     extra = {}
