@@ -99,6 +99,10 @@ void ds_gemm_f16x2_set_balance_slots(int slots);
 /* the same balance unit for the big-tile launches (default 256 = one workgroup per CU); rows past the last whole
    round go to 8-wave 128x128 tiles in the same grid.  Test hook. */
 void ds_gemm_f16x2_set_big_slots(int slots);
+/* The row partition a packed-operand launch of cfg 0 / 3 / 4 / 6 / 7 uses for an M x N product with the given store
+   mode: rows [0, m_off) -> nbig main tiles, rows [m_off, M) -> nsmall tail tiles (0: one program over all rows).
+   Pure arithmetic, no device work: the CPU test-suite checks the partition with it. */
+int ds_gemm_f16x2_plan(int cfg, int M, int N, int store, int* m_off, int* nbig, int* nsmall);
 
 /* ---- row kernels of the denoiser -------------------------------------------------------------- */
 /* DalleMaskImageEmbedding.forward, sound_synthesis/modeling/embeddings/dalle_mask_image_embedding.py:36-58

@@ -14,3 +14,53 @@ def test_pack_planes_round_trip_and_formula():
     for r, k in ((0, 0), (5, 9), (17, 40), (36, 95), (12, 31)):       # the address formula of diffsound_hip.h
         off = ((r // 16) * (K // 32) + k // 32) * 512 + (r % 16) * 32 + (((k // 8) % 4) ^ ((r // 4) % 4)) * 8 + k % 8
         assert flat[0, off] == x2[0, r, k] and flat[1, off] == x2[1, r, k]
+
+
+def test_balanced_launch_row_partition():
+    """ds_gemm_f16x2_plan: the row partition of the balanced launches (default 128x128 + 64x64 tail; the big-tile
+    candidates + 128x128 tail) -- main tiles fill whole rounds of the balance unit, the tail tiles cover exactly the
+    remaining rows, the split lies on a packed row group, and the denoiser's shapes get the documented grids."""
+    import ctypes as C
+    from text_to_sound_synthesis_amd import _lib as L
+    lib = L.lib()
+    geo = {0: (128, 128, 64, 64), 7: (128, 128, 64, 64), 3: (256, 256, 128, 128), 4: (256, 128, 128, 128),
+           6: (128, 256, 128, 128)}
+
+    def plan(cfg, M, N, store=L.STORE_ROW):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        L.check(lib.ds_gemm_f16x2_plan(cfg, M, N, store, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    ceil = lambda a, b: (a + b - 1) // b
+    try:
+        for slots in (512, 256, 64, 8, 1):
+            lib.ds_gemm_f16x2_set_balance_slots(slots)
+            lib.ds_gemm_f16x2_set_big_slots(slots)
+            for cfg, (BM, BN, tbm, tbn) in geo.items():
+                for M in (1, 63, 128, 265, 530, 795, 2120, 4240, 16384, 16960, 33920):
+                    for N in (96, 256, 1024, 3072, 4096):
+                        m_off, nbig, nsmall = plan(cfg, M, N)
+                        tn = ceil(N, BN)
+                        assert 0 < m_off <= M and nbig == ceil(m_off, BM) * tn
+                        if nsmall == 0:
+                            assert m_off == M
+                            # no admissible split: no whole number of rounds fits, or the rows divide exactly
+                            rbs = [rb for rb in range(1, M // BM + 1) if (rb * tn) % slots == 0]
+                            assert not rbs or max(rbs) * BM == M
+                        else:
+                            assert m_off % BM == 0 and m_off % 16 == 0 and m_off < M
+                            assert (m_off // BM * tn) % slots == 0
+                            assert all(((rb * tn) % slots) for rb in range(m_off // BM + 1, M // BM + 1))   # the largest
+                            assert nsmall == ceil(M - m_off, tbm) * ceil(N, tbn)
+                        assert plan(cfg, M, N, L.STORE_BATCH_T)[2] == 0          # transposed store: never split
+        lib.ds_gemm_f16x2_set_balance_slots(512)
+        lib.ds_gemm_f16x2_set_big_slots(256)
+        # B = 64 (M = 16960): default = 2 / 6 / 8 rounds of 512 slots + 64x64 tiles on the last 576 rows
+        assert plan(0, 16960, 1024) == (16384, 1024, 9 * 16) and plan(0, 16960, 3072) == (16384, 3072, 9 * 48)
+        assert plan(0, 16960, 4096) == (16384, 4096, 9 * 64)
+        # candidates: one workgroup per CU -> 1 / 3 / 4 rounds of 256x256 tiles, 128x128 tiles on the last 576 rows
+        assert plan(3, 16960, 1024) == (16384, 256, 5 * 8) and plan(3, 16960, 3072) == (16384, 768, 5 * 24)
+        assert plan(3, 16960, 4096) == (16384, 1024, 5 * 32) and plan(4, 16960, 1024) == (16384, 512, 5 * 8)
+    finally:
+        lib.ds_gemm_f16x2_set_balance_slots(512)
+        lib.ds_gemm_f16x2_set_big_slots(256)

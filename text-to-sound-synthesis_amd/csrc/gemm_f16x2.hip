@@ -546,6 +546,27 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_hybrid_kernel(const Gemm
     else ds_gemm_f16x2_body<64, 64, 2>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
 }
 
+// Row partition of a balanced launch: the first m_off rows go to BM x BN tiles (nbig of them = a whole number of rounds
+// of `slots` resident workgroups), the rows after them to tbm x tbn tail tiles (nsmall of them) in the same grid.
+// nsmall == 0: one program over all rows.  Pure arithmetic (ds_gemm_f16x2_plan exposes it to the CPU tests).
+struct BalancePlan { int m_off, nbig, nsmall; };
+static BalancePlan ds_balance_plan(int M, int N, int BM, int BN, int slots, int tbm, int tbn, bool tail_ok) {
+    const int tn = (N + BN - 1) / BN;
+    int rb = M / BM;                                 // full BM-row tiles available
+    while (rb > 0 && ((long)rb * tn) % slots != 0) --rb;
+    BalancePlan pl;
+    if (rb == 0 || rb * BM == M || !tail_ok) {
+        pl.m_off = M;
+        pl.nbig = ((M + BM - 1) / BM) * tn;
+        pl.nsmall = 0;
+    } else {
+        pl.m_off = rb * BM;
+        pl.nbig = rb * tn;
+        pl.nsmall = ((M - pl.m_off + tbm - 1) / tbm) * ((N + tbn - 1) / tbn);
+    }
+    return pl;
+}
+
 // ---- big-tile candidates (opt-in: ds_gemm_f16x2_force_tile(3 / 4 / 6), packed operands only) -------------------------
 // One 8-wave workgroup per CU.  256x256 (waves of 128x64): half the L2->LDS bytes and three quarters of the LDS->VGPR
 // bytes per MFMA of the 128x128 program; 256x128 / 128x256 with a three-stage ring keep two k-tiles in flight.  The
@@ -566,25 +587,20 @@ static int g_big_slots = 256;   // one big workgroup per CU; a test hook shrinks
 extern "C" void ds_gemm_f16x2_set_big_slots(int n) { g_big_slots = n > 0 ? n : 256; }
 template <int BM, int BN, int WGM, int WGN, int NS>
 static int launch_big(const GemmParams& p, hipStream_t s) {
-    const int tn = (p.N + BN - 1) / BN;
-    int rb = p.M / BM;                               // full BM-row tiles available
-    while (rb > 0 && ((long)rb * tn) % g_big_slots != 0) --rb;
-    if (rb == 0 || (p.store != DS_STORE_ROW && p.store != DS_STORE_ATTN)) rb = (p.M + BM - 1) / BM;   // no tail program
-    const int m_off = rb * BM < p.M ? rb * BM : p.M;
+    const BalancePlan pl = ds_balance_plan(p.M, p.N, BM, BN, g_big_slots, 128, 128,
+                                           p.store == DS_STORE_ROW || p.store == DS_STORE_ATTN);
+    const int m_off = pl.m_off, nbig = pl.nbig, nsmall = pl.nsmall;
     GemmParams pb = p, ps = p;
     pb.M = m_off;
     ps.M = p.M - m_off;
-    int nsmall = 0;
-    if (ps.M > 0) {
+    if (nsmall > 0) {
         const size_t rg = (size_t)m_off / 16;
         ps.A = (const float*)((const _Float16*)p.A + rg * (p.K / HBK) * 512);       // packed planes: row-group offset
         if (p.store == DS_STORE_ATTN) ps.row_off = p.row_off + m_off;   // destinations are computed from absolute rows
         else if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
         else ps.C = p.C + (size_t)m_off * p.ldc;
         if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
-        nsmall = ((ps.M + 127) / 128) * ((p.N + 127) / 128);
     }
-    const int nbig = ((m_off + BM - 1) / BM) * tn;
     const size_t lds = (size_t)NS * 2 * (BM + BN) * HLD * sizeof(unsigned short);   // >= the tail program's 64 KB
     static bool attr_set = false;
     if (!attr_set) {
@@ -645,12 +661,10 @@ extern "C" void ds_gemm_f16x2_set_balance_slots(int n) { g_balance_slots = n > 0
 // 128x128 tiles for the largest row range that fills whole rounds of slots, 64x64 tiles for the rows after it
 template <bool REG = false>   // REG: the register-staged programs (force_tile 7)
 static int launch_hybrid(const GemmParams& p, hipStream_t s) {
-    const int tn = (p.N + 127) / 128;
-    int rb = p.M / 128;                              // full 128-row tiles available
-    while (rb > 0 && ((long)rb * tn) % g_balance_slots != 0) --rb;
-    const int m_off = rb * 128;
-    if (rb == 0 || m_off == p.M || (p.store != DS_STORE_ROW && p.store != DS_STORE_ATTN))
-        return launch_h2<128, 128, REG ? 3 : 2>(p, s);
+    const BalancePlan pl = ds_balance_plan(p.M, p.N, 128, 128, g_balance_slots, 64, 64,
+                                           p.store == DS_STORE_ROW || p.store == DS_STORE_ATTN);
+    if (pl.nsmall == 0) return launch_h2<128, 128, REG ? 3 : 2>(p, s);
+    const int m_off = pl.m_off;
     GemmParams pb = p, ps = p;
     pb.M = m_off;
     ps.M = p.M - m_off;
@@ -660,8 +674,7 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     else if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
     else ps.C = p.C + (size_t)m_off * p.ldc;
     if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
-    const int nbig = rb * tn;
-    const int nsmall = ((ps.M + 63) / 64) * ((p.N + 63) / 64);
+    const int nbig = pl.nbig, nsmall = pl.nsmall;
     const size_t lds = (size_t)2 * 2 * (128 + 128) * HLD * sizeof(unsigned short);
     const void* kern = REG ? (const void*)ds_gemm_f16x2_hybrid_reg_kernel : (const void*)ds_gemm_f16x2_hybrid_kernel;
     static bool attr_set = false;
@@ -676,6 +689,22 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     if (REG) hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_reg_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
     else hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
     DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// the row partition a packed-operand launch of configuration cfg would use (no device work; CPU tests call it)
+extern "C" int ds_gemm_f16x2_plan(int cfg, int M, int N, int store, int* m_off, int* nbig, int* nsmall) {
+    DS_CHECK_ARG(M > 0 && N > 0 && m_off && nbig && nsmall, "bad arguments");
+    const bool tail_ok = store == DS_STORE_ROW || store == DS_STORE_ATTN;
+    BalancePlan pl;
+    switch (cfg) {
+        case 0: case 7: pl = ds_balance_plan(M, N, 128, 128, g_balance_slots, 64, 64, tail_ok); break;
+        case 3: pl = ds_balance_plan(M, N, 256, 256, g_big_slots, 128, 128, tail_ok); break;
+        case 4: pl = ds_balance_plan(M, N, 256, 128, g_big_slots, 128, 128, tail_ok); break;
+        case 6: pl = ds_balance_plan(M, N, 128, 256, g_big_slots, 128, 128, tail_ok); break;
+        default: DS_CHECK_ARG(false, "cfg has no balanced launch");
+    }
+    *m_off = pl.m_off; *nbig = pl.nbig; *nsmall = pl.nsmall;
     return 0;
 }
 
