@@ -64,3 +64,49 @@ def test_balanced_launch_row_partition():
     finally:
         lib.ds_gemm_f16x2_set_balance_slots(512)
         lib.ds_gemm_f16x2_set_big_slots(256)
+
+
+def test_vt_store_unit_bookkeeping_mirror():
+    """Host mirror of the V^T branch of the staged attention store (csrc/gemm_f16x2.hip: 8 consecutive keys of one d
+    per 16-byte store, units aligned in a sample's own key index, a slab of SR rows touching at most two samples):
+    every (sample, key) of the slab's valid rows is written exactly once from the right staged row, for the slab
+    geometries of the 4-wave tiles (SR = 64 / 128) and of the big-tile candidates (SR = 128 slabs of 256-row tiles,
+    SR = 256), including slabs that end or start past the last row."""
+    def slab_writes(ms, SR, M, L, row_off=0):
+        g0 = ms + row_off
+        b0, pos0 = divmod(g0, L)
+        rows_here = min(M - ms, SR)
+        if rows_here <= 0:
+            return {}
+        seg0 = min(L - pos0, rows_here)
+        u0 = ((pos0 + seg0 + 7) >> 3) - (pos0 >> 3)
+        seg1 = rows_here - seg0
+        units = u0 + ((seg1 + 7) >> 3)
+        out = {}
+        for u in range(units):
+            first = u < u0
+            b = b0 if first else b0 + 1
+            k0 = ((pos0 >> 3) + u) * 8 if first else (u - u0) * 8
+            rl0 = k0 - pos0 if first else seg0 + k0
+            lo_ok, hi_ok = (0, seg0) if first else (seg0, rows_here)
+            for e in range(8):
+                if lo_ok <= rl0 + e < hi_ok:
+                    assert (b, k0 + e) not in out
+                    out[(b, k0 + e)] = rl0 + e               # staged row (slab-local) that supplies this key
+        return out
+
+    L = 265
+    for B in (1, 2, 3, 8):
+        M = B * L
+        for BM, SR in ((64, 64), (128, 128), (256, 128), (256, 256)):
+            for row_off in (0, 128 * 3):
+                seen = {}
+                for m0 in range(0, M, BM):
+                    for sl in range(BM // SR):
+                        ms = m0 + sl * SR
+                        assert SR <= L + 1                      # a slab never touches three samples
+                        for (b, key), rl in slab_writes(ms, SR, M, L, row_off).items():
+                            assert (b, key) not in seen
+                            seen[(b, key)] = ms + rl + row_off
+                want = {divmod(r + row_off, L): r + row_off for r in range(M)}
+                assert seen == want, (B, BM, SR, row_off)
