@@ -646,6 +646,215 @@ static void run_reg(const char* name, const _Float16* A, const _Float16* W, floa
     fflush(stdout);
 }
 
+
+// ---- ping-pong variant (round-2 candidate; the structure cdna_hip_programming.md calls "256^2 8-phase"): one 8-wave
+// workgroup per CU, 256x256 tile, waves 2 (M) x 4 (N) of 128x64, two 64 KB LDS buffers (k-tiles of 32 x two planes).
+// A k-tile is consumed in FOUR phases, one 64x32 quadrant pair of the wave tile each (12 MFMAs):
+//     phase 0: read A-sub0 (8 x ds_read_b128) + B-sub0 (4)  -> quadrant (A0, B0)
+//     phase 1: read B-sub1 (4)                              -> (A0, B1)
+//     phase 2: read A-sub1 (8)                              -> (A1, B1)
+//     phase 3: (B-sub0 is still in registers)               -> (A1, B0)
+// and staged in four QUARTERS of 16 KB (A-sub0 rows of both wave rows, B-sub0, B-sub1, A-sub1), one quarter issued per
+// phase (2 DMA instructions per wave), LEAD quarters ahead of the phase that computes: the wait of a phase is a
+// COUNTED vmcnt(2 (LEAD - 2)) -- never 0 in the steady state -- so LEAD-2 quarters stay in flight across the barriers.
+// Each phase = { ds_read sub-tile; issue a quarter; vmcnt(n); barrier; MFMAs under setprio(1); barrier }, and the two
+// wave rows run one barrier apart (the second row passes one extra barrier up front), so on every SIMD one wave
+// issues MFMAs while the other reads LDS and issues DMA.
+// Hazards (phase numbers g = 4 tile + p; quarter q = 4 tile + type is needed at phase 4 tile + {0, 0, 1, 2}[type]):
+//   RAW: the wait of phase g retires the quarters <= g + 2 of this wave, the barrier behind it makes that true of every
+//        wave of its row, the other row is at most one barrier away -> quarter q is read in phase >= (its wait) + 1.
+//   WAR: quarter g + LEAD lands on the region whose previous occupant was last read >= 2 phases earlier (LEAD <= 6).
+// Same MFMA order per accumulator as probe_kernel -> bit-identical results.
+// FLAGS bit 0: the two wave rows run one barrier apart (ping-pong); bit 1: s_setprio(1) around the MFMA clusters
+template <int LEAD, int GM, int FLAGS = 3>
+__global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long a_plane, const _Float16* W,
+                                                    long long w_plane, float* C, int M, int N, int K,
+                                                    unsigned long long* clk) {
+    static_assert(LEAD == 5 || LEAD == 6, "quarters in flight: see the WAR analysis");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int BM = 256, BN = 256;
+    constexpr int APL = BM * HLD, BPL = BN * HLD, STAGE = 2 * (APL + BPL);   // halves; STAGE * 2 = 64 KB
+    _Float16* smem = (_Float16*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (N + BN - 1) / BN, nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm_, tn_;
+    {
+        const int tiles_m = (M + BM - 1) / BM;
+        const int per = GM * tiles_n, grp = bid / per, first = grp * GM;
+        const int gsz = tiles_m - first < GM ? tiles_m - first : GM;
+        const int in = bid - grp * per;
+        tm_ = first + in % gsz;
+        tn_ = in / gsz;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    const int nk = K / HBK;                       // even (K % 64 == 0)
+    // this wave's two 16-row groups of each quarter type: 0 = A-sub0, 1 = B-sub0, 2 = B-sub1, 3 = A-sub1
+    // wave-uniform 64-bit bases (SGPRs) + one per-lane byte offset: keeps the eight tile pointers out of the VGPR file
+    unsigned long long src[4][2];
+    int ldsoff[4][2];
+    const unsigned lane16 = lane * 16;
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = 2 * wave + k, plane = idx >> 3, r = idx & 7;
+            const bool isA = ty == 0 || ty == 3;
+            const int s = isA ? (ty == 3) : (ty == 2);
+            const int gip = isA ? (r >> 2) * 8 + s * 4 + (r & 3)       // 16-row group inside the 256-row plane
+                                : (r >> 1) * 4 + s * 2 + (r & 1);
+            int rg = ((isA ? m0 : n0) >> 4) + gip;
+            const int rgs = ((isA ? M : N) + 15) >> 4;
+            if (rg >= rgs) rg = rgs - 1;
+            const unsigned long long a_ = (unsigned long long)((isA ? A + plane * a_plane : W + plane * w_plane) + (size_t)rg * nk * 512);
+            src[ty][k] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
+                         __builtin_amdgcn_readfirstlane((unsigned)a_);
+            ldsoff[ty][k] = __builtin_amdgcn_readfirstlane(((isA ? 0 : 32) + plane * 16 + gip) * 1024);
+        }
+#define PP_ISSUE(tile_, ty_, buf_)                                                                   \
+    do {                                                                                             \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                \
+            __builtin_amdgcn_global_load_lds((gptr)((const unsigned char*)(src[ty_][k] + (unsigned long long)(tile_) * 1024) + lane16), \
+                                             (lptr)(smem_raw + (buf_) * (STAGE * 2) + ldsoff[ty_][k]), 16, 0, 0); \
+    } while (0)
+#define PP_FENCE()                                                                                   \
+    do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_BAR()                                                                                     \
+    do { PP_FENCE(); __builtin_amdgcn_s_barrier(); PP_FENCE(); } while (0)
+    const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    h8 a0[2][2], a1[2][2];          // [ks][row block of the current A-sub]: hi, lo planes
+    h8 b0[2][2], b1[2][2];          // [B-sub][ks]: hi, lo planes
+#define PP_READ_A(buf_, s_)                                                                          \
+    do {                                                                                             \
+        const _Float16* Ac = smem + (buf_) * STAGE + (wr * 128 + (s_) * 64 + l31) * HLD;             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) {                                       \
+                a0[ks][ib] = *(const h8*)(Ac + ib * 32 * HLD + swz[ks]);                             \
+                a1[ks][ib] = *(const h8*)(Ac + APL + ib * 32 * HLD + swz[ks]);                       \
+            }                                                                                        \
+    } while (0)
+#define PP_READ_B(buf_, s_)                                                                          \
+    do {                                                                                             \
+        const _Float16* Bc = smem + (buf_) * STAGE + 2 * APL + (wc * 64 + (s_) * 32 + l31) * HLD;    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            b0[s_][ks] = *(const h8*)(Bc + swz[ks]);                                                 \
+            b1[s_][ks] = *(const h8*)(Bc + BPL + swz[ks]);                                           \
+        }                                                                                            \
+    } while (0)
+    // quadrant (A-sub sa, B-sub sb): per accumulator the order is ks 0 {a1 b0, a0 b1, a0 b0}, ks 1 {...}
+#define PP_QUAD(sa_, sb_)                                                                            \
+    do {                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks][ib], b0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b1[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+        }                                                                                            \
+    } while (0)
+    // one phase: P = phase within the k-tile (compile time), BUF = parity of the k-tile t (compile time)
+#define PP_PHASE(P, BUF)                                                                             \
+    do {                                                                                             \
+        if (P == 0) { PP_READ_A(BUF, 0); PP_READ_B(BUF, 0); }                                        \
+        if (P == 1) PP_READ_B(BUF, 1);                                                               \
+        if (P == 2) PP_READ_A(BUF, 1);                                                               \
+        PP_FENCE();                                                                                  \
+        {                                                                                            \
+            constexpr int dq = (P) + LEAD;                     /* quarter 4 t + dq */                \
+            const int tq = t + (dq >> 2);                                                            \
+            if (tq < nk) {                                                                           \
+                PP_ISSUE(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                       \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");                \
+            } else {                                                                                 \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* tail: nothing younger to count */ \
+            }                                                                                        \
+        }                                                                                            \
+        PP_BAR();                                                                                    \
+        if (FLAGS & 2) __builtin_amdgcn_s_setprio(1);                                                \
+        if (P == 0) PP_QUAD(0, 0);                                                                   \
+        if (P == 1) PP_QUAD(0, 1);                                                                   \
+        if (P == 2) PP_QUAD(1, 1);                                                                   \
+        if (P == 3) PP_QUAD(1, 0);                                                                   \
+        if (FLAGS & 2) __builtin_amdgcn_s_setprio(0);                                                \
+        PP_BAR();                                                                                    \
+    } while (0)
+    // prologue: quarters 0 .. LEAD-1 (k-tile 0 and the first LEAD-4 quarters of k-tile 1), quarters 0 and 1 landed
+#pragma unroll
+    for (int q = 0; q < LEAD; ++q)
+        if ((q >> 2) < nk) PP_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");
+    PP_BAR();
+    if ((FLAGS & 1) && wr == 1) PP_BAR();   // the second wave row runs one barrier behind the first
+    for (int t = 0; t < nk; t += 2) {
+        PP_PHASE(0, 0); PP_PHASE(1, 0); PP_PHASE(2, 0); PP_PHASE(3, 0);
+        ++t;
+        PP_PHASE(0, 1); PP_PHASE(1, 1); PP_PHASE(2, 1); PP_PHASE(3, 1);
+        --t;
+    }
+    if ((FLAGS & 1) && wr == 0) PP_BAR();   // ... and the first row waits for it at the end
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + (wc * 2 + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wr * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    if (tid == 0 && clk) {
+        clk[2 * blockIdx.x] = __builtin_readcyclecounter() - t0;
+        clk[2 * blockIdx.x + 1] = wall_clock64() - w0;
+    }
+}
+
+template <int LEAD, int GM, int FLAGS = 3>
+static void run_pp(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
+                   unsigned long long* clk) {
+    const size_t lds = (size_t)2 * 2 * (256 + 256) * HLD * 2;
+    hipFuncSetAttribute((const void*)pp_kernel<LEAD, GM, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i)
+        hipLaunchKernelGGL((pp_kernel<LEAD, GM, FLAGS>), dim3(tiles), dim3(512), lds, 0, A, (long long)M * K, W, (long long)N * K, C,
+                           M, N, K, clk);
+    const int reps = 30;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL((pp_kernel<LEAD, GM, FLAGS>), dim3(tiles), dim3(512), lds, 0, A, (long long)M * K, W, (long long)N * K, C,
+                           M, N, K, clk);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) printf("  launch error: %s\n", hipGetErrorString(err));
+    std::vector<unsigned long long> h(2 * tiles);
+    hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, wall = 0;
+    for (int i = 0; i < tiles; ++i) { cyc += h[2 * i]; wall += h[2 * i + 1]; }
+    const double us = ms * 1e3 / reps;
+    printf("%-26s LEAD%d GM%-2d 256x256 8w  M=%d N=%d K=%d: %8.1f us  %6.1f TF-eq  clock %.2f GHz  block life %.0f cyc  (%d tiles = %.2f rounds)\n",
+           name, LEAD, GM, M, N, K, us, 2.0 * M * N * K / us / 1e6, cyc / wall * 0.1, cyc / tiles, tiles, tiles / 256.0);
+    fflush(stdout);
+}
+
 template <int NS, int GM>
 static void run_sp(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
                    unsigned long long* clk) {
@@ -749,6 +958,11 @@ int main() {
     run<128, 128, 16, 2, 8>("packed 2-stage occ2", A, W, C, MM, N, K, clk);                         \
     run_reg<128, 128, 2, 8>("packed reg-staged 2-ahead", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_reg<128, 64, 3, 8>("packed reg-staged 2-ahead", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
+    run_pp<6, 4>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
+    run_pp<5, 4>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
+    run_pp<6, 4, 1>("8-phase, no setprio", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);           \
+    run_pp<6, 4, 2>("8-phase, rows in lockstep", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);     \
+    run_pp<6, 8>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
     run_big<256, 256, 2, 4, 2, 4>("big 256x256 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 4, 2, 2, 4>("big 256x256 8w (4x2)", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 2, 4, 2, 4, 1>("big 256x256 8w sched1", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
