@@ -90,8 +90,9 @@ int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 /* cfg: -1 automatic (default); 0 = 128x128 (balanced launch for packed operands), 1 = 128x64, 2 = 64x64 tiles of one
    4-wave workgroup; 3 = 256x256, 4 = 256x128 (3-stage ring), 6 = 128x256 (3-stage ring) tiles of one 8-wave workgroup
    per CU -- the big-tile candidates; 7 = cfg 0 with the packed tiles staged through registers two k-tiles ahead
-   instead of LDS-DMA.  3 / 4 / 6 / 7 are unmeasured candidates for packed operands only (others fall back to 0);
-   every cfg produces the same bits. */
+   instead of LDS-DMA; 8 = cfg 3's tile with the ping-pong main loop (four phases per k-tile, quarter-granular
+   prefetch under a counted vmcnt, wave rows one barrier apart, s_setprio around the MFMA clusters).  3 / 4 / 6 / 7 / 8
+   are unmeasured candidates for packed operands only (others fall back to 0); every cfg produces the same bits. */
 void ds_gemm_f16x2_force_tile(int cfg);
 /* packed-operand launches that pick the 128x128 tile are balanced: 128x128 tiles over the leading rows that fill
    whole rounds of `slots` resident workgroups (default 512 = 256 CUs x 2), 64x64 tiles over the rest.  Test hook. */
@@ -99,7 +100,7 @@ void ds_gemm_f16x2_set_balance_slots(int slots);
 /* the same balance unit for the big-tile launches (default 256 = one workgroup per CU); rows past the last whole
    round go to 8-wave 128x128 tiles in the same grid.  Test hook. */
 void ds_gemm_f16x2_set_big_slots(int slots);
-/* The row partition a packed-operand launch of cfg 0 / 3 / 4 / 6 / 7 uses for an M x N product with the given store
+/* The row partition a packed-operand launch of cfg 0 / 3 / 4 / 6 / 7 / 8 uses for an M x N product with the given store
    mode: rows [0, m_off) -> nbig main tiles, rows [m_off, M) -> nsmall tail tiles (0: one program over all rows).
    Pure arithmetic, no device work: the CPU test-suite checks the partition with it. */
 int ds_gemm_f16x2_plan(int cfg, int M, int N, int store, int* m_off, int* nbig, int* nsmall);

@@ -71,7 +71,8 @@ def test_vqmodel_forward_is_decode_of_encode():
 
 
 # ---- big-tile candidates of the split GEMM (8-wave workgroups, ds_gemm_f16x2_force_tile 3 / 4 / 6) ------------------
-BIG_TILES = (3, 4, 6, 7)     # 7: the 4-wave programs with register-staged packed tiles (balanced launch: set_balance_slots)
+BIG_TILES = (3, 4, 6, 7, 8)  # 7: the 4-wave programs with register-staged packed tiles (balanced launch: set_balance_slots);
+                             # 8: the 256x256 tile with the ping-pong (8-phase) main loop
 # These kernels were written after the round's GPU budget was spent and have never run on hardware; a defect in a new
 # main loop could hang the device, so they stay out of the default GPU run until their first supervised execution.
 big = pytest.mark.skipif(os.environ.get("DIFFSOUND_TEST_BIG_TILES") != "1",

@@ -24,7 +24,7 @@ def test_balanced_launch_row_partition():
     from text_to_sound_synthesis_amd import _lib as L
     lib = L.lib()
     geo = {0: (128, 128, 64, 64), 7: (128, 128, 64, 64), 3: (256, 256, 128, 128), 4: (256, 128, 128, 128),
-           6: (128, 256, 128, 128)}
+           6: (128, 256, 128, 128), 8: (256, 256, 128, 128)}
 
     def plan(cfg, M, N, store=L.STORE_ROW):
         a, b, c = C.c_int(), C.c_int(), C.c_int()

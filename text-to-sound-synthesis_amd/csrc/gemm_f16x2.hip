@@ -51,7 +51,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave tiles are made of 32x32 blocks");
-    static_assert(AMODE == 2 || (NT == 256 && NS == 2), "register staging is written for 256 threads, two stages");
+    static_assert(AMODE == 2 || AMODE == 4 || (NT == 256 && NS == 2), "register staging is written for 256 threads, two stages");
     constexpr int SA = BM / 64;   // 8-element (2 x float4) staging chunks per thread (A)
     constexpr int SB = BN / 64;   // 16-byte staging chunks per thread per plane (B)
     constexpr int APL = BM * HLD, BPL = BN * HLD;       // plane strides (halves)
@@ -206,7 +206,122 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     } while (0)
 
     const int nk = p.K / HBK;
-    if constexpr (AMODE >= 2) {
+    if constexpr (AMODE == 4) {
+        // Ping-pong main loop (opt-in candidate, force_tile 8; tools/probe/probe_gemm_f16x2.hip pp_kernel carries the
+        // derivation): 256x256 tile, waves 2 x 4 of 128x64, two 64 KB buffers.  A k-tile is consumed in four phases
+        // (quadrants of the wave tile, 12 MFMAs each: A-sub0 x B-sub0, A-sub0 x B-sub1, A-sub1 x B-sub1, A-sub1 x
+        // B-sub0) and staged as four 16 KB quarters (A-sub0 rows of both wave rows, B-sub0, B-sub1, A-sub1), one per
+        // phase, LEAD quarters ahead, retired by a COUNTED vmcnt(2 (LEAD - 2)); the two wave rows run one barrier
+        // apart, so each SIMD always has one wave in its MFMA cluster (under s_setprio 1) and one reading LDS / issuing
+        // DMA.  Quarter q = 4 tile + type is read in phase >= (the wait that retires it) + 1; it lands on a region
+        // whose previous occupant was last read >= 2 phases earlier.
+        static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4 && NS == 2, "one geometry");
+        constexpr int LEAD = 6;
+        unsigned long long q_src[4][2];      // wave-uniform bases of this wave's two 16-row groups per quarter type
+        int q_lds[4][2];
+        const unsigned lane16 = lane * 16;
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty)       // 0 = A-sub0, 1 = B-sub0, 2 = B-sub1, 3 = A-sub1
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = 2 * wave + k, plane = idx >> 3, r = idx & 7;
+                const bool isA = ty == 0 || ty == 3;
+                const int sub = isA ? (ty == 3) : (ty == 2);
+                const int gip = isA ? (r >> 2) * 8 + sub * 4 + (r & 3) : (r >> 1) * 4 + sub * 2 + (r & 1);
+                int rg = ((isA ? m0 : n0) >> 4) + gip;
+                const int rgs = ((isA ? p.M : p.N) + 15) >> 4;
+                if (rg >= rgs) rg = rgs - 1;                 // tail groups re-read the last group (never stored)
+                const _Float16* base = isA ? (const _Float16*)p.A + (plane ? p.a_plane : 0)
+                                           : (const _Float16*)p.W + (plane ? pl1 : 0);
+                const unsigned long long a_ = (unsigned long long)(base + (size_t)rg * nk * 512);
+                q_src[ty][k] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
+                               __builtin_amdgcn_readfirstlane((unsigned)a_);
+                q_lds[ty][k] = __builtin_amdgcn_readfirstlane(((isA ? 0 : 32) + plane * 16 + gip) * 1024);
+            }
+#define H4_ISSUE(tile_, ty_, buf_)                                                                  \
+    do {                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                               \
+            __builtin_amdgcn_global_load_lds(                                                       \
+                (ds_gptr)((const unsigned char*)(q_src[ty_][k] + (unsigned long long)(tile_) * 1024) + lane16), \
+                (ds_lptr)(smem_raw + (buf_) * (STAGE * 2) + q_lds[ty_][k]), 16, 0, 0);              \
+    } while (0)
+#define H4_FENCE()                                                                                  \
+    do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define H4_BAR()                                                                                    \
+    do { H4_FENCE(); __builtin_amdgcn_s_barrier(); H4_FENCE(); } while (0)
+        h8 pa0[2][2], pa1[2][2];             // [ks][row block of the current A-sub]: hi, lo
+        h8 pb0[2][2], pb1[2][2];             // [B-sub][ks]: hi, lo
+#define H4_READ_A(buf_, s_)                                                                         \
+    do {                                                                                            \
+        const _Float16* Ac = smem + (buf_) * STAGE + (wm * 128 + (s_) * 64 + l31) * HLD;            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) {                                      \
+                pa0[ks][ib] = *(const h8*)(Ac + ib * 32 * HLD + swz[ks]);                           \
+                pa1[ks][ib] = *(const h8*)(Ac + APL + ib * 32 * HLD + swz[ks]);                     \
+            }                                                                                       \
+    } while (0)
+#define H4_READ_B(buf_, s_)                                                                         \
+    do {                                                                                            \
+        const _Float16* Bc = smem + (buf_) * STAGE + 2 * APL + (wn * 64 + (s_) * 32 + l31) * HLD;   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
+            pb0[s_][ks] = *(const h8*)(Bc + swz[ks]);                                               \
+            pb1[s_][ks] = *(const h8*)(Bc + BPL + swz[ks]);                                         \
+        }                                                                                           \
+    } while (0)
+        // per accumulator: ks 0 {a1 b0, a0 b1, a0 b0}, ks 1 {...} -- the order of every other program of this file
+#define H4_QUAD(sa_, sb_)                                                                           \
+    do {                                                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                        \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa1[ks][ib], pb0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                        \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa0[ks][ib], pb1[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                        \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa0[ks][ib], pb0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+        }                                                                                           \
+    } while (0)
+#define H4_PHASE(P, BUF)                                                                            \
+    do {                                                                                            \
+        if (P == 0) { H4_READ_A(BUF, 0); H4_READ_B(BUF, 0); }                                       \
+        if (P == 1) H4_READ_B(BUF, 1);                                                              \
+        if (P == 2) H4_READ_A(BUF, 1);                                                              \
+        H4_FENCE();                                                                                 \
+        {                                                                                           \
+            constexpr int dq = (P) + LEAD;                    /* quarter 4 t + dq */                \
+            const int tq = t + (dq >> 2);                                                           \
+            if (tq < nk) {                                                                          \
+                H4_ISSUE(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                      \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");               \
+            } else {                                                                                \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* tail: nothing younger to count */ \
+            }                                                                                       \
+        }                                                                                           \
+        H4_BAR();                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                              \
+        if (P == 0) H4_QUAD(0, 0);                                                                  \
+        if (P == 1) H4_QUAD(0, 1);                                                                  \
+        if (P == 2) H4_QUAD(1, 1);                                                                  \
+        if (P == 3) H4_QUAD(1, 0);                                                                  \
+        __builtin_amdgcn_s_setprio(0);                                                              \
+        H4_BAR();                                                                                   \
+    } while (0)
+#pragma unroll
+        for (int q = 0; q < LEAD; ++q)
+            if ((q >> 2) < nk) H4_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");
+        H4_BAR();
+        if (wm == 1) H4_BAR();               // the second wave row runs one barrier behind the first
+        int t = 0;
+        for (; t + 1 < nk; t += 2) {
+            H4_PHASE(0, 0); H4_PHASE(1, 0); H4_PHASE(2, 0); H4_PHASE(3, 0);
+            ++t;
+            H4_PHASE(0, 1); H4_PHASE(1, 1); H4_PHASE(2, 1); H4_PHASE(3, 1);
+            --t;
+        }
+        if (t < nk) { H4_PHASE(0, 0); H4_PHASE(1, 0); H4_PHASE(2, 0); H4_PHASE(3, 0); }   // odd number of k-tiles
+        if (wm == 0) H4_BAR();               // ... and the first row waits for it at the end
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (AMODE >= 2) {
         // LDS image of a stage = 2*(BM+BN) rows of 64 B: A hi rows, A lo rows, B hi rows, B lo rows.  One DMA
         // instruction of a wave fills 16 consecutive rows = one packed 16-row x 32-k tile (lane l -> bytes 16 l);
         // the wave owns the 16-row groups g = wave + NW i.
@@ -407,7 +522,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     // The staged epilogues reuse the operand stages (NS * STAGE halves) as the tile buffer.  A tile that does not fit
     // (256x256: 256 KB of fp32 against 128 KB of stages) goes through in SLABS row slabs of SR rows, each filled by
     // the waves whose rows lie in it; SLABS = 1 for every 4-wave instantiation.
-    constexpr int LDS_BYTES = AMODE == 2 ? NS * STAGE * 2 : 2 * STAGE * 2;
+    constexpr int LDS_BYTES = AMODE == 2 ? NS * STAGE * 2 : 2 * STAGE * 2;   // (AMODE 4: two 64 KB buffers)
     constexpr int SLABS = (BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES;
     static_assert(WGM % SLABS == 0, "a wave's rows must lie in one slab");
     constexpr int SR = BM / SLABS;
@@ -573,19 +688,19 @@ static BalancePlan ds_balance_plan(int M, int N, int BM, int BN, int slots, int 
 // balanced launch gives the big tiles the rows that fill whole rounds of 256 CUs and the rows after them to 8-wave
 // 128x128 tiles (waves of 64x32) in the same grid.  Results are bit-identical to the 4-wave programs (same MFMA order
 // per accumulator).  tools/probe/probe_gemm_f16x2.hip holds the bare main loops; see DESIGN.md section 3.
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, int AMODE = 2>
 __global__ __launch_bounds__(WGM * WGN * 64, 1) void ds_gemm_f16x2_big_kernel(const GemmParams pb, const GemmParams ps,
                                                                               const int nbig) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     static_assert(WGM * WGN == 8, "the tail program below is written for 8 waves");
     const int bid = blockIdx.x;   // uniform branch: a workgroup runs one of the two programs
-    if (bid < nbig) ds_gemm_f16x2_body<BM, BN, 2, WGM, WGN, NS>(pb, bid, nbig, smem_dyn);
+    if (bid < nbig) ds_gemm_f16x2_body<BM, BN, AMODE, WGM, WGN, NS>(pb, bid, nbig, smem_dyn);
     else ds_gemm_f16x2_body<128, 128, 2, 2, 4, 2>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
 }
 
 static int g_big_slots = 256;   // one big workgroup per CU; a test hook shrinks it so small shapes get a tail program
 extern "C" void ds_gemm_f16x2_set_big_slots(int n) { g_big_slots = n > 0 ? n : 256; }
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, int AMODE = 2>
 static int launch_big(const GemmParams& p, hipStream_t s) {
     const BalancePlan pl = ds_balance_plan(p.M, p.N, BM, BN, g_big_slots, 128, 128,
                                            p.store == DS_STORE_ROW || p.store == DS_STORE_ATTN);
@@ -604,7 +719,7 @@ static int launch_big(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)NS * 2 * (BM + BN) * HLD * sizeof(unsigned short);   // >= the tail program's 64 KB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS>,
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS, AMODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -612,7 +727,7 @@ static int launch_big(const GemmParams& p, hipStream_t s) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS>), dim3(nbig + nsmall), dim3(WGM * WGN * 64), lds, s,
+    hipLaunchKernelGGL((ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS, AMODE>), dim3(nbig + nsmall), dim3(WGM * WGN * 64), lds, s,
                        pb, ps, nbig);
     DS_CHECK_LAUNCH();
     return 0;
@@ -699,7 +814,7 @@ extern "C" int ds_gemm_f16x2_plan(int cfg, int M, int N, int store, int* m_off, 
     BalancePlan pl;
     switch (cfg) {
         case 0: case 7: pl = ds_balance_plan(M, N, 128, 128, g_balance_slots, 64, 64, tail_ok); break;
-        case 3: pl = ds_balance_plan(M, N, 256, 256, g_big_slots, 128, 128, tail_ok); break;
+        case 3: case 8: pl = ds_balance_plan(M, N, 256, 256, g_big_slots, 128, 128, tail_ok); break;
         case 4: pl = ds_balance_plan(M, N, 256, 128, g_big_slots, 128, 128, tail_ok); break;
         case 6: pl = ds_balance_plan(M, N, 128, 256, g_big_slots, 128, 128, tail_ok); break;
         default: DS_CHECK_ARG(false, "cfg has no balanced launch");
@@ -750,6 +865,7 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
         case 7: return launch_hybrid<true>(p, stream);
         case 1: return launch_h<128, 64>(p, stream);
         case 3: return launch_big<256, 256, 2, 4, 2>(p, stream);
+        case 8: return launch_big<256, 256, 2, 4, 2, 4>(p, stream);
         case 4: return launch_big<256, 128, 4, 2, 3>(p, stream);
         case 6: return launch_big<128, 256, 2, 4, 3>(p, stream);
         default: return launch_h<64, 64>(p, stream);

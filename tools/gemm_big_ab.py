@@ -15,7 +15,7 @@ ap.add_argument("--batch", type=int, default=64)
 args = ap.parse_args()
 M = args.batch * 265
 SHAPES = [("qkv", 3072, 1024), ("proj/q2", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
-NAMES = {-1: "default", 3: "256x256", 4: "256x128/3", 6: "128x256/3", 7: "128x128 reg-staged"}
+NAMES = {-1: "default", 3: "256x256", 4: "256x128/3", 6: "128x256/3", 7: "128x128 reg-staged", 8: "256x256 ping-pong"}
 
 
 def split(a):
