@@ -308,7 +308,8 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
 #pragma unroll
         for (int q = 0; q < LEAD; ++q)
             if ((q >> 2) < nk) H4_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");
+        if (4 * nk >= LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");   // quarters 0, 1 landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // fewer than LEAD quarters exist
         H4_BAR();
         if (wm == 1) H4_BAR();               // the second wave row runs one barrier behind the first
         int t = 0;

@@ -796,7 +796,8 @@ __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long
 #pragma unroll
     for (int q = 0; q < LEAD; ++q)
         if ((q >> 2) < nk) PP_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");
+    if (4 * nk >= LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");   // quarters 0, 1 landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // fewer than LEAD quarters exist
     PP_BAR();
     if ((FLAGS & 1) && wr == 1) PP_BAR();   // the second wave row runs one barrier behind the first
     for (int t = 0; t < nk; t += 2) {
