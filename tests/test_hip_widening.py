@@ -81,7 +81,7 @@ big = pytest.mark.skipif(os.environ.get("DIFFSOUND_TEST_BIG_TILES") != "1",
 
 @big
 @pytest.mark.parametrize("M,N,K", [(4240, 4096, 1024), (4240, 1024, 4096), (2100, 1024, 1024), (700, 256, 1024),
-                                   (300, 96, 64)])
+                                   (300, 96, 64), (300, 96, 32), (520, 512, 96)])     # incl. 1, 2, 3 k-tiles
 def test_f16x2_big_tiles_bit_identical(M, N, K):
     """256x256 / 256x128 / 128x256 tiles of one 8-wave workgroup (slab-staged epilogues, three-stage DMA ring) and their
     balanced launch with an 8-wave 128x128 tail program: same bits as the loader-split 4-wave GEMM, for row-major
