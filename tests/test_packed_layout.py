@@ -110,3 +110,53 @@ def test_vt_store_unit_bookkeeping_mirror():
                             seen[(b, key)] = ms + rl + row_off
                 want = {divmod(r + row_off, L): r + row_off for r in range(M)}
                 assert seen == want, (B, BM, SR, row_off)
+
+
+def test_ping_pong_schedule_hazards():
+    """Happens-before check of the ping-pong main loop's schedule (csrc/gemm_f16x2.hip AMODE 4, probe pp_kernel).
+    Model: both wave rows run the same phase program {ds_read; issue quarter g + LEAD; counted wait; barrier; MFMAs;
+    barrier}, the second row one barrier behind; an event before barrier instance k (in either row) happens before every
+    event after instance k (in both rows).  A wait in phase w retires this wave's quarters <= w + 2; a ds_read issued in
+    phase g has completed by that row's second barrier of phase g.
+      RAW: quarter q must be retired by BOTH rows' waits before any row reads it.
+      WAR: a quarter may be issued on a region only after BOTH rows have completed the reads of its previous occupant,
+           and never on a region read in the issuing phase.
+    LEAD = 5 and 6 satisfy both; 7 does not."""
+    need_off = (0, 0, 1, 2)               # quarter type -> phase (within its k-tile) of its first read
+    reads = {0: (0, 1), 1: (2,), 2: (3,), 3: ()}     # phase within the k-tile -> quarter types read (B-sub0 kept in regs)
+    last_read = {0: 0, 1: 0, 2: 1, 3: 2}            # quarter type -> phase (within its k-tile) of its last read
+
+    def b1(row, g):                        # barrier instance numbers (prologue barrier = 1, the extra one of row 1 = 2)
+        return 2 * g + 2 + row
+
+    def b2(row, g):
+        return 2 * g + 3 + row
+
+    def before_read(row, g):               # the barrier instance that precedes the ds_reads of phase g
+        return b2(row, g - 1) if g > 0 else 1 + row
+
+    def hazards(LEAD, nk=6):
+        bad = []
+        for q in range(4 * nk):
+            tile, ty = divmod(q, 4)
+            g_need = 4 * tile + need_off[ty]
+            w = max(q - 2, -1)                                   # phase whose wait retires q (-1: the prologue wait)
+            for reader in (0, 1):
+                for waiter in (0, 1):
+                    retired_at = b1(waiter, w) if w >= 0 else 1
+                    if retired_at > before_read(reader, g_need):
+                        bad.append(("RAW", q, reader, waiter))
+            g_issue = q - LEAD
+            if g_issue < 0 or tile < 2:
+                continue                                         # prologue quarters / first use of a buffer
+            g_prev = 4 * (tile - 2) + last_read[ty]              # last read of the region's previous occupant
+            for reader in (0, 1):
+                for issuer in (0, 1):
+                    if b2(reader, g_prev) > before_read(issuer, g_issue):      # issue sits where the phase's reads sit
+                        bad.append(("WAR", q, reader, issuer))
+            if tile - 2 == g_issue // 4 and ty in reads[g_issue % 4]:
+                bad.append(("WAR-own-phase", q))
+        return bad
+
+    assert hazards(5) == [] and hazards(6) == []
+    assert any(h[0] == "WAR" for h in hazards(7))

@@ -696,7 +696,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void ds_gemm_f16x2_big_kernel(co
     static_assert(WGM * WGN == 8, "the tail program below is written for 8 waves");
     const int bid = blockIdx.x;   // uniform branch: a workgroup runs one of the two programs
     if (bid < nbig) ds_gemm_f16x2_body<BM, BN, AMODE, WGM, WGN, NS>(pb, bid, nbig, smem_dyn);
-    else ds_gemm_f16x2_body<128, 128, 2, 2, 4, 2>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
+    // tail rows: 8-wave 128x128 tiles on a four-stage ring (128 KB, within every big program's allocation) -- the tail
+    // runs on a few CUs only, so it is bound by the DMA round trip per k-tile; three tiles in flight hide it
+    else ds_gemm_f16x2_body<128, 128, 2, 2, 4, 4>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
 }
 
 static int g_big_slots = 256;   // one big workgroup per CU; a test hook shrinks it so small shapes get a tail program
@@ -717,7 +719,8 @@ static int launch_big(const GemmParams& p, hipStream_t s) {
         else ps.C = p.C + (size_t)m_off * p.ldc;
         if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
     }
-    const size_t lds = (size_t)NS * 2 * (BM + BN) * HLD * sizeof(unsigned short);   // >= the tail program's 64 KB
+    const size_t lds = (size_t)NS * 2 * (BM + BN) * HLD * sizeof(unsigned short);   // >= the tail program's 128 KB
+    static_assert((size_t)NS * 2 * (BM + BN) * HLD * sizeof(unsigned short) >= 4u * 2 * 256 * HLD * sizeof(unsigned short), "tail ring");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS, AMODE>,
