@@ -981,5 +981,12 @@ int main() {
     QCASE(16384, 1024, 4096)
     QCASE(16960, 1024, 1024)
     QCASE(16960, 3072, 1024)
+    // the tail program of the balanced big-tile launch alone: 576 rows (B = 64) on 8-wave 128x128 tiles, 2 vs 4 stages
+#define TCASE(N, K)                                                                                 \
+    run_big<128, 128, 2, 4, 2, 8>("tail 128x128 8w", A, W, C, 576, N, K, clk);                      \
+    run_big<128, 128, 2, 4, 4, 8>("tail 128x128 8w", A, W, C2, 576, N, K, clk); differ(C, C2, 576, N);
+    TCASE(1024, 1024)
+    TCASE(1024, 4096)
+    TCASE(4096, 1024)
     return 0;
 }
