@@ -1,0 +1,123 @@
+"""Randomised cross-checks of the oracle's sampler pieces against the LIVE reference (imported from /root/reference
+through oracle/ref_harness.py): broader than the committed golden vectors -- other step counts and codebook sizes, many
+random states, every timestep.  Skipped on boxes without the reference tree (the goldens are what travels)."""
+import os
+import sys
+
+import pytest
+import torch
+
+import diffsound_oracle as O
+
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/Diffsound/sound_synthesis"),
+                                reason="reference tree not on this box")
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import ref_harness as rh
+    rh.install()
+    from sound_synthesis.modeling.transformers import diffusion_transformer as D
+    return rh, D
+
+
+@pytest.mark.parametrize("T,N", [(100, 257), (10, 257), (100, 513), (50, 2049), (1000, 257)])
+def test_schedule_buffers_any_size(ref, T, N):
+    """alpha_schedule + the log buffers (:122-151, :193-231) for other step counts / class counts than the goldens'."""
+    _, D = ref
+    import numpy as np
+    at, bt, ct, att, btt, ctt = D.alpha_schedule(T, N=N)
+    lg = lambda x: torch.log(torch.tensor(x.astype("float64")))
+    want = {"log_at": lg(at), "log_bt": lg(bt), "log_ct": lg(ct), "log_cumprod_at": lg(att), "log_cumprod_bt": lg(btt),
+            "log_cumprod_ct": lg(ctt)}
+    want["log_1_min_ct"] = D.log_1_min_a(want["log_ct"])
+    want["log_1_min_cumprod_ct"] = D.log_1_min_a(want["log_cumprod_ct"])
+    got = O.make_schedule(T, N)
+    for k, v in want.items():
+        a, b = got[k], v.float()
+        assert torch.equal(torch.isinf(a), torch.isinf(b)), k
+        fin = ~torch.isinf(b)
+        assert torch.equal(a[fin], b[fin]), k
+
+
+@pytest.fixture(scope="module")
+def dt10(ref):
+    rh, _ = ref
+    return rh.build_dalle(n_layer=1, diffusion_step=10, n_embed=256)
+
+
+def _random_state(B, K1, L, gen, mask_frac):
+    tok = torch.randint(0, K1 - 1, (B, L), generator=gen)
+    tok[torch.rand(B, L, generator=gen) < mask_frac] = K1 - 1
+    return tok
+
+
+def test_posterior_and_gumbel_every_timestep(ref, dt10):
+    """q_posterior (:293-339) and log_sample_categorical (:359-368) on random predicted distributions and random
+    partially masked states, for every timestep of a T = 10 model, incl. t = 0 (the wrap to index T)."""
+    _, D = ref
+    dt = dt10.transformer
+    sched = O.make_schedule(10, 257)
+    gen = torch.Generator().manual_seed(7)
+    for t_val in range(10):
+        for mask_frac in (0.0, 0.4, 1.0):
+            B, L = 3, 265
+            x_t = _random_state(B, 257, L, gen, mask_frac)
+            log_x_t = D.index_to_log_onehot(x_t, 257)
+            log_x0 = torch.log_softmax(torch.randn(B, 256, L, generator=gen) * 3, dim=1)
+            log_x0 = torch.cat((log_x0, torch.full((B, 1, L), -70.0)), 1).clamp(-70, 0)
+            t = torch.full((B,), t_val, dtype=torch.long)
+            want = dt.q_posterior(log_x_start=log_x0, log_x_t=log_x_t, t=t)
+            got = O.q_posterior(sched, log_x0, O.log_onehot(x_t, 257), t)
+            assert torch.equal(O.log_onehot(x_t, 257), log_x_t)
+            assert (got - want).abs().max() < 2e-5, (t_val, mask_frac)
+            u = torch.rand(B, 257, L, generator=gen)
+            rand_like = torch.rand_like
+            torch.rand_like = lambda x, *a, **k: u
+            try:
+                want_tok = D.log_onehot_to_index(dt.log_sample_categorical(want))
+            finally:
+                torch.rand_like = rand_like
+            assert torch.equal(O.gumbel_sample(want, u), want_tok)
+
+
+def test_q_sample_every_timestep(ref, dt10):
+    """q_sample (:370-377) = q_pred + Gumbel draw, for every timestep."""
+    _, D = ref
+    dt = dt10.transformer
+    sched = O.make_schedule(10, 257)
+    gen = torch.Generator().manual_seed(11)
+    for t_val in range(10):
+        x0 = torch.randint(0, 256, (2, 265), generator=gen)
+        t = torch.full((2,), t_val, dtype=torch.long)
+        u = torch.rand(2, 257, 265, generator=gen)
+        rand_like = torch.rand_like
+        torch.rand_like = lambda x, *a, **k: u
+        try:
+            want = dt.q_sample(log_x_start=D.index_to_log_onehot(x0, 257), t=t)
+        finally:
+            torch.rand_like = rand_like
+        assert torch.equal(O.q_sample(sched, x0, t, u, 257).argmax(1), D.log_onehot_to_index(want))
+
+
+@pytest.mark.parametrize("sample_type", ["top0.85r", "top0.5r", "top0.999r", "top1p", "top10p", "top100p"])
+def test_truncation_wrappers(ref, dt10, sample_type):
+    """The top-r / top-k wrappers (dalle_spec.py:146-177) on random, peaked and tied distributions."""
+    gen = torch.Generator().manual_seed(3)
+    cases = [torch.log_softmax(torch.randn(2, 256, 265, generator=gen) * s, dim=1) for s in (0.1, 1.0, 6.0)]
+    tied = torch.full((2, 256, 265), -5.545177)            # uniform over 256 classes: all tied
+    cases.append(tied)
+    for lp in cases:
+        lp = torch.cat((lp, torch.full((2, 1, 265), -70.0)), 1).clamp(-70, 0)
+        dt10.this_save_path = None       # the reference's top-k branch reads this attribute (dalle_spec.py:150)
+        want = dt10.predict_start_with_truncation(lambda: lp, sample_type)()
+        if sample_type.endswith("r"):
+            got = O.truncate_top_r(lp, float(sample_type[3:-1]))
+        else:
+            got = O.truncate_top_k(lp, int(sample_type[3:-1]))
+        if lp is not cases[-1] or sample_type.endswith("r"):
+            assert torch.equal(got, want), sample_type
+        else:                                           # exact ties: which k of the tied classes survive is unspecified
+            assert torch.equal((got > -70).sum(1), (want > -70).sum(1))
