@@ -234,7 +234,6 @@ class TrainStep:
                 tab.backward(dtab)
             g[pfx + ".emb.weight"], g[pfx + ".linear.weight"], g[pfx + ".linear.bias"] = e.grad, w.grad, b.grad
 
-        dcond_unused = None
         for li in reversed(range(len(saved))):
             s, blk = saved[li], tr.blocks[li]
             p = "transformer.blocks.%d." % li
