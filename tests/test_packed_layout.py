@@ -121,10 +121,10 @@ def test_ping_pong_schedule_hazards():
       RAW: quarter q must be retired by BOTH rows' waits before any row reads it.
       WAR: a quarter may be issued on a region only after BOTH rows have completed the reads of its previous occupant,
            and never on a region read in the issuing phase.
-    LEAD = 5 and 6 satisfy both; 7 does not."""
-    need_off = (0, 0, 1, 2)               # quarter type -> phase (within its k-tile) of its first read
-    reads = {0: (0, 1), 1: (2,), 2: (3,), 3: ()}     # phase within the k-tile -> quarter types read (B-sub0 kept in regs)
-    last_read = {0: 0, 1: 0, 2: 1, 3: 2}            # quarter type -> phase (within its k-tile) of its last read
+    Order {A-sub0, B-sub0, B-sub1, A-sub1} (B-sub0 kept in registers): LEAD 5 and 6 are legal, 7 is not.
+    Order {B-sub0, A-sub0, B-sub1, A-sub1} with B-sub0 read one phase early (the probe's FLAGS bit 2): 5, 6, 7 legal, 8 not."""
+    # per order: quarter type -> phase of its (only / last) read relative to its k-tile's phase 0
+    orders = {"a-first": (0, 0, 1, 2), "b-first": (-1, 0, 1, 2)}
 
     def b1(row, g):                        # barrier instance numbers (prologue barrier = 1, the extra one of row 1 = 2)
         return 2 * g + 2 + row
@@ -133,30 +133,33 @@ def test_ping_pong_schedule_hazards():
         return 2 * g + 3 + row
 
     def before_read(row, g):               # the barrier instance that precedes the ds_reads of phase g
-        return b2(row, g - 1) if g > 0 else 1 + row
+        return b2(row, g - 1) if g > 0 else 1 + row        # (g = -1, the prologue read of b-first: after the same)
 
-    def hazards(LEAD, nk=6):
+    def hazards(read_off, LEAD, nk=6):
         bad = []
         for q in range(4 * nk):
             tile, ty = divmod(q, 4)
-            g_need = 4 * tile + need_off[ty]
+            g_read = 4 * tile + read_off[ty]
             w = max(q - 2, -1)                                   # phase whose wait retires q (-1: the prologue wait)
             for reader in (0, 1):
                 for waiter in (0, 1):
                     retired_at = b1(waiter, w) if w >= 0 else 1
-                    if retired_at > before_read(reader, g_need):
+                    if retired_at > before_read(reader, max(g_read, 0)):
                         bad.append(("RAW", q, reader, waiter))
             g_issue = q - LEAD
             if g_issue < 0 or tile < 2:
                 continue                                         # prologue quarters / first use of a buffer
-            g_prev = 4 * (tile - 2) + last_read[ty]              # last read of the region's previous occupant
+            g_prev = 4 * (tile - 2) + read_off[ty]               # (last) read of the region's previous occupant
             for reader in (0, 1):
                 for issuer in (0, 1):
                     if b2(reader, g_prev) > before_read(issuer, g_issue):      # issue sits where the phase's reads sit
                         bad.append(("WAR", q, reader, issuer))
-            if tile - 2 == g_issue // 4 and ty in reads[g_issue % 4]:
+            if g_prev == g_issue:
                 bad.append(("WAR-own-phase", q))
         return bad
 
-    assert hazards(5) == [] and hazards(6) == []
-    assert any(h[0] == "WAR" for h in hazards(7))
+    assert hazards(orders["a-first"], 5) == [] and hazards(orders["a-first"], 6) == []
+    assert any(h[0] == "WAR" for h in hazards(orders["a-first"], 7))
+    for lead in (5, 6, 7):
+        assert hazards(orders["b-first"], lead) == [], lead
+    assert any(h[0] == "WAR" for h in hazards(orders["b-first"], 8))

@@ -665,12 +665,16 @@ static void run_reg(const char* name, const _Float16* A, const _Float16* W, floa
 //        wave of its row, the other row is at most one barrier away -> quarter q is read in phase >= (its wait) + 1.
 //   WAR: quarter g + LEAD lands on the region whose previous occupant was last read >= 2 phases earlier (LEAD <= 6).
 // Same MFMA order per accumulator as probe_kernel -> bit-identical results.
-// FLAGS bit 0: the two wave rows run one barrier apart (ping-pong); bit 1: s_setprio(1) around the MFMA clusters
+// FLAGS bit 0: the two wave rows run one barrier apart (ping-pong); bit 1: s_setprio(1) around the MFMA clusters;
+// bit 2: quarter order {B-sub0, A-sub0, B-sub1, A-sub1} with the NEXT tile's B-sub0 read in phase 3 into a second
+//        register set -> 8 / 4 / 8 / 4 ds_reads per phase instead of 12 / 4 / 8 / 0, every region is re-staged >= 3
+//        phases after its last read at LEAD 6, so LEAD 7 (five quarters = 80 KB in flight) becomes legal
 template <int LEAD, int GM, int FLAGS = 3>
 __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long a_plane, const _Float16* W,
                                                     long long w_plane, float* C, int M, int N, int K,
                                                     unsigned long long* clk) {
-    static_assert(LEAD == 5 || LEAD == 6, "quarters in flight: see the WAR analysis");
+    constexpr bool ORD = (FLAGS & 4) != 0;
+    static_assert(LEAD == 5 || LEAD == 6 || (ORD && LEAD == 7), "quarters in flight: see the WAR analysis");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int BM = 256, BN = 256;
     constexpr int APL = BM * HLD, BPL = BN * HLD, STAGE = 2 * (APL + BPL);   // halves; STAGE * 2 = 64 KB
@@ -696,6 +700,7 @@ __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long
     const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     const int nk = K / HBK;                       // even (K % 64 == 0)
     // this wave's two 16-row groups of each quarter type: 0 = A-sub0, 1 = B-sub0, 2 = B-sub1, 3 = A-sub1
+    // (ORD: 0 = B-sub0, 1 = A-sub0, 2 = B-sub1, 3 = A-sub1)
     // wave-uniform 64-bit bases (SGPRs) + one per-lane byte offset: keeps the eight tile pointers out of the VGPR file
     unsigned long long src[4][2];
     int ldsoff[4][2];
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int idx = 2 * wave + k, plane = idx >> 3, r = idx & 7;
-            const bool isA = ty == 0 || ty == 3;
+            const bool isA = ORD ? (ty & 1) : (ty == 0 || ty == 3);
             const int s = isA ? (ty == 3) : (ty == 2);
             const int gip = isA ? (r >> 2) * 8 + s * 4 + (r & 3)       // 16-row group inside the 256-row plane
                                 : (r >> 1) * 4 + s * 2 + (r & 1);
@@ -736,7 +741,8 @@ __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     h8 a0[2][2], a1[2][2];          // [ks][row block of the current A-sub]: hi, lo planes
-    h8 b0[2][2], b1[2][2];          // [B-sub][ks]: hi, lo planes
+    h8 b0[3][2], b1[3][2];          // [slot][ks]: hi, lo planes; slot 0 = B-sub0 (ORD: of even k-tiles), 1 = B-sub1,
+                                    // 2 = B-sub0 of odd k-tiles (ORD only)
 #define PP_READ_A(buf_, s_)                                                                          \
     do {                                                                                             \
         const _Float16* Ac = smem + (buf_) * STAGE + (wr * 128 + (s_) * 64 + l31) * HLD;             \
@@ -746,32 +752,33 @@ __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long
                 a1[ks][ib] = *(const h8*)(Ac + APL + ib * 32 * HLD + swz[ks]);                       \
             }                                                                                        \
     } while (0)
-#define PP_READ_B(buf_, s_)                                                                          \
+#define PP_READ_B(buf_, s_, slot_)                                                                   \
     do {                                                                                             \
         const _Float16* Bc = smem + (buf_) * STAGE + 2 * APL + (wc * 64 + (s_) * 32 + l31) * HLD;    \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
-            b0[s_][ks] = *(const h8*)(Bc + swz[ks]);                                                 \
-            b1[s_][ks] = *(const h8*)(Bc + BPL + swz[ks]);                                           \
+            b0[slot_][ks] = *(const h8*)(Bc + swz[ks]);                                              \
+            b1[slot_][ks] = *(const h8*)(Bc + BPL + swz[ks]);                                        \
         }                                                                                            \
     } while (0)
     // quadrant (A-sub sa, B-sub sb): per accumulator the order is ks 0 {a1 b0, a0 b1, a0 b0}, ks 1 {...}
-#define PP_QUAD(sa_, sb_)                                                                            \
+#define PP_QUAD(sa_, sb_, sl_)                                                                       \
     do {                                                                                             \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
             _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
-                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks][ib], b0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks][ib], b0[sl_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
             _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
-                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b1[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b1[sl_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
             _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
-                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b0[sl_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
         }                                                                                            \
     } while (0)
     // one phase: P = phase within the k-tile (compile time), BUF = parity of the k-tile t (compile time)
 #define PP_PHASE(P, BUF)                                                                             \
     do {                                                                                             \
-        if (P == 0) { PP_READ_A(BUF, 0); PP_READ_B(BUF, 0); }                                        \
-        if (P == 1) PP_READ_B(BUF, 1);                                                               \
+        if (P == 0) { PP_READ_A(BUF, 0); if (!ORD) PP_READ_B(BUF, 0, 0); }                           \
+        if (P == 1) PP_READ_B(BUF, 1, 1);                                                            \
         if (P == 2) PP_READ_A(BUF, 1);                                                               \
+        if (P == 3 && ORD && t + 1 < nk) PP_READ_B((BUF) ^ 1, 0, (BUF) ? 0 : 2);   /* next tile's B-sub0 */ \
         PP_FENCE();                                                                                  \
         {                                                                                            \
             constexpr int dq = (P) + LEAD;                     /* quarter 4 t + dq */                \
@@ -785,10 +792,10 @@ __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long
         }                                                                                            \
         PP_BAR();                                                                                    \
         if (FLAGS & 2) __builtin_amdgcn_s_setprio(1);                                                \
-        if (P == 0) PP_QUAD(0, 0);                                                                   \
-        if (P == 1) PP_QUAD(0, 1);                                                                   \
-        if (P == 2) PP_QUAD(1, 1);                                                                   \
-        if (P == 3) PP_QUAD(1, 0);                                                                   \
+        if (P == 0) PP_QUAD(0, 0, (ORD && (BUF)) ? 2 : 0);                                           \
+        if (P == 1) PP_QUAD(0, 1, 1);                                                                \
+        if (P == 2) PP_QUAD(1, 1, 1);                                                                \
+        if (P == 3) PP_QUAD(1, 0, (ORD && (BUF)) ? 2 : 0);                                           \
         if (FLAGS & 2) __builtin_amdgcn_s_setprio(0);                                                \
         PP_BAR();                                                                                    \
     } while (0)
@@ -800,6 +807,7 @@ __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // fewer than LEAD quarters exist
     PP_BAR();
     if ((FLAGS & 1) && wr == 1) PP_BAR();   // the second wave row runs one barrier behind the first
+    if (ORD) { PP_READ_B(0, 0, 0); PP_FENCE(); }   // k-tile 0's B-sub0 (quarter 0, retired by the prologue wait)
     for (int t = 0; t < nk; t += 2) {
         PP_PHASE(0, 0); PP_PHASE(1, 0); PP_PHASE(2, 0); PP_PHASE(3, 0);
         ++t;
@@ -964,6 +972,8 @@ int main() {
     run_pp<6, 4, 1>("8-phase, no setprio", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);           \
     run_pp<6, 4, 2>("8-phase, rows in lockstep", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);     \
     run_pp<6, 8>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
+    run_pp<6, 4, 7>("8-phase, balanced reads", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);       \
+    run_pp<7, 4, 7>("8-phase, balanced reads", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);       \
     run_big<256, 256, 2, 4, 2, 4>("big 256x256 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 4, 2, 2, 4>("big 256x256 8w (4x2)", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 2, 4, 2, 4, 1>("big 256x256 8w sched1", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
