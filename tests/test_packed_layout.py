@@ -163,3 +163,86 @@ def test_ping_pong_schedule_hazards():
     for lead in (5, 6, 7):
         assert hazards(orders["b-first"], lead) == [], lead
     assert any(h[0] == "WAR" for h in hazards(orders["b-first"], 8))
+
+
+def test_ping_pong_tile_data_path_emulation():
+    """Index plumbing of the 256x256 ping-pong program (csrc/gemm_f16x2.hip AMODE 4 / probe pp_kernel), emulated in
+    numpy for one tile over two k-tiles: packed planes in 'global memory' -> the wave's two 16-row groups of each
+    16 KB quarter (q_src / q_lds) -> the 64 KB stage image -> the ds_read_b128 fragment addresses with the XOR chunk
+    swizzle (per wave row / column, A-sub / B-sub) -> the operand layout of v_mfma_f32_32x32x16_f16 (lane l holds row
+    l % 32, k = 8 (l / 32) .. +7) -> the accumulator layout (col = l % 32, row = (r & 3) + 8 (r >> 2) + 4 (l / 32)).
+    The result must equal a1 b0 + a0 b1 + a0 b0 summed over k, and every byte of a stage must be written exactly once."""
+    import numpy as np
+    from text_to_sound_synthesis_amd import _lib as L
+    rng = np.random.default_rng(3)
+    BM = BN = 256
+    K, nk = 64, 2
+    Ah = rng.integers(-8, 9, size=(2, BM, K)).astype(np.float16)          # [plane][row][k], small ints: exact sums
+    Wh = rng.integers(-8, 9, size=(2, BN, K)).astype(np.float16)
+    Ap = L.pack_planes(torch.from_numpy(Ah)).numpy().reshape(2, -1)       # packed planes, flat halves per plane
+    Wp = L.pack_planes(torch.from_numpy(Wh)).numpy().reshape(2, -1)
+    HLD, APL, BPL = 32, BM * 32, BN * 32
+    STAGE = 2 * (APL + BPL)                                               # halves per buffer
+    m0 = n0 = 0
+    for order in ("a-first", "b-first"):
+        lds = np.full((2, STAGE), np.nan, dtype=np.float32)               # two buffers, in halves
+        written = np.zeros((2, STAGE), dtype=np.int32)
+
+        def issue(tile, ty, buf):
+            for wave in range(8):
+                for k in range(2):
+                    idx = 2 * wave + k
+                    plane, r = idx >> 3, idx & 7
+                    isA = (ty & 1) == 1 if order == "b-first" else ty in (0, 3)
+                    sub = (ty == 3) if isA else (ty == 2)
+                    gip = (r >> 2) * 8 + sub * 4 + (r & 3) if isA else (r >> 1) * 4 + sub * 2 + (r & 1)
+                    rg = ((m0 if isA else n0) >> 4) + gip
+                    src = (Ap if isA else Wp)[plane]
+                    g_off = rg * nk * 512 + tile * 512                   # halves: one packed 16-row x 32-k tile = 512
+                    l_off = ((0 if isA else 32) + plane * 16 + gip) * 512    # 1 KB per group = 512 halves
+                    lds[buf, l_off:l_off + 512] = src[g_off:g_off + 512]    # lane l moves 8 halves at 8 l: linear copy
+                    written[buf, l_off:l_off + 512] += 1
+
+        C = np.zeros((BM, BN), dtype=np.float64)
+        lane = np.arange(64)
+        l31, hh = lane & 31, lane >> 5
+        for t in range(nk):
+            buf = t & 1
+            for ty in range(4):
+                issue(t, ty, buf)
+            assert (written[buf] == t // 2 + 1).all()                     # the four quarters tile the 64 KB stage
+            for wave in range(8):
+                wr, wc = wave >> 2, wave & 3
+                for ks in range(2):
+                    swz = ((2 * ks + hh) ^ ((l31 >> 2) & 3)) * 8          # halves inside the 32-half row
+                    frag = lambda base_row, plane_off: np.stack(
+                        [lds[buf, plane_off + (base_row + l31) * HLD + swz + e] for e in range(8)], axis=1)   # [lane][8]
+                    for sa in range(2):
+                        for ib in range(2):
+                            arow = wr * 128 + sa * 64 + ib * 32
+                            a0, a1 = frag(arow, 0), frag(arow, APL)
+                            for sb in range(2):
+                                bcol = wc * 64 + sb * 32
+                                b0, b1 = frag(bcol, 2 * APL), frag(bcol, 2 * APL + BPL)
+                                # MFMA 32x32x16: operand row = lane % 32, k slots 8 (lane / 32) .. +7
+                                def mm(a, b):
+                                    am = np.zeros((32, 16)); bm = np.zeros((32, 16))
+                                    for l in range(64):
+                                        am[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = a[l]
+                                        bm[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = b[l]
+                                    return am @ bm.T                       # [row of A block][row of B block = column]
+                                d = mm(a1, b0) + mm(a0, b1) + mm(a0, b0)
+                                # accumulator register r of lane l: col = l % 32, row = (r & 3) + 8 (r >> 2) + 4 (l / 32);
+                                # the epilogue maps block (i = 2 sa + ib, j = sb) to rows (wr 4 + i) 32.., cols (wc 2 + j) 32..
+                                i, j = 2 * sa + ib, sb
+                                for r in range(16):
+                                    for l in range(64):
+                                        row = (wr * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                                        col = (wc * 2 + j) * 32 + (l & 31)
+                                        # d is indexed [A row in block][B row in block]; the lane's register r holds
+                                        # exactly that element
+                                        C[row, col] += d[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+        A0, A1 = Ah[0].astype(np.float64), Ah[1].astype(np.float64)
+        W0, W1 = Wh[0].astype(np.float64), Wh[1].astype(np.float64)
+        want = A1 @ W0.T + A0 @ W1.T + A0 @ W0.T
+        assert np.array_equal(C, want), order
