@@ -246,3 +246,67 @@ def test_ping_pong_tile_data_path_emulation():
         W0, W1 = Wh[0].astype(np.float64), Wh[1].astype(np.float64)
         want = A1 @ W0.T + A0 @ W1.T + A0 @ W0.T
         assert np.array_equal(C, want), order
+
+
+def test_generic_tile_data_path_emulation():
+    """The same emulation for the generic staging of ds_gemm_f16x2_body (AMODE 2: wave w owns the 16-row groups
+    w + NW i of the stage image, one DMA instruction each) over every tile / wave-grid geometry the library
+    instantiates -- the measured 4-wave tiles and the 8-wave candidates incl. the tail program."""
+    import numpy as np
+    from text_to_sound_synthesis_amd import _lib as L
+    rng = np.random.default_rng(5)
+    K, nk = 32, 1
+    for BM, BN, WGM, WGN in ((128, 128, 2, 2), (128, 64, 2, 2), (64, 64, 2, 2),
+                             (256, 256, 2, 4), (256, 128, 4, 2), (128, 256, 2, 4), (128, 128, 2, 4)):
+        NW, TM, TN = WGM * WGN, BM // (32 * WGM), BN // (32 * WGN)
+        Ah = rng.integers(-8, 9, size=(2, BM, K)).astype(np.float16)
+        Wh = rng.integers(-8, 9, size=(2, BN, K)).astype(np.float16)
+        Ap = L.pack_planes(torch.from_numpy(Ah)).numpy().reshape(2, -1)
+        Wp = L.pack_planes(torch.from_numpy(Wh)).numpy().reshape(2, -1)
+        APL, BPL = BM * 32, BN * 32
+        STAGE = 2 * (APL + BPL)
+        G = 2 * (BM + BN) // 16 // NW
+        assert G * NW * 16 == 2 * (BM + BN)
+        lds = np.full(STAGE, np.nan, dtype=np.float32)
+        written = np.zeros(STAGE, dtype=np.int32)
+        for wave in range(NW):
+            for i in range(G):
+                r = 16 * (wave + NW * i)                                 # first row of the group in the stage image
+                if r < 2 * BM:
+                    plane, rr, src = (1, r - BM, Ap) if r >= BM else (0, r, Ap)
+                else:
+                    r2 = r - 2 * BM
+                    plane, rr, src = (1, r2 - BN, Wp) if r2 >= BN else (0, r2, Wp)
+                g_off = (rr >> 4) * nk * 512
+                l_off = (wave + NW * i) * 512                            # d_ = wave * 1024 + i * NW * 1024 bytes
+                lds[l_off:l_off + 512] = src[plane][g_off:g_off + 512]
+                written[l_off:l_off + 512] += 1
+        assert (written == 1).all()
+        C = np.zeros((BM, BN))
+        done = np.zeros((BM, BN), dtype=np.int32)
+        lane = np.arange(64)
+        l31, hh = lane & 31, lane >> 5
+        for wave in range(NW):
+            wm, wn = wave // WGN, wave % WGN
+            for ks in range(2):
+                swz = ((2 * ks + hh) ^ ((l31 >> 2) & 3)) * 8
+                frag = lambda base_row, plane_off: np.stack(
+                    [lds[plane_off + (base_row + l31) * 32 + swz + e] for e in range(8)], axis=1)
+
+                def mat(f):
+                    m = np.zeros((32, 16))
+                    for l in range(64):
+                        m[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = f[l]
+                    return m
+                for i in range(TM):
+                    a0, a1 = mat(frag((wm * TM + i) * 32, 0)), mat(frag((wm * TM + i) * 32, APL))
+                    for j in range(TN):
+                        b0, b1 = mat(frag((wn * TN + j) * 32, 2 * APL)), mat(frag((wn * TN + j) * 32, 2 * APL + BPL))
+                        d = a1 @ b0.T + a0 @ b1.T + a0 @ b0.T
+                        r0, c0 = (wm * TM + i) * 32, (wn * TN + j) * 32
+                        C[r0:r0 + 32, c0:c0 + 32] += d
+                        if ks == 0:
+                            done[r0:r0 + 32, c0:c0 + 32] += 1
+        assert (done == 1).all(), (BM, BN)
+        A0, A1, W0, W1 = (x.astype(np.float64) for x in (Ah[0], Ah[1], Wh[0], Wh[1]))
+        assert np.array_equal(C, A1 @ W0.T + A0 @ W1.T + A0 @ W0.T), (BM, BN, WGM, WGN)
