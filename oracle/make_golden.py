@@ -292,8 +292,123 @@ def dalle_sample():
          fr05=out["cond1_cont1_fr0.5_image"][..., s], fr1=out["cond1_cont1_fr1.0_image"][..., s])
 
 
+N1_B = 8                 # clips of the full-configuration trajectory golden
+N1_WAVE_HEAD = 32768     # samples of each waveform that are stored
+
+
+def traj_full():
+    """N1 (judge's row): end-to-end same-seed parity AT THE BENCHMARKED CONFIGURATION -- 19 layers, T = 100, K = 256,
+    top0.85r, 8 captions.  Runs the reference's own loop (diffusion_transformer.py:587-659: 100 x p_sample :639-641)
+    with the per-step noise injected, then dalle_spec.py:80-91 decode_to_img and vocoder/modules.py:129 forward.
+    The conditioning is the reference's CLIPTextEmbedding of 8 synthetic captions (its rows are fp16 values, stored
+    as fp16 without loss).  Besides the tokens after every step the file keeps, per (step, clip, position), the two
+    quantities that decide whether a rounding-level logit difference can change a token:
+      gap      top-1 minus top-2 of (gumbel + log posterior), the Gumbel-argmax margin      (:358-364)
+      tmargin  min over classes of |mass ranked before the class - r|, the top-r cut margin (dalle_spec.py:160-173)
+    so that the GPU test can demand that every disagreement sits on a near-tie."""
+    torch.manual_seed(0)
+    caps = synth.synth_captions(N1_B, seed=11)
+    tk = rh.reference_tokenize(caps)
+    clip = rh.build_clip_text()
+    cond = clip(tk["token"].clone()).float()
+    assert torch.equal(cond, cond.half().float())
+    m = rh.build_dalle(n_layer=19, diffusion_step=100, n_embed=256)
+    voc = rh.build_vocoder()
+    dt = m.transformer
+    inner = dt.predict_start
+    r = 0.85
+    tm = []
+
+    def ps_with_margin(*a, **k):      # the reference wrapper's own arithmetic, plus the recorded cut margin
+        out = inner(*a, **k)
+        srt = torch.sort(out, 1, descending=True)[0]
+        before = torch.exp(srt).cumsum(1)
+        tm.append((before - r).abs().min(1)[0].clone())
+        return out
+    dt.predict_start = m.predict_start_with_truncation(ps_with_margin, "top0.85r")
+    trace, gaps = [], []
+    step = [99]
+    orig_lsc = dt.log_sample_categorical
+
+    def lsc(logits):
+        u = synth.synth_uniform(tuple(logits.shape), key="n1.u%d" % step[0])
+        g = -torch.log(-torch.log(u + 1e-30) + 1e-30)
+        top2 = (g + logits).topk(2, dim=1)[0]
+        gaps.append((top2[:, 0] - top2[:, 1]).clone())
+        with InjectNoise(lambda shp: u):
+            out = orig_lsc(logits)
+        trace.append(out.argmax(1).clone())
+        step[0] -= 1
+        return out
+    dt.log_sample_categorical = lsc
+    t0 = time.time()
+    out = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, batch_size=N1_B)
+    print("reference 100-step loop, B=%d: %.1f s" % (N1_B, time.time() - t0))
+    tokens = out["content_token"]
+    assert step[0] == -1 and torch.equal(tokens, trace[-1])
+    mel = m.decode_to_img(tokens, (N1_B, 256, 5, 53))
+    wave = voc((mel[:, 0] + 1) / 2)
+    with open(os.path.join(OUT, "traj_T100_L19_captions.json"), "w") as f:
+        json.dump(caps, f)
+    save("traj_T100_L19", caption_tokens=tk["token"].to(torch.int32), cond_emb=cond.half(),
+         step_tokens=torch.stack(trace).to(torch.int16), gap=torch.stack(gaps).half(),
+         tmargin=torch.stack(tm).half(), tokens=tokens.to(torch.int16), mel=mel[:, 0],
+         wave_head=wave[:, 0, :N1_WAVE_HEAD])
+
+
+def signatures():
+    """the Python signatures of the drop-in boundary, dumped from the reference itself.  The
+    evaluation script is parsed (it imports soundfile / PIL / pandas at module level); the model classes are imported
+    under the harness and read with inspect.  Each entry: [[name, default-or-null, kind], ...]."""
+    import ast
+    import inspect
+    rh.install()
+    out = {}
+
+    def from_ast(path, cls, methods):
+        tree = ast.parse(open(path).read())
+        node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+        for fn in node.body:
+            if isinstance(fn, ast.FunctionDef) and fn.name in methods:
+                a = fn.args
+                pos = a.posonlyargs + a.args
+                defs = [None] * (len(pos) - len(a.defaults)) + [ast.unparse(d) for d in a.defaults]
+                out["%s.%s" % (cls, fn.name)] = [[x.arg, d, "POSITIONAL_OR_KEYWORD"] for x, d in zip(pos, defs)]
+
+    def from_obj(name, fn):
+        sig = inspect.signature(fn)
+        out[name] = [[p.name, None if p.default is inspect.Parameter.empty else repr(p.default), p.kind.name]
+                     for p in sig.parameters.values()]
+    from_ast(os.path.join(rh.REF_ROOT, "evaluation", "generate_samples_batch.py"), "Diffsound",
+             ("__init__", "generate_sample", "inference_generate_sample_with_condition", "read_tsv"))
+    from sound_synthesis.modeling.models.dalle_spec import DALLE
+    from sound_synthesis.modeling.transformers.diffusion_transformer import DiffusionTransformer
+    from sound_synthesis.modeling.transformers.transformer_utils import Text2ImageTransformer
+    from sound_synthesis.modeling.codecs.spec_codec.vqgan import VQModel
+    from specvqgan.modules.vqvae.quantize import VectorQuantizer
+    from vocoder.modules import Generator
+    for cls, names in ((DALLE, ("generate_content", "get_ema_model", "decode_to_img", "get_tokens", "prepare_condition",
+                                "prepare_content", "forward", "sample")),
+                       (DiffusionTransformer, ("sample", "sample_fast", "p_sample", "predict_start", "q_sample",
+                                               "forward")),
+                       (Text2ImageTransformer, ("forward",)),
+                       (VQModel, ("decode", "encode", "forward")),
+                       (VectorQuantizer, ("get_codebook_entry", "forward")),
+                       (Generator, ("__init__", "forward"))):
+        for n in names:
+            f = getattr(cls, n)
+            from_obj("%s.%s" % (cls.__name__, n), getattr(f, "__wrapped__", f))
+    with open(os.path.join(OUT, "signatures.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("wrote signatures.json (%d callables)" % len(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--signatures-only" in sys.argv:
+        return signatures()
+    if "--n1-only" in sys.argv:
+        return traj_full()
     if "--dsample-only" in sys.argv:
         return dalle_sample()
     if "--solver-only" in sys.argv:
@@ -392,6 +507,8 @@ def main():
     train_loss()
     solver_schedule()
     dalle_sample()
+    signatures()
+    traj_full()
     print("done in %.1fs" % (time.time() - t0))
 
 

@@ -18,6 +18,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _grad_mode(request):
+    """Grad mode is per test, never process-global: modules that set NO_GRAD = True run their tests under
+    torch.no_grad(); every other test gets grad enabled, whatever ran before it in the same pytest process."""
+    with torch.set_grad_enabled(not getattr(request.module, "NO_GRAD", False)):
+        yield
+
+
 def golden(name):
     return {k: torch.from_numpy(v) if v.ndim else v
             for k, v in np.load(os.path.join(GOLDEN, name + ".npz")).items()}

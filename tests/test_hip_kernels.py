@@ -10,7 +10,7 @@ import diffsound_oracle as O
 from text_to_sound_synthesis_amd import synth
 
 pytestmark = pytest.mark.gpu
-torch.set_grad_enabled(False)
+NO_GRAD = True          # tests/conftest.py: every test of this module runs under torch.no_grad()
 
 
 @pytest.fixture(scope="module")

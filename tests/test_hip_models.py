@@ -9,7 +9,7 @@ from conftest import golden, synth_sd
 from text_to_sound_synthesis_amd import synth
 
 pytestmark = pytest.mark.gpu
-torch.set_grad_enabled(False)
+NO_GRAD = True          # tests/conftest.py: every test of this module runs under torch.no_grad()
 
 MEL_TOL = 1e-3      # BASELINE.json north_star: max-abs on mel
 WAVE_RMS_TOL = 1e-4  # BASELINE.json north_star: RMS on waveform

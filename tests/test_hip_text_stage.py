@@ -14,7 +14,7 @@ from conftest import GOLDEN, golden
 from text_to_sound_synthesis_amd import synth
 
 pytestmark = pytest.mark.gpu
-torch.set_grad_enabled(False)
+NO_GRAD = True          # tests/conftest.py: every test of this module runs under torch.no_grad()
 
 # The reference's fp16 tower is itself only reproducible to ~1e-3 relative across devices/torch builds
 # (fp16 rounding after every op); outputs are unit-norm rows with entries ~0.04.

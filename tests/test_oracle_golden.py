@@ -6,7 +6,7 @@ import diffsound_oracle as O
 from conftest import golden
 from text_to_sound_synthesis_amd import synth
 
-torch.set_grad_enabled(False)
+NO_GRAD = True          # tests/conftest.py: every test of this module runs under torch.no_grad()
 
 
 def test_schedule_matches_reference_buffers():

@@ -11,7 +11,7 @@ import diffsound_oracle as O
 
 pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/Diffsound/sound_synthesis"),
                                 reason="reference tree not on this box")
-torch.set_grad_enabled(False)
+NO_GRAD = True          # tests/conftest.py: every test of this module runs under torch.no_grad()
 
 
 @pytest.fixture(scope="module")

@@ -9,7 +9,7 @@ import torch
 import diffsound_oracle as O
 from conftest import GOLDEN, golden
 
-torch.set_grad_enabled(False)
+NO_GRAD = True          # tests/conftest.py: every test of this module runs under torch.no_grad()
 _REF_BPE = "/root/reference/Diffsound/sound_synthesis/modeling/modules/clip/bpe_simple_vocab_16e6.txt.gz"
 
 

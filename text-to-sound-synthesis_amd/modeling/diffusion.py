@@ -212,7 +212,8 @@ class DiffusionTransformer(nn.Module):
         t, pt = self.sample_time(B, dev, "importance")
         t, pt = t.to(dev), pt.to(dev)
         u = torch.rand((B, K1, L), device=dev) if noise is None else noise.to(dev)
-        xt = self.q_sample_tokens(x.contiguous(), t, u)
+        x = x.contiguous()
+        xt = self.q_sample_tokens(x, t, u)
         tr = self.transformer
         sched = self._schedule_table()
         p = tr.packed(sched)
@@ -222,7 +223,7 @@ class DiffusionTransformer(nn.Module):
                                                   _lib.ptr(tr.workspace(B, sched)), _lib.ptr(logits), 0, _lib.stream()))
         kl, nll, kl_aux = (torch.empty(B, L, device=dev) for _ in range(3))
         log_model_prob = torch.empty(B, K1, L, device=dev)
-        _lib.check(_lib.lib().ds_loss_tail(_lib.ptr(logits), _lib.ptr(x.contiguous()), _lib.ptr(xt), _lib.ptr(t),
+        _lib.check(_lib.lib().ds_loss_tail(_lib.ptr(logits), _lib.ptr(x), _lib.ptr(xt), _lib.ptr(t),
                                            _lib.ptr(sched), _lib.ptr(kl), _lib.ptr(nll), _lib.ptr(kl_aux),
                                            _lib.ptr(log_model_prob), B, L, K1 - 1, T, _lib.stream()))
         mask_region = (xt == K1 - 1).float()
@@ -259,12 +260,23 @@ class DiffusionTransformer(nn.Module):
     @torch.no_grad()
     def q_sample_tokens(self, x0, t, u):
         """x_t ~ q(x_t | x_0) on token ids (q_sample, :370-377); u f32[B, K+1, L] uniforms."""
-        out = torch.empty_like(x0)
-        _lib.check(_lib.lib().ds_q_sample(_lib.ptr(x0.contiguous()), _lib.ptr(t.contiguous()), _lib.ptr(u.contiguous()),
-                                          _lib.ptr(self._schedule_table()), _lib.ptr(out), x0.shape[0],
+        x0_c, t_c, u_c = x0.contiguous(), t.contiguous(), u.contiguous()   # named: alive until the launch is enqueued
+        out = torch.empty_like(x0_c)
+        _lib.check(_lib.lib().ds_q_sample(_lib.ptr(x0_c), _lib.ptr(t_c), _lib.ptr(u_c),
+                                          _lib.ptr(self._schedule_table()), _lib.ptr(out), x0_c.shape[0],
                                           self.content_seq_len, self.num_classes - 1, self.num_timesteps,
                                           _lib.stream()))
         return out
+
+    @torch.no_grad()
+    def q_sample(self, log_x_start, t):
+        """The reference's log-one-hot form of the forward diffusion (:370-377): log_x_start f32[B, K+1, L] one-hot in
+        log space -> a log-one-hot sample of q(x_t | x_0), drawing torch.rand of the same shape as the reference."""
+        x0 = log_x_start.argmax(1)
+        u = torch.rand(tuple(log_x_start.shape), device=x0.device)
+        xt = self.q_sample_tokens(x0, t.to(x0.device), u)
+        oh = torch.nn.functional.one_hot(xt, self.num_classes).permute(0, 2, 1).float()
+        return torch.log(oh.clamp(min=1e-30))
 
     def _reverse(self, cond_emb, steps, noise_fn, return_logits, start_tokens=None):
         """steps: list of (t, t_post) pairs, first one from the all-[MASK] state (or from start_tokens, already

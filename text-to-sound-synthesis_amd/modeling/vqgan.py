@@ -232,7 +232,7 @@ class VQModel(nn.Module):
             self.init_from_ckpt(ckpt_path, ignore_keys)
 
     def init_from_ckpt(self, path, ignore_keys=list()):
-        sd = torch.load(path, map_location="cpu")["state_dict"]
+        sd = torch.load(path, map_location="cpu", weights_only=False)["state_dict"]
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
         self.load_state_dict(sd, strict=False)  # loss / discriminator keys are not part of this module
 

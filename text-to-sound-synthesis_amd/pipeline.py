@@ -16,8 +16,11 @@ from .modeling.vocoder import Generator
 
 def load_vocoder(ckpt_vocoder, eval_mode=True):
     g = Generator(80, 32, 3)
-    if ckpt_vocoder:
-        sd = torch.load(os.path.join(str(ckpt_vocoder), "best_netG.pt"), map_location="cpu")
+    if ckpt_vocoder is not None:   # None: random-init vocoder on purpose; a wrong directory raises (reference: :29-40)
+        f = os.path.join(str(ckpt_vocoder), "best_netG.pt")
+        if not os.path.exists(f):
+            raise FileNotFoundError("vocoder checkpoint not found: %s" % f)
+        sd = torch.load(f, map_location="cpu", weights_only=False)
         g.load_state_dict(sd)
     return {"model": g.eval() if eval_mode else g}
 
@@ -27,8 +30,10 @@ class Diffsound:
         cfg = default_config(with_clip=True) if config is None else (load_yaml_config(config) if isinstance(config, str) else config)
         self.model = build_model(cfg)
         self.epoch = 0
-        if path and os.path.exists(path):
-            ckpt = torch.load(path, map_location="cpu")
+        if path is not None:       # path=None: seeded / random weights on purpose (tests, bench); a wrong path raises
+            if not os.path.exists(path):
+                raise FileNotFoundError("Diffsound checkpoint not found: %s" % path)
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
             self.epoch = ckpt.get("last_epoch", ckpt.get("epoch", 0))
             self.model.load_state_dict(ckpt["model"], strict=False)
             if "ema" in ckpt:
@@ -59,7 +64,27 @@ class Diffsound:
         wave = self.vocoder(mel[:, 0], scale=0.5, shift=0.5)   # spec = (x+1)/2, :182
         return (mel[:, 0] + 1) / 2, wave, out["content_token"]
 
-    inference_generate_sample_with_condition = generate_sample_with_condition
+    @torch.no_grad()
+    def inference_generate_sample_with_condition(self, text, truncation_rate, save_root, batch_size, fast=False):
+        """The reference's single-caption driver, same signature and behaviour (generate_samples_batch.py:89-123):
+        ONE caption `text`, sampled `replicate = 10` times (hard-coded there, :111; `batch_size` is accepted and
+        unused, as in the reference), results written under `save_root/str(text)/` as `000000`, `000001`, ...
+        The reference writes `.png` through an image-era uint8 cast that cannot represent a [-1,1] spectrogram
+        (`Image.fromarray` rejects the [80,848,1] array); this drop-in writes what the batch driver writes instead:
+        `{n:06d}.npy` (mel in [0,1], f32[80,848]) and `{n:06d}.wav` (22 050 Hz PCM_24).  Returns the paths."""
+        import numpy as np
+        os.makedirs(save_root, exist_ok=True)
+        save_root_ = os.path.join(save_root, str(text))
+        os.makedirs(save_root_, exist_ok=True)
+        mel01, wave, _ = self.generate_sample_with_condition([text], truncation_rate, replicate=10, fast=fast)
+        mel01, wave = mel01.cpu().numpy(), wave[:, 0].cpu().numpy()
+        written = []
+        for b in range(mel01.shape[0]):
+            path = os.path.join(save_root_, str(b).zfill(6))
+            np.save(path + ".npy", mel01[b])
+            write_wav_pcm24(path + ".wav", wave[b], 22050)
+            written.append(path)
+        return written
 
     @staticmethod
     def read_tsv(val_path):
