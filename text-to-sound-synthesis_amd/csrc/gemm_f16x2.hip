@@ -234,8 +234,8 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
                 const _Float16* base = isA ? (const _Float16*)p.A + (plane ? p.a_plane : 0)
                                            : (const _Float16*)p.W + (plane ? pl1 : 0);
                 const unsigned long long a_ = (unsigned long long)(base + (size_t)rg * nk * 512);
-                q_src[ty][k] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
-                               __builtin_amdgcn_readfirstlane((unsigned)a_);
+                q_src[ty][k] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
+                               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);   // (unsigned): the builtin returns int -- without it the low word is SIGN-extended into the high one
                 q_lds[ty][k] = __builtin_amdgcn_readfirstlane(((isA ? 0 : 32) + plane * 16 + gip) * 1024);
             }
 #define H4_ISSUE(tile_, ty_, buf_)                                                                  \

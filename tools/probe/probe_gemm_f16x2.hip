@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256, 1) void sp_kernel(const _Float16* A, long long
         else { r -= 2 * BM; base = W; if (r >= BN) { r -= BN; base += w_plane; } rg = (n0 + r) >> 4; rgs = (N + 15) >> 4; }
         if (rg >= rgs) rg = rgs - 1;
         const unsigned long long a_ = (unsigned long long)(base + (size_t)rg * nk * 512);
-        src[i] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
-                 __builtin_amdgcn_readfirstlane((unsigned)a_);
+        src[i] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
+                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);
     }
     const unsigned lane16 = lane * 16;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
@@ -718,8 +718,8 @@ __global__ __launch_bounds__(512, 1) void pp_kernel(const _Float16* A, long long
             const int rgs = ((isA ? M : N) + 15) >> 4;
             if (rg >= rgs) rg = rgs - 1;
             const unsigned long long a_ = (unsigned long long)((isA ? A + plane * a_plane : W + plane * w_plane) + (size_t)rg * nk * 512);
-            src[ty][k] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
-                         __builtin_amdgcn_readfirstlane((unsigned)a_);
+            src[ty][k] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
+                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);   // (unsigned): the builtin returns int -- without it the low word is SIGN-extended into the high one
             ldsoff[ty][k] = __builtin_amdgcn_readfirstlane(((isA ? 0 : 32) + plane * 16 + gip) * 1024);
         }
 #define PP_ISSUE(tile_, ty_, buf_)                                                                   \
@@ -966,31 +966,39 @@ int main() {
 #define QCASE(MM, N, K)                                                                             \
     run<128, 128, 16, 2, 8>("packed 2-stage occ2", A, W, C, MM, N, K, clk);                         \
     run_reg<128, 128, 2, 8>("packed reg-staged 2-ahead", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
-    run_reg<128, 64, 3, 8>("packed reg-staged 2-ahead", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
-    run_pp<6, 4>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
-    run_pp<5, 4>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
-    run_pp<6, 4, 1>("8-phase, no setprio", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);           \
-    run_pp<6, 4, 2>("8-phase, rows in lockstep", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);     \
-    run_pp<6, 8>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
-    run_pp<6, 4, 7>("8-phase, balanced reads", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);       \
-    run_pp<7, 4, 7>("8-phase, balanced reads", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);       \
     run_big<256, 256, 2, 4, 2, 4>("big 256x256 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 4, 2, 2, 4>("big 256x256 8w (4x2)", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 2, 4, 2, 4, 1>("big 256x256 8w sched1", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 256, 2, 4, 2, 4, 2>("big 256x256 8w sched2", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 128, 4, 2, 3, 8, 1>("big 256x128 8w sched1", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 128, 4, 2, 3, 8>("big 256x128 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
-    run_big<256, 128, 4, 2, 2, 8>("big 256x128 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<128, 256, 2, 4, 3, 8>("big 128x256 8w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<256, 128, 2, 2, 3, 8>("big 256x128 4w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N); \
     run_big<128, 128, 2, 2, 4, 8>("big 128x128 4w", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);
+#define PCASE(MM, N, K)                                                                             \
+    run<128, 128, 16, 2, 8>("packed 2-stage occ2", A, W, C, MM, N, K, clk);                         \
+    run_pp<6, 4>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
+    run_pp<5, 4>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
+    run_pp<6, 4, 1>("8-phase, no setprio", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);           \
+    run_pp<6, 4, 2>("8-phase, rows in lockstep", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);     \
+    run_pp<6, 8>("ping-pong 8-phase", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);                \
+    run_pp<6, 4, 7>("8-phase, balanced reads", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);       \
+    run_pp<7, 4, 7>("8-phase, balanced reads", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);
     // M = 16384 = whole rounds for every tile (what a balanced launch would give the big tiles), 16960 = the real shape
+    if (!getenv("PROBE_PP_ONLY")) {
     QCASE(16384, 1024, 1024)
     QCASE(16384, 3072, 1024)
-    QCASE(16384, 4096, 1024)
     QCASE(16384, 1024, 4096)
     QCASE(16960, 1024, 1024)
-    QCASE(16960, 3072, 1024)
+    }
+    if (!getenv("PROBE_NO_PP")) {
+    PCASE(16384, 1024, 1024)
+    PCASE(16384, 3072, 1024)
+    PCASE(16384, 4096, 1024)
+    PCASE(16384, 1024, 4096)
+    PCASE(16960, 1024, 1024)
+    PCASE(16960, 3072, 1024)
+    }
     // the tail program of the balanced big-tile launch alone: 576 rows (B = 64) on 8-wave 128x128 tiles, 2 vs 4 stages
 #define TCASE(N, K)                                                                                 \
     run_big<128, 128, 2, 4, 2, 8>("tail 128x128 8w", A, W, C, 576, N, K, clk);                      \
