@@ -144,13 +144,24 @@ def cpu_baseline(n_layer, codes, T):
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over one denoiser step at
-    B=64 (profiles/r01_pmc_denoiser_step_b64.json, made by tools/pmc_step.py + tools/pmc_summarize.py with the
-    gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); PMC counters cannot be read inside this process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_denoiser_step_b64.json")
-    if not os.path.exists(path):
-        return None, None
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary over one denoiser step at
+    B=64 (profiles/r*_pmc_denoiser_step_b64.json, made on the GPU box by tools/profile_round.sh: tools/pmc_step.py under
+    separate --pmc passes, tools/pmc_summarize.py with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).
+    PMC counters cannot be read inside this process, so the number is a committed measurement -- and it is reported
+    ONLY while the kernel sources still hash to what was measured (`_meta.source_sha16`); otherwise traffic is null
+    and the note says the profile is stale."""
+    import glob
+    from text_to_sound_synthesis_amd.build import source_fingerprint
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_denoiser_step_b64.json")))
+    if not files:
+        return None, "no PMC summary under profiles/"
+    path = files[-1]
     table = json.load(open(path))
+    meta = table.get("_meta", {})
+    now = source_fingerprint()
+    if meta.get("source_sha16") != now:
+        return None, ("stale: %s was measured on kernel sources %s, the tree is %s -- re-run tools/profile_round.sh"
+                      % (os.path.basename(path), meta.get("source_sha16", "(unrecorded)"), now))
     want = kernel.split(" (")[0].replace(" ", "")
     want = want[:-1] if want.endswith(">") else want     # "<128,128" also matches "<128,128,2>"
     for name, r in table.items():
@@ -158,10 +169,9 @@ def pmc_traffic(kernel):
         if key.startswith(want) and r.get("hbm_read_MB_per_launch") is not None:
             rd, wr = r["hbm_read_MB_per_launch"], r["hbm_write_MB_per_launch"] or 0.0
             return round((rd + wr) * 1e6), ("bytes per launch = %.0f MB read (2 x FETCH_SIZE) + %.0f MB written (WRITE_SIZE), "
-                                            "mean of %d dispatches, L2 hit rate %.2f; algorithmic operand + result bytes of "
-                                            "the same launches average 276 MB (DESIGN.md section 3); source profiles/"
-                                            "r01_pmc_denoiser_step_b64.json" % (rd, wr, r["dispatches"], r["l2_hit_rate"]))
-    return None, None
+                                            "mean of %d dispatches, L2 hit rate %.2f; source profiles/%s (kernel sources %s)"
+                                            % (rd, wr, r["dispatches"], r["l2_hit_rate"], os.path.basename(path), now))
+    return None, "kernel not in %s" % os.path.basename(path)
 
 
 def timed_loop(one_step, warmup, steps, device, world):
@@ -305,15 +315,14 @@ def main():
                 t = torch.full((B,), T - 2 - i, device=dev, dtype=torch.long)
                 x = dt.p_sample_tokens(x, kv, t, u, initial=False)
             L.ds_profile_enable(0)
-            ms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+            ms, fl, n = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
             _lib.check(L.ds_profile_collect(ms, fl, n))
             fmt, passes, mfma_peak, what = KIND[precision]
-            names = [fmt % bb for bb in ((128, 128), (128, 64), (64, 64))]
+            names = [fmt % bb for bb in ((128, 128), (128, 64), (64, 64))] + ["(unused)"]
             if precision == "f16x2":   # packed-operand launches of the 128x128 config go through the balanced kernel
                 names[0] = "ds_gemm_f16x2_hybrid_kernel (128x128 tiles + 64x64 tail tiles)"
-                if os.environ.get("DIFFSOUND_F16X2_TILE"):   # A/B run of an opt-in candidate (include/diffsound_hip.h)
-                    names[0] = "split-GEMM candidate cfg %s (DIFFSOUND_F16X2_TILE)" % os.environ["DIFFSOUND_F16X2_TILE"]
-            dom = max(range(3), key=lambda c: ms[c])   # the kernel symbol with the largest total time
+                names[3] = "ds_gemm_f16x2_ps_kernel (per-sample 288x256 tiles, 8-phase ping-pong main loop)"
+            dom = max(range(4), key=lambda c: ms[c])   # the kernel symbol with the largest total time
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             peak = mfma_peak / passes                  # ceiling in algorithmic (2MNK) flops of this formulation
             # the committed PMC passes ran the default f16x2 step at B=64; other legs / sizes have no measurement
@@ -327,7 +336,8 @@ def main():
                     "mfma_passes_per_flop": passes, "mfma_peak": mfma_peak,
                     "all_gemm_tiles": {names[c]: {"launches": int(n[c]),
                                                   "avg_launch_us": round(ms[c] * 1e3 / max(1, n[c]), 2),
-                                                  "tflops": round(fl[c] / max(ms[c], 1e-9) / 1e9, 2)} for c in range(3)},
+                                                  "tflops": round(fl[c] / max(ms[c], 1e-9) / 1e9, 2)}
+                                       for c in range(4) if n[c]},
                     "all_gemm_tflops": round(sum(fl) / (sum(ms) * 1e-3) / 1e12, 2)}
         roof = leg(args.precision)
         if args.precision != "fp32":                   # the exact-fp32 MFMA kernel on the same shapes, for reference

@@ -87,21 +87,21 @@ int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
    affine + swish; bias, residual, row store) in the same fp32-class 3-pass formulation: A fp32, W = the two fp16
    planes [N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart), out_scale = 2^-s */
 int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
-/* cfg: -1 automatic (default); 0 = 128x128 (balanced launch for packed operands), 1 = 128x64, 2 = 64x64 tiles of one
-   4-wave workgroup; 3 = 256x256, 4 = 256x128 (3-stage ring), 6 = 128x256 (3-stage ring) tiles of one 8-wave workgroup
-   per CU -- the big-tile candidates; 7 = cfg 0 with the packed tiles staged through registers two k-tiles ahead
-   instead of LDS-DMA; 8 = cfg 3's tile with the ping-pong main loop (four phases per k-tile, quarter-granular
-   prefetch under a counted vmcnt, wave rows one barrier apart, s_setprio around the MFMA clusters).  3 / 4 / 6 / 7 / 8
-   are unmeasured candidates for packed operands only (others fall back to 0); every cfg produces the same bits. */
+/* cfg: -1 automatic (default): the per-sample ping-pong program (gemm_f16x2_ps.hip: one 288 x 256 tile of an 8-wave
+   workgroup per (sample, 256 columns)) when the problem has packed operands, rows_per_sample in (240, 273] with
+   M % rows_per_sample == 0, N % 256 == 0, K % 64 == 0, a row / packed / attention store and a grid that fills whole
+   rounds of the 256 CUs (the denoiser's GEMMs at batch 64); else 128x128 (balanced launch for packed operands) /
+   128x64 / 64x64 tiles of a 4-wave workgroup by grid size.  0 / 1 / 2 pin those three; 9 pins the per-sample program
+   for every problem it can compute, whatever the grid (tests).  Every cfg produces the same bits.
+   PROCESS-GLOBAL test / measurement switch, like every *_force_tile, *_set_balance_slots and ds_profile_* entry:
+   not for use while another thread or stream of the process is launching GEMMs. */
 void ds_gemm_f16x2_force_tile(int cfg);
 /* packed-operand launches that pick the 128x128 tile are balanced: 128x128 tiles over the leading rows that fill
-   whole rounds of `slots` resident workgroups (default 512 = 256 CUs x 2), 64x64 tiles over the rest.  Test hook. */
+   whole rounds of `slots` resident workgroups (default 512 = 256 CUs x 2), 64x64 tiles over the rest.  Test hook
+   (process-global). */
 void ds_gemm_f16x2_set_balance_slots(int slots);
-/* the same balance unit for the big-tile launches (default 256 = one workgroup per CU); rows past the last whole
-   round go to 8-wave 128x128 tiles in the same grid.  Test hook. */
-void ds_gemm_f16x2_set_big_slots(int slots);
-/* The row partition a packed-operand launch of cfg 0 / 3 / 4 / 6 / 7 / 8 uses for an M x N product with the given store
-   mode: rows [0, m_off) -> nbig main tiles, rows [m_off, M) -> nsmall tail tiles (0: one program over all rows).
+/* The row partition a packed-operand launch of cfg 0 uses for an M x N product with the given store mode: rows
+   [0, m_off) -> nbig main tiles, rows [m_off, M) -> nsmall tail tiles (0: one program over all rows).
    Pure arithmetic, no device work: the CPU test-suite checks the partition with it. */
 int ds_gemm_f16x2_plan(int cfg, int M, int N, int store, int* m_off, int* nbig, int* nsmall);
 
@@ -266,7 +266,8 @@ int ds_denoiser_step_ex(const ds_denoiser* h, const int64_t* tokens_in, const in
 
 /* per-launch HIP-event timing of the denoiser's GEMM launches (measurement only, bench.py) */
 int ds_profile_enable(int on);
-/* arrays of 3, indexed by block-tile config (0: 128x128, 1: 128x64, 2: 64x64) */
+/* arrays of 4, indexed by GEMM program (0: 128x128, 1: 128x64, 2: 64x64 tiles; 3: the per-sample 288x256 ping-pong
+   program of the f16x2 mode) */
 int ds_profile_collect(double* ms, double* flops, int64_t* launches);
 
 /* ---- SpecVQGAN decoder / MelGAN helpers ------------------------------------------------------- */

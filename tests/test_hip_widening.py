@@ -70,27 +70,25 @@ def test_vqmodel_forward_is_decode_of_encode():
     assert x.shape == (2, 1, 80, 848) and torch.equal(x, mel)
 
 
-# ---- big-tile candidates of the split GEMM (8-wave workgroups, ds_gemm_f16x2_force_tile 3 / 4 / 6) ------------------
-BIG_TILES = (3, 4, 6, 7, 8)  # 7: the 4-wave programs with register-staged packed tiles (balanced launch: set_balance_slots);
-                             # 8: the 256x256 tile with the ping-pong (8-phase) main loop
-# These kernels were written after the round's GPU budget was spent and have never run on hardware; a defect in a new
-# main loop could hang the device, so they stay out of the default GPU run until their first supervised execution.
-big = pytest.mark.skipif(os.environ.get("DIFFSOUND_TEST_BIG_TILES") != "1",
-                         reason="opt-in big-tile GEMM programs, not yet executed on a GPU: set DIFFSOUND_TEST_BIG_TILES=1")
+# ---- the per-sample ping-pong program of the split GEMM (gemm_f16x2_ps.hip; ds_gemm_f16x2_force_tile(9)) -----------
+# The default launch takes it only for grids of whole CU rounds (B = 64: covered by the batch-size sweep and the
+# full-configuration parity tests); force_tile(9) runs it on small batches so that every store family, every sample
+# offset (265 b mod 16), the last sample's clamped row groups and 2 .. 128 k-tiles are compared bit for bit with the
+# loader-split 4-wave GEMM.
+PS = 9
 
 
-@big
-@pytest.mark.parametrize("M,N,K", [(4240, 4096, 1024), (4240, 1024, 4096), (2100, 1024, 1024), (700, 256, 1024),
-                                   (300, 96, 64), (300, 96, 32), (520, 512, 96)])     # incl. 1, 2, 3 k-tiles
-def test_f16x2_big_tiles_bit_identical(M, N, K):
-    """256x256 / 256x128 / 128x256 tiles of one 8-wave workgroup (slab-staged epilogues, three-stage DMA ring) and their
-    balanced launch with an 8-wave 128x128 tail program: same bits as the loader-split 4-wave GEMM, for row-major
-    output with residual and for packed split output with GELU2; several balance units so that every shape runs with
-    and without a tail program."""
+@pytest.mark.parametrize("B,N,K", [(5, 1024, 1024), (3, 1024, 4096), (17, 256, 64), (2, 4096, 1024), (16, 512, 128)])
+def test_f16x2_per_sample_program_bit_identical(B, N, K):
+    """Row-major output with bias + residual (in place, like the denoiser's projections) and packed split output with
+    GELU2: same bits as the loader-split 4-wave GEMM; rows of other samples inside a tile's 288-row window and the
+    ninth block's rows past the sample are never written."""
     from test_hip_split_gemm import relerr, rnd, torch_split
     from text_to_sound_synthesis_amd import _lib as L
-    A, W, b, R = rnd((M, K), "bg.A", 2.0).cuda(), rnd((N, K), "bg.W", 0.05).cuda(), rnd((N,), "bg.b").cuda(), \
-        rnd((M, N), "bg.R").cuda()
+    Lq = 265
+    M = B * Lq
+    A, W, b, R = rnd((M, K), "ps.A", 2.0).cuda(), rnd((N, K), "ps.W", 0.05).cuda(), rnd((N,), "ps.b").cuda(), \
+        rnd((M, N), "ps.R").cuda()
     W2, sc = L.split_f16x2(W)
     W2p, _ = L.split_f16x2(W, packed=True)
     A2p = L.pack_planes(torch_split(A))
@@ -100,65 +98,60 @@ def test_f16x2_big_tiles_bit_identical(M, N, K):
     assert relerr((ref - R).cpu(), (A.double() @ W.double().t() + b.double()).float().cpu()) < 2e-6
     refg = torch.empty(M, N, device="cuda")
     L.gemm(A, W2, refg, M, N, K, bias=b, act=L.ACT_GELU2, split2=sc)
+    refn = torch.empty(M, N, device="cuda")
+    L.gemm(A, W2, refn, M, N, K, bias=b, split2=sc)
     try:
-        for tile in BIG_TILES:
-            for slots in (256, 8, 1):
-                L.lib().ds_gemm_f16x2_force_tile(tile)
-                L.lib().ds_gemm_f16x2_set_big_slots(slots)
-                L.lib().ds_gemm_f16x2_set_balance_slots(2 * slots)
-                for rep in range(2):
-                    out = torch.full((M, N), float("nan"), device="cuda")
-                    L.gemm(A2p, W2p, out, M, N, K, bias=b, R=R, split2=sc, a_plane=M16 * K)
-                    assert torch.equal(out, ref), "tile %d slots %d" % (tile, slots)
-                if N % 32 == 0:
-                    outs = torch.zeros(2, M16 * N, device="cuda", dtype=torch.float16)
-                    L.gemm(A2p, W2p, outs, M, N, K, bias=b, act=L.ACT_GELU2, split2=sc, a_plane=M16 * K, c_plane=M16 * N)
-                    assert torch.equal(L.unpack_planes(outs, M, N), torch_split(refg)), "packed, tile %d slots %d" % (tile, slots)
+        L.lib().ds_gemm_f16x2_force_tile(PS)
+        for rep in range(2):
+            out = R.clone()                                   # in place: C aliases R
+            L.gemm(A2p, W2p, out, M, N, K, bias=b, R=out, split2=sc, a_plane=M16 * K, rows_per_sample=Lq)
+            assert torch.equal(out, ref)
+        guard = torch.full((M + 64, N), float("nan"), device="cuda")      # nothing past row M is touched
+        L.gemm(A2p, W2p, guard, M, N, K, bias=b, split2=sc, a_plane=M16 * K, rows_per_sample=Lq)
+        assert torch.isnan(guard[M:]).all() and torch.equal(guard[:M], refn)
+        outs = torch.zeros(2, M16 * N, device="cuda", dtype=torch.float16)
+        L.gemm(A2p, W2p, outs, M, N, K, bias=b, act=L.ACT_GELU2, split2=sc, a_plane=M16 * K, c_plane=M16 * N,
+               rows_per_sample=Lq)
+        assert torch.equal(L.unpack_planes(outs, M, N), torch_split(refg))
     finally:
         L.lib().ds_gemm_f16x2_force_tile(-1)
-        L.lib().ds_gemm_f16x2_set_big_slots(256)
-        L.lib().ds_gemm_f16x2_set_balance_slots(512)
 
 
-@big
-@pytest.mark.parametrize("B", [3, 8])
-def test_f16x2_big_tiles_attention_store_bit_identical(B):
-    """The attention-ready QKV store (Q planes, K image, V^T image) through the big tiles: slabs of 128 or 256 rows
-    crossing sample boundaries, with and without the tail program."""
+@pytest.mark.parametrize("B", [1, 3, 8])
+def test_f16x2_per_sample_program_attention_store_bit_identical(B):
+    """The attention-ready stores (QKV: Q planes, K image, V^T image; cross-attention Q alone) through the per-sample
+    tiles: units of 8 keys that straddle the 128 / 256-row slab edges are written in two parts."""
     from test_hip_split_gemm import rnd, torch_split
     from text_to_sound_synthesis_amd import _lib as L
     Lq, H, D = 265, 16, 1024
-    M, N, K = B * Lq, 3 * D, D
-    A, W, b = rnd((M, K), "ba.A", 2.0).cuda(), rnd((N, K), "ba.W", 0.05).cuda(), rnd((N,), "ba.b").cuda()
-    W2p, sc = L.split_f16x2(W, packed=True)
+    M, K = B * Lq, D
+    A = rnd((M, K), "pa.A", 2.0).cuda()
     A2p = L.pack_planes(torch_split(A))
     M16 = (M + 15) // 16 * 16
+    for N in (3 * D, D):
+        W, b = rnd((N, K), "pa.W%d" % N, 0.05).cuda(), rnd((N,), "pa.b%d" % N).cuda()
+        W2p, sc = L.split_f16x2(W, packed=True)
 
-    def run():
-        qh = torch.full((2, B, H, Lq, 64), float("nan"), device="cuda", dtype=torch.float16)
-        img = torch.zeros(B, H, 4, 288 * 64, device="cuda", dtype=torch.float16)
-        L.gemm(A2p, W2p, qh, M, N, K, bias=b, split2=sc, a_plane=M16 * K, store=L.STORE_ATTN, rows_per_sample=Lq,
-               attn=(img, H, 288, B * H * Lq * 64))
-        return qh, img
-    q_ref, img_ref = run()                                   # default launch (tested against the host packing elsewhere)
-    try:
-        for tile in BIG_TILES:
-            for slots in (256, 4, 1):
-                L.lib().ds_gemm_f16x2_force_tile(tile)
-                L.lib().ds_gemm_f16x2_set_big_slots(slots)
-                L.lib().ds_gemm_f16x2_set_balance_slots(2 * slots)
-                qh, img = run()
-                assert torch.equal(qh, q_ref) and torch.equal(img, img_ref), "tile %d slots %d" % (tile, slots)
-    finally:
-        L.lib().ds_gemm_f16x2_force_tile(-1)
-        L.lib().ds_gemm_f16x2_set_big_slots(256)
-        L.lib().ds_gemm_f16x2_set_balance_slots(512)
+        def run():
+            qh = torch.full((2, B, H, Lq, 64), float("nan"), device="cuda", dtype=torch.float16)
+            img = torch.zeros(B, H, 4, 288 * 64, device="cuda", dtype=torch.float16) if N == 3 * D else None
+            L.gemm(A2p, W2p, qh, M, N, K, bias=b, split2=sc, a_plane=M16 * K, store=L.STORE_ATTN, rows_per_sample=Lq,
+                   attn=(img, H, 288, B * H * Lq * 64))
+            return qh, img
+        L.lib().ds_gemm_f16x2_force_tile(2 if B == 1 else 1)   # 4-wave tiles (checked against the host packing elsewhere)
+        try:
+            q_ref, img_ref = run()
+            L.lib().ds_gemm_f16x2_force_tile(PS)
+            qh, img = run()
+        finally:
+            L.lib().ds_gemm_f16x2_force_tile(-1)
+        assert torch.equal(qh, q_ref)
+        assert img is None or torch.equal(img, img_ref)
 
 
-@big
-def test_denoiser_step_with_big_tiles_gives_the_same_tokens():
-    """A whole sampling step of the 19-layer denoiser at B = 8 with every GEMM forced onto a big tile: tokens equal the
-    default launch's."""
+def test_denoiser_step_with_per_sample_program_gives_the_same_tokens():
+    """A whole sampling step of the 19-layer denoiser at B = 8 with every eligible GEMM forced onto the per-sample
+    program: logits and tokens equal the 4-wave programs'."""
     from test_hip_split_gemm import build
     from text_to_sound_synthesis_amd import _lib as L
     m = build(19, mode="f16x2")
@@ -171,25 +164,17 @@ def test_denoiser_step_with_big_tiles_gives_the_same_tokens():
     u = synth.synth_uniform((B, 257, 265), key="bt.u").cuda()
     kv = dt.transformer.condition_kv(cond, dt._schedule_table())
     want = dt.p_sample_tokens(x, kv, t, u, False).clone()
+    want_logits = dt.transformer(x, cond, t).clone()
     try:
-        for tile in BIG_TILES:
-            L.lib().ds_gemm_f16x2_force_tile(tile)
-            L.lib().ds_gemm_f16x2_set_big_slots(4)
-            L.lib().ds_gemm_f16x2_set_balance_slots(8)
-            got = dt.p_sample_tokens(x, kv, t, u, False)
-            assert torch.equal(got, want), "tile %d" % tile
+        L.lib().ds_gemm_f16x2_force_tile(PS)
+        got = dt.p_sample_tokens(x, kv, t, u, False)
+        assert torch.equal(got, want)
+        assert torch.equal(dt.transformer(x, cond, t), want_logits)
     finally:
         L.lib().ds_gemm_f16x2_force_tile(-1)
-        L.lib().ds_gemm_f16x2_set_big_slots(256)
-        L.lib().ds_gemm_f16x2_set_balance_slots(512)
 
 
 # ---- loss settings the golden vector does not cover (other mask weights / auxiliary weights / timesteps) --------------
-unverified = pytest.mark.skipif(os.environ.get("DIFFSOUND_TEST_BIG_TILES") != "1" and os.environ.get("DIFFSOUND_TEST_UNVERIFIED") != "1",
-                                reason="kernel arguments never exercised on a GPU yet: set DIFFSOUND_TEST_UNVERIFIED=1")
-
-
-@unverified
 @pytest.mark.parametrize("aux,adaptive,mask_w,ts", [
     (5.0e-4, True, [1, 1], [99, 0, 1]),
     (0.0, True, [1, 1], [0, 0, 0]),

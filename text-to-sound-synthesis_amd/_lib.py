@@ -54,7 +54,6 @@ _PROTOS = {
     "ds_conv2d_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_gemm_f16x2_force_tile": (None, [C.c_int]),
     "ds_gemm_f16x2_set_balance_slots": (None, [C.c_int]),
-    "ds_gemm_f16x2_set_big_slots": (None, [C.c_int]),
     "ds_gemm_f16x2_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ds_denoiser_set_split_weights": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_f), _vp, _f]),
     "ds_embed": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),

@@ -198,11 +198,12 @@ extern "C" int ds_profile_enable(int on) {
     g_prof = on != 0;
     return 0;
 }
-// Waits for the recorded launches; per block-tile config c (0: 128x128, 1: 128x64, 2: 64x64 -- each is
-// its own kernel symbol) returns summed duration ms[c], algorithmic flops[c] (2MNK) and launches[c].
+// Waits for the recorded launches; per GEMM program c (0: 128x128, 1: 128x64, 2: 64x64 tiles, 3: the per-sample
+// ping-pong program -- each is its own kernel symbol) returns summed duration ms[c], algorithmic flops[c] (2MNK) and
+// launches[c].
 extern "C" int ds_profile_collect(double* ms, double* flops, int64_t* launches) {
     DS_CHECK_ARG(ms && flops && launches, "null pointer");
-    for (int c = 0; c < 3; ++c) { ms[c] = 0.0; flops[c] = 0.0; launches[c] = 0; }
+    for (int c = 0; c < 4; ++c) { ms[c] = 0.0; flops[c] = 0.0; launches[c] = 0; }
     for (auto& r : g_recs) {
         float e = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&e, r.a, r.b) == hipSuccess) ms[r.tile] += e;
@@ -323,7 +324,7 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
     // y = act(A W^T + b) (+ R) for layer-l weight `slot`; A (and optionally C) pre-split in f16x2 mode
     auto lin = [&](int l, int slot, int bslot, const float* A, int lda, long long ap, const float* R, float* C, int N,
                    int K, int act, long long cp) {
-        return dense(A, lda, h->P(l, slot), h->P(l, bslot), R, C, N, M, N, K, act, s, DS_STORE_ROW, 0, h->P3(l, slot),
+        return dense(A, lda, h->P(l, slot), h->P(l, bslot), R, C, N, M, N, K, act, s, DS_STORE_ROW, L, h->P3(l, slot),
                      h->split_mode, h->S3(l, slot), ap, cp);
     };
     TRY(ds_embed(tokens, d.tok_emb, d.pos_emb, w.x, M, L, D, s));

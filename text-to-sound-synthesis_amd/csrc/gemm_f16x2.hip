@@ -41,17 +41,18 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* ds_gptr;
 typedef __attribute__((address_space(3))) void* ds_lptr;
 
-// the whole workgroup program for output tile `bid` of `nblk` (both as launched; remapped below).
-// WGM x WGN waves (default 2 x 2 = 256 threads); NS = LDS stages of the AMODE 2 ring (2: one tile in flight;
-// 3: two tiles in flight, counted vmcnt).  The 8-wave instantiations are the big-tile candidates of DESIGN.md
-// section 3 (opt-in through ds_gemm_f16x2_force_tile until measured).
-template <int BM, int BN, int AMODE, int WGM = 2, int WGN = 2, int NS = 2>
+// the whole workgroup program for output tile `bid` of `nblk` (both as launched; remapped below): 4 waves (2 x 2),
+// two LDS stages.  (Round 2 measured the 8-wave big-tile, register-staged and deeper-ring variants of this loop
+// against it and against the per-sample ping-pong program of gemm_f16x2_ps.hip -- profiles/r02_probe_*.txt -- and
+// removed them: none beat this loop by more than a few per cent on the shapes it still serves.)
+template <int BM, int BN, int AMODE>
 __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid, const int nblk,
                                                    unsigned char* smem_raw) {
+    constexpr int WGM = 2, WGN = 2, NS = 2;
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave tiles are made of 32x32 blocks");
-    static_assert(AMODE == 2 || AMODE == 4 || (NT == 256 && NS == 2), "register staging is written for 256 threads, two stages");
+    static_assert(AMODE == 0 || AMODE == 2, "0: fp32 A split by the loader, 2: packed split planes by LDS-DMA");
     constexpr int SA = BM / 64;   // 8-element (2 x float4) staging chunks per thread (A)
     constexpr int SB = BN / 64;   // 16-byte staging chunks per thread per plane (B)
     constexpr int APL = BM * HLD, BPL = BN * HLD;       // plane strides (halves)
@@ -206,123 +207,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     } while (0)
 
     const int nk = p.K / HBK;
-    if constexpr (AMODE == 4) {
-        // Ping-pong main loop (opt-in candidate, force_tile 8; tools/probe/probe_gemm_f16x2.hip pp_kernel carries the
-        // derivation): 256x256 tile, waves 2 x 4 of 128x64, two 64 KB buffers.  A k-tile is consumed in four phases
-        // (quadrants of the wave tile, 12 MFMAs each: A-sub0 x B-sub0, A-sub0 x B-sub1, A-sub1 x B-sub1, A-sub1 x
-        // B-sub0) and staged as four 16 KB quarters (A-sub0 rows of both wave rows, B-sub0, B-sub1, A-sub1), one per
-        // phase, LEAD quarters ahead, retired by a COUNTED vmcnt(2 (LEAD - 2)); the two wave rows run one barrier
-        // apart, so each SIMD always has one wave in its MFMA cluster (under s_setprio 1) and one reading LDS / issuing
-        // DMA.  Quarter q = 4 tile + type is read in phase >= (the wait that retires it) + 1; it lands on a region
-        // whose previous occupant was last read >= 2 phases earlier.
-        static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4 && NS == 2, "one geometry");
-        constexpr int LEAD = 6;
-        unsigned long long q_src[4][2];      // wave-uniform bases of this wave's two 16-row groups per quarter type
-        int q_lds[4][2];
-        const unsigned lane16 = lane * 16;
-#pragma unroll
-        for (int ty = 0; ty < 4; ++ty)       // 0 = A-sub0, 1 = B-sub0, 2 = B-sub1, 3 = A-sub1
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int idx = 2 * wave + k, plane = idx >> 3, r = idx & 7;
-                const bool isA = ty == 0 || ty == 3;
-                const int sub = isA ? (ty == 3) : (ty == 2);
-                const int gip = isA ? (r >> 2) * 8 + sub * 4 + (r & 3) : (r >> 1) * 4 + sub * 2 + (r & 1);
-                int rg = ((isA ? m0 : n0) >> 4) + gip;
-                const int rgs = ((isA ? p.M : p.N) + 15) >> 4;
-                if (rg >= rgs) rg = rgs - 1;                 // tail groups re-read the last group (never stored)
-                const _Float16* base = isA ? (const _Float16*)p.A + (plane ? p.a_plane : 0)
-                                           : (const _Float16*)p.W + (plane ? pl1 : 0);
-                const unsigned long long a_ = (unsigned long long)(base + (size_t)rg * nk * 512);
-                q_src[ty][k] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
-                               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);   // (unsigned): the builtin returns int -- without it the low word is SIGN-extended into the high one
-                q_lds[ty][k] = __builtin_amdgcn_readfirstlane(((isA ? 0 : 32) + plane * 16 + gip) * 1024);
-            }
-#define H4_ISSUE(tile_, ty_, buf_)                                                                  \
-    do {                                                                                            \
-        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                               \
-            __builtin_amdgcn_global_load_lds(                                                       \
-                (ds_gptr)((const unsigned char*)(q_src[ty_][k] + (unsigned long long)(tile_) * 1024) + lane16), \
-                (ds_lptr)(smem_raw + (buf_) * (STAGE * 2) + q_lds[ty_][k]), 16, 0, 0);              \
-    } while (0)
-#define H4_FENCE()                                                                                  \
-    do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define H4_BAR()                                                                                    \
-    do { H4_FENCE(); __builtin_amdgcn_s_barrier(); H4_FENCE(); } while (0)
-        h8 pa0[2][2], pa1[2][2];             // [ks][row block of the current A-sub]: hi, lo
-        h8 pb0[2][2], pb1[2][2];             // [B-sub][ks]: hi, lo
-#define H4_READ_A(buf_, s_)                                                                         \
-    do {                                                                                            \
-        const _Float16* Ac = smem + (buf_) * STAGE + (wm * 128 + (s_) * 64 + l31) * HLD;            \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
-            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) {                                      \
-                pa0[ks][ib] = *(const h8*)(Ac + ib * 32 * HLD + swz[ks]);                           \
-                pa1[ks][ib] = *(const h8*)(Ac + APL + ib * 32 * HLD + swz[ks]);                     \
-            }                                                                                       \
-    } while (0)
-#define H4_READ_B(buf_, s_)                                                                         \
-    do {                                                                                            \
-        const _Float16* Bc = smem + (buf_) * STAGE + 2 * APL + (wn * 64 + (s_) * 32 + l31) * HLD;   \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
-            pb0[s_][ks] = *(const h8*)(Bc + swz[ks]);                                               \
-            pb1[s_][ks] = *(const h8*)(Bc + BPL + swz[ks]);                                         \
-        }                                                                                           \
-    } while (0)
-        // per accumulator: ks 0 {a1 b0, a0 b1, a0 b0}, ks 1 {...} -- the order of every other program of this file
-#define H4_QUAD(sa_, sb_)                                                                           \
-    do {                                                                                            \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
-            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                        \
-                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa1[ks][ib], pb0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
-            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                        \
-                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa0[ks][ib], pb1[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
-            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                        \
-                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa0[ks][ib], pb0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
-        }                                                                                           \
-    } while (0)
-#define H4_PHASE(P, BUF)                                                                            \
-    do {                                                                                            \
-        if (P == 0) { H4_READ_A(BUF, 0); H4_READ_B(BUF, 0); }                                       \
-        if (P == 1) H4_READ_B(BUF, 1);                                                              \
-        if (P == 2) H4_READ_A(BUF, 1);                                                              \
-        H4_FENCE();                                                                                 \
-        {                                                                                           \
-            constexpr int dq = (P) + LEAD;                    /* quarter 4 t + dq */                \
-            const int tq = t + (dq >> 2);                                                           \
-            if (tq < nk) {                                                                          \
-                H4_ISSUE(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                      \
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");               \
-            } else {                                                                                \
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* tail: nothing younger to count */ \
-            }                                                                                       \
-        }                                                                                           \
-        H4_BAR();                                                                                   \
-        __builtin_amdgcn_s_setprio(1);                                                              \
-        if (P == 0) H4_QUAD(0, 0);                                                                  \
-        if (P == 1) H4_QUAD(0, 1);                                                                  \
-        if (P == 2) H4_QUAD(1, 1);                                                                  \
-        if (P == 3) H4_QUAD(1, 0);                                                                  \
-        __builtin_amdgcn_s_setprio(0);                                                              \
-        H4_BAR();                                                                                   \
-    } while (0)
-#pragma unroll
-        for (int q = 0; q < LEAD; ++q)
-            if ((q >> 2) < nk) H4_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
-        if (4 * nk >= LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory");   // quarters 0, 1 landed
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // fewer than LEAD quarters exist
-        H4_BAR();
-        if (wm == 1) H4_BAR();               // the second wave row runs one barrier behind the first
-        int t = 0;
-        for (; t + 1 < nk; t += 2) {
-            H4_PHASE(0, 0); H4_PHASE(1, 0); H4_PHASE(2, 0); H4_PHASE(3, 0);
-            ++t;
-            H4_PHASE(0, 1); H4_PHASE(1, 1); H4_PHASE(2, 1); H4_PHASE(3, 1);
-            --t;
-        }
-        if (t < nk) { H4_PHASE(0, 0); H4_PHASE(1, 0); H4_PHASE(2, 0); H4_PHASE(3, 0); }   // odd number of k-tiles
-        if (wm == 0) H4_BAR();               // ... and the first row waits for it at the end
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if constexpr (AMODE >= 2) {
+    if constexpr (AMODE == 2) {
         // LDS image of a stage = 2*(BM+BN) rows of 64 B: A hi rows, A lo rows, B hi rows, B lo rows.  One DMA
         // instruction of a wave fills 16 consecutive rows = one packed 16-row x 32-k tile (lane l -> bytes 16 l);
         // the wave owns the 16-row groups g = wave + NW i.
@@ -379,99 +264,10 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb0[ks][j], c, 0, 0, 0); \
                     acc[i][j] = c;                                                                  \
                 }                                                                                   \
-        if (TM * TN <= 4) {                                                                         \
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0); /* DS reads */           \
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);   /* MFMA */               \
-        } else { /* big wave tiles: one fragment register set, k-step by k-step (VGPR budget) */    \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);                          \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM * TN, 0);                            \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);                          \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM * TN, 0);                            \
-        }                                                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0); /* DS reads */               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);   /* MFMA */                   \
     } while (0)
         static_assert(HBK == 32, "two 16-wide k-steps per tile");
-        if constexpr (AMODE == 3) {
-            // Register staging of the PACKED tiles (opt-in candidate, force_tile 7): the same lane -> byte mapping as
-            // the DMA, but global -> VGPR -> ds_write_b128 with two register sets, so the loads of tile kt+2 are in
-            // flight while tile kt is computed -- twice the latency tolerance of the two-stage DMA ring at the same
-            // LDS footprint (the third stage is 8 G VGPRs).  Ordinary loads: the compiler places the vmcnt waits.
-            static_assert(NW == 4 && NS == 2, "written for the 4-wave programs");
-            u32x4 rX[G], rY[G];
-#define H_RLOAD(R, tile_)                                                                           \
-    do {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < G; ++i) R[i] = *(const u32x4*)(src[i] + (size_t)(tile_) * 512); \
-    } while (0)
-#define H_RWRITE(R, stage_)                                                                         \
-    do {                                                                                            \
-        unsigned char* d_ = smem_raw + (stage_) * (STAGE * 2) + wave * 1024 + lane * 16;            \
-        _Pragma("unroll") for (int i = 0; i < G; ++i) *(u32x4*)(d_ + i * (NW * 1024)) = R[i];       \
-    } while (0)
-#define H_RCOMPUTE(cur_)                                                                            \
-    do {                                                                                            \
-        const _Float16* Ac = smem + (cur_) * STAGE + (wm * TM * 32 + l31) * HLD;                    \
-        const _Float16* Bc = smem + (cur_) * STAGE + 2 * APL + (wn * TN * 32 + l31) * HLD;          \
-        h8 fa0[2][TM], fa1[2][TM], fb0[2][TN], fb1[2][TN];                                          \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
-                fa0[ks][i] = *(const h8*)(Ac + i * 32 * HLD + swz[ks]);                             \
-                fa1[ks][i] = *(const h8*)(Ac + APL + i * 32 * HLD + swz[ks]);                       \
-            }                                                                                       \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
-                fb0[ks][j] = *(const h8*)(Bc + j * 32 * HLD + swz[ks]);                             \
-                fb1[ks][j] = *(const h8*)(Bc + BPL + j * 32 * HLD + swz[ks]);                       \
-            }                                                                                       \
-        }                                                                                           \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                    \
-                    f32x16 c = acc[i][j];                                                           \
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[ks][i], fb0[ks][j], c, 0, 0, 0); \
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb1[ks][j], c, 0, 0, 0); \
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[ks][i], fb0[ks][j], c, 0, 0, 0); \
-                    acc[i][j] = c;                                                                  \
-                }                                                                                   \
-    } while (0)
-            // RX holds tile kt+1 (landed or landing), RY receives tile kt+2; tile kt is in stage cur
-#define H_RBODY(RX, RY)                                                                             \
-    do {                                                                                            \
-        H_RLOAD(RY, kt + 2 < nk ? kt + 2 : nk - 1);                                                 \
-        H_RCOMPUTE(cur);                                                                            \
-        H_RWRITE(RX, cur ^ 1);                                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x020, G, 0);             /* VMEM loads first */        \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0); /* fragment reads */         \
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);   /* MFMAs */                  \
-        __builtin_amdgcn_sched_group_barrier(0x200, G, 0);             /* staging writes last */    \
-        __syncthreads();                                                                            \
-        cur ^= 1;                                                                                   \
-        ++kt;                                                                                       \
-    } while (0)
-            H_RLOAD(rX, 0);
-            H_RWRITE(rX, 0);
-            H_RLOAD(rX, nk > 1 ? 1 : 0);
-            __syncthreads();
-            int cur = 0, kt = 0;
-            while (kt + 1 < nk) {
-                H_RBODY(rX, rY);
-                H_RBODY(rY, rX);
-            }
-            if (kt < nk) H_RBODY(rX, rY);
-        } else if constexpr (NS > 2) {
-            // ring of NS stages, NS-1 tiles in flight: tile kt has landed once at most the G (NS-2) younger DMA
-            // instructions of this wave are outstanding (vmcnt counts in issue order)
-#pragma unroll
-            for (int t = 0; t < NS - 1; ++t)
-                if (t < nk) H_DMA(t, t * 512);
-            int cur = 0, nxt = NS - 1;
-            for (int kt = 0; kt < nk; ++kt) {
-                if (kt + NS - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();   // tile kt visible to every wave, and stage `nxt` (tile kt-1) is free
-                if (kt + NS - 1 < nk) H_DMA(nxt, (kt + NS - 1) * 512);
-                H_COMPUTE_ALL(cur);
-                cur = cur + 1 == NS ? 0 : cur + 1;
-                nxt = nxt + 1 == NS ? 0 : nxt + 1;
-            }
-        } else {
         H_DMA(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             // Tile kt must have landed before anyone crosses the barrier.  The wait is written out: hipcc adds a
@@ -482,7 +278,6 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
             __syncthreads();   // ... and stage (kt+1)&1 is free
             if (kt + 1 < nk) H_DMA((kt + 1) & 1, (kt + 1) * 512);
             H_COMPUTE_ALL(kt & 1);
-        }
         }
     } else {
         const int nk = p.K / HBK;
@@ -523,7 +318,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     // The staged epilogues reuse the operand stages (NS * STAGE halves) as the tile buffer.  A tile that does not fit
     // (256x256: 256 KB of fp32 against 128 KB of stages) goes through in SLABS row slabs of SR rows, each filled by
     // the waves whose rows lie in it; SLABS = 1 for every 4-wave instantiation.
-    constexpr int LDS_BYTES = AMODE == 2 ? NS * STAGE * 2 : 2 * STAGE * 2;   // (AMODE 4: two 64 KB buffers)
+    constexpr int LDS_BYTES = NS * STAGE * 2;
     constexpr int SLABS = (BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES;
     static_assert(WGM % SLABS == 0, "a wave's rows must lie in one slab");
     constexpr int SR = BM / SLABS;
@@ -683,69 +478,6 @@ static BalancePlan ds_balance_plan(int M, int N, int BM, int BN, int slots, int 
     return pl;
 }
 
-// ---- big-tile candidates (opt-in: ds_gemm_f16x2_force_tile(3 / 4 / 6), packed operands only) -------------------------
-// One 8-wave workgroup per CU.  256x256 (waves of 128x64): half the L2->LDS bytes and three quarters of the LDS->VGPR
-// bytes per MFMA of the 128x128 program; 256x128 / 128x256 with a three-stage ring keep two k-tiles in flight.  The
-// balanced launch gives the big tiles the rows that fill whole rounds of 256 CUs and the rows after them to 8-wave
-// 128x128 tiles (waves of 64x32) in the same grid.  Results are bit-identical to the 4-wave programs (same MFMA order
-// per accumulator).  tools/probe/probe_gemm_f16x2.hip holds the bare main loops; see DESIGN.md section 3.
-template <int BM, int BN, int WGM, int WGN, int NS, int AMODE = 2>
-__global__ __launch_bounds__(WGM * WGN * 64, 1) void ds_gemm_f16x2_big_kernel(const GemmParams pb, const GemmParams ps,
-                                                                              const int nbig) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    static_assert(WGM * WGN == 8, "the tail program below is written for 8 waves");
-    const int bid = blockIdx.x;   // uniform branch: a workgroup runs one of the two programs
-    if (bid < nbig) ds_gemm_f16x2_body<BM, BN, AMODE, WGM, WGN, NS>(pb, bid, nbig, smem_dyn);
-    // tail rows: 8-wave 128x128 tiles on a four-stage ring (128 KB, within every big program's allocation) -- the tail
-    // runs on a few CUs only, so it is bound by the DMA round trip per k-tile; three tiles in flight hide it
-    else ds_gemm_f16x2_body<128, 128, 2, 2, 4, 4>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
-}
-
-static int g_big_slots = 256;   // one big workgroup per CU; a test hook shrinks it so small shapes get a tail program
-extern "C" void ds_gemm_f16x2_set_big_slots(int n) { g_big_slots = n > 0 ? n : 256; }
-template <int BM, int BN, int WGM, int WGN, int NS, int AMODE = 2>
-static int launch_big(const GemmParams& p, hipStream_t s) {
-    const BalancePlan pl = ds_balance_plan(p.M, p.N, BM, BN, g_big_slots, 128, 128,
-                                           p.store == DS_STORE_ROW || p.store == DS_STORE_ATTN);
-    const int m_off = pl.m_off, nbig = pl.nbig, nsmall = pl.nsmall;
-    GemmParams pb = p, ps = p;
-    pb.M = m_off;
-    ps.M = p.M - m_off;
-    if (nsmall > 0) {
-        const size_t rg = (size_t)m_off / 16;
-        ps.A = (const float*)((const _Float16*)p.A + rg * (p.K / HBK) * 512);       // packed planes: row-group offset
-        if (p.store == DS_STORE_ATTN) ps.row_off = p.row_off + m_off;   // destinations are computed from absolute rows
-        else if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
-        else ps.C = p.C + (size_t)m_off * p.ldc;
-        if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
-    }
-    const size_t lds = (size_t)NS * 2 * (BM + BN) * HLD * sizeof(unsigned short);   // >= the tail program's 128 KB
-    static_assert((size_t)NS * 2 * (BM + BN) * HLD * sizeof(unsigned short) >= 4u * 2 * 256 * HLD * sizeof(unsigned short), "tail ring");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS, AMODE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return -2;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((ds_gemm_f16x2_big_kernel<BM, BN, WGM, WGN, NS, AMODE>), dim3(nbig + nsmall), dim3(WGM * WGN * 64), lds, s,
-                       pb, ps, nbig);
-    DS_CHECK_LAUNCH();
-    return 0;
-}
-
-// the balanced launch of ds_gemm_f16x2_hybrid_kernel with the register-staged programs (opt-in candidate, force_tile 7)
-__global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_hybrid_reg_kernel(const GemmParams pb, const GemmParams ps,
-                                                                         const int nbig) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    const int bid = blockIdx.x;
-    if (bid < nbig) ds_gemm_f16x2_body<128, 128, 3>(pb, bid, nbig, smem_dyn);
-    else ds_gemm_f16x2_body<64, 64, 3>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
-}
-
 template <int BM, int BN, int AMODE>
 static int launch_h2(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * sizeof(unsigned short);
@@ -772,17 +504,18 @@ static int launch_h(const GemmParams& p, hipStream_t s) {
 
 extern int g_last_tile;
 extern "C" void ds_gemm_f16x2_force_tile(int t) { g_force_tile_h = t; }
+bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid);   // gemm_f16x2_ps.hip
+int ds_launch_gemm_f16x2_ps(const GemmParams& p, hipStream_t s);
 
 // resident 128x128 workgroups on the chip (256 CUs x 2); a test hook shrinks it so small shapes take the hybrid path
 static int g_balance_slots = 512;
 extern "C" void ds_gemm_f16x2_set_balance_slots(int n) { g_balance_slots = n > 0 ? n : 512; }
 
 // 128x128 tiles for the largest row range that fills whole rounds of slots, 64x64 tiles for the rows after it
-template <bool REG = false>   // REG: the register-staged programs (force_tile 7)
 static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     const BalancePlan pl = ds_balance_plan(p.M, p.N, 128, 128, g_balance_slots, 64, 64,
                                            p.store == DS_STORE_ROW || p.store == DS_STORE_ATTN);
-    if (pl.nsmall == 0) return launch_h2<128, 128, REG ? 3 : 2>(p, s);
+    if (pl.nsmall == 0) return launch_h2<128, 128, 2>(p, s);
     const int m_off = pl.m_off;
     GemmParams pb = p, ps = p;
     pb.M = m_off;
@@ -795,18 +528,17 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
     const int nbig = pl.nbig, nsmall = pl.nsmall;
     const size_t lds = (size_t)2 * 2 * (128 + 128) * HLD * sizeof(unsigned short);
-    const void* kern = REG ? (const void*)ds_gemm_f16x2_hybrid_reg_kernel : (const void*)ds_gemm_f16x2_hybrid_kernel;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_hybrid_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
         attr_set = true;
     }
-    if (REG) hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_reg_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
-    else hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
+    hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -816,13 +548,8 @@ extern "C" int ds_gemm_f16x2_plan(int cfg, int M, int N, int store, int* m_off, 
     DS_CHECK_ARG(M > 0 && N > 0 && m_off && nbig && nsmall, "bad arguments");
     const bool tail_ok = store == DS_STORE_ROW || store == DS_STORE_ATTN;
     BalancePlan pl;
-    switch (cfg) {
-        case 0: case 7: pl = ds_balance_plan(M, N, 128, 128, g_balance_slots, 64, 64, tail_ok); break;
-        case 3: case 8: pl = ds_balance_plan(M, N, 256, 256, g_big_slots, 128, 128, tail_ok); break;
-        case 4: pl = ds_balance_plan(M, N, 256, 128, g_big_slots, 128, 128, tail_ok); break;
-        case 6: pl = ds_balance_plan(M, N, 128, 256, g_big_slots, 128, 128, tail_ok); break;
-        default: DS_CHECK_ARG(false, "cfg has no balanced launch");
-    }
+    DS_CHECK_ARG(cfg == 0, "only configuration 0 (128x128 + 64x64 tail tiles) has a balanced launch");
+    pl = ds_balance_plan(M, N, 128, 128, g_balance_slots, 64, 64, tail_ok);
     *m_off = pl.m_off; *nbig = pl.nbig; *nsmall = pl.nsmall;
     return 0;
 }
@@ -850,28 +577,29 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(!p.c_split || p.N % 8 == 0, "packed output needs N % 8 == 0");
     DS_CHECK_ARG(p.act == DS_ACT_NONE || p.act == DS_ACT_GELU2, "unsupported activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
+    // Full-batch denoiser GEMMs (packed operands, one sample = 265 rows, N in 256-column tiles, a grid of whole
+    // rounds of the 256 CUs): the per-sample ping-pong program of gemm_f16x2_ps.hip.  force_tile(9) takes it for
+    // every shape it can compute (tests: small batches), force_tile(0 / 1 / 2) never.
+    if ((g_force_tile_h < 0 && ds_gemm_f16x2_ps_applies(p, true)) ||
+        (g_force_tile_h == 9 && ds_gemm_f16x2_ps_applies(p, false))) {
+        g_last_tile = 3;
+        return ds_launch_gemm_f16x2_ps(p, stream);
+    }
     // Tile choice from the measured sweep (profiles/r01_gemm_tile_sweep_f16x2.txt, B=64): 128x128 reaches
     // ~235-250 TF-eq once the grid has >= 3 rounds of 512 resident blocks; below that 128x64 (3 blocks/CU,
     // ~205-230 TF-eq) quantises better; 64x64 (~190) only wins for tiny grids.
     int best;
-    if (g_force_tile_h >= 0) {
+    if (g_force_tile_h >= 0 && g_force_tile_h <= 2) {
         best = g_force_tile_h;
     } else {
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups
         best = t128 >= (p.a_split ? 1000 : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
     }
-    if (best >= 3 && (!p.a_split || (best != 7 && p.store == DS_STORE_ATTN && p.rows_per_sample < 256)))
-        best = 0;   // the candidates take packed operands only; big slabs must not span more than two samples
-    g_last_tile = best >= 3 ? 0 : best;   // the profiler has three classes; the candidates stand in for class 0
+    g_last_tile = best;
     switch (best) {
-        case 0: return p.a_split ? launch_hybrid<false>(p, stream) : launch_h<128, 128>(p, stream);
-        case 7: return launch_hybrid<true>(p, stream);
+        case 0: return p.a_split ? launch_hybrid(p, stream) : launch_h<128, 128>(p, stream);
         case 1: return launch_h<128, 64>(p, stream);
-        case 3: return launch_big<256, 256, 2, 4, 2>(p, stream);
-        case 8: return launch_big<256, 256, 2, 4, 2, 4>(p, stream);
-        case 4: return launch_big<256, 128, 4, 2, 3>(p, stream);
-        case 6: return launch_big<128, 256, 2, 4, 3>(p, stream);
         default: return launch_h<64, 64>(p, stream);
     }
 }

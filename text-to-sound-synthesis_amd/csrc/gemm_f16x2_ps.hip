@@ -1,0 +1,421 @@
+// The denoiser's f16x2 GEMM at full batch: per-sample 288 x 256 tiles on an 8-phase ping-pong main loop.
+//
+//   C[m][n] = store( act( out_scale * sum_k A[m][k] * W'[n][k] + bias[n] ) + R[m][n] )        (gemm_f16x2.hip)
+//
+// Same arithmetic and, per accumulator, the same MFMA order as every program of gemm_f16x2.hip (ks 0 {a1 w0, a0 w1,
+// a0 w0}, ks 1 {...}) -- results are bit-identical (tests/test_hip_split_gemm.py).  What differs is the decomposition:
+//
+// * Tile = ONE SAMPLE.  The activation matrices of the denoiser have M = B * L rows, L = 265 (the 5 x 53 token grid).
+//   265 never divides into 128- or 256-row tiles: at B = 64, 256-row tiles are 66.25 row tiles = 1.05 / 3.14 / 4.19
+//   rounds of the 256 CUs for N = 1024 / 3072 / 4096 (measured: the 256 x 256 ping-pong loop drops from 344 to 245
+//   TF-eq at N = 1024).  A tile of 288 rows = 9 MFMA blocks that covers exactly the rows of one sample gives
+//   B * N / 256 tiles: whole rounds at B = 64 for every GEMM of the network, no tail program, 265 / 288 = 92 % of the
+//   MFMA work useful.  Tile rows are [m0, m0 + 288), m0 = 16 floor(L b / 16) (packed planes come in 16-row groups);
+//   they contain the sample's rows [L b, L b + L) (needs (L b mod 16) + L <= 288: L <= 273); only those are stored.
+// * 8 waves = 2 (M) x 4 (N), one workgroup per CU.  Blocks 0..7 of the tile: wave (wr, wc) owns rows wr 128 + [0, 128),
+//   columns wc 64 + [0, 64) (4 x 2 blocks).  The NINTH block row (tile rows 256..287, 32 x 256) is split by COLUMNS over
+//   all eight waves: wave (wr, wc) adds the 32 x 32 block at columns (2 wc + wr) 32 -- B-sub `wr` of its own column
+//   range, whose fragments it already holds -- so every wave runs the same program: 54 MFMAs per k-tile, 144
+//   accumulator registers.
+// * Main loop: the "256^2 8-phase" structure of cdna_hip_programming.md section 5 for two fp16 planes x 32 k per
+//   k-tile (= the bytes of a 64-wide bf16 k-step).  A k-tile is consumed in four phases (quadrants of the wave tile,
+//   12 MFMAs each; phase 3 also reads and multiplies the ninth block) and staged by LDS-DMA in four quarters (A-sub0,
+//   B-sub0, B-sub1, A-sub1 + the ninth block's rows), one per phase, LEAD = 6 quarters ahead of the phase that
+//   computes.  The wait of a phase is a COUNTED vmcnt(9) -- the four youngest quarters (2 + 2 + 2 + 3 instructions per
+//   wave) stay in flight across the barriers, never vmcnt(0) in the steady state.  Each phase = { ds_read a sub-tile;
+//   issue a quarter; vmcnt; barrier; MFMAs under s_setprio(1); barrier }, and the two wave rows run one barrier
+//   apart, so on every SIMD one wave issues MFMAs while its partner reads LDS and issues DMA.
+//   Hazards (phase g = 4 tile + p; quarter q = 4 tile + type is first needed at phase 4 tile + {0, 0, 1, 2}[type]):
+//     RAW  the wait of phase g retires this wave's quarters <= g + 2, the barrier behind it does so for every wave of
+//          its row, the other row is at most one barrier away -> a quarter is read in a phase AFTER the one that
+//          retires it (quarter 4t+3 incl. the ninth block's rows: retired in phase 4t+1, read in phases 4t+2 / 4t+3);
+//     WAR  quarter g + 6 lands on the region of quarter g - 2, last read two or more phases before phase g.
+//   Waves 4..7 repeat the ninth-block loads of waves 0..3 (same bytes to the same LDS address) so that every wave
+//   counts the same number of instructions.
+// * Measured (tools/probe/probe_gemm_f16x2.hip ps_kernel, M = 16960): 343 / 374 / 385 / 412 TF-eq at
+//   (N, K) = (1024, 1024) / (3072, 1024) / (4096, 1024) / (1024, 4096) against 253 / 286 / 290 / 283 for the
+//   128 x 128 two-workgroups-per-CU program on the same shapes (profiles/r02_probe_per_sample.txt).
+// Epilogue: the three store families of gemm_f16x2.hip (row-major fp32 + residual; packed split planes; attention-ready
+// Q / K / V^T), staged through the operand stages in three row slabs (tile rows 0..127: wave row 0, 128..255: wave row
+// 1, 256..287: every wave's ninth block) and written with 16-byte stores.  One kernel instantiation per family.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* ds_gptr;
+typedef __attribute__((address_space(3))) void* ds_lptr;
+
+#define PS_HLD 32          // halves per LDS row (64-byte rows, chunks swizzled by (row >> 2) & 3: the packed-plane image)
+#define PS_BM 288
+#define PS_BN 256
+#define PS_LEAD 6
+#define PS_GM 4            // raster: groups of 4 sample tiles x all column tiles (measured: 4 beats 2 and 8 by ~10 %)
+#define PS_LDS_BYTES (2 * 2 * (PS_BM + PS_BN) * PS_HLD * 2)   // two stages of 68 KB
+
+enum { PS_EPI_ROW = 0, PS_EPI_SPLIT = 1, PS_EPI_ATTN = 2 };
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int BM = PS_BM, BN = PS_BN, HLD = PS_HLD, LEAD = PS_LEAD;
+    constexpr int APL = BM * HLD, BPL = BN * HLD, STAGE = 2 * (APL + BPL);   // halves; STAGE * 2 bytes = 68 KB
+    _Float16* smem = (_Float16*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int L = p.rows_per_sample;
+    const int tiles_n = p.N / BN, nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {   // each XCD works a contiguous run of tiles
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm_, tn_;
+    {
+        const int tiles_m = p.M / L;
+        const int per = PS_GM * tiles_n, grp = bid / per, first = grp * PS_GM;
+        const int gsz = tiles_m - first < PS_GM ? tiles_m - first : PS_GM;
+        const int in = bid - grp * per;
+        tm_ = first + in % gsz;
+        tn_ = in / gsz;
+    }
+    const int row_lo = tm_ * L;                     // the sample's rows [row_lo, row_lo + L) are what this tile stores
+    const int m0 = (row_lo >> 4) << 4, n0 = tn_ * BN;
+    const int nk = p.K / 32;                        // even (K % 64 == 0)
+    const _Float16* Ap = (const _Float16*)p.A;
+    const _Float16* Wp = (const _Float16*)p.W;
+    // wave-uniform 64-bit bases (SGPRs) + one per-lane byte offset keep the tile pointers out of the VGPR file
+    unsigned long long src[4][2], src8;             // quarter types: 0 = A-sub0, 1 = B-sub0, 2 = B-sub1, 3 = A-sub1 (+ block 8)
+    int ldsoff[4][2], ldsoff8;
+    const unsigned lane16 = lane * 16;
+    const int rgsA = (p.M + 15) >> 4, rgsB = (p.N + 15) >> 4;
+    // (unsigned) on the builtin's result: it returns int, and the conversion to 64 bits would SIGN-extend the low word
+#define PS_BASE(dst_, ptr_)                                                                          \
+    do {                                                                                             \
+        const unsigned long long a_ = (unsigned long long)(ptr_);                                    \
+        dst_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) | \
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);           \
+    } while (0)
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = 2 * wave + k, plane = idx >> 3, r = idx & 7;
+            const bool isA = (ty == 0 || ty == 3);
+            const int s = isA ? (ty == 3) : (ty == 2);
+            const int gip = isA ? (r >> 2) * 8 + s * 4 + (r & 3)       // 16-row group inside rows 0..255 of the A plane
+                                : (r >> 1) * 4 + s * 2 + (r & 1);
+            int rg = ((isA ? m0 : n0) >> 4) + gip;
+            const int rgs = isA ? rgsA : rgsB;
+            if (rg >= rgs) rg = rgs - 1;                               // groups past the end re-read the last one (never stored)
+            PS_BASE(src[ty][k], (isA ? Ap + plane * p.a_plane : Wp + plane * p.w3_plane) + (size_t)rg * nk * 512);
+            ldsoff[ty][k] = __builtin_amdgcn_readfirstlane((isA ? plane * 18 + gip : 36 + plane * 16 + gip) * 1024);
+        }
+    {   // block 8: groups 16, 17 of both planes = 4 KB; wave w (and w + 4) loads piece e = w & 3
+        const int e = wave & 3, plane = e >> 1, gip = 16 + (e & 1);
+        int rg = (m0 >> 4) + gip;
+        if (rg >= rgsA) rg = rgsA - 1;
+        PS_BASE(src8, Ap + plane * p.a_plane + (size_t)rg * nk * 512);
+        ldsoff8 = __builtin_amdgcn_readfirstlane((plane * 18 + gip) * 1024);
+    }
+#define PS_ISSUE(tile_, ty_, buf_)                                                                   \
+    do {                                                                                             \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                \
+            __builtin_amdgcn_global_load_lds((ds_gptr)((const unsigned char*)(src[ty_][k] + (unsigned long long)(tile_) * 1024) + lane16), \
+                                             (ds_lptr)(smem_raw + (buf_) * (STAGE * 2) + ldsoff[ty_][k]), 16, 0, 0); \
+        if ((ty_) == 3)                                                                              \
+            __builtin_amdgcn_global_load_lds((ds_gptr)((const unsigned char*)(src8 + (unsigned long long)(tile_) * 1024) + lane16), \
+                                             (ds_lptr)(smem_raw + (buf_) * (STAGE * 2) + ldsoff8), 16, 0, 0); \
+    } while (0)
+#define PS_FENCE()                                                                                   \
+    do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PS_BAR()                                                                                     \
+    do { PS_FENCE(); __builtin_amdgcn_s_barrier(); PS_FENCE(); } while (0)
+    const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
+    f32x16 acc[4][2], acc8;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc8[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    h8 a0[2][2], a1[2][2];          // [ks][row block of the current A-sub]: hi, lo planes
+    h8 b0[2][2], b1[2][2];          // [B-sub][ks]: hi, lo planes
+    h8 e0[2], e1[2];                // block 8 [ks]: hi, lo planes
+#define PS_READ_A(buf_, s_)                                                                          \
+    do {                                                                                             \
+        const _Float16* Ac = smem + (buf_) * STAGE + (wr * 128 + (s_) * 64 + l31) * HLD;             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) {                                       \
+                a0[ks][ib] = *(const h8*)(Ac + ib * 32 * HLD + swz[ks]);                             \
+                a1[ks][ib] = *(const h8*)(Ac + APL + ib * 32 * HLD + swz[ks]);                       \
+            }                                                                                        \
+    } while (0)
+#define PS_READ_E(buf_)                                                                              \
+    do {                                                                                             \
+        const _Float16* Ec = smem + (buf_) * STAGE + (256 + l31) * HLD;                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            e0[ks] = *(const h8*)(Ec + swz[ks]);                                                     \
+            e1[ks] = *(const h8*)(Ec + APL + swz[ks]);                                               \
+        }                                                                                            \
+    } while (0)
+#define PS_READ_B(buf_, s_)                                                                          \
+    do {                                                                                             \
+        const _Float16* Bc = smem + (buf_) * STAGE + 2 * APL + (wc * 64 + (s_) * 32 + l31) * HLD;    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            b0[s_][ks] = *(const h8*)(Bc + swz[ks]);                                                 \
+            b1[s_][ks] = *(const h8*)(Bc + BPL + swz[ks]);                                           \
+        }                                                                                            \
+    } while (0)
+    // quadrant (A-sub sa, B-sub sb): per accumulator ks 0 {a1 b0, a0 b1, a0 b0}, ks 1 {...}
+#define PS_QUAD(sa_, sb_)                                                                            \
+    do {                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks][ib], b0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b1[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+        }                                                                                            \
+    } while (0)
+#define PS_EXTRA(sb_)                                                                                \
+    do {                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1[ks], b0[sb_][ks], acc8, 0, 0, 0);       \
+            acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0[ks], b1[sb_][ks], acc8, 0, 0, 0);       \
+            acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0[ks], b0[sb_][ks], acc8, 0, 0, 0);       \
+        }                                                                                            \
+    } while (0)
+    // one phase: P = phase within the k-tile (compile time), BUF = parity of the k-tile t (compile time)
+#define PS_PHASE(P, BUF)                                                                             \
+    do {                                                                                             \
+        if (P == 0) { PS_READ_A(BUF, 0); PS_READ_B(BUF, 0); }                                        \
+        if (P == 1) PS_READ_B(BUF, 1);                                                               \
+        if (P == 2) PS_READ_A(BUF, 1);                                                               \
+        if (P == 3) PS_READ_E(BUF);                                                                  \
+        PS_FENCE();                                                                                  \
+        {                                                                                            \
+            constexpr int dq = (P) + LEAD;                     /* quarter 4 t + dq */                \
+            const int tq = t + (dq >> 2);                                                            \
+            if (tq < nk) {                                                                           \
+                PS_ISSUE(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                       \
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   /* the 4 youngest quarters: 2+2+2+3 */ \
+            } else {                                                                                 \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* tail: nothing younger to count */ \
+            }                                                                                        \
+        }                                                                                            \
+        PS_BAR();                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        if (P == 0) PS_QUAD(0, 0);                                                                   \
+        if (P == 1) PS_QUAD(0, 1);                                                                   \
+        if (P == 2) PS_QUAD(1, 1);                                                                   \
+        if (P == 3) { PS_QUAD(1, 0); if (wr == 0) PS_EXTRA(0); else PS_EXTRA(1); }                   \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+        PS_BAR();                                                                                    \
+    } while (0)
+    // prologue: quarters 0 .. 5 (k-tile 0 and types 0, 1 of k-tile 1) = 13 instructions per wave; quarters 0 and 1 have
+    // landed once only the 4 youngest (2 + 3 + 2 + 2 = 9) are outstanding
+#pragma unroll
+    for (int q = 0; q < LEAD; ++q)
+        if ((q >> 2) < nk) PS_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
+    if (4 * nk >= LEAD) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PS_BAR();
+    if (wr == 1) PS_BAR();          // the second wave row runs one barrier behind the first
+    for (int t = 0; t < nk; t += 2) {
+        PS_PHASE(0, 0); PS_PHASE(1, 0); PS_PHASE(2, 0); PS_PHASE(3, 0);
+        ++t;
+        PS_PHASE(0, 1); PS_PHASE(1, 1); PS_PHASE(2, 1); PS_PHASE(3, 1);
+        --t;
+    }
+    if (wr == 0) PS_BAR();          // ... and the first row waits for it at the end
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue -------------------------------------------------------------------------------------------------
+    // The lane / wave indices are re-derived from an opaque copy of the thread id so that none of them stays live
+    // across the main loop (which runs at the 256-register cap: one of them used to be spilled to scratch).
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int l31e = tid_e & 31, hhe = (tid_e >> 5) & 1, wre = tid_e >> 8, wce = (tid_e >> 6) & 3;
+    // valid tile rows [off, vhi): the sample's rows (and not past the matrix)
+    const int off = row_lo - m0;
+    int vhi = off + L;
+    if (vhi > p.M - m0) vhi = p.M - m0;
+    const float osc = p.out_scale;
+    // every value of slab SL (0: wave row 0's rows, 1: wave row 1's, 2: the ninth block of every wave) with its
+    // slab-local row `rl` and tile column `cl`; STORE(rl, cl, v) writes it to the staging buffer
+#define PS_SLAB_VALUES(SL, STORE)                                                                    \
+    do {                                                                                             \
+        if ((SL) < 2) {                                                                              \
+            if (wre == (SL)) {                                                                        \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                  \
+                        const int cl = (wce * 2 + j) * 32 + l31e;                                      \
+                        const float bv = p.bias ? p.bias[n0 + cl] : 0.f;                             \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                             \
+                            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hhe;                 \
+                            float v = acc[i][j][r] * osc + bv;                                       \
+                            if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));            \
+                            STORE(rl, cl, v);                                                        \
+                        }                                                                            \
+                    }                                                                                \
+            }                                                                                        \
+        } else {                                                                                     \
+            const int cl = (wce * 2 + wre) * 32 + l31e;                                                 \
+            const float bv = p.bias ? p.bias[n0 + cl] : 0.f;                                         \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hhe;                                      \
+                float v = acc8[r] * osc + bv;                                                        \
+                if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));                        \
+                STORE(rl, cl, v);                                                                    \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+
+    if constexpr (EPI == PS_EPI_ROW) {
+        // row-major fp32 (+ residual): T[rows][256] floats (<= 128 KB), 16-byte residual loads and stores
+        float* Tf = (float*)smem_raw;
+#define PS_ST_F32(rl_, cl_, v_) Tf[(rl_) * BN + (cl_)] = (v_)
+#define PS_ROW_SLAB(SL)                                                                              \
+    do {                                                                                             \
+        __syncthreads();                    /* the operand stages / the previous slab are free */    \
+        PS_SLAB_VALUES(SL, PS_ST_F32);                                                               \
+        __syncthreads();                                                                             \
+        constexpr int rows_ = (SL) < 2 ? 128 : 32;                                                   \
+        for (int c = tid_e; c < rows_ * (BN / 4); c += 512) {                                          \
+            const int cc = c & (BN / 4 - 1), rl = c / (BN / 4), trow = (SL) * 128 + rl;              \
+            if (trow >= off && trow < vhi) {                                                         \
+                const size_t row = (size_t)(m0 + trow);                                              \
+                const int col = n0 + cc * 4;                                                         \
+                f32x4 val = *(const f32x4*)(Tf + rl * BN + cc * 4);                                  \
+                if (p.R) val += *(const f32x4*)(p.R + row * p.ldr + col);                            \
+                *(f32x4*)(p.C + row * p.ldc + col) = val;                                            \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+        PS_ROW_SLAB(0); PS_ROW_SLAB(1); PS_ROW_SLAB(2);
+    } else {
+        // fp16 split outputs: T[plane][rows][256] halves (<= 128 KB), 16-byte stores
+        _Float16* T = smem;
+#define PS_ST_SPLIT(rl_, cl_, v_)                                                                    \
+    do {                                                                                             \
+        const _Float16 hi_ = ds_split_hi(v_);                                                        \
+        T[(rl_) * BN + (cl_)] = hi_;                                                                 \
+        T[SR * BN + (rl_) * BN + (cl_)] = ds_split_lo(v_, hi_);                                      \
+    } while (0)
+        const int hw = p.attn_heads * 64;
+        const int which = EPI == PS_EPI_ATTN ? n0 / hw : 0;            // block-uniform: Q, K or V columns
+        const int b = tm_;                                               // the sample of this tile
+#define PS_SPLIT_SLAB(SL)                                                                            \
+    do {                                                                                             \
+        constexpr int SR = (SL) < 2 ? 128 : 32;                                                      \
+        __syncthreads();                                                                             \
+        PS_SLAB_VALUES(SL, PS_ST_SPLIT);                                                             \
+        __syncthreads();                                                                             \
+        if (EPI == PS_EPI_SPLIT || which < 2) {           /* 8 consecutive columns of a row per store */ \
+            constexpr int CPR = BN / 8;                                                              \
+            for (int c = tid_e; c < 2 * SR * CPR; c += 512) {                                          \
+                const int cc = c % CPR, rl = (c / CPR) % SR, pl = c / (CPR * SR);                    \
+                const int trow = (SL) * 128 + rl;                                                    \
+                if (trow >= off && trow < vhi) {                                                     \
+                    const int row = m0 + trow, col = n0 + cc * 8;                                    \
+                    const u32x4 val = *(const u32x4*)(T + (pl * SR + rl) * BN + cc * 8);             \
+                    _Float16* dst;                                                                   \
+                    if (EPI == PS_EPI_SPLIT) {                                                       \
+                        dst = (_Float16*)p.C + (size_t)pl * p.c_plane + ds_packed_off(row, col, p.ldc >> 5); \
+                    } else {                                                                         \
+                        const int pos = trow - off;                                                  \
+                        const int hc = col - which * hw, head = hc >> 6, d = hc & 63;                \
+                        const size_t bh = (size_t)b * p.attn_heads + head;                           \
+                        if (which == 0)                                                              \
+                            dst = (_Float16*)p.C + (size_t)pl * p.attn_qplane + (bh * L + pos) * 64 + d; \
+                        else                                                                         \
+                            dst = (_Float16*)p.attn_kv + (bh * 4 + pl) * ((size_t)p.attn_nkey * 64) + ds_attn_k_off(pos, d); \
+                    }                                                                                \
+                    *(u32x4*)dst = val;                                                              \
+                }                                                                                    \
+            }                                                                                        \
+        } else {                                          /* V^T: 8 consecutive keys of one d per store */ \
+            /* valid tile rows of this slab [lo, hi); key = tile row - off; units of 8 keys are aligned in the   */ \
+            /* sample's own key index, so a unit that straddles a slab edge is written in two parts (2-byte stores) */ \
+            const int lo = (SL) * 128 > off ? (SL) * 128 : off;                                      \
+            const int hi = (SL) * 128 + SR < vhi ? (SL) * 128 + SR : vhi;                            \
+            const int u_first = lo < hi ? (lo - off) >> 3 : 0;                                       \
+            const int units = lo < hi ? ((hi - off + 7) >> 3) - u_first : 0;                         \
+            const int pln = p.attn_nkey * 64;                                                        \
+            for (int c = tid_e; c < 2 * BN * units; c += 512) {                                        \
+                const int cl = c % BN, u = (c / BN) % units, pl = c / (BN * units);                  \
+                const int k0 = (u_first + u) * 8;                   /* first key of the unit */      \
+                const int r0 = k0 + off - (SL) * 128;               /* its slab-local row (may be < 0) */ \
+                const int hc = n0 + cl - 2 * hw, head = hc >> 6, d = hc & 63;                        \
+                _Float16* dst = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2 + pl) * (size_t)pln + \
+                                ds_attn_vt_off(k0, d, p.attn_nkey);                                  \
+                const _Float16* src_ = T + (pl * SR) * BN + cl;                                      \
+                const int rlo = lo - (SL) * 128, rhi = hi - (SL) * 128;                              \
+                if (r0 >= rlo && r0 + 8 <= rhi) {                                                    \
+                    h8 val;                                                                          \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) val[e] = src_[(r0 + e) * BN];      \
+                    *(h8*)dst = val;                                                                 \
+                } else {                                                                             \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                    \
+                        if (r0 + e >= rlo && r0 + e < rhi) dst[e] = src_[(r0 + e) * BN];             \
+                }                                                                                    \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+        PS_SPLIT_SLAB(0); PS_SPLIT_SLAB(1); PS_SPLIT_SLAB(2);
+    }
+}
+
+// Whether the per-sample program serves this problem, and pays: packed operands, sample-structured rows with
+// 256 < L + 15 <= 288, N in whole 256-column tiles, an even number of k-tiles, 16-byte-aligned row stores, and a grid
+// that fills the 256 CUs in (nearly) whole rounds.
+bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid) {
+    const int L = p.rows_per_sample;
+    if (!p.a_split || L <= 0 || L > PS_BM - 15 || L <= 240 || p.M % L != 0) return false;
+    if (p.N % PS_BN != 0 || p.K % 64 != 0 || p.lda != p.K || p.ldw != p.K) return false;
+    if (p.store == DS_STORE_ROW && !p.c_split) {
+        if (((p.N | p.ldc | p.ldr) & 3) != 0 || (((uintptr_t)p.C | (uintptr_t)p.R) & 15) != 0) return false;
+    } else if (p.store == DS_STORE_ROW) {
+        if (p.R) return false;
+    } else if (p.store == DS_STORE_ATTN) {
+        if (p.row_off != 0 || p.attn_heads * 64 % PS_BN != 0) return false;
+    } else {
+        return false;
+    }
+    if (!need_full_grid) return true;
+    const long tiles = (long)(p.M / L) * (p.N / PS_BN);
+    const long rounds = (tiles + 255) / 256;
+    // measurement hook: DIFFSOUND_PS_MIN_TILES=n takes the program for every grid of >= n tiles (two half-batches on two
+    // streams share the chip: 128-tile grids then run side by side)
+    static const int env_min = getenv("DIFFSOUND_PS_MIN_TILES") ? atoi(getenv("DIFFSOUND_PS_MIN_TILES")) : 0;
+    if (env_min > 0) return tiles >= env_min;
+    return tiles >= 192 && tiles * 100 >= rounds * 256 * 85;     // >= 85 % of the CU-rounds it occupies do work
+}
+
+template <int EPI>
+static int launch_ps(const GemmParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_ps_kernel<EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
+        if (e != hipSuccess) {
+            ds_set_error("gemm_f16x2_ps: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        attr_set = true;
+    }
+    const int tiles = (p.M / p.rows_per_sample) * (p.N / PS_BN);
+    hipLaunchKernelGGL((ds_gemm_f16x2_ps_kernel<EPI>), dim3(tiles), dim3(512), PS_LDS_BYTES, s, p);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+int ds_launch_gemm_f16x2_ps(const GemmParams& p, hipStream_t s) {
+    if (p.store == DS_STORE_ATTN) return launch_ps<PS_EPI_ATTN>(p, s);
+    return p.c_split ? launch_ps<PS_EPI_SPLIT>(p, s) : launch_ps<PS_EPI_ROW>(p, s);
+}

@@ -1,7 +1,6 @@
-"""A/B timing of the packed-operand f16x2 GEMM on the denoiser's shapes (B=64): default launch (balanced 128x128 +
-64x64 tail) against the opt-in candidates (force_tile 3 = 256x256, 4 = 256x128, 6 = 128x256: 8-wave workgroups;
-7 = the default tiles with register-staged packed operands),
-with a bit-compare of the outputs.  Run on the GPU box:  python tools/gemm_big_ab.py [--batch 64]"""
+"""A/B timing of the packed-operand f16x2 GEMM on the denoiser's shapes (B=64): the per-sample ping-pong program
+(gemm_f16x2_ps.hip; the default at this size) against the balanced 128x128 + 64x64-tail launch (force_tile 0), with a
+bit-compare of the outputs.  Run on the GPU box:  python tools/gemm_big_ab.py [--batch 64]"""
 import argparse
 import os
 import sys
@@ -15,7 +14,7 @@ ap.add_argument("--batch", type=int, default=64)
 args = ap.parse_args()
 M = args.batch * 265
 SHAPES = [("qkv", 3072, 1024), ("proj/q2", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
-NAMES = {-1: "default", 3: "256x256", 4: "256x128/3", 6: "128x256/3", 7: "128x128 reg-staged", 8: "256x256 ping-pong"}
+NAMES = {0: "128x128 balanced", 9: "per-sample ping-pong", -1: "default"}
 
 
 def split(a):
@@ -50,7 +49,7 @@ for name, N, K in SHAPES:
     for tile in NAMES:
         L.lib().ds_gemm_f16x2_force_tile(tile)
         out = torch.empty(M, N, device="cuda")
-        run = lambda: L.gemm(A2, W2p, out, M, N, K, R=R, split2=sc, a_plane=M16 * K)
+        run = lambda: L.gemm(A2, W2p, out, M, N, K, R=R, split2=sc, a_plane=M16 * K, rows_per_sample=265)
         run()
         torch.cuda.synchronize()
         if ref is None:

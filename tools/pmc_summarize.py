@@ -8,7 +8,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from text_to_sound_synthesis_amd.build import source_fingerprint
 
 src, out_csv, out_json = sys.argv[1:4]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -37,6 +41,9 @@ with open(out_csv, "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(rows)
-json.dump({r["kernel"]: r for r in rows}, open(out_json, "w"), indent=1)
+table = {r["kernel"]: r for r in rows}
+# bench.py reports roofline.traffic from this file only while the kernel sources are the ones that were measured
+table["_meta"] = {"source_sha16": source_fingerprint(), "workload": "tools/pmc_step.py: two B=64 denoiser forwards, default precision"}
+json.dump(table, open(out_json, "w"), indent=1)
 for r in rows[:8]:
     print(r)

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, OCC) void probe_kernel(const _Float16* A, long
     __syncthreads();
     READS(0);
     for (int kt = 0; kt < nk; ++kt) {
-        if (!(PROBE & 8)) __syncthreads();
+        if (!(PROBE & 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (the product writes this wait out too)
         if (!(PROBE & 1) && kt + 1 < nk) DMA((kt + 1) & 1, (kt + 1) * HBK);
         if (!(PROBE & 4)) READS(kt & 1);
         if (!(PROBE & 2)) {
@@ -864,6 +864,246 @@ static void run_pp(const char* name, const _Float16* A, const _Float16* W, float
     fflush(stdout);
 }
 
+// ---- per-sample ping-pong variant ("ps"): the pp_kernel main loop on a 288 x 256 tile that covers exactly ONE sample
+// (RPS = 265 rows) of the denoiser's activation matrix.  M = B * 265 rows never divide into 256-row tiles (B = 64:
+// 66.25 row tiles -> 1.05 / 3.14 / 4.19 rounds of 256 CUs), but B * N / 256 per-sample tiles are whole rounds at B = 64
+// for every N of the network, with no tail program.  Tile rows = [m0, m0 + 288), m0 = 16 floor(265 b / 16) (packed
+// planes come in 16-row groups), which contains the sample's rows [265 b, 265 b + 265); only those are stored.
+// Blocks 0..7 (rows 0..255 of the tile) are pp_kernel's: wave (wr, wc) owns rows wr 128 + [0, 128), columns wc 64 +
+// [0, 64).  The ninth block row (rows 256..287, 32 x 256) is split by COLUMNS over all eight waves: wave (wr, wc) adds
+// the 32 x 32 block at columns (2 wc + wr) 32 -- B-sub `wr` of its own column range, whose fragments it already holds --
+// so every wave runs 54 instead of 48 MFMAs per k-tile (265 / 288 = 92 % useful), 16 more accumulator registers, 4 more
+// fragment reads.  The block-8 rows travel with the A-sub1 quarter (3 instead of 2 DMA instructions per wave; waves
+// 4..7 repeat the loads of waves 0..3 -- same bytes to the same LDS address -- so that every wave counts the same):
+// four consecutive quarters are always one of each type = 9 instructions, so the steady-state wait is vmcnt(9).
+// Block 8 is read and multiplied in phase 3 (which reads nothing in pp_kernel): its quarter (type 3 of tile t) is retired
+// by the wait of phase 4t + 1, and the region is re-staged by quarter 4t + 11, issued in phase 4t + 5 -- two phases
+// after the last read (pp_kernel's WAR rule).
+template <int GM>
+__global__ __launch_bounds__(512, 1) void ps_kernel(const _Float16* A, long long a_plane, const _Float16* W,
+                                                    long long w_plane, float* C, int M, int N, int K,
+                                                    unsigned long long* clk) {
+    constexpr int LEAD = 6, RPS = 265;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int BM = 288, BN = 256;
+    constexpr int APL = BM * HLD, BPL = BN * HLD, STAGE = 2 * (APL + BPL);   // halves; STAGE * 2 = 68 KB
+    _Float16* smem = (_Float16*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (N + BN - 1) / BN, nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm_, tn_;
+    {
+        const int tiles_m = M / RPS;
+        const int per = GM * tiles_n, grp = bid / per, first = grp * GM;
+        const int gsz = tiles_m - first < GM ? tiles_m - first : GM;
+        const int in = bid - grp * per;
+        tm_ = first + in % gsz;
+        tn_ = in / gsz;
+    }
+    const int row_lo = tm_ * RPS, row_hi = row_lo + RPS;      // the rows this tile stores
+    const int m0 = (row_lo >> 4) << 4, n0 = tn_ * BN;
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    const int nk = K / HBK;                       // even (K % 64 == 0)
+    unsigned long long src[4][2], src8;           // quarter types: 0 = A-sub0, 1 = B-sub0, 2 = B-sub1, 3 = A-sub1 (+ block 8)
+    int ldsoff[4][2], ldsoff8;
+    const unsigned lane16 = lane * 16;
+    const int rgsA = (M + 15) >> 4, rgsB = (N + 15) >> 4;
+#define PS_BASE(dst_, ptr_)                                                                          \
+    do {                                                                                             \
+        const unsigned long long a_ = (unsigned long long)(ptr_);                                    \
+        dst_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) | \
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);           \
+    } while (0)
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = 2 * wave + k, plane = idx >> 3, r = idx & 7;
+            const bool isA = (ty == 0 || ty == 3);
+            const int s = isA ? (ty == 3) : (ty == 2);
+            const int gip = isA ? (r >> 2) * 8 + s * 4 + (r & 3)       // 16-row group inside rows 0..255 of the A plane
+                                : (r >> 1) * 4 + s * 2 + (r & 1);
+            int rg = ((isA ? m0 : n0) >> 4) + gip;
+            const int rgs = isA ? rgsA : rgsB;
+            if (rg >= rgs) rg = rgs - 1;
+            PS_BASE(src[ty][k], (isA ? A + plane * a_plane : W + plane * w_plane) + (size_t)rg * nk * 512);
+            ldsoff[ty][k] = __builtin_amdgcn_readfirstlane((isA ? plane * 18 + gip : 36 + plane * 16 + gip) * 1024);
+        }
+    {   // block 8: groups 16, 17 of both planes = 4 KB; wave w (and w + 4) loads piece e = w & 3
+        const int e = wave & 3, plane = e >> 1, gip = 16 + (e & 1);
+        int rg = (m0 >> 4) + gip;
+        if (rg >= rgsA) rg = rgsA - 1;
+        PS_BASE(src8, A + plane * a_plane + (size_t)rg * nk * 512);
+        ldsoff8 = __builtin_amdgcn_readfirstlane((plane * 18 + gip) * 1024);
+    }
+#define PS_ISSUE(tile_, ty_, buf_)                                                                   \
+    do {                                                                                             \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                \
+            __builtin_amdgcn_global_load_lds((gptr)((const unsigned char*)(src[ty_][k] + (unsigned long long)(tile_) * 1024) + lane16), \
+                                             (lptr)(smem_raw + (buf_) * (STAGE * 2) + ldsoff[ty_][k]), 16, 0, 0); \
+        if ((ty_) == 3)                                                                              \
+            __builtin_amdgcn_global_load_lds((gptr)((const unsigned char*)(src8 + (unsigned long long)(tile_) * 1024) + lane16), \
+                                             (lptr)(smem_raw + (buf_) * (STAGE * 2) + ldsoff8), 16, 0, 0); \
+    } while (0)
+    const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
+    f32x16 acc[4][2], acc8;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc8[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    h8 a0[2][2], a1[2][2];          // [ks][row block of the current A-sub]: hi, lo planes
+    h8 b0[2][2], b1[2][2];          // [B-sub][ks]: hi, lo planes
+    h8 e0[2], e1[2];                // block 8 [ks]: hi, lo planes
+#define PS_READ_A(buf_, s_)                                                                          \
+    do {                                                                                             \
+        const _Float16* Ac = smem + (buf_) * STAGE + (wr * 128 + (s_) * 64 + l31) * HLD;             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) {                                       \
+                a0[ks][ib] = *(const h8*)(Ac + ib * 32 * HLD + swz[ks]);                             \
+                a1[ks][ib] = *(const h8*)(Ac + APL + ib * 32 * HLD + swz[ks]);                       \
+            }                                                                                        \
+    } while (0)
+#define PS_READ_E(buf_)                                                                              \
+    do {                                                                                             \
+        const _Float16* Ec = smem + (buf_) * STAGE + (256 + l31) * HLD;                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            e0[ks] = *(const h8*)(Ec + swz[ks]);                                                     \
+            e1[ks] = *(const h8*)(Ec + APL + swz[ks]);                                               \
+        }                                                                                            \
+    } while (0)
+#define PS_READ_B(buf_, s_)                                                                          \
+    do {                                                                                             \
+        const _Float16* Bc = smem + (buf_) * STAGE + 2 * APL + (wc * 64 + (s_) * 32 + l31) * HLD;    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            b0[s_][ks] = *(const h8*)(Bc + swz[ks]);                                                 \
+            b1[s_][ks] = *(const h8*)(Bc + BPL + swz[ks]);                                           \
+        }                                                                                            \
+    } while (0)
+#define PS_QUAD(sa_, sb_)                                                                            \
+    do {                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks][ib], b0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b1[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[2 * (sa_) + ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b0[sb_][ks], acc[2 * (sa_) + ib][sb_], 0, 0, 0); \
+        }                                                                                            \
+    } while (0)
+#define PS_EXTRA(sb_)                                                                                \
+    do {                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1[ks], b0[sb_][ks], acc8, 0, 0, 0);       \
+            acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0[ks], b1[sb_][ks], acc8, 0, 0, 0);       \
+            acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0[ks], b0[sb_][ks], acc8, 0, 0, 0);       \
+        }                                                                                            \
+    } while (0)
+#define PS_PHASE(P, BUF)                                                                             \
+    do {                                                                                             \
+        if (P == 0) { PS_READ_A(BUF, 0); PS_READ_B(BUF, 0); }                                        \
+        if (P == 1) PS_READ_B(BUF, 1);                                                               \
+        if (P == 2) PS_READ_A(BUF, 1);                                                               \
+        if (P == 3) PS_READ_E(BUF);                                                                  \
+        PP_FENCE();                                                                                  \
+        {                                                                                            \
+            constexpr int dq = (P) + LEAD;                     /* quarter 4 t + dq */                \
+            const int tq = t + (dq >> 2);                                                            \
+            if (tq < nk) {                                                                           \
+                PS_ISSUE(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                       \
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  /* the 4 youngest quarters: 2+2+2+3 */ \
+            } else {                                                                                 \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* tail: nothing younger to count */ \
+            }                                                                                        \
+        }                                                                                            \
+        PP_BAR();                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        if (P == 0) PS_QUAD(0, 0);                                                                   \
+        if (P == 1) PS_QUAD(0, 1);                                                                   \
+        if (P == 2) PS_QUAD(1, 1);                                                                   \
+        if (P == 3) { PS_QUAD(1, 0); if (wr == 0) PS_EXTRA(0); else PS_EXTRA(1); }                   \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+        PP_BAR();                                                                                    \
+    } while (0)
+    // prologue: quarters 0 .. 5 (k-tile 0 and types 0, 1 of k-tile 1) = 13 instructions; quarters 0, 1 landed once
+    // only the 4 youngest (2 + 3 + 2 + 2 = 9) are outstanding
+#pragma unroll
+    for (int q = 0; q < LEAD; ++q)
+        if ((q >> 2) < nk) PS_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
+    if (4 * nk >= LEAD) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();   // the second wave row runs one barrier behind the first
+    for (int t = 0; t < nk; t += 2) {
+        PS_PHASE(0, 0); PS_PHASE(1, 0); PS_PHASE(2, 0); PS_PHASE(3, 0);
+        ++t;
+        PS_PHASE(0, 1); PS_PHASE(1, 1); PS_PHASE(2, 1); PS_PHASE(3, 1);
+        --t;
+    }
+    if (wr == 0) PP_BAR();   // ... and the first row waits for it at the end
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + (wc * 2 + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wr * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row >= row_lo && row < row_hi && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    {
+        const int col = n0 + (wc * 2 + wr) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 256 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (row >= row_lo && row < row_hi && col < N) C[(size_t)row * N + col] = acc8[r];
+        }
+    }
+    if (tid == 0 && clk) {
+        clk[2 * blockIdx.x] = __builtin_readcyclecounter() - t0;
+        clk[2 * blockIdx.x + 1] = wall_clock64() - w0;
+    }
+}
+
+template <int GM>
+static void run_ps(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
+                   unsigned long long* clk) {
+    const size_t lds = (size_t)2 * 2 * (288 + 256) * HLD * 2;
+    hipFuncSetAttribute((const void*)ps_kernel<GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (M / 265) * ((N + 255) / 256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i)
+        hipLaunchKernelGGL((ps_kernel<GM>), dim3(tiles), dim3(512), lds, 0, A, (long long)M * K, W, (long long)N * K, C, M, N, K, clk);
+    const int reps = 30;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL((ps_kernel<GM>), dim3(tiles), dim3(512), lds, 0, A, (long long)M * K, W, (long long)N * K, C, M, N, K, clk);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) printf("  launch error: %s\n", hipGetErrorString(err));
+    std::vector<unsigned long long> h(2 * tiles);
+    hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, wall = 0;
+    for (int i = 0; i < tiles; ++i) { cyc += h[2 * i]; wall += h[2 * i + 1]; }
+    const double us = ms * 1e3 / reps;
+    printf("%-26s GM%-2d 288x256 8w per-sample M=%d N=%d K=%d: %8.1f us  %6.1f TF-eq  clock %.2f GHz  block life %.0f cyc  (%d tiles = %.2f rounds)\n",
+           name, GM, M, N, K, us, 2.0 * M * N * K / us / 1e6, cyc / wall * 0.1, cyc / tiles, tiles, tiles / 256.0);
+    fflush(stdout);
+}
+
 template <int NS, int GM>
 static void run_sp(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
                    unsigned long long* clk) {
@@ -990,6 +1230,21 @@ int main() {
     QCASE(16384, 3072, 1024)
     QCASE(16384, 1024, 4096)
     QCASE(16960, 1024, 1024)
+    }
+    if (getenv("PROBE_PS")) {
+#define SCASE(MM, N, K)                                                                             \
+    hipMemset(C, 0xff, (size_t)MM * N * 4); hipMemset(C2, 0xff, (size_t)MM * N * 4);                \
+    run<128, 128, 16, 2, 8>("packed 2-stage occ2", A, W, C, MM, N, K, clk);                         \
+    run_ps<4>("per-sample ping-pong", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);               \
+    run_ps<8>("per-sample ping-pong", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);               \
+    run_ps<2>("per-sample ping-pong", A, W, C2, MM, N, K, clk); differ(C, C2, MM, N);
+    SCASE(16960, 1024, 1024)
+    SCASE(16960, 3072, 1024)
+    SCASE(16960, 4096, 1024)
+    SCASE(16960, 1024, 4096)
+    SCASE(2 * 265, 1024, 1024)
+    SCASE(3 * 265, 256, 64)
+    return 0;
     }
     if (!getenv("PROBE_NO_PP")) {
     PCASE(16384, 1024, 1024)
