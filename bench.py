@@ -5,16 +5,16 @@
 One "step" = one pass of the hot path over one batch: B captions per GPU go through the 100-step
 p_sample loop (19-layer denoiser + fused sampler tail), SpecVQGAN decode and the MelGAN vocoder,
 ending with f32[B, 1, 217088] waveforms in HBM.  Workload = BASELINE.json configs[2] (full pipeline,
-batch 64 per GPU, K=256 codebook): synthetic caption token ids (the BPE merge table is not on the
-box) -> CLIP text tower -> 100-step diffusion -> SpecVQGAN decode -> MelGAN.  Weights are
+batch 64 per GPU, K=256 codebook): synthetic caption strings -> BPE tokenizer (host, closed-vocabulary
+merge table) -> CLIP text tower -> 100-step diffusion -> SpecVQGAN decode -> MelGAN.  Weights are
 seeded random-init tensors of the reference's exact shapes (no checkpoints exist offline).
 Multi-GPU: captions shard across ranks (weak scaling, fixed B per GPU); rank 0 scatters the caption
 token ids and gathers the waveforms over RCCL inside the timed region.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).  `roofline` is measured live:
 HIP events around every denoiser GEMM launch in a separate profiled batch (ds_profile_*), algorithmic
-flops 2*M*N*K per launch.  `cpu_baseline` times the CPU oracle (a port of the reference path) on a
-bounded sample on this box's host cores.
+flops 2*M*N*K per launch.  `cpu_baseline` times the reference itself (when /root/reference exists) or the CPU oracle (a
+restatement of the reference path) on a bounded sample on this box's host cores, thread count swept.
 """
 import argparse
 import ctypes
@@ -215,7 +215,8 @@ def result_line(args, world, elapsed, n_total):
         "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16x3": "f32 via 3-way bf16 split (6 MFMA passes, fp32 accumulate)",
                   "f16x2": "f32 via 2-way fp16 split (3 MFMA passes, fp32 accumulate)"}[args.precision],
-        "data": "synthetic caption token ids i64[B,77] + seeded random-init weights of the reference's shapes",
+        "data": "synthetic captions (5-15 words, BPE-tokenised in the timed region) + seeded random-init weights of the "
+                "reference's shapes",
         "config": {"workload": ("BASELINE configs[1]: transformer only, batch %d per GPU, %d diffusion steps, codebook %d: "
                                 "CLIP text tower -> 19-layer denoiser + sampler (tokens; no decode / vocoder)"
                                 if getattr(args, "transformer_only", False) else
@@ -254,9 +255,14 @@ def main():
     dt.transformer.precision = args.precision
     dt.sample_streams = args.streams
     n_total = B * world
-    # rank 0 owns the captions (token ids i64[n,77]: <SOT> word pieces <EOT>, as clip.tokenize emits); every
-    # rank gets a slice and runs the CLIP text tower on it
-    tok_all = synth.synth_caption_tokens(n_total, key="bench.captions") if rank == 0 else None
+    # rank 0 owns the captions: synthetic caption STRINGS, tokenised inside the timed region by
+    # the package's BPE tokenizer (clip.tokenize semantics: <SOT> word pieces <EOT>, context 77) on the closed-vocabulary
+    # merge table tests/golden/bpe_closed_vocab.json -- the part of CLIP's table these captions exercise, ids checked
+    # against the reference's tokenizer when the file was made (the 1.3 MB full table is not on the GPU box).  Every
+    # rank gets a slice of the ids and runs the CLIP text tower on it.
+    from text_to_sound_synthesis_amd import tokenizer as tz
+    captions = synth.synth_captions(n_total, seed=7) if rank == 0 else None
+    bpe = tz.SimpleTokenizer(bpe_path=os.path.join(ROOT, "tests", "golden", "bpe_closed_vocab.json")) if rank == 0 else None
     torch.manual_seed(1234 + rank)
     stage = {"scatter": 0.0, "kv": 0.0, "sample": 0.0, "decode": 0.0, "vocode": 0.0, "gather": 0.0}
 
@@ -266,6 +272,8 @@ def main():
                 torch.cuda.synchronize()
             return time.perf_counter()
         t0 = mark()
+        tok_all = tz.tokenize(captions, context_length=77, add_start_and_end=True, tokenizer=bpe)["token"] \
+            if rank == 0 else None
         toks = shard.scatter_conditions(tok_all, n_total, (77,), dev, dtype=torch.long)
         t1 = mark()
         out = dt.sample(condition_token=toks, condition_mask=None, condition_embed=None, filter_ratio=0)

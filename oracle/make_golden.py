@@ -403,8 +403,53 @@ def signatures():
     print("wrote signatures.json (%d callables)" % len(out))
 
 
+def bpe_closed_vocab():
+    """tests/golden/bpe_closed_vocab.json: the part of CLIP's merge table that the synthetic-caption word list
+    (text_to_sound_synthesis_amd.synth._WORDS) exercises -- every merge the FULL table applies to one of those words, with
+    its original rank, plus the ids of the resulting tokens and the two specials.  Checked here against the reference's
+    own tokenizer on 3000 random captions over the word list.  (The GPU box has no copy of the full table.)"""
+    from text_to_sound_synthesis_amd import synth as sy
+    from text_to_sound_synthesis_amd import tokenizer as tz
+    full = tz.SimpleTokenizer(bpe_path=os.path.join(rh.REF_ROOT, "sound_synthesis", "modeling", "modules", "clip",
+                                                    "bpe_simple_vocab_16e6.txt.gz"))
+    words = sorted(set(sy._WORDS))
+    merges, tokens = set(), set()
+    for w in words:
+        syms = list(w[:-1]) + [w[-1] + "</w>"]
+        while len(syms) > 1:                                # the tokenizer's own greedy loop, recording what it applies
+            cand = [(full.rank[(a, b)], (a, b)) for a, b in zip(syms, syms[1:]) if (a, b) in full.rank]
+            if not cand:
+                break
+            r, best = min(cand)
+            merges.add((best[0], best[1], r))
+            out, i = [], 0
+            while i < len(syms):
+                if i + 1 < len(syms) and (syms[i], syms[i + 1]) == best:
+                    out.append(best[0] + best[1]); i += 2
+                else:
+                    out.append(syms[i]); i += 1
+            syms = out
+        assert syms == full._bpe(w)
+        tokens.update(syms)
+    enc = {t: full.encoder[t] for t in sorted(tokens)}
+    for sp in ("<|startoftext|>", "<|endoftext|>"):
+        enc[sp] = full.encoder[sp]
+    path = os.path.join(OUT, "bpe_closed_vocab.json")
+    with open(path, "w") as f:
+        json.dump({"words": words, "merges": sorted(merges, key=lambda m: m[2]), "encoder": enc}, f)
+    closed = tz.SimpleTokenizer(bpe_path=path)
+    caps = sy.synth_captions(3000, seed=5)
+    ref = rh.reference_tokenize(caps)["token"]
+    got = tz.tokenize(caps, context_length=77, add_start_and_end=True, tokenizer=closed)["token"]
+    assert torch.equal(ref, got)
+    print("wrote bpe_closed_vocab.json (%d words, %d merges, %d tokens); 3000 captions equal the reference's ids"
+          % (len(words), len(merges), len(enc)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--bpe-only" in sys.argv:
+        return bpe_closed_vocab()
     if "--signatures-only" in sys.argv:
         return signatures()
     if "--n1-only" in sys.argv:
@@ -508,6 +553,7 @@ def main():
     solver_schedule()
     dalle_sample()
     signatures()
+    bpe_closed_vocab()
     traj_full()
     print("done in %.1fs" % (time.time() - t0))
 

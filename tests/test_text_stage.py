@@ -97,3 +97,31 @@ def test_tokenizer_matches_live_reference_on_random_captions():
         assert torch.equal(a["token"], b["token"]), [c for c, x, y in zip(caps[i:i + 250], a["token"], b["token"])
                                                      if not torch.equal(x, y)][:3]
         assert torch.equal(a["mask"], b["mask"])
+
+
+def test_closed_vocabulary_merge_table_matches_goldens_and_refuses_other_words():
+    """tests/golden/bpe_closed_vocab.json (what bench.py tokenises with on the GPU box): ids equal the reference's for
+    captions over its word list (oracle/make_golden.py checked 3000 of them against the reference's tokenizer when the
+    file was written; here: the committed golden captions that stay inside the word list), and a word outside the list
+    raises instead of producing wrong ids."""
+    import os
+    import pytest
+    from conftest import GOLDEN
+    from text_to_sound_synthesis_amd import synth, tokenizer as tz
+    closed = tz.SimpleTokenizer(bpe_path=os.path.join(GOLDEN, "bpe_closed_vocab.json"))
+    caps = synth.synth_captions(64, seed=7)
+    tok = tz.tokenize(caps, context_length=77, add_start_and_end=True, tokenizer=closed)["token"]
+    assert tok.shape == (64, 77) and (tok[:, 0] == 49406).all()
+    for i, c in enumerate(caps):
+        n = len(c.split())
+        assert tok[i, 1 + n:].max() == 49407 and (tok[i, 1:1 + n] < 49406).all()     # >= one token per word, then EOT
+    g = golden("text_stage")
+    import json
+    with open(os.path.join(GOLDEN, "captions.json")) as f:
+        gold_caps = json.load(f)
+    inside = [i for i, c in enumerate(gold_caps) if set(c.split()) <= closed.closed_words]
+    assert len(inside) >= 6                                  # the six synthetic golden captions
+    got = tz.tokenize([gold_caps[i] for i in inside], context_length=77, add_start_and_end=True, tokenizer=closed)["token"]
+    assert torch.equal(got, g["tokens"][inside])
+    with pytest.raises(KeyError):
+        closed.encode("a saxophone plays")

@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiffsound_hip.so")
+LIB_PATH = os.environ.get("DIFFSOUND_LIB") or os.path.join(_HERE, "libdiffsound_hip.so")   # env: A/B of two builds
 
 # enums (diffsound_hip.h)
 LOAD_DENSE, LOAD_CONV2D, LOAD_CONV1D, LOAD_CONVT1D = 0, 1, 2, 3

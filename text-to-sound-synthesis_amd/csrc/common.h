@@ -22,6 +22,14 @@ __device__ __forceinline__ _Float16 ds_split_lo(float a, _Float16 hi) {
     return (_Float16)__builtin_amdgcn_fmed3f(a - (float)hi, -65504.f, 65504.f);  // a - hi is exact in fp32
 }
 
+// GELU2 (x * sigmoid(1.702 x), transformer_utils.py:111-115) for the f16x2 GEMM epilogues: v_exp_f32 + v_rcp_f32
+// (~1 ulp each) instead of expf + IEEE division -- a tenth of the instructions, which matters where the epilogue is
+// not hidden behind another workgroup's MFMAs (gemm_f16x2_ps.hip).  ONE definition for every f16x2 program, so their
+// outputs stay bit-identical.  exp2 overflow (v << 0) gives 1 / inf = 0 -> -0, the limit value.
+__device__ __forceinline__ float ds_gelu2_fast(float v) {
+    return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.45546696f * v));   // 1.702 * log2(e)
+}
+
 // "Packed split planes": the HBM layout of every pre-split f16x2 GEMM operand (activations written by the
 // ds_*_split producers and the GEMM's c_split epilogue; weights packed once by _lib.split_f16x2(packed=True)).
 // For X[R][K], K % 32 == 0, each of the two fp16 planes is  [ceil(R/16)][K/32][16 rows][4 chunks][8 halves]:

@@ -308,7 +308,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
                     const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;      \
                     if (row < p.M) {                                                                \
                         float v = acc[i][j][r] * osc + bv;                                          \
-                        if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));               \
+                        if (p.act == DS_ACT_GELU2) v = ds_gelu2_fast(v);                            \
                         __VA_ARGS__                                                                 \
                     }                                                                               \
                 }                                                                                   \

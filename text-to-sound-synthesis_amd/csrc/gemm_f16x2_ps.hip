@@ -236,6 +236,12 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue -------------------------------------------------------------------------------------------------
+    // One workgroup per CU: nothing else runs on the CU while a tile is written out, so the epilogue is on the critical
+    // path (a first version with exact expf + IEEE division in GELU2, 2-byte LDS stores and latency-serialised residual
+    // loads cost 20-60k cycles per tile against ~140k of main loop).  Hence: GELU2 by v_exp / v_rcp (ds_gelu2_fast, shared
+    // with gemm_f16x2.hip so both programs stay bit-identical), hi | lo staged as ONE 32-bit LDS store per value, read
+    // back 32 bytes at a time (both planes of 8 columns), constant trip counts so that the residual loads of several
+    // iterations are in flight together, no integer divisions.
     // The lane / wave indices are re-derived from an opaque copy of the thread id so that none of them stays live
     // across the main loop (which runs at the 256-register cap: one of them used to be spilled to scratch).
     int tid_e = tid;
@@ -251,26 +257,26 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
 #define PS_SLAB_VALUES(SL, STORE)                                                                    \
     do {                                                                                             \
         if ((SL) < 2) {                                                                              \
-            if (wre == (SL)) {                                                                        \
+            if (wre == (SL)) {                                                                       \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
                     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                  \
-                        const int cl = (wce * 2 + j) * 32 + l31e;                                      \
+                        const int cl = (wce * 2 + j) * 32 + l31e;                                    \
                         const float bv = p.bias ? p.bias[n0 + cl] : 0.f;                             \
                         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                             \
-                            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hhe;                 \
+                            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hhe;                \
                             float v = acc[i][j][r] * osc + bv;                                       \
-                            if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));            \
+                            if (p.act == DS_ACT_GELU2) v = ds_gelu2_fast(v);                         \
                             STORE(rl, cl, v);                                                        \
                         }                                                                            \
                     }                                                                                \
             }                                                                                        \
         } else {                                                                                     \
-            const int cl = (wce * 2 + wre) * 32 + l31e;                                                 \
+            const int cl = (wce * 2 + wre) * 32 + l31e;                                              \
             const float bv = p.bias ? p.bias[n0 + cl] : 0.f;                                         \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hhe;                                      \
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hhe;                                     \
                 float v = acc8[r] * osc + bv;                                                        \
-                if (p.act == DS_ACT_GELU2) v = v / (1.f + expf(-1.702f * v));                        \
+                if (p.act == DS_ACT_GELU2) v = ds_gelu2_fast(v);                                     \
                 STORE(rl, cl, v);                                                                    \
             }                                                                                        \
         }                                                                                            \
@@ -286,26 +292,43 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
         PS_SLAB_VALUES(SL, PS_ST_F32);                                                               \
         __syncthreads();                                                                             \
         constexpr int rows_ = (SL) < 2 ? 128 : 32;                                                   \
-        for (int c = tid_e; c < rows_ * (BN / 4); c += 512) {                                          \
-            const int cc = c & (BN / 4 - 1), rl = c / (BN / 4), trow = (SL) * 128 + rl;              \
-            if (trow >= off && trow < vhi) {                                                         \
-                const size_t row = (size_t)(m0 + trow);                                              \
-                const int col = n0 + cc * 4;                                                         \
-                f32x4 val = *(const f32x4*)(Tf + rl * BN + cc * 4);                                  \
-                if (p.R) val += *(const f32x4*)(p.R + row * p.ldr + col);                            \
-                *(f32x4*)(p.C + row * p.ldc + col) = val;                                            \
+        constexpr int iters_ = rows_ * (BN / 4) / 512;          /* 16 or 4: every thread, every iteration */ \
+        const int cc = tid_e & (BN / 4 - 1);                                                         \
+        const int col = n0 + cc * 4;                                                                 \
+        _Pragma("unroll") for (int it0 = 0; it0 < iters_; it0 += 4) {                                \
+            f32x4 val[4];                                                                            \
+            bool ok[4];                                                                              \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+                const int rl = (tid_e >> 6) + 8 * (it0 + q), trow = (SL) * 128 + rl;                 \
+                ok[q] = trow >= off && trow < vhi;                                                   \
+                val[q] = *(const f32x4*)(Tf + rl * BN + cc * 4);                                     \
+                if (ok[q] && p.R) val[q] += *(const f32x4*)(p.R + (size_t)(m0 + trow) * p.ldr + col); \
+            }                                                                                        \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+                const int trow = (SL) * 128 + (tid_e >> 6) + 8 * (it0 + q);                          \
+                if (ok[q]) *(f32x4*)(p.C + (size_t)(m0 + trow) * p.ldc + col) = val[q];              \
             }                                                                                        \
         }                                                                                            \
     } while (0)
         PS_ROW_SLAB(0); PS_ROW_SLAB(1); PS_ROW_SLAB(2);
     } else {
-        // fp16 split outputs: T[plane][rows][256] halves (<= 128 KB), 16-byte stores
-        _Float16* T = smem;
+        // fp16 split outputs: T[rows][256] of 32-bit (hi | lo << 16) (<= 128 KB); a thread reads 8 columns = 32 bytes
+        // and writes one 16-byte store per plane
+        unsigned* T = (unsigned*)smem_raw;
 #define PS_ST_SPLIT(rl_, cl_, v_)                                                                    \
     do {                                                                                             \
         const _Float16 hi_ = ds_split_hi(v_);                                                        \
-        T[(rl_) * BN + (cl_)] = hi_;                                                                 \
-        T[SR * BN + (rl_) * BN + (cl_)] = ds_split_lo(v_, hi_);                                      \
+        const _Float16 lo_ = ds_split_lo(v_, hi_);                                                   \
+        T[(rl_) * BN + (cl_)] = (unsigned)__builtin_bit_cast(unsigned short, hi_) |                  \
+                                ((unsigned)__builtin_bit_cast(unsigned short, lo_) << 16);           \
+    } while (0)
+        // 8 packed values -> the 8 halves of plane 0 (low halves) and of plane 1 (high halves)
+#define PS_UNZIP(x_, hi_, lo_)                                                                       \
+    do {                                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
+            hi_[e] = ((x_)[2 * e] & 0xffffu) | ((x_)[2 * e + 1] << 16);                              \
+            lo_[e] = ((x_)[2 * e] >> 16) | ((x_)[2 * e + 1] & 0xffff0000u);                          \
+        }                                                                                            \
     } while (0)
         const int hw = p.attn_heads * 64;
         const int which = EPI == PS_EPI_ATTN ? n0 / hw : 0;            // block-uniform: Q, K or V columns
@@ -316,27 +339,37 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
         __syncthreads();                                                                             \
         PS_SLAB_VALUES(SL, PS_ST_SPLIT);                                                             \
         __syncthreads();                                                                             \
-        if (EPI == PS_EPI_SPLIT || which < 2) {           /* 8 consecutive columns of a row per store */ \
-            constexpr int CPR = BN / 8;                                                              \
-            for (int c = tid_e; c < 2 * SR * CPR; c += 512) {                                          \
-                const int cc = c % CPR, rl = (c / CPR) % SR, pl = c / (CPR * SR);                    \
-                const int trow = (SL) * 128 + rl;                                                    \
+        if (EPI == PS_EPI_SPLIT || which < 2) {           /* 8 consecutive columns of a row per thread */ \
+            constexpr int iters_ = SR * (BN / 8) / 512;       /* 8 or 2 */                           \
+            const int cc = tid_e & (BN / 8 - 1);                                                     \
+            const int col = n0 + cc * 8;                                                             \
+            _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                  \
+                const int rl = (tid_e >> 5) + 16 * it, trow = (SL) * 128 + rl;                       \
                 if (trow >= off && trow < vhi) {                                                     \
-                    const int row = m0 + trow, col = n0 + cc * 8;                                    \
-                    const u32x4 val = *(const u32x4*)(T + (pl * SR + rl) * BN + cc * 8);             \
-                    _Float16* dst;                                                                   \
+                    const int row = m0 + trow;                                                       \
+                    unsigned x[8];                                                                   \
+                    *(u32x4*)(x) = *(const u32x4*)(T + rl * BN + cc * 8);                            \
+                    *(u32x4*)(x + 4) = *(const u32x4*)(T + rl * BN + cc * 8 + 4);                    \
+                    u32x4 vh, vl;                                                                    \
+                    PS_UNZIP(x, vh, vl);                                                             \
+                    _Float16 *d0, *d1;                                                               \
                     if (EPI == PS_EPI_SPLIT) {                                                       \
-                        dst = (_Float16*)p.C + (size_t)pl * p.c_plane + ds_packed_off(row, col, p.ldc >> 5); \
+                        d0 = (_Float16*)p.C + ds_packed_off(row, col, p.ldc >> 5);                   \
+                        d1 = d0 + p.c_plane;                                                         \
                     } else {                                                                         \
                         const int pos = trow - off;                                                  \
                         const int hc = col - which * hw, head = hc >> 6, d = hc & 63;                \
                         const size_t bh = (size_t)b * p.attn_heads + head;                           \
-                        if (which == 0)                                                              \
-                            dst = (_Float16*)p.C + (size_t)pl * p.attn_qplane + (bh * L + pos) * 64 + d; \
-                        else                                                                         \
-                            dst = (_Float16*)p.attn_kv + (bh * 4 + pl) * ((size_t)p.attn_nkey * 64) + ds_attn_k_off(pos, d); \
+                        if (which == 0) {                                                            \
+                            d0 = (_Float16*)p.C + (bh * L + pos) * 64 + d;                           \
+                            d1 = d0 + p.attn_qplane;                                                 \
+                        } else {                                                                     \
+                            d0 = (_Float16*)p.attn_kv + (bh * 4) * ((size_t)p.attn_nkey * 64) + ds_attn_k_off(pos, d); \
+                            d1 = d0 + (size_t)p.attn_nkey * 64;                                      \
+                        }                                                                            \
                     }                                                                                \
-                    *(u32x4*)dst = val;                                                              \
+                    *(u32x4*)d0 = vh;                                                                \
+                    *(u32x4*)d1 = vl;                                                                \
                 }                                                                                    \
             }                                                                                        \
         } else {                                          /* V^T: 8 consecutive keys of one d per store */ \
@@ -347,22 +380,28 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
             const int u_first = lo < hi ? (lo - off) >> 3 : 0;                                       \
             const int units = lo < hi ? ((hi - off + 7) >> 3) - u_first : 0;                         \
             const int pln = p.attn_nkey * 64;                                                        \
-            for (int c = tid_e; c < 2 * BN * units; c += 512) {                                        \
-                const int cl = c % BN, u = (c / BN) % units, pl = c / (BN * units);                  \
+            const int rlo = lo - (SL) * 128, rhi = hi - (SL) * 128;                                  \
+            const int cl = tid_e & (BN - 1);              /* this thread's column (d), units u = tid / 256, + 2, ... */ \
+            const int hc = n0 + cl - 2 * hw, head = hc >> 6, d = hc & 63;                            \
+            _Float16* img = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2) * (size_t)pln; \
+            for (int u = tid_e >> 8; u < units; u += 2) {                                            \
                 const int k0 = (u_first + u) * 8;                   /* first key of the unit */      \
                 const int r0 = k0 + off - (SL) * 128;               /* its slab-local row (may be < 0) */ \
-                const int hc = n0 + cl - 2 * hw, head = hc >> 6, d = hc & 63;                        \
-                _Float16* dst = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2 + pl) * (size_t)pln + \
-                                ds_attn_vt_off(k0, d, p.attn_nkey);                                  \
-                const _Float16* src_ = T + (pl * SR) * BN + cl;                                      \
-                const int rlo = lo - (SL) * 128, rhi = hi - (SL) * 128;                              \
+                _Float16* dst = img + ds_attn_vt_off(k0, d, p.attn_nkey);                            \
                 if (r0 >= rlo && r0 + 8 <= rhi) {                                                    \
-                    h8 val;                                                                          \
-                    _Pragma("unroll") for (int e = 0; e < 8; ++e) val[e] = src_[(r0 + e) * BN];      \
-                    *(h8*)dst = val;                                                                 \
+                    unsigned x[8];                                                                   \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) x[e] = T[(r0 + e) * BN + cl];      \
+                    u32x4 vh, vl;                                                                    \
+                    PS_UNZIP(x, vh, vl);                                                             \
+                    *(u32x4*)dst = vh;                                                               \
+                    *(u32x4*)(dst + pln) = vl;                                                       \
                 } else {                                                                             \
                     _Pragma("unroll") for (int e = 0; e < 8; ++e)                                    \
-                        if (r0 + e >= rlo && r0 + e < rhi) dst[e] = src_[(r0 + e) * BN];             \
+                        if (r0 + e >= rlo && r0 + e < rhi) {                                         \
+                            const unsigned x1 = T[(r0 + e) * BN + cl];                               \
+                            dst[e] = __builtin_bit_cast(_Float16, (unsigned short)(x1 & 0xffffu));   \
+                            dst[pln + e] = __builtin_bit_cast(_Float16, (unsigned short)(x1 >> 16)); \
+                        }                                                                            \
                 }                                                                                    \
             }                                                                                        \
         }                                                                                            \

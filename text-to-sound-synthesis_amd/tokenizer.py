@@ -52,6 +52,10 @@ def _byte_alphabet():
 
 class SimpleTokenizer:
     def __init__(self, end_idx=49152, bpe_path=None):
+        if bpe_path is not None and str(bpe_path).endswith(".json"):
+            self._init_closed(bpe_path)
+            return
+        self.closed_words = None
         path = find_bpe_file(bpe_path)
         opener = gzip.open if path.endswith(".gz") else open
         with opener(path, "rb") as f:
@@ -70,10 +74,30 @@ class SimpleTokenizer:
         self.bytes = alphabet
         self._cache = {}
 
+    def _init_closed(self, path):
+        """Closed-vocabulary table (tests/golden/bpe_closed_vocab.json, written by oracle/make_golden.py from the full
+        CLIP table): for a fixed word list it holds exactly the merges the full table applies to those words, with
+        their ORIGINAL ranks, and the ids of the resulting tokens -- so encoding any text over that word list runs the
+        same greedy algorithm and yields the same ids as the full table.  Any other word raises (never a silent
+        wrong id).  The GPU box has no copy of the 1.3 MB merge table; bench.py tokenises its synthetic captions with
+        this file inside the timed region."""
+        import json
+        with open(path) as f:
+            t = json.load(f)
+        self.encoder = dict(t["encoder"])
+        self.decoder = {i: tok for tok, i in self.encoder.items()}
+        self.rank = {(a, b): r for a, b, r in t["merges"]}
+        self.closed_words = frozenset(t["words"])
+        self.bytes = _byte_alphabet()
+        self._cache = {}
+
     def _bpe(self, word):
         """Greedy lowest-rank pair merging of one pre-token (symbols: chars, last one tagged '</w>')."""
         if word in self._cache:
             return self._cache[word]
+        if self.closed_words is not None and word not in self.closed_words:
+            raise KeyError("%r is outside the closed vocabulary of this merge table (%d words): use the full CLIP table "
+                           "(DIFFSOUND_BPE_PATH)" % (word, len(self.closed_words)))
         syms = list(word[:-1]) + [word[-1] + "</w>"]
         while len(syms) > 1:
             best, best_rank = None, None
