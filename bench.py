@@ -164,13 +164,19 @@ def pmc_traffic(kernel):
                       % (os.path.basename(path), meta.get("source_sha16", "(unrecorded)"), now))
     want = kernel.split(" (")[0].replace(" ", "")
     want = want[:-1] if want.endswith(">") else want     # "<128,128" also matches "<128,128,2>"
-    for name, r in table.items():
-        key = name.replace(" ", "")
-        if key.startswith(want) and r.get("hbm_read_MB_per_launch") is not None:
-            rd, wr = r["hbm_read_MB_per_launch"], r["hbm_write_MB_per_launch"] or 0.0
-            return round((rd + wr) * 1e6), ("bytes per launch = %.0f MB read (2 x FETCH_SIZE) + %.0f MB written (WRITE_SIZE), "
-                                            "mean of %d dispatches, L2 hit rate %.2f; source profiles/%s (kernel sources %s)"
-                                            % (rd, wr, r["dispatches"], r["l2_hit_rate"], os.path.basename(path), now))
+    # every instantiation of the program (e.g. the three epilogue families of ds_gemm_f16x2_ps_kernel), weighted by launches
+    hit = [r for name, r in table.items() if name != "_meta" and name.replace(" ", "").startswith(want)
+           and r.get("hbm_read_MB_per_launch") is not None]
+    if hit:
+        n = sum(r["dispatches"] for r in hit)
+        rd = sum(r["hbm_read_MB_per_launch"] * r["dispatches"] for r in hit) / n
+        wr = sum((r["hbm_write_MB_per_launch"] or 0.0) * r["dispatches"] for r in hit) / n
+        l2 = sum(r["l2_hit_rate"] * r["dispatches"] for r in hit) / n
+        return round((rd + wr) * 1e6), ("bytes per launch = %.0f MB read (2 x FETCH_SIZE; Infinity-Cache hits included) + %.0f MB "
+                                        "written (WRITE_SIZE), mean of %d dispatches of %d kernel symbols, L2 hit rate %.2f; "
+                                        "algorithmic operand + residual + result bytes of the same launches average 276 MB "
+                                        "(DESIGN.md section 3); source profiles/%s (kernel sources %s)"
+                                        % (rd, wr, n, len(hit), l2, os.path.basename(path), now))
     return None, "kernel not in %s" % os.path.basename(path)
 
 

@@ -288,26 +288,33 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
 #define PS_ST_F32(rl_, cl_, v_) Tf[(rl_) * BN + (cl_)] = (v_)
 #define PS_ROW_SLAB(SL)                                                                              \
     do {                                                                                             \
+        constexpr int rows_ = (SL) < 2 ? 128 : 32;                                                   \
+        constexpr int iters_ = rows_ * (BN / 4) / 512;          /* 16 or 4: every thread, every iteration */ \
+        constexpr int pf_ = iters_ < 8 ? iters_ : 8;            /* iterations whose residual is prefetched */ \
+        const int cc = tid_e & (BN / 4 - 1);                                                         \
+        const int col = n0 + cc * 4;                                                                 \
+        /* part of the slab's residual values is requested BEFORE the staging barriers (32 registers; all 144 */ \
+        /* accumulators are still live in slab 0): their HBM latency runs under the accumulator -> LDS pass */ \
+        f32x4 res[pf_];                                                                              \
+        _Pragma("unroll") for (int it = 0; it < pf_; ++it) {                                         \
+            const int trow = (SL) * 128 + (tid_e >> 6) + 8 * it;                                     \
+            res[it] = f32x4{0.f, 0.f, 0.f, 0.f};                                                     \
+            if (p.R && trow >= off && trow < vhi) res[it] = *(const f32x4*)(p.R + (size_t)(m0 + trow) * p.ldr + col); \
+        }                                                                                            \
         __syncthreads();                    /* the operand stages / the previous slab are free */    \
         PS_SLAB_VALUES(SL, PS_ST_F32);                                                               \
         __syncthreads();                                                                             \
-        constexpr int rows_ = (SL) < 2 ? 128 : 32;                                                   \
-        constexpr int iters_ = rows_ * (BN / 4) / 512;          /* 16 or 4: every thread, every iteration */ \
-        const int cc = tid_e & (BN / 4 - 1);                                                         \
-        const int col = n0 + cc * 4;                                                                 \
-        _Pragma("unroll") for (int it0 = 0; it0 < iters_; it0 += 4) {                                \
-            f32x4 val[4];                                                                            \
-            bool ok[4];                                                                              \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
-                const int rl = (tid_e >> 6) + 8 * (it0 + q), trow = (SL) * 128 + rl;                 \
-                ok[q] = trow >= off && trow < vhi;                                                   \
-                val[q] = *(const f32x4*)(Tf + rl * BN + cc * 4);                                     \
-                if (ok[q] && p.R) val[q] += *(const f32x4*)(p.R + (size_t)(m0 + trow) * p.ldr + col); \
-            }                                                                                        \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
-                const int trow = (SL) * 128 + (tid_e >> 6) + 8 * (it0 + q);                          \
-                if (ok[q]) *(f32x4*)(p.C + (size_t)(m0 + trow) * p.ldc + col) = val[q];              \
-            }                                                                                        \
+        f32x4 res2[iters_ - pf_ > 0 ? iters_ - pf_ : 1];                                             \
+        _Pragma("unroll") for (int it = pf_; it < iters_; ++it) {                                    \
+            const int trow = (SL) * 128 + (tid_e >> 6) + 8 * it;                                     \
+            res2[it - pf_] = f32x4{0.f, 0.f, 0.f, 0.f};                                              \
+            if (p.R && trow >= off && trow < vhi) res2[it - pf_] = *(const f32x4*)(p.R + (size_t)(m0 + trow) * p.ldr + col); \
+        }                                                                                            \
+        _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                      \
+            const int rl = (tid_e >> 6) + 8 * it, trow = (SL) * 128 + rl;                            \
+            if (trow >= off && trow < vhi)                                                           \
+                *(f32x4*)(p.C + (size_t)(m0 + trow) * p.ldc + col) =                                 \
+                    *(const f32x4*)(Tf + rl * BN + cc * 4) + (it < pf_ ? res[it < pf_ ? it : 0] : res2[it >= pf_ ? it - pf_ : 0]); \
         }                                                                                            \
     } while (0)
         PS_ROW_SLAB(0); PS_ROW_SLAB(1); PS_ROW_SLAB(2);
