@@ -118,8 +118,10 @@ def test_adamw_matches_torch(L):
     assert close(p.cpu(), ref.detach(), 2e-6)
 
 
-def test_training_step_gradients_vs_oracle_autograd():
-    """The whole backward of the denoiser on the HIP kernels (modeling/train.py, exact-fp32 first version): loss and
+@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
+def test_training_step_gradients_vs_oracle_autograd(precision):
+    """The whole backward of the denoiser on the HIP kernels (modeling/train.py; linear layers on the exact-fp32 MFMA or
+    on the 3-pass fp16 split GEMM incl. dX and dW, gradients rescaled by an exact power of two into fp16's range): loss and
     EVERY parameter gradient of the 2-layer model against autograd through the oracle (which the CPU suite pins to
     the reference's loss.backward()), then one AdamW update against torch.optim.AdamW."""
     import diffsound_oracle as O
@@ -143,7 +145,7 @@ def test_training_step_gradients_vs_oracle_autograd():
     with torch.enable_grad():
         _, _, loss_ref, _ = O.train_loss(sd, x0, cond, t, pt, u)
         loss_ref.backward()
-    step = TrainStep(dt)
+    step = TrainStep(dt, precision=precision)
     loss, grads = step.loss_and_grads(x0.cuda(), cond.cuda(), t.cuda(), pt.cuda(), u.cuda())
     print("loss %.6f (oracle %.6f, reference %.6f)" % (loss.item(), loss_ref.item(), float(g["loss"])))
     assert abs(loss.item() - float(g["loss"])) < 2e-4 * float(g["loss"])
@@ -165,6 +167,7 @@ def test_training_step_gradients_vs_oracle_autograd():
         err = (got - want).abs().max().item() / want.abs().max().item()
         worst.append((err, name, want.abs().max().item()))
     worst.sort(reverse=True)
+    print("precision %s: worst per-tensor gradient error %.2e" % (precision, worst[0][0]))
     for err, name, mag in worst[:12]:
         print("  grad rel err %.2e  |g|max %.2e  %s" % (err, mag, name))
     assert not missing, missing

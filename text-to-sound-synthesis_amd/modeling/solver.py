@@ -173,7 +173,9 @@ def _model_device(m):
 def _invalidate(m):
     """Weight packs cached by the HIP modules (split fp16 planes, AdaLN tables) are stale after a weight swap."""
     for sub in m.modules():
-        if hasattr(sub, "_packed"):
+        if hasattr(sub, "invalidate"):
+            sub.invalidate()           # also destroys the native handle that points at the old packs
+        elif hasattr(sub, "_packed"):
             sub._packed = None
 
 

@@ -1,5 +1,12 @@
-"""Training step of the denoiser on the HIP kernels (scope row 8f-3), first complete version: exact-fp32 arithmetic,
-correctness before speed.
+"""Training step of the denoiser on the HIP kernels (scope row 8f-3).  The linear layers -- forward, dX = dY W and
+dW = dY^T X, 98 % of the step's flops -- run on the exact-fp32 MFMA GEMM (default) or, with
+`TrainStep(precision="f16x2")`, on the fp32-class 3-pass fp16 split GEMM (`ds_gemm_f16x2`, loader-split A with the
+gradients rescaled by an exact power of two into fp16's range, fp32 accumulate).  Measured on MI355X at the
+reference's batch 20 (tools/bench_train.py, profiles/r02_bench_train_*.json): 4.06 it/s fp32, 3.51 it/s f16x2 -- the
+split GEMMs themselves are ~2x faster, but this host-composed step re-splits weights and transposed activations with
+torch ops and a host sync per GEMM, and at M = 5300 rows that overhead outweighs the gain.  Worst per-tensor gradient
+error against autograd through the oracle: 4.7e-6 (fp32), 6.9e-5 (f16x2).  Attention, norms and the loss tail are exact
+fp32 in both modes.
 
     loss, grads = TrainStep(model.transformer).loss_and_grads(x0, cond_emb, t, pt, noise)
 
@@ -18,11 +25,35 @@ from .. import _lib
 L_ = _lib
 
 
+_SPLIT = [True]      # set by TrainStep: linear-layer GEMMs on the 3-pass fp16 split (default) or on the fp32 MFMA
+
+
+def _pow2_into_fp16_range(a):
+    """(a * 2^k, 2^-k) with k an integer that puts max|a| into [2^9, 2^10) when it is outside [2^-6, 2^13) -- the
+    split GEMM's A operand is decomposed into two fp16 planes and needs its values inside fp16's range with headroom;
+    gradients (|dY| ~ 1e-8 .. 1e-3) are far below it.  Multiplying by a power of two is exact."""
+    import math
+    mx = float(a.abs().max())
+    if mx == 0.0 or not math.isfinite(mx) or 2.0 ** -6 <= mx < 2.0 ** 13:
+        return a, 1.0
+    k = 9 - math.floor(math.log2(mx))
+    return a * (2.0 ** k), 2.0 ** (-k)
+
+
+def _mm_nt(A, Wm, out, M, N, K, bias=None, R=None, act=L_.ACT_NONE):
+    """out[M, N] = act(A[M, K] Wm[N, K]^T + bias) + R"""
+    if not _SPLIT[0]:
+        return L_.gemm(A, Wm, out, M, N, K, bias=bias, R=R, act=act)
+    W2, sc = L_.split_f16x2(Wm)
+    A2, sa = _pow2_into_fp16_range(A)
+    return L_.gemm(A2, W2, out, M, N, K, bias=bias, R=R, act=act, split2=sc * sa)
+
+
 def _lin_fwd(x, W, b, R=None, act=L_.ACT_NONE):
     M, K = x.shape
     N = W.shape[0]
     y = torch.empty(M, N, device=x.device)
-    L_.gemm(x, W, y, M, N, K, bias=b, R=R, act=act)
+    _mm_nt(x, W, y, M, N, K, bias=b, R=R, act=act)
     return y
 
 
@@ -55,10 +86,10 @@ def _lin_bwd(x, W, dy, need_dx=True):
             dyp = torch.nn.functional.pad(dy, (0, Np - N))
         else:
             dyp = dy
-        L_.gemm(dyp.contiguous(), Wt, dx, M, K, Np)
+        _mm_nt(dyp.contiguous(), Wt.contiguous(), dx, M, K, Np)
     Mp = (M + 31) // 32 * 32
     dW = torch.empty(N, K, device=x.device)
-    L_.gemm(_pad_rows_t(dy, Mp), _pad_rows_t(x, Mp), dW, N, K, Mp)
+    _mm_nt(_pad_rows_t(dy, Mp), _pad_rows_t(x, Mp), dW, N, K, Mp)
     return dx, dW, _colsum(dy)[0]
 
 
@@ -133,9 +164,11 @@ class _Attn:
 
 
 class TrainStep:
-    def __init__(self, diffusion_transformer):
+    def __init__(self, diffusion_transformer, precision="fp32"):
+        assert precision in ("f16x2", "fp32")
         self.dt = diffusion_transformer
         self.tr = diffusion_transformer.transformer
+        self.precision = precision
 
     @torch.no_grad()
     def loss_and_grads(self, x0, cond_emb, t, pt, noise):
@@ -143,6 +176,7 @@ class TrainStep:
         f32[B, K+1, L] uniforms for q_sample.  Returns (loss scalar as forward() reports it, {parameter name relative to
         the DiffusionTransformer: gradient}).  Gradients are those of that loss."""
         dt, tr = self.dt, self.tr
+        _SPLIT[0] = self.precision == "f16x2"
         dev = x0.device
         B, Lx = x0.shape
         D, H, K = tr.n_embd, tr.n_head, tr.num_codes
@@ -293,4 +327,4 @@ class TrainStep:
             gr = gr.contiguous()
             L_.check(L_.lib().ds_adamw(L_.ptr(p_.data), L_.ptr(gr), L_.ptr(m), L_.ptr(v), p_.numel(), lr, betas[0], betas[1],
                                        eps, weight_decay, step, L_.stream()))
-        self.tr._packed = None     # cached weight packs / AdaLN tables are stale now
+        self.tr.invalidate()       # cached weight packs / AdaLN tables are stale now (frees the native handle too)

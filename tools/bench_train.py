@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-layer", type=int, default=19)
     ap.add_argument("--codes", type=int, default=256)
+    ap.add_argument("--precision", default="fp32", choices=("f16x2", "fp32"),
+                    help="linear-layer GEMMs (forward, dX, dW): 3-pass fp16 split or exact-fp32 MFMA")
     ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,7 +79,7 @@ def main():
                 times["grads"] += time.perf_counter() - t0
             return out
 
-    solver = Solver(Timed(dt), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+    solver = Solver(Timed(dt, precision=args.precision), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                     scheduler=PlateauWarmupLR(3.0e-6, factor=0.5, patience=25000, min_lr=1.0e-6, threshold=1.0e-1,
                                               warmup_lr=4.5e-4, warmup=1000),
                     clip_grad_norm=GradClipWindow(0, 5000, 0.5),
@@ -110,7 +112,7 @@ def main():
         print(json.dumps({
             "metric": "training iterations/s (denoiser step: loss + backward + clip + AdamW + EMA)", "value": args.steps / el,
             "unit": "it/s", "samples_per_s": args.steps * B * world / el, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "dtype": "f32", "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "dtype": "f32 via 2-way fp16 split (linear layers fwd + dX + dW), fp32 elsewhere" if args.precision == "f16x2" else "f32", "data": "synthetic",
             "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
             "ms": {k: 1e3 * v / args.steps for k, v in times.items()},
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
