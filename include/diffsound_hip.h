@@ -83,9 +83,12 @@ void ds_gemm_bf16x3_force_tile(int cfg);
  * a0b0 + a0b1 + a1b0 per k-step, epilogue multiplies by out_scale = 2^-s.  |A| must stay below 65504
  * (gemm_f16x2.hip). */
 int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
-/* the DS_LOAD_CONV2D contraction (3x3 conv over a channels-last image: Cin, H, Wd, up; prologue none or GroupNorm
-   affine + swish; bias, residual, row store) in the same fp32-class 3-pass formulation: A fp32, W = the two fp16
-   planes [N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart), out_scale = 2^-s */
+/* the conv-family loaders in the same fp32-class 3-pass formulation: A fp32 (split while it is staged), W = the two fp16
+   planes [groups][N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart, groups w_gstride apart), out_scale = 2^-s.
+   d->loader: DS_LOAD_CONV2D (3x3 conv over a channels-last image: Cin, H, Wd, up; prologue none or GroupNorm affine +
+   swish), DS_LOAD_CONV1D (taps, dil, reflect padding; prologue none / LeakyReLU), DS_LOAD_CONVT1D (groups = ct_r
+   phases, DS_STORE_CONVT; vocoder/modules.py:104-111), DS_LOAD_DENSE (1x1 convs).  Bias, residual, row store; Cin % 32
+   == 0, N % 4 == 0.  (A descriptor with loader 0 and the conv2d geometry H > 0, K == 9 Cin is taken as DS_LOAD_CONV2D.) */
 int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 /* cfg: -1 automatic (default): the per-sample ping-pong program (gemm_f16x2_ps.hip: one 288 x 256 tile of an 8-wave
    workgroup per (sample, 256 columns)) when the problem has packed operands, rows_per_sample in (240, 273] with

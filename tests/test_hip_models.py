@@ -286,12 +286,23 @@ def test_vocoder_vs_reference(voc):
     assert (wave - ref).abs().max() < 1e-3
 
 
-def test_vocoder_short_and_batched(voc, sd_vocoder):
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
+def test_vocoder_short_and_batched(voc, sd_vocoder, precision):
+    """Both arithmetic modes of the MelGAN stack (every Conv1d / ConvTranspose1d / 1x1 conv on the 3-pass fp16 split of
+    conv_f16x2.hip, or on the exact-fp32 MFMA) against the CPU oracle: other length, batch > 1 (reflection padding at
+    every sample edge, polyphase phases, LeakyReLU prologue, residual epilogue)."""
     mel = synth.synth_uniform((3, 80, 53), key="voc.short")
     ref = O.melgan_generator(sd_vocoder, mel)
-    got = voc(mel.cuda()).cpu()
+    old = voc.conv_precision
+    try:
+        voc.conv_precision = precision
+        got = voc(mel.cuda()).cpu()
+    finally:
+        voc.conv_precision = old
     assert got.shape == ref.shape == (3, 1, 53 * 256)
-    assert (got - ref).pow(2).mean().sqrt() < WAVE_RMS_TOL
+    rms = (got - ref).pow(2).mean().sqrt().item()
+    print("vocoder %s: wave RMS vs oracle %.2e" % (precision, rms))
+    assert rms < WAVE_RMS_TOL
 
 
 def test_full_size_properties_B32():

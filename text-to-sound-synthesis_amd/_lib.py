@@ -185,8 +185,8 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
     if split3:
         d.w3_plane = N * d.ldw
         check(lib().ds_gemm_bf16x3(C.byref(d), stream()))
-    elif split2 is not None and conv_split:        # 3x3 conv on the fp16 matrix cores (conv_f16x2.hip)
-        d.w3_plane = N * d.ldw
+    elif split2 is not None and conv_split:        # conv-family loaders on the fp16 matrix cores (conv_f16x2.hip)
+        d.w3_plane = w_plane if w_plane is not None else max(1, groups) * N * d.ldw
         d.out_scale = split2
         check(lib().ds_conv2d_f16x2(C.byref(d), stream()))
     elif split2 is not None:

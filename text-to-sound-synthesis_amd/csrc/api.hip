@@ -64,14 +64,17 @@ extern "C" int ds_gemm_bf16x3(const ds_gemm_desc* d, ds_stream_t stream) {
     return ds_launch_gemm_bf16x3(p, (hipStream_t)stream);
 }
 
-// 3x3 conv (DS_LOAD_CONV2D geometry of the descriptor) on the fp16 matrix cores; W = split_f16x2 planes
+// the conv-family loaders of the descriptor (DS_LOAD_CONV2D / CONV1D / CONVT1D / DENSE) on the fp16 matrix cores; W =
+// split_f16x2 planes.  loader 0 (DS_LOAD_DENSE) in the descriptor of a caller that predates the other loaders meant the
+// 3x3 conv: the conv2d geometry fields (H > 0 and K == 9 Cin) select it.
 extern "C" int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
     DS_CHECK_ARG(d && d->A && d->W && d->C, "null pointer");
     DS_CHECK_ARG(d->w3_plane > 0, "w3_plane (plane stride of the split weights) is required");
     GemmParams p;
     memset(&p, 0, sizeof(p));
     fill(p, d);
-    return ds_launch_conv2d_f16x2(p, (hipStream_t)stream);
+    const int loader = (d->loader == DS_LOAD_DENSE && d->H > 0 && d->Cin > 0 && d->K == 9 * d->Cin) ? DS_LOAD_CONV2D : d->loader;
+    return ds_launch_conv2d_f16x2(p, (hipStream_t)stream, loader);
 }
 
 extern "C" int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {

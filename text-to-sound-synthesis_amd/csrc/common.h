@@ -117,4 +117,4 @@ struct GemmParams {
 int ds_launch_gemm(const GemmParams& p, hipStream_t stream, int loader);
 int ds_launch_gemm_bf16x3(const GemmParams& p, hipStream_t stream);  // gemm_bf16x3.hip
 int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream);   // gemm_f16x2.hip
-int ds_launch_conv2d_f16x2(const GemmParams& p, hipStream_t stream); // conv_f16x2.hip
+int ds_launch_conv2d_f16x2(const GemmParams& p, hipStream_t stream, int loader); // conv_f16x2.hip

@@ -1,7 +1,10 @@
-// 3x3 convolution over channels-last images as an implicit GEMM on the fp16 matrix cores with the 2-way fp16 split
-// of gemm_f16x2.hip (fp32-class results, 3 MFMA passes):  the SpecVQGAN decoder / encoder convolutions
-// (specvqgan/modules/diffusionmodules/model.py:37-77,92-151), which ran on the 16x slower fp32 MFMA
-// (gemm_f32.hip, DS_LOAD_CONV2D: same loader semantics, same prologue, same epilogue).
+// Convolutions over channels-last tensors as implicit GEMMs on the fp16 matrix cores with the 2-way fp16 split of
+// gemm_f16x2.hip (fp32-class results, 3 MFMA passes): the gather-GEMM loaders of gemm_f32.hip (same loader semantics,
+// same prologues, same epilogues) in front of the split arithmetic, instead of the 16x slower fp32 MFMA:
+//   DS_LOAD_CONV2D   3x3 convs of the SpecVQGAN decoder / encoder (specvqgan/modules/diffusionmodules/model.py:37-77,92-151)
+//   DS_LOAD_CONV1D   MelGAN's k7 / dilated k3 Conv1d with ReflectionPad1d (vocoder/modules.py:72-85,95-127)
+//   DS_LOAD_CONVT1D  MelGAN's ConvTranspose1d(k = 2r, s = r) as r polyphase GEMMs (blockIdx.y = phase), DS_STORE_CONVT
+//   DS_LOAD_DENSE    1x1 convs (ResnetBlock shortcut / second conv), optional LeakyReLU(0.2) prologue
 //
 //   C[m][n] = sum_{tap, c} pro(X)[pixel(m) + tap][c] * W[n][tap][c] * 2^s ... * 2^-s + bias[n] (+ R[m][n])
 //
@@ -17,7 +20,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define CLD 32  // halves per LDS row
 
-template <int BM, int BN, int PRO>
+template <int BM, int BN, int LOADER, int PRO>
 __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -36,6 +39,8 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int g = blockIdx.y;                            // group = ConvTranspose1d phase (1 group otherwise)
+    const float* Ag = p.A + (size_t)g * p.a_gstride;
 
     // staging chunk c = tid + 256 i: row c>>2, the 8 consecutive k at (c&3)*8 of the 32-wide k-tile
     int a_b[SA], a_y[SA], a_x[SA], a_dst[SA];
@@ -45,14 +50,28 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
         const int row = (tid + 256 * i) >> 2;
         int m = m0 + row;
         if (m >= p.M) m = p.M - 1;
-        const int hw = p.H * p.W_;
-        a_b[i] = m / hw;
-        const int rem = m - a_b[i] * hw;
-        a_y[i] = rem / p.W_;
-        a_x[i] = rem - a_y[i] * p.W_;
+        if constexpr (LOADER == DS_LOAD_CONV2D) {
+            const int hw = p.H * p.W_;
+            a_b[i] = m / hw;
+            const int rem = m - a_b[i] * hw;
+            a_y[i] = rem / p.W_;
+            a_x[i] = rem - a_y[i] * p.W_;
+        } else if constexpr (LOADER == DS_LOAD_CONV1D) {
+            a_b[i] = m / p.W_;
+            a_x[i] = m - a_b[i] * p.W_;
+            a_y[i] = 0;
+        } else if constexpr (LOADER == DS_LOAD_CONVT1D) {   // rows of phase g are (b, q'); source index s0 = q' + (g < p)
+            a_b[i] = m / p.ct_tin;
+            a_x[i] = m - a_b[i] * p.ct_tin + (g < p.ct_p ? 1 : 0);
+            a_y[i] = 0;
+        } else {                                             // dense rows
+            a_b[i] = 0;
+            a_x[i] = m;
+            a_y[i] = 0;
+        }
         a_dst[i] = row * CLD + (((tid & 3) ^ ((row >> 2) & 3)) * 8);
     }
-    const unsigned short* w2 = (const unsigned short*)p.W;
+    const unsigned short* w2 = (const unsigned short*)p.W + (size_t)g * p.w_gstride;
     const unsigned short* b_base[SB];
     int b_dst[SB];
 #pragma unroll
@@ -71,24 +90,43 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
     // raw loads of k-tile k0: address math + two 16-byte loads per slot, no branch on loaded data
 #define C_LOAD(k0_)                                                                                 \
     do {                                                                                            \
-        const int tap = (k0_) / p.Cin, c0 = (k0_) - tap * p.Cin + ck8;                              \
-        const int ky = tap / 3, kx = tap - ky * 3;                                                  \
+        const int tap = LOADER == DS_LOAD_DENSE ? 0 : (k0_) / p.Cin;                                \
+        const int c0 = (k0_) - tap * p.Cin + ck8;                                                   \
         _Pragma("unroll") for (int i = 0; i < SA; ++i) {                                            \
-            int sy = a_y[i] + ky - 1, sx = a_x[i] + kx - 1;                                         \
-            bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W_;                                  \
-            sy = ok ? sy : a_y[i];                                                                  \
-            sx = ok ? sx : a_x[i];                                                                  \
-            int hs = p.H, ws = p.W_;                                                                \
-            if (p.up == 1) { sy >>= 1; sx >>= 1; hs >>= 1; ws >>= 1; }                              \
-            if (p.up == 2) {                                                                        \
-                hs = 2 * p.H; ws = 2 * p.W_;                                                        \
-                sy = 2 * a_y[i] + ky; sx = 2 * a_x[i] + kx;                                         \
-                ok = sy < hs && sx < ws;                                                            \
-                sy = ok ? sy : 2 * a_y[i];                                                          \
-                sx = ok ? sx : 2 * a_x[i];                                                          \
+            const float* src;                                                                       \
+            if constexpr (LOADER == DS_LOAD_CONV2D) {                                               \
+                const int ky = tap / 3, kx = tap - ky * 3;                                          \
+                int sy = a_y[i] + ky - 1, sx = a_x[i] + kx - 1;                                     \
+                bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W_;                              \
+                sy = ok ? sy : a_y[i];                                                              \
+                sx = ok ? sx : a_x[i];                                                              \
+                int hs = p.H, ws = p.W_;                                                            \
+                if (p.up == 1) { sy >>= 1; sx >>= 1; hs >>= 1; ws >>= 1; }                          \
+                if (p.up == 2) {                                                                    \
+                    hs = 2 * p.H; ws = 2 * p.W_;                                                    \
+                    sy = 2 * a_y[i] + ky; sx = 2 * a_x[i] + kx;                                     \
+                    ok = sy < hs && sx < ws;                                                        \
+                    sy = ok ? sy : 2 * a_y[i];                                                      \
+                    sx = ok ? sx : 2 * a_x[i];                                                      \
+                }                                                                                   \
+                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));                         \
+                src = Ag + ((size_t)(a_b[i] * hs + sy) * ws + sx) * p.Cin + c0;                     \
+            } else if constexpr (LOADER == DS_LOAD_CONV1D) {                                        \
+                int ts = a_x[i] + (tap - (p.taps - 1) / 2) * p.dil;   /* ReflectionPad1d */         \
+                if (ts < 0) ts = -ts;                                                               \
+                if (ts >= p.W_) ts = 2 * (p.W_ - 1) - ts;                                           \
+                okmask |= 1u << i;                                                                  \
+                src = Ag + ((size_t)a_b[i] * p.W_ + ts) * p.Cin + c0;                               \
+            } else if constexpr (LOADER == DS_LOAD_CONVT1D) {                                       \
+                int s_ = a_x[i] - tap;   /* tap 0: x[s0] * W[:,:,phase]; 1: x[s0-1] * W[:,:,phase+r] */ \
+                const bool ok = s_ >= 0 && s_ < p.ct_tin;                                           \
+                s_ = ok ? s_ : 0;                                                                   \
+                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));                         \
+                src = Ag + ((size_t)a_b[i] * p.ct_tin + s_) * p.Cin + c0;                           \
+            } else {                                                                                \
+                okmask |= 1u << i;                                                                  \
+                src = Ag + (size_t)a_x[i] * p.lda + c0;                                             \
             }                                                                                       \
-            okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));                             \
-            const float* src = p.A + ((size_t)(a_b[i] * hs + sy) * ws + sx) * p.Cin + c0;           \
             ra[2 * i] = *(const f32x4*)src;                                                         \
             ra[2 * i + 1] = *(const f32x4*)(src + 4);                                               \
         }                                                                                           \
@@ -102,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
     do {                                                                                            \
         _Float16* As_ = smem + (stage_) * STAGE;                                                    \
         _Float16* Bs_ = As_ + 2 * APL;                                                              \
-        const int ch0 = (k0_) - ((k0_) / p.Cin) * p.Cin + ck8;                                      \
+        const int ch0 = LOADER == DS_LOAD_DENSE ? (k0_) + ck8 : (k0_) - ((k0_) / p.Cin) * p.Cin + ck8; \
         _Pragma("unroll") for (int i = 0; i < SA; ++i) {                                            \
             h8 s0, s1;                                                                              \
             const bool ok = (okmask >> i) & 1u;                                                     \
@@ -115,6 +153,9 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
                         const float y = v[e] * sc[e] + sh[e];                                       \
                         v[e] = y / (1.f + expf(-y));                                                \
                     }                                                                               \
+                }                                                                                   \
+                if constexpr (PRO == DS_PRO_LRELU) {                                                \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e]; \
                 }                                                                                   \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
                     const float a = ok ? v[e] : 0.f;   /* zero padding lives in the activated domain */ \
@@ -197,58 +238,99 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
         }
     __syncthreads();
     constexpr int CPR = BN / 4;
+    float* Cg = p.C + (size_t)g * p.c_gstride;
+    const float* Rg = p.R ? p.R + (size_t)g * p.c_gstride : nullptr;
     for (int c = tid; c < BM * CPR; c += 256) {
         const int cc = c % CPR, rl = c / CPR;
         const int row = m0 + rl, col = n0 + cc * 4;
         if (row < p.M && col < p.N) {
             f32x4 val = *(const f32x4*)(Tf + rl * BN + cc * 4);
-            if (p.R) val += *(const f32x4*)(p.R + (size_t)row * p.ldr + col);
-            *(f32x4*)(p.C + (size_t)row * p.ldc + col) = val;
+            if (Rg) val += *(const f32x4*)(Rg + (size_t)row * p.ldr + col);
+            size_t orow = row;
+            if (p.store == DS_STORE_CONVT) {            // row (b, q') of phase g -> output time t = q r + g - p
+                const int b = row / p.ct_tin, qq = row - b * p.ct_tin + (g < p.ct_p ? 1 : 0);
+                orow = (size_t)b * p.ct_tin * p.ct_r + (qq * p.ct_r + g - p.ct_p);
+            }
+            *(f32x4*)(Cg + orow * p.ldc + col) = val;
         }
     }
 }
 
-template <int BM, int BN, int PRO>
+template <int BM, int BN, int LOADER, int PRO>
 static int conv_launch(const GemmParams& p, hipStream_t s) {
     const size_t stage = (size_t)2 * 2 * (BM + BN) * CLD * sizeof(unsigned short);
     const size_t tile = (size_t)BM * BN * sizeof(float);
     const size_t lds = stage > tile ? stage : tile;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_conv2d_f16x2_kernel<BM, BN, PRO>,
+        hipError_t e = hipFuncSetAttribute((const void*)ds_conv2d_f16x2_kernel<BM, BN, LOADER, PRO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
-            ds_set_error("conv2d_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            ds_set_error("conv_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((ds_conv2d_f16x2_kernel<BM, BN, PRO>), dim3(tiles), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((ds_conv2d_f16x2_kernel<BM, BN, LOADER, PRO>), dim3(tiles, p.groups > 0 ? p.groups : 1), dim3(256),
+                       lds, s, p);
     DS_CHECK_LAUNCH();
     return 0;
 }
 
-// p.A: channels-last fp32 image; p.W: 2 row-major fp16 planes [N][ldw] of W * 2^s (K = 9 * Cin ordered [tap][c]),
-// w3_plane halves apart; p.out_scale = 2^-s.
-int ds_launch_conv2d_f16x2(const GemmParams& p, hipStream_t stream) {
-    DS_CHECK_ARG(p.M > 0 && p.N > 0 && p.Cin > 0 && p.Cin % 32 == 0 && p.K == 9 * p.Cin, "conv2d: K = 9*Cin, Cin % 32 == 0");
-    DS_CHECK_ARG(p.H > 0 && p.W_ > 0 && p.M % (p.H * p.W_) == 0, "conv2d: M = samples * H * W");
+template <int LOADER, int PRO>
+static int conv_tile(const GemmParams& p, hipStream_t s) {
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.groups > 0 ? p.groups : 1);
+    if (t128 >= 256 && p.N > 64) return conv_launch<128, 128, LOADER, PRO>(p, s);
+    return conv_launch<64, 64, LOADER, PRO>(p, s);
+}
+
+// p.A: channels-last fp32 tensor; p.W: 2 row-major fp16 planes [groups][N][ldw] of W * 2^s (K ordered [tap][c]),
+// w3_plane halves apart; p.out_scale = 2^-s.  loader: DS_LOAD_CONV2D (K = 9 Cin), DS_LOAD_CONV1D (K = taps Cin, reflect
+// padding), DS_LOAD_CONVT1D (K = 2 Cin, groups = r phases, DS_STORE_CONVT) or DS_LOAD_DENSE (K = lda-contiguous rows).
+int ds_launch_conv2d_f16x2(const GemmParams& p, hipStream_t stream, int loader) {
+    DS_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % 32 == 0, "K must be a positive multiple of 32");
     DS_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && ((uintptr_t)p.C & 15) == 0 &&
                      ((uintptr_t)p.R & 15) == 0,
                  "operands must be 16-byte aligned");
-    DS_CHECK_ARG(p.ldw >= p.K && p.ldw % 8 == 0 && p.w3_plane % 8 == 0 && p.w3_plane >= (long long)p.N * p.ldw,
+    DS_CHECK_ARG(p.ldw >= p.K && p.ldw % 8 == 0 && p.w3_plane % 8 == 0 &&
+                     p.w3_plane >= (long long)(p.groups > 0 ? p.groups : 1) * p.N * p.ldw && p.w_gstride % 8 == 0,
                  "split-weight strides must be multiples of 8");
     DS_CHECK_ARG(p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.R || p.ldr % 4 == 0), "N, ldc, ldr must be multiples of 4");
-    DS_CHECK_ARG(p.store == DS_STORE_ROW && p.act == DS_ACT_NONE && p.groups <= 1, "row store, no activation, no groups");
-    DS_CHECK_ARG(p.pro == DS_PRO_NONE || (p.pro == DS_PRO_AFFINE_SWISH && p.pro_scale && p.pro_shift),
-                 "prologue: none or GroupNorm affine + swish");
+    DS_CHECK_ARG(p.act == DS_ACT_NONE, "no activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
-    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (t128 >= 256) {
-        return p.pro == DS_PRO_NONE ? conv_launch<128, 128, DS_PRO_NONE>(p, stream)
-                                    : conv_launch<128, 128, DS_PRO_AFFINE_SWISH>(p, stream);
+    switch (loader) {
+        case DS_LOAD_CONV2D:
+            DS_CHECK_ARG(p.Cin > 0 && p.Cin % 32 == 0 && p.K == 9 * p.Cin, "conv2d: K = 9*Cin, Cin % 32 == 0");
+            DS_CHECK_ARG(p.H > 0 && p.W_ > 0 && p.M % (p.H * p.W_) == 0, "conv2d: M = samples * H * W");
+            DS_CHECK_ARG(p.store == DS_STORE_ROW && p.groups <= 1, "conv2d: row store, no groups");
+            DS_CHECK_ARG(p.pro == DS_PRO_NONE || (p.pro == DS_PRO_AFFINE_SWISH && p.pro_scale && p.pro_shift),
+                         "conv2d prologue: none or GroupNorm affine + swish");
+            return p.pro == DS_PRO_NONE ? conv_tile<DS_LOAD_CONV2D, DS_PRO_NONE>(p, stream)
+                                        : conv_tile<DS_LOAD_CONV2D, DS_PRO_AFFINE_SWISH>(p, stream);
+        case DS_LOAD_CONV1D:
+            DS_CHECK_ARG(p.Cin > 0 && p.Cin % 32 == 0 && p.taps > 0 && p.K == p.taps * p.Cin && p.dil > 0,
+                         "conv1d: K = taps*Cin, Cin % 32 == 0");
+            DS_CHECK_ARG(p.W_ > 0 && p.M % p.W_ == 0 && (p.taps - 1) / 2 * p.dil < p.W_, "conv1d: M = samples * T");
+            DS_CHECK_ARG(p.store == DS_STORE_ROW && p.groups <= 1, "conv1d: row store, no groups");
+            DS_CHECK_ARG(p.pro == DS_PRO_NONE || p.pro == DS_PRO_LRELU, "conv1d prologue: none or LeakyReLU(0.2)");
+            return p.pro == DS_PRO_NONE ? conv_tile<DS_LOAD_CONV1D, DS_PRO_NONE>(p, stream)
+                                        : conv_tile<DS_LOAD_CONV1D, DS_PRO_LRELU>(p, stream);
+        case DS_LOAD_CONVT1D:
+            DS_CHECK_ARG(p.Cin > 0 && p.Cin % 32 == 0 && p.K == 2 * p.Cin, "convT1d: K = 2*Cin, Cin % 32 == 0");
+            DS_CHECK_ARG(p.ct_r > 0 && p.groups == p.ct_r && p.ct_tin > 0 && p.M % p.ct_tin == 0 && p.ct_p >= 0 &&
+                             p.ct_p < p.ct_r && p.store == DS_STORE_CONVT && !p.R,
+                         "convT1d: groups = stride phases, M = samples * T_in, CONVT store, no residual");
+            DS_CHECK_ARG(p.pro == DS_PRO_NONE || p.pro == DS_PRO_LRELU, "convT1d prologue: none or LeakyReLU(0.2)");
+            return p.pro == DS_PRO_NONE ? conv_tile<DS_LOAD_CONVT1D, DS_PRO_NONE>(p, stream)
+                                        : conv_tile<DS_LOAD_CONVT1D, DS_PRO_LRELU>(p, stream);
+        case DS_LOAD_DENSE:
+            DS_CHECK_ARG(p.lda >= p.K && p.lda % 4 == 0 && p.store == DS_STORE_ROW && p.groups <= 1,
+                         "dense: lda >= K, row store, no groups");
+            DS_CHECK_ARG(p.pro == DS_PRO_NONE || p.pro == DS_PRO_LRELU, "dense prologue: none or LeakyReLU(0.2)");
+            return p.pro == DS_PRO_NONE ? conv_tile<DS_LOAD_DENSE, DS_PRO_NONE>(p, stream)
+                                        : conv_tile<DS_LOAD_DENSE, DS_PRO_LRELU>(p, stream);
+        default:
+            DS_CHECK_ARG(false, "unknown loader");
     }
-    return p.pro == DS_PRO_NONE ? conv_launch<64, 64, DS_PRO_NONE>(p, stream)
-                                : conv_launch<64, 64, DS_PRO_AFFINE_SWISH>(p, stream);
 }

@@ -3,7 +3,8 @@
 Same constructor, `model.N.*` state-dict keys (weight_g / weight_v / bias, as left by
 torch.nn.utils.weight_norm, :18-23) and forward signature: mel f32[B, 80, T] in [0,1] ->
 waveform f32[B, 1, 256*T].  Weight norm is folded once at pack time (the reference recomputes it on
-every call); activations are channels-last [B, T, C]; every layer is the gather-GEMM:
+every call); activations are channels-last [B, T, C]; every layer is the gather-GEMM -- on the fp16 matrix cores with
+the fp32-class 3-pass split (`conv_precision = "f16x2"`, default; conv_f16x2.hip) or on the exact-fp32 MFMA ("fp32"):
   Conv1d k7 / dilated k3 (ReflectionPad1d)  -> conv1d loader, LeakyReLU(0.2) applied while staging A
   ConvTranspose1d(k=2r, s=r)                -> r polyphase GEMMs with K = 2*Cin (no zero-stuffing)
   ResnetBlock                               -> 3 GEMMs, shortcut added through the residual epilogue
@@ -11,6 +12,8 @@ every call); activations are channels-last [B, T, C]; every layer is the gather-
 The whole batch goes through at once (the reference vocodes sample by sample,
 evaluation/generate_samples_batch.py:183-187).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -70,6 +73,7 @@ class Generator(nn.Module):
         model += [nn.Identity(), nn.Identity(), WNConv1d(ngf, 1, 7), nn.Identity()]
         self.model = nn.Sequential(*model)
         self.n_residual_layers = n_residual_layers
+        self.conv_precision = os.environ.get("DIFFSOUND_VOCODER_CONV", "f16x2")   # "f16x2" | "fp32"
         self._pk = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
 
@@ -110,8 +114,24 @@ class Generator(nn.Module):
         last = layers[i + 2]
         wl = last.folded()                                       # [1, 32, 7] -> [7 taps][32]
         pk["last"] = (wl[0].permute(1, 0).contiguous(), float(last.bias.item()))
+        # fp16 split planes of every GEMM weight (W * 2^s as hi + lo, out_scale = 2^-s) for conv_precision = "f16x2"
+        sp = lambda w: _lib.split_f16x2(w.reshape(-1, w.shape[-1]))
+        pk["first_s"] = sp(pk["first"][0])
+        for st in pk["stages"]:
+            st["ct_s"] = sp(st["ct"][0])
+            for rb in st["res"]:
+                for k in ("c3", "c1", "sc"):
+                    rb[k + "_s"] = sp(rb[k][0])
         self._pk = pk
         return pk
+
+    def _mm(self, A, w, ws, out, M, N, K, **kw):
+        """One gather-GEMM of the stack in the selected arithmetic (w: fp32 weights, ws: their split planes + scale)."""
+        if self.conv_precision == "f16x2" and N % 4 == 0:
+            return _lib.gemm(A, ws[0], out, M, N, K, split2=ws[1], conv_split=True, **kw)
+        if self.conv_precision not in ("f16x2", "fp32"):
+            raise ValueError("conv_precision must be 'f16x2' or 'fp32', got %r" % (self.conv_precision,))
+        return _lib.gemm(A, w, out, M, N, K, **kw)
 
     @torch.no_grad()
     def forward(self, x, scale=1.0, shift=0.0):
@@ -128,24 +148,24 @@ class Generator(nn.Module):
         w, b = pk["first"]
         c = w.shape[0]
         y = torch.empty(B, T, c, device=dev)
-        _lib.gemm(h, w, y, B * T, c, 7 * cpad, bias=b, loader=_lib.LOAD_CONV1D, Cin=cpad, Wd=T, taps=7, dil=1)
+        self._mm(h, w, pk["first_s"], y, B * T, c, 7 * cpad, bias=b, loader=_lib.LOAD_CONV1D, Cin=cpad, Wd=T, taps=7, dil=1)
         h = y
         for st in pk["stages"]:
             r, cin, cout = st["r"], st["cin"], st["cout"]
             w, b = st["ct"]
             y = torch.empty(B, T * r, cout, device=dev)
-            _lib.gemm(h, w, y, B * T, cout, 2 * cin, bias=b, ldc=cout, loader=_lib.LOAD_CONVT1D, pro=_lib.PRO_LRELU,
-                      store=_lib.STORE_CONVT, groups=r, w_gstride=cout * 2 * cin, Cin=cin, Wd=T,
-                      ct_r=r, ct_p=r // 2 + r % 2, ct_tin=T)
+            self._mm(h, w, st["ct_s"], y, B * T, cout, 2 * cin, bias=b, ldc=cout, loader=_lib.LOAD_CONVT1D,
+                     pro=_lib.PRO_LRELU, store=_lib.STORE_CONVT, groups=r, w_gstride=cout * 2 * cin, Cin=cin, Wd=T,
+                     ct_r=r, ct_p=r // 2 + r % 2, ct_tin=T)
             h, T = y, T * r
             for rb in st["res"]:
                 M = B * T
                 h1 = torch.empty(B, T, cout, device=dev)
-                _lib.gemm(h, rb["c3"][0], h1, M, cout, 3 * cout, bias=rb["c3"][1], loader=_lib.LOAD_CONV1D,
-                          pro=_lib.PRO_LRELU, Cin=cout, Wd=T, taps=3, dil=rb["dil"])
+                self._mm(h, rb["c3"][0], rb["c3_s"], h1, M, cout, 3 * cout, bias=rb["c3"][1], loader=_lib.LOAD_CONV1D,
+                         pro=_lib.PRO_LRELU, Cin=cout, Wd=T, taps=3, dil=rb["dil"])
                 sc = torch.empty(B, T, cout, device=dev)
-                _lib.gemm(h, rb["sc"][0], sc, M, cout, cout, bias=rb["sc"][1])
-                _lib.gemm(h1, rb["c1"][0], sc, M, cout, cout, bias=rb["c1"][1], R=sc, pro=_lib.PRO_LRELU)
+                self._mm(h, rb["sc"][0], rb["sc_s"], sc, M, cout, cout, bias=rb["sc"][1])
+                self._mm(h1, rb["c1"][0], rb["c1_s"], sc, M, cout, cout, bias=rb["c1"][1], R=sc, pro=_lib.PRO_LRELU)
                 h = sc
         wl, bl = pk["last"]
         taps = torch.empty(B * T, 8, device=dev)
