@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
                     const f32x4 sh = *(const f32x4*)(p.pro_shift + (size_t)a_b[i] * p.Cin + ch0 + 4 * q); \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                 \
                         const float y = v[e] * sc[e] + sh[e];                                       \
-                        v[e] = y / (1.f + expf(-y));                                                \
+                        v[e] = y * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * y)); /* swish by v_exp / v_rcp: the prologue runs once per tap on every element and bounded the kernel with expf + IEEE division */ \
                     }                                                                               \
                 }                                                                                   \
                 if constexpr (PRO == DS_PRO_LRELU) {                                                \
