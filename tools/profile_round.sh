@@ -12,13 +12,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
-timeout 900 python "$ROOT/bench.py" > "$OUT/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"
-
-timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench --output-format csv -- \
-    python "$ROOT/bench.py" --steps 1 --warmup 1 > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/bench_prof.err"
-cp "$OUT/prof/bench_kernel_stats.csv" "$OUT/${TAG}_bench_default_kernel_stats.csv" 2>/dev/null || \
-    find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/${TAG}_bench_default_kernel_stats.csv" \;
-
+# PMC passes first: bench.py quotes roofline.traffic from their summary (and only while the kernel sources match it)
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
     NAME=$(echo "$SET" | tr ' ' '_')
     # (the exact form used in round 1: --kernel-trace is allowed next to --pmc, the sys / hip / hsa domains are not)
@@ -27,4 +21,13 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BU
 done
 python "$ROOT/tools/pmc_summarize.py" "$OUT/pmc_step" "$OUT/${TAG}_pmc_denoiser_step_b64.csv" \
     "$OUT/${TAG}_pmc_denoiser_step_b64.json" > "$OUT/pmc_summarize.log" 2>&1 || true
+cp "$OUT/${TAG}_pmc_denoiser_step_b64.json" "$ROOT/profiles/" 2>/dev/null || true
+
+timeout 900 python "$ROOT/bench.py" > "$OUT/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"
+
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench --output-format csv -- \
+    python "$ROOT/bench.py" --steps 1 --warmup 1 > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/bench_prof.err"
+cp "$OUT/prof/bench_kernel_stats.csv" "$OUT/${TAG}_bench_default_kernel_stats.csv" 2>/dev/null || \
+    find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/${TAG}_bench_default_kernel_stats.csv" \;
+
 ls -la "$OUT"
