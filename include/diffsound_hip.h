@@ -11,6 +11,9 @@
  * (a hipStream_t, passed as void*); the return value is 0 on success, -1 for a rejected argument,
  * -2 for a failed launch, and ds_last_error_string() describes the last failure of the calling
  * thread.  No function allocates, frees or synchronises.  Activations are channels-last.
+ * Compute entries keep no state between calls (a ds_denoiser handle only holds the caller's weight pointers).  The
+ * exceptions are the TEST / MEASUREMENT switches -- ds_gemm*_force_tile, ds_gemm_f16x2_set_balance_slots, ds_profile_* --
+ * which are process-global and must not be flipped while another thread or stream of the process is launching.
  */
 #ifndef DIFFSOUND_HIP_H
 #define DIFFSOUND_HIP_H
