@@ -283,8 +283,17 @@ def test_conv2d_3x3_f16x2_and_stride2(L, up, gn, shape):
     assert e32 < 3e-6 and e16 < max(3e-6, 1.2 * e32)
 
 
+def _conv_mm(L, split, x, w, out, M, N, K, **kw):
+    """the gather-GEMM on the exact-fp32 MFMA (gemm_f32.hip) or on the 3-pass fp16 split (conv_f16x2.hip)"""
+    if not split:
+        return L.gemm(x, w, out, M, N, K, **kw)
+    w2, sc = L.split_f16x2(w.reshape(-1, w.shape[-1]))
+    return L.gemm(x, w2, out, M, N, K, split2=sc, conv_split=True, **kw)
+
+
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("taps,dil", [(7, 1), (3, 1), (3, 3), (3, 9)])
-def test_conv1d_reflect(L, taps, dil):
+def test_conv1d_reflect(L, taps, dil, split):
     B, T, Cin, Cout = 2, 212, 64, 96
     x = rnd((B, T, Cin), "c1.x")
     w, bias = rnd((Cout, Cin, taps), "c1.w", 0.1), rnd((Cout,), "c1.b")
@@ -293,13 +302,26 @@ def test_conv1d_reflect(L, taps, dil):
     ref = F.conv1d(F.pad(xin, (pad, pad), mode="reflect"), w.double(), bias.double(), dilation=dil).permute(0, 2, 1).float()
     wp = w.permute(0, 2, 1).reshape(Cout, -1).contiguous().cuda()
     out = torch.empty(B, T, Cout, device="cuda")
-    L.gemm(x.cuda(), wp, out, B * T, Cout, taps * Cin, bias=bias.cuda(), loader=L.LOAD_CONV1D, pro=L.PRO_LRELU,
-           Cin=Cin, Wd=T, taps=taps, dil=dil)
+    _conv_mm(L, split, x.cuda(), wp, out, B * T, Cout, taps * Cin, bias=bias.cuda(), loader=L.LOAD_CONV1D,
+             pro=L.PRO_LRELU, Cin=Cin, Wd=T, taps=taps, dil=dil)
     assert relerr(out.cpu(), ref) < 3e-6
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_conv1x1_lrelu_residual(L, split):
+    """MelGAN ResnetBlock's second conv: 1x1 over LeakyReLU(h), added onto the shortcut in place (dense loader)."""
+    M, Cin, Cout = 2 * 1000 + 13, 64, 64
+    h, sc_ = rnd((M, Cin), "c11.h"), rnd((M, Cout), "c11.sc")
+    w, bias = rnd((Cout, Cin), "c11.w", 0.1), rnd((Cout,), "c11.b")
+    ref = (F.leaky_relu(h.double(), 0.2) @ w.double().t() + bias.double() + sc_.double()).float()
+    out = sc_.clone().cuda()
+    _conv_mm(L, split, h.cuda(), w.cuda(), out, M, Cout, Cin, bias=bias.cuda(), R=out, pro=L.PRO_LRELU)
+    assert relerr(out.cpu(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("r", [8, 2])
-def test_conv_transpose1d_polyphase(L, r):
+def test_conv_transpose1d_polyphase(L, r, split):
     B, T, Cin, Cout = 2, 53, 64, 32
     x = rnd((B, T, Cin), "ct.x")
     w, bias = rnd((Cin, Cout, 2 * r), "ct.w", 0.1), rnd((Cout,), "ct.b")
@@ -307,9 +329,10 @@ def test_conv_transpose1d_polyphase(L, r):
                              padding=r // 2).permute(0, 2, 1).float()
     wph = w.permute(2, 1, 0).reshape(2, r, Cout, Cin).permute(1, 2, 0, 3).reshape(r, Cout, 2 * Cin).contiguous().cuda()
     out = torch.full((B, T * r, Cout), float("nan"), device="cuda")
-    L.gemm(x.cuda(), wph, out, B * T, Cout, 2 * Cin, bias=bias.cuda(), ldc=Cout, loader=L.LOAD_CONVT1D,
-           pro=L.PRO_LRELU, store=L.STORE_CONVT, groups=r, w_gstride=Cout * 2 * Cin, Cin=Cin, Wd=T,
-           ct_r=r, ct_p=r // 2, ct_tin=T)
+    _conv_mm(L, split, x.cuda(), wph, out, B * T, Cout, 2 * Cin, bias=bias.cuda(), ldc=Cout, loader=L.LOAD_CONVT1D,
+             pro=L.PRO_LRELU, store=L.STORE_CONVT, groups=r, w_gstride=Cout * 2 * Cin, Cin=Cin, Wd=T,
+             ct_r=r, ct_p=r // 2, ct_tin=T)
+    assert not torch.isnan(out).any()
     assert relerr(out.cpu(), ref) < 3e-6
 
 
