@@ -84,7 +84,9 @@ int ds_gemm_bf16x3(const ds_gemm_desc* d, ds_stream_t stream);
 void ds_gemm_bf16x3_force_tile(int cfg);
 /* Cheaper variant: W*2^s and A are split into two fp16 planes each (22 significant bits), three fp16 MFMA passes
  * a0b0 + a0b1 + a1b0 per k-step, epilogue multiplies by out_scale = 2^-s.  |A| must stay below 65504
- * (gemm_f16x2.hip). */
+ * (gemm_f16x2.hip).  groups > 1 (row-major operands, plain row store, no bias / residual): group g computes
+ * A + g a_gstride (floats) times W + g w_gstride (halves, both planes) into C + g c_gstride -- with a_gstride =
+ * w_gstride = K this is a split-K launch whose partial results the caller sums (ds_colsum). */
 int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 /* the conv-family loaders in the same fp32-class 3-pass formulation: A fp32 (split while it is staged), W = the two fp16
    planes [groups][N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart, groups w_gstride apart), out_scale = 2^-s.
@@ -214,6 +216,22 @@ int ds_axpy(float* y, const float* x, float a, long long n, ds_stream_t stream);
 /* fused AdamW update (torch.optim.AdamW semantics), step >= 1 */
 int ds_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int step, ds_stream_t stream);
+/* The same update with the iteration's scalars in device memory, hyper = { lr, 1 - beta1^step, sqrt(1 - beta2^step),
+ * grad_scale } (g is multiplied by grad_scale first: the clip coefficient / the inverse loss scale): a captured
+ * hipGraph replays fixed kernel arguments, so what changes per iteration is read through this pointer. */
+int ds_adamw_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2,
+                 float eps, float weight_decay, ds_stream_t stream);
+/* Operand preparation for the training step's split GEMMs (forward  y = x W^T,  dX = dY W,  dW = dY^T X -- what
+ * loss.backward() runs for every nn.Linear of Text2ImageTransformer, engine/solver_spec.py:308-331):
+ *   dst = scale * src   (transpose 0)   or   scale * src^T   (transpose 1),   src fp32 [rows][ld_src] (cols valid),
+ * written as fp32 [drows][ld_dst] (dst_f16 0) or as two row-major fp16 planes hi | lo, `plane` halves apart
+ * (dst_f16 1: the W operand of ds_gemm_f16x2 with a_split 0).  drows = transpose ? cols : rows; destination columns past
+ * the valid ones up to ld_dst (ld_dst % 8 == 0) are written as zeros.  scale must be a power of two for the split to be
+ * exact. */
+int ds_convert_operand(const float* src, int rows, int cols, long long ld_src, int transpose, float scale, void* dst,
+                       long long ld_dst, long long plane, int dst_f16, ds_stream_t stream);
+/* *out = max(*out, max_i |x[i]|)  (the caller zeroes *out; calibration of the training step's loss scale) */
+int ds_amax(const float* x, long long n, float* out, ds_stream_t stream);
 
 /* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
 enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */

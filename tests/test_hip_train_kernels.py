@@ -118,6 +118,88 @@ def test_adamw_matches_torch(L):
     assert close(p.cpu(), ref.detach(), 2e-6)
 
 
+@pytest.mark.parametrize("transpose", [0, 1])
+@pytest.mark.parametrize("f16", [0, 1])
+def test_convert_operand(L, transpose, f16):
+    """ds_convert_operand: scale * src or its transpose, as fp32 or as the hi | lo fp16 planes of the split GEMM's W
+    operand, zero padding up to ld_dst -- exactly what torch computes for the same definition (RNE casts)."""
+    rows, cols, ld_src = 531, 1003, 1008
+    src = torch.zeros(rows, ld_src)
+    src[:, :cols] = rnd((rows, cols), "cv.src", 40.0)
+    src[0, 0], src[1, 1], src[2, 2] = 7.0e4, -9.9e9, 3.0e-7            # saturation and the subnormal low plane
+    src[:, cols:] = 123.0                                               # columns past `cols` must not be read as data
+    scale = 2.0 ** 3
+    want = (src[:, :cols] * scale).t() if transpose else src[:, :cols] * scale
+    drows, dvalid = want.shape
+    ld_dst = (dvalid + 31) // 32 * 32
+    full = torch.zeros(drows, ld_dst)
+    full[:, :dvalid] = want
+    dev_src = src.cuda()
+    if f16:
+        dst = torch.full((2, drows, ld_dst), 0x7777, dtype=torch.int16, device="cuda")
+        plane = drows * ld_dst
+    else:
+        dst = torch.full((drows, ld_dst), float("nan"), device="cuda")
+        plane = 0
+    L.check(L.lib().ds_convert_operand(L.ptr(dev_src), rows, cols, ld_src, transpose, scale, L.ptr(dst), ld_dst, plane, f16,
+                                       L.stream()))
+    if f16:
+        hi = full.clamp(-65504.0, 65504.0).half()
+        lo = (full - hi.float()).clamp(-65504.0, 65504.0).half()
+        got = dst.cpu().view(torch.float16)
+        assert torch.equal(got[0], hi) and torch.equal(got[1], lo)
+    else:
+        assert torch.equal(dst.cpu(), full)
+
+
+def test_gemm_f16x2_split_k_groups(L):
+    """The dW launch of the training step: C = A W^T with the contraction split into `groups` K-ranges of one grouped
+    ds_gemm_f16x2 launch (row-major fp32 A, fp16-plane W), partial products summed by ds_colsum -- against float64 and
+    against the ungrouped launch."""
+    N, K, Mp, S = 320, 192, 1024, 4
+    a = rnd((N, Mp), "sk.a", 30.0)
+    x = rnd((K, Mp), "sk.x", 2.0)
+    ref = a.double() @ x.double().t()
+    ac, xc = a.cuda(), x.cuda()
+    planes = torch.empty(2, K, Mp, dtype=torch.int16, device="cuda")
+    L.check(L.lib().ds_convert_operand(L.ptr(xc), K, Mp, Mp, 0, 1.0, L.ptr(planes), Mp, K * Mp, 1, L.stream()))
+    one = torch.empty(N, K, device="cuda")
+    L.gemm(ac, planes, one, N, K, Mp, split2=0.5, w_plane=K * Mp)
+    part = torch.full((S, N * K), float("nan"), device="cuda")
+    Kc = Mp // S
+    L.gemm(ac, planes, part, N, K, Kc, lda=Mp, ldw=Mp, ldc=K, groups=S, a_gstride=Kc, w_gstride=Kc, c_gstride=N * K,
+           split2=0.5, w_plane=K * Mp)
+    out = torch.empty(N, K, device="cuda")
+    L.check(L.lib().ds_colsum(L.ptr(part), L.ptr(out), 1, S, N * K, N * K, 0, 0, L.stream()))
+    scale = ref.abs().max().item()
+    assert (one.cpu().double() - 0.5 * ref).abs().max().item() < 2e-6 * scale
+    assert (out.cpu().double() - 0.5 * ref).abs().max().item() < 2e-6 * scale
+    for g in range(S):       # every group is the product over its own K-range
+        pr = a[:, g * Kc:(g + 1) * Kc].double() @ x[:, g * Kc:(g + 1) * Kc].double().t()
+        assert (part[g].view(N, K).cpu().double() - 0.5 * pr).abs().max().item() < 2e-6 * scale
+
+
+def test_amax_and_adamw_dev(L):
+    x = rnd((100003,), "am.x", 3.0)
+    x[4711] = -17.25
+    out = torch.zeros(1, device="cuda")
+    xc = x.cuda()
+    L.check(L.lib().ds_amax(L.ptr(xc), xc.numel(), L.ptr(out), L.stream()))
+    assert out.item() == 17.25
+    n = 50001
+    p0, g1 = rnd((n,), "awd.p"), rnd((n,), "awd.g", 0.1)
+    pa, ma, va = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb, mb, vb = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    gc = g1.cuda()
+    g_scaled = (gc * 0.25).contiguous()
+    import math
+    for step in (1, 2):
+        L.check(L.lib().ds_adamw(L.ptr(pa), L.ptr(g_scaled), L.ptr(ma), L.ptr(va), n, 3e-3, 0.9, 0.96, 1e-8, 4.5e-2, step, L.stream()))
+        hyper = torch.tensor([3e-3, 1.0 - 0.9 ** step, math.sqrt(1.0 - 0.96 ** step), 0.25], device="cuda")
+        L.check(L.lib().ds_adamw_dev(L.ptr(pb), L.ptr(gc), L.ptr(mb), L.ptr(vb), n, L.ptr(hyper), 0.9, 0.96, 1e-8, 4.5e-2, L.stream()))
+    assert close(pb.cpu(), pa.cpu(), 1e-6) and close(mb.cpu(), ma.cpu(), 1e-6)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "f16x2"])
 def test_training_step_gradients_vs_oracle_autograd(precision):
     """The whole backward of the denoiser on the HIP kernels (modeling/train.py; linear layers on the exact-fp32 MFMA or
@@ -241,3 +323,41 @@ def test_solver_three_iterations_vs_cpu_autograd():
     w_end = dict(dt.named_parameters())[key].detach()
     assert not torch.equal(w_end, w_start)
     assert close(solver.ema.state_dict()[key].cpu(), ema_want.cpu(), 1e-6)
+
+
+def test_graphed_iteration_matches_eager():
+    """TrainStep.capture: gradients -> clip -> AdamW of the split-GEMM training step replayed as one hipGraph, three
+    iterations with a changing batch (t, noise) and learning rate, against the eager Solver on an identical model."""
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.solver import GradClipWindow, GraphSolver, Solver
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+
+    def make():
+        m = build_model(default_config(n_layer=2, diffusion_step=100))
+        m.load_state_dict({**dict(synth_sd("dalle", 2)), **synth_sd("encoder")}, strict=False)
+        m = m.cuda().eval()
+        dt = m.transformer
+        dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]
+        return dt
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0").cuda()
+    cond = synth.synth_cond_emb(3, key="tl.c").cuda()
+    pt = (torch.ones(3) / 100).cuda()
+    batches = [(torch.tensor([57, 0, 93]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u").cuda()),
+               (torch.tensor([3, 99, 41]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u2").cuda()),
+               (torch.tensor([12, 12, 70]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u3").cuda())]
+    dt_e, dt_g = make(), make()
+    eager = Solver(TrainStep(dt_e, precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5))
+    graph = GraphSolver(TrainStep(dt_g, precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5))
+    key = "transformer.blocks.1.mlp.0.weight"
+    for it, (t, u) in enumerate(batches):
+        eager.lr = graph.lr = 1e-3 * (it + 1)
+        oe = eager.step(x0, cond, t, pt, u)
+        og = graph.step(x0, cond, t, pt, u)
+        le, lg, ne, ng = float(oe["loss"]), float(og["loss"]), float(oe["grad_norm"]), float(og["grad_norm"])
+        print("iter %d: loss eager %.6f graph %.6f   |g| eager %.5f graph %.5f" % (it, le, lg, ne, ng))
+        assert abs(le - lg) <= 1e-5 * abs(le) and abs(ne - ng) <= 1e-4 * ne
+        we, wg = dict(dt_e.named_parameters())[key].detach(), dict(dt_g.named_parameters())[key].detach()
+        assert close(wg.cpu(), we.cpu(), 1e-5)
+    assert torch.equal(dt_e.Lt_count.cpu(), dt_g.Lt_count.cpu())
+    assert graph.train_step.loss_scale_exp == eager.train_step.loss_scale_exp

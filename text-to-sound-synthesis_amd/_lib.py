@@ -91,6 +91,9 @@ _PROTOS = {
     "ds_embed_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_axpy": (C.c_int, [_vp, _vp, _f, _i64, _vp]),
     "ds_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, C.c_int, _vp]),
+    "ds_adamw_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
+    "ds_convert_operand": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, _f, _vp, _i64, _i64, C.c_int, _vp]),
+    "ds_amax": (C.c_int, [_vp, _i64, _vp, _vp]),
     "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),
     "ds_denoiser_destroy": (None, [_vp]),
     "ds_denoiser_workspace_bytes": (_i64, [_vp, C.c_int]),

@@ -438,9 +438,20 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     }
 }
 
+// blockIdx.y = group (row-major operands only): A / W / C advance by the group strides -- the training step's split-K
+// dW GEMMs are `groups` K-ranges of one product (a_gstride = w_gstride = K per group, partial results c_gstride apart)
 template <int BM, int BN, int AMODE>
 __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    if (AMODE == 0) {                     // blockIdx.y is 0 in an ungrouped launch
+        GemmParams q = p;
+        const size_t g = blockIdx.y;
+        q.A = p.A + g * (size_t)p.a_gstride;
+        q.W = (const float*)((const _Float16*)p.W + g * (size_t)p.w_gstride);
+        q.C = p.C + g * (size_t)p.c_gstride;
+        ds_gemm_f16x2_body<BM, BN, AMODE>(q, blockIdx.x, gridDim.x, smem_dyn);
+        return;
+    }
     ds_gemm_f16x2_body<BM, BN, AMODE>(p, blockIdx.x, gridDim.x, smem_dyn);
 }
 
@@ -492,7 +503,8 @@ static int launch_h2(const GemmParams& p, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE>), dim3(tiles), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE>), dim3(tiles, AMODE == 0 && p.groups > 1 ? p.groups : 1),
+                       dim3(256), lds, s, p);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -577,6 +589,9 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(!p.c_split || p.N % 8 == 0, "packed output needs N % 8 == 0");
     DS_CHECK_ARG(p.act == DS_ACT_NONE || p.act == DS_ACT_GELU2, "unsupported activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
+    DS_CHECK_ARG(p.groups <= 1 || (!p.a_split && !p.c_split && p.store == DS_STORE_ROW && !p.R && !p.bias &&
+                                   p.a_gstride % 4 == 0 && p.w_gstride % 8 == 0 && p.c_gstride % 4 == 0),
+                 "groups: row-major operands, plain row store, no bias / residual, 16-byte aligned group strides");
     // Full-batch denoiser GEMMs (packed operands, one sample = 265 rows, N in 256-column tiles, a grid of whole
     // rounds of the 256 CUs): the per-sample ping-pong program of gemm_f16x2_ps.hip.  force_tile(9) takes it for
     // every shape it can compute (tests: small batches), force_tile(0 / 1 / 2) never.
@@ -592,7 +607,7 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     if (g_force_tile_h >= 0 && g_force_tile_h <= 2) {
         best = g_force_tile_h;
     } else {
-        const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.groups > 1 ? p.groups : 1);
         // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups
         best = t128 >= (p.a_split ? 1000 : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
     }

@@ -224,3 +224,158 @@ extern "C" int ds_axpy(float* y, const float* x, float a, long long n, ds_stream
     return 0;
 }
 
+
+// ---- operand preparation for the training step's split GEMMs (modeling/train.py, precision "f16x2") ---------------------
+// dst = scale * src  or  scale * src^T, written either as fp32 or as the two row-major fp16 planes (hi, lo) that
+// ds_gemm_f16x2 takes as its W operand.  The destination has drows rows of ld_dst elements: columns [0, dvalid) carry
+// data, columns [dvalid, ld_dst) are written as zeros (the GEMM's K granule / the split-K padding).  One kernel for the
+// four uses of the backward (dX: W^T planes;  dW: X^T planes and dY^T in fp32) and for the forward's weight planes, so
+// that no torch transpose / pad / cast and no host-side scale search sits between two GEMMs.
+//   non-transposed: a thread converts 8 consecutive elements of a row (2 x 16-byte loads, one 16-byte store per plane)
+//   transposed:     64 x 64 tiles through LDS (rows padded to 65 words: conflict-free both ways); 8 consecutive lanes
+//                   write one 128-byte (fp16) / 256-byte (fp32) run of a destination row
+typedef _Float16 tr_h8 __attribute__((ext_vector_type(8)));
+
+template <bool F16>
+__device__ __forceinline__ void tr_store8(const float (&v)[8], void* dst, long long idx, long long plane) {
+    if (F16) {
+        tr_h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hi[e] = ds_split_hi(v[e]);
+            lo[e] = ds_split_lo(v[e], hi[e]);
+        }
+        _Float16* d = (_Float16*)dst + idx;
+        *(tr_h8*)d = hi;
+        *(tr_h8*)(d + plane) = lo;
+    } else {
+        float* d = (float*)dst + idx;
+        *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void ds_convert_rows_kernel(const float* __restrict__ src, int rows, int cols,
+                                                              long long ld_src, float scale, void* __restrict__ dst,
+                                                              long long ld_dst, long long plane) {
+    const int chunks = (int)(ld_dst >> 3);
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= (long long)rows * chunks) return;
+    const int r = (int)(w / chunks), c0 = (int)(w - (long long)r * chunks) * 8;
+    float v[8];
+    const float* s = src + (size_t)r * ld_src + c0;
+    if (c0 + 8 <= cols && (((uintptr_t)s) & 15) == 0) {
+        const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e] * scale; v[4 + e] = b[e] * scale; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c0 + e < cols ? s[e] * scale : 0.f;
+    }
+    tr_store8<F16>(v, dst, (long long)r * ld_dst + c0, plane);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void ds_convert_transpose_kernel(const float* __restrict__ src, int rows, int cols,
+                                                                   long long ld_src, float scale, void* __restrict__ dst,
+                                                                   long long ld_dst, long long plane) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;     // source tile; destination rows c0.., columns r0..
+    const int tid = threadIdx.x;
+    {
+        const int c = tid & 63;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = (tid >> 6) + 4 * it;
+            t[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * ld_src + c0 + c] * scale : 0.f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int w = tid + 256 * it, chunk = w & 7, cl = w >> 3;        // destination row c0 + cl, columns r0 + 8 chunk ..
+        if (c0 + cl >= cols || r0 + chunk * 8 >= ld_dst) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t[chunk * 8 + e][cl];
+        tr_store8<F16>(v, dst, (long long)(c0 + cl) * ld_dst + r0 + chunk * 8, plane);
+    }
+}
+
+// dst_f16 != 0: dst = fp16 planes [2][drows][ld_dst] (plane halves apart), else fp32 [drows][ld_dst];
+// drows = transpose ? cols : rows.  ld_dst % 8 == 0 and >= the number of valid destination columns.
+extern "C" int ds_convert_operand(const float* src, int rows, int cols, long long ld_src, int transpose, float scale,
+                                  void* dst, long long ld_dst, long long plane, int dst_f16, ds_stream_t stream) {
+    DS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols, "bad arguments");
+    DS_CHECK_ARG(ld_dst % 8 == 0 && ld_dst >= (transpose ? rows : cols), "ld_dst: a multiple of 8 covering the valid columns");
+    DS_CHECK_ARG(((uintptr_t)dst & 15) == 0 && (!dst_f16 || (plane % 8 == 0 && plane >= (long long)(transpose ? cols : rows) * ld_dst)),
+                 "dst alignment / plane stride");
+    hipStream_t s = (hipStream_t)stream;
+    if (!transpose) {
+        const long long work = (long long)rows * (ld_dst >> 3);
+        const dim3 grid((unsigned)((work + 255) / 256));
+        if (dst_f16) hipLaunchKernelGGL(ds_convert_rows_kernel<true>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, dst, ld_dst, plane);
+        else hipLaunchKernelGGL(ds_convert_rows_kernel<false>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, dst, ld_dst, plane);
+    } else {
+        // tiles over [0, ld_dst) source rows (rows past `rows` produce the zero padding) x the source columns
+        const dim3 grid((unsigned)((ld_dst + 63) / 64), (unsigned)((cols + 63) / 64));
+        if (dst_f16) hipLaunchKernelGGL(ds_convert_transpose_kernel<true>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, dst, ld_dst, plane);
+        else hipLaunchKernelGGL(ds_convert_transpose_kernel<false>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, dst, ld_dst, plane);
+    }
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- max |x| into *out (caller zeroes it): non-negative floats order like their bit patterns -------------------------
+__global__ __launch_bounds__(256) void ds_amax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float a = fabsf(x[i]);
+        m = a > m ? a : m;                    // NaN never wins: a calibration quantity, not a validity check
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float other = __shfl_xor(m, o);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+extern "C" int ds_amax(const float* x, long long n, float* out, ds_stream_t stream) {
+    DS_CHECK_ARG(x && out && n > 0, "bad arguments");
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(ds_amax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       (unsigned*)out);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- AdamW with the step's scalars in device memory: hyper = { lr, 1 - beta1^step, sqrt(1 - beta2^step), grad_scale } ----
+// (a captured hipGraph replays the same kernel arguments every iteration; the learning rate, the bias corrections and
+// the clip coefficient of the iteration are therefore read from a 4-float device buffer the host refreshes)
+__global__ __launch_bounds__(256) void ds_adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, long long n,
+                                                           const float* __restrict__ hyper, float b1, float b2, float eps,
+                                                           float wd) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2];
+    const float gi = g[i] * hyper[3];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float pi = p[i] * (1.f - lr * wd);
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+    p[i] = pi;
+}
+
+extern "C" int ds_adamw_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
+                            float beta2, float eps, float weight_decay, ds_stream_t stream) {
+    DS_CHECK_ARG(p && g && m && v && hyper && n > 0, "bad arguments");
+    hipLaunchKernelGGL(ds_adamw_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       hyper, beta1, beta2, eps, weight_decay);
+    DS_CHECK_LAUNCH();
+    return 0;
+}

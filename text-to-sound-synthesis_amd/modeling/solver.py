@@ -225,3 +225,32 @@ class Solver:
             self.clip_grad_norm.load_state_dict(state["clip_grad_norm"])
         if self.ema is not None and "ema" in state:
             self.ema.load_state_dict(state["ema"])
+
+
+class GraphSolver:
+    """`Solver.step` for one GPU with  gradients -> global-norm clip -> AdamW  replayed as ONE hipGraph
+    (`TrainStep.capture`): per iteration the host copies the batch into the graph's static tensors, writes four scalars
+    (lr, the two bias corrections, -- the clip coefficient is computed inside the graph) and launches the graph; the LR
+    schedule and the EMA stay host-driven, in the reference's order (engine/solver_spec.py:308-331).  The graph is
+    captured on the first batch (shapes are fixed from then on)."""
+
+    def __init__(self, train_step, lr=3.0e-6, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, scheduler=None,
+                 clip_grad_norm=None, ema=None):
+        self.train_step, self.lr = train_step, float(lr)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.scheduler, self.clip_grad_norm, self.ema = scheduler, clip_grad_norm, ema
+        self.iteration_graph = None
+        self.last_iter = -1
+
+    def step(self, *batch):
+        if self.iteration_graph is None:
+            max_norm = self.clip_grad_norm.max_norm if self.clip_grad_norm is not None else None
+            self.iteration_graph = self.train_step.capture(*batch, betas=self.betas, eps=self.eps,
+                                                           weight_decay=self.weight_decay, max_norm=max_norm)
+        out = self.iteration_graph(*batch, lr=self.lr)
+        self.last_iter += 1
+        if self.scheduler is not None:
+            self.lr = self.scheduler.step(out["loss"])
+        if self.ema is not None:
+            self.ema.update(iteration=self.last_iter)
+        return {"loss": out["loss"], "lr": self.lr, "grad_norm": out["grad_norm"]}

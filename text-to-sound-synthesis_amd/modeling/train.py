@@ -1,23 +1,39 @@
-"""Training step of the denoiser on the HIP kernels (scope row 8f-3).  The linear layers -- forward, dX = dY W and
-dW = dY^T X, 98 % of the step's flops -- run on the exact-fp32 MFMA GEMM (default) or, with
-`TrainStep(precision="f16x2")`, on the fp32-class 3-pass fp16 split GEMM (`ds_gemm_f16x2`, loader-split A with the
-gradients rescaled by an exact power of two into fp16's range, fp32 accumulate).  Measured on MI355X at the
-reference's batch 20 (tools/bench_train.py, profiles/r02_bench_train_*.json): 4.06 it/s fp32, 3.51 it/s f16x2 -- the
-split GEMMs themselves are ~2x faster, but this host-composed step re-splits weights and transposed activations with
-torch ops and a host sync per GEMM, and at M = 5300 rows that overhead outweighs the gain.  Worst per-tensor gradient
-error against autograd through the oracle: 4.7e-6 (fp32), 6.9e-5 (f16x2).  Attention, norms and the loss tail are exact
-fp32 in both modes.
+"""Training step of the denoiser on the HIP kernels (scope row 8f-3).
 
     loss, grads = TrainStep(model.transformer).loss_and_grads(x0, cond_emb, t, pt, noise)
 
 follows DiffusionTransformer._train_loss / forward (diffusion_transformer.py:408-476,539-577) and what
-`loss.backward()` produces for every parameter of `Text2ImageTransformer` (engine/solver_spec.py back-propagates
-exactly this).  Every GEMM-shaped contraction of the forward and the backward runs on the fp32-MFMA gather-GEMM
-(`ds_gemm`), the row / elementwise pieces on csrc/train.hip, norm.hip and sampler.hip; torch is used for memory and
-for layout copies (transposes, head split / merge, zero padding to the GEMM's 32-wide K granule) and for the
-100-row timestep-embedding table, which is weight preparation.  Nothing here is tuned: the packed-plane / LDS-DMA
-machinery of the sampling path is not used, activations are kept in fp32, attention probabilities are materialised.
+`loss.backward()` produces for every parameter of `Text2ImageTransformer` (engine/solver_spec.py:308-331 back-propagates
+exactly this), without an autograd graph: the forward keeps the activations the backward needs, every nn.Linear
+contributes three GEMMs (y = x W^T, dX = dY W, dW = dY^T X -- 98 % of the step's flops), the row / elementwise
+pieces run on csrc/train.hip, norm.hip and sampler.hip.  The self-attention Q | K | V projections and the
+cross-attention K | V projections are fused into one linear each (one GEMM of N = 3D / 2D instead of three / two).
+
+Two GEMM backends (`TrainStep(precision=...)`), both behind the same step:
+
+  "fp32"   exact-fp32 MFMA (`ds_gemm`); transposed / padded operands are made by torch.  The reference arithmetic.
+  "f16x2"  the fp32-class 3-pass fp16 split GEMM (`ds_gemm_f16x2`, fp32 A split by the loader, W operand = two fp16
+           planes) with NOTHING on the host between two launches:
+             * weights are split once per step by `ds_convert_operand` into W planes (forward) and W^T planes (dX), with a
+               per-matrix power-of-two pre-scale refreshed every `rescale_interval` steps (weights move slowly);
+             * dW = dY^T X takes dY^T (fp32) and X^T (planes) from the same kernel (transpose + zero padding fused) and
+               runs as a split-K launch (`groups` K-ranges fill the chip: a 1024 x 1024 dW is only 64 tiles) whose partial
+               sums `ds_colsum` adds in a fixed order;
+             * the gradients' magnitude (|dY| ~ 1e-8 .. 1e-2, far below fp16's range) is handled by ONE loss scale 2^k
+               for the whole backward -- d logits is multiplied by it, every dX carries it, the dW GEMMs' epilogue and
+               one multiply over the small gradients take it out again; k comes from a calibration pass (max |dY| over
+               every GEMM input of one backward, one host sync) -- not from a max + sync in front of every GEMM.
+               A split value keeps an absolute precision of 2^-25, so anything above 2^-3 after scaling is fp32-class;
+               the calibration puts the largest |dY| at 2^12..2^13.
+           The step then has no host synchronisation at all and can be captured in a hipGraph (`capture`): one graph
+           launch per iteration instead of ~3000 kernel launches from Python.
+
+Attention (scores, softmax, PV and their backward from the materialised probabilities), the norms and the loss tail are
+exact fp32 in both modes.  Worst per-tensor gradient error against autograd through the oracle, all 63 tensors of the
+2-layer test model: see tests/test_hip_train_kernels.py.
 """
+import math
+
 import torch
 
 from .. import _lib
@@ -25,43 +41,8 @@ from .. import _lib
 L_ = _lib
 
 
-_SPLIT = [True]      # set by TrainStep: linear-layer GEMMs on the 3-pass fp16 split (default) or on the fp32 MFMA
-
-
-def _pow2_into_fp16_range(a):
-    """(a * 2^k, 2^-k) with k an integer that puts max|a| into [2^9, 2^10) when it is outside [2^-6, 2^13) -- the
-    split GEMM's A operand is decomposed into two fp16 planes and needs its values inside fp16's range with headroom;
-    gradients (|dY| ~ 1e-8 .. 1e-3) are far below it.  Multiplying by a power of two is exact."""
-    import math
-    mx = float(a.abs().max())
-    if mx == 0.0 or not math.isfinite(mx) or 2.0 ** -6 <= mx < 2.0 ** 13:
-        return a, 1.0
-    k = 9 - math.floor(math.log2(mx))
-    return a * (2.0 ** k), 2.0 ** (-k)
-
-
-def _mm_nt(A, Wm, out, M, N, K, bias=None, R=None, act=L_.ACT_NONE):
-    """out[M, N] = act(A[M, K] Wm[N, K]^T + bias) + R"""
-    if not _SPLIT[0]:
-        return L_.gemm(A, Wm, out, M, N, K, bias=bias, R=R, act=act)
-    W2, sc = L_.split_f16x2(Wm)
-    A2, sa = _pow2_into_fp16_range(A)
-    return L_.gemm(A2, W2, out, M, N, K, bias=bias, R=R, act=act, split2=sc * sa)
-
-
-def _lin_fwd(x, W, b, R=None, act=L_.ACT_NONE):
-    M, K = x.shape
-    N = W.shape[0]
-    y = torch.empty(M, N, device=x.device)
-    _mm_nt(x, W, y, M, N, K, bias=b, R=R, act=act)
-    return y
-
-
-def _pad_rows_t(a, kp):
-    """a [M, C] -> a^T zero-padded to [C, kp] (kp = M rounded up to the GEMM's K granule)"""
-    out = torch.zeros(a.shape[1], kp, device=a.device)
-    out[:, :a.shape[0]] = a.t()
-    return out
+def _ceil(a, b):
+    return (a + b - 1) // b * b
 
 
 def _colsum(x, G=1, R=None, accumulate_into=None):
@@ -72,25 +53,121 @@ def _colsum(x, G=1, R=None, accumulate_into=None):
     return out
 
 
-def _lin_bwd(x, W, dy, need_dx=True):
-    """y = x W^T + b  ->  (dx = dy W, dW = dy^T x, db = column sums of dy)"""
-    M, K = x.shape
-    N = W.shape[0]
-    dx = None
-    if need_dx:
-        dx = torch.empty(M, K, device=x.device)
-        Wt = W.t().contiguous()                                   # [K, N]: rows are K-contiguous operands of the GEMM
-        Np = (N + 31) // 32 * 32
-        if Np != N:
-            Wt = torch.nn.functional.pad(Wt, (0, Np - N))
-            dyp = torch.nn.functional.pad(dy, (0, Np - N))
-        else:
-            dyp = dy
-        _mm_nt(dyp.contiguous(), Wt.contiguous(), dx, M, K, Np)
-    Mp = (M + 31) // 32 * 32
-    dW = torch.empty(N, K, device=x.device)
-    _mm_nt(_pad_rows_t(dy, Mp), _pad_rows_t(x, Mp), dW, N, K, Mp)
-    return dx, dW, _colsum(dy)[0]
+def _convert(src, rows, cols, ld_src, transpose, scale, dst, ld_dst, plane, f16):
+    L_.check(L_.lib().ds_convert_operand(L_.ptr(src), rows, cols, ld_src, int(transpose), float(scale), L_.ptr(dst), ld_dst,
+                                         plane, int(f16), L_.stream()))
+    return dst
+
+
+class _Linear:
+    """One (possibly fused) nn.Linear of the step: W [N][K] fp32, bias [N], plus what the GEMM backend derived from W."""
+
+    def __init__(self, key, W, b):
+        self.key, self.W, self.b = key, W, b
+        self.N, self.K = W.shape
+        self.extra = {}
+
+
+class _Fp32Gemm:
+    """Backend "fp32": every GEMM on the exact-fp32 MFMA kernel; transposes and zero padding by torch."""
+    name = "fp32"
+
+    def prepare(self, lin):
+        pass
+
+    def fwd(self, lin, x, R=None):
+        M = x.shape[0]
+        y = torch.empty(M, lin.N, device=x.device)
+        return L_.gemm(x, lin.W, y, M, lin.N, lin.K, bias=lin.b, R=R)
+
+    def dx(self, lin, dy):
+        M, N, K = dy.shape[0], lin.N, lin.K
+        Np = _ceil(N, 32)
+        Wt = lin.extra.get("Wt")
+        if Wt is None:                                  # [K][Np]: rows are K-contiguous operands of the GEMM
+            Wt = torch.zeros(K, Np, device=dy.device)
+            Wt[:, :N] = lin.W.t()
+            lin.extra["Wt"] = Wt
+        dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
+        out = torch.empty(M, K, device=dy.device)
+        return L_.gemm(dyp.contiguous(), Wt, out, M, K, Np)
+
+    def dw(self, lin, x, dy, inv_scale):
+        M = x.shape[0]
+        Mp = _ceil(M, 32)
+
+        def pad_t(a):                                   # a [M][C] -> a^T zero-padded to [C][Mp]
+            out = torch.zeros(a.shape[1], Mp, device=a.device)
+            out[:, :M] = a.t()
+            return out
+        dW = torch.empty(lin.N, lin.K, device=x.device)
+        L_.gemm(pad_t(dy), pad_t(x), dW, lin.N, lin.K, Mp)
+        if inv_scale != 1.0:
+            dW.mul_(inv_scale)
+        return dW
+
+
+class _SplitGemm:
+    """Backend "f16x2": every linear-layer GEMM on the 3-pass fp16 split kernel, operands prepared on the device."""
+    name = "f16x2"
+
+    def __init__(self):
+        self.wexp = {}              # key -> s: the weight is split as W * 2^s (max |W| 2^s in [2^13, 2^14))
+
+    def refresh_scales(self, lins):
+        """One host sync for all matrices: s = 13 - floor(log2 max|W|)."""
+        mx = torch.stack([l.W.detach().abs().max() for l in lins]).tolist()
+        for l, m in zip(lins, mx):
+            self.wexp[l.key] = 0 if (m == 0.0 or not math.isfinite(m)) else 13 - math.floor(math.log2(m))
+
+    def prepare(self, lin):
+        s = self.wexp[lin.key]
+        N, K = lin.N, lin.K
+        Np = _ceil(N, 32)
+        lin.extra["osc"] = 2.0 ** (-s)
+        lin.extra["Wf"] = _convert(lin.W, N, K, K, 0, 2.0 ** s, torch.empty(2, N, K, dtype=torch.int16, device=lin.W.device),
+                                   K, N * K, 1)
+        lin.extra["Wt"] = _convert(lin.W, N, K, K, 1, 2.0 ** s, torch.empty(2, K, Np, dtype=torch.int16, device=lin.W.device),
+                                   Np, K * Np, 1)
+
+    def fwd(self, lin, x, R=None):
+        M = x.shape[0]
+        y = torch.empty(M, lin.N, device=x.device)
+        return L_.gemm(x, lin.extra["Wf"], y, M, lin.N, lin.K, bias=lin.b, R=R, split2=lin.extra["osc"])
+
+    def dx(self, lin, dy):
+        M, N, K = dy.shape[0], lin.N, lin.K
+        Np = _ceil(N, 32)
+        if Np != N:                                     # K granule of the GEMM: zero-padded copy (not hit by this network)
+            dy = _convert(dy, M, N, N, 0, 1.0, torch.empty(M, Np, device=dy.device), Np, 0, 0)
+        out = torch.empty(M, K, device=dy.device)
+        return L_.gemm(dy, lin.extra["Wt"], out, M, K, Np, split2=lin.extra["osc"])
+
+    @staticmethod
+    def split_k(N, K):
+        """K-ranges of a dW launch: enough 128 x 128 tiles for about two rounds of the 512 resident workgroups."""
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        s = 1
+        while s < 8 and tiles * s * 2 <= 1024:
+            s *= 2
+        return s
+
+    def dw(self, lin, x, dy, inv_scale):
+        M, N, K = x.shape[0], lin.N, lin.K
+        S = self.split_k(N, K)
+        Mp = _ceil(M, 32 * S)
+        dev = x.device
+        At = _convert(dy, M, N, N, 1, 1.0, torch.empty(N, Mp, device=dev), Mp, 0, 0)                   # dY^T, fp32
+        Xt = _convert(x, M, K, K, 1, 1.0, torch.empty(2, K, Mp, dtype=torch.int16, device=dev), Mp, K * Mp, 1)   # X^T planes
+        dW = torch.empty(N, K, device=dev)
+        if S == 1:
+            return L_.gemm(At, Xt, dW, N, K, Mp, split2=inv_scale, w_plane=K * Mp)
+        part = torch.empty(S, N * K, device=dev)
+        Kc = Mp // S
+        L_.gemm(At, Xt, part, N, K, Kc, lda=Mp, ldw=Mp, ldc=K, groups=S, a_gstride=Kc, w_gstride=Kc, c_gstride=N * K,
+                split2=inv_scale, w_plane=K * Mp)
+        L_.check(L_.lib().ds_colsum(L_.ptr(part), L_.ptr(dW), 1, S, N * K, N * K, 0, 0, L_.stream()))
+        return dW
 
 
 def _norm_fwd(x, mode, L, table=None, t=None, gamma=None, beta=None):
@@ -113,14 +190,16 @@ def _norm_bwd(x, dy, mode, L, table=None, t=None, gamma=None):
 
 
 def _heads(x, B, Lx, H, Lp):
-    """[B*Lx, H*64] -> [B*H, Lp, 64] zero-padded"""
+    """[B*Lx, H*64] (a column range of a fused projection is fine: any row stride) -> [B*H, Lp, 64] zero-padded"""
     out = torch.zeros(B * H, Lp, 64, device=x.device)
-    out[:, :Lx] = x.view(B, Lx, H, 64).permute(0, 2, 1, 3).reshape(B * H, Lx, 64)
+    out.view(B, H, Lp, 64)[:, :, :Lx].copy_(x.view(B, Lx, H, 64).permute(0, 2, 1, 3))
     return out
 
 
-def _merge(x4, B, Lx, H):
-    return x4[:, :Lx].reshape(B, H, Lx, 64).permute(0, 2, 1, 3).reshape(B * Lx, H * 64).contiguous()
+def _merge_into(out, x4, B, Lx, H):
+    """[B*H, Lp, 64] -> out [B*Lx, H*64] (any row stride)"""
+    out.view(B, Lx, H, 64).copy_(x4.view(B, H, -1, 64)[:, :, :Lx].permute(0, 2, 1, 3))   # .view: never a silent copy
+    return out
 
 
 class _Attn:
@@ -128,7 +207,7 @@ class _Attn:
 
     def __init__(self, q, k, v, B, Lq, Lk, H):
         self.B, self.Lq, self.Lk, self.H = B, Lq, Lk, H
-        self.Lqp, self.Lkp = (Lq + 31) // 32 * 32, (Lk + 31) // 32 * 32
+        self.Lqp, self.Lkp = _ceil(Lq, 32), _ceil(Lk, 32)
         G = B * H
         self.q4, self.k4, self.v4 = _heads(q, B, Lq, H, self.Lqp), _heads(k, B, Lk, H, self.Lkp), _heads(v, B, Lk, H, self.Lkp)
         S = torch.empty(G, self.Lqp, self.Lkp, device=q.device)
@@ -140,9 +219,10 @@ class _Attn:
         o4 = torch.empty(G, self.Lqp, 64, device=q.device)
         L_.gemm(self.P, vT, o4, self.Lqp, 64, self.Lkp, groups=G, a_gstride=self.Lqp * self.Lkp, w_gstride=64 * self.Lkp,
                 c_gstride=self.Lqp * 64)
-        self.out = _merge(o4, B, Lq, H)
+        self.out = _merge_into(torch.empty(B * Lq, H * 64, device=q.device), o4, B, Lq, H)
 
-    def backward(self, dO):
+    def backward(self, dO, dq_out, dk_out, dv_out):
+        """dO [B*Lq, H*64] -> writes dQ / dK / dV into the given [rows, H*64] views (column ranges of a fused gradient)"""
         B, Lq, Lk, H, Lqp, Lkp = self.B, self.Lq, self.Lk, self.H, self.Lqp, self.Lkp
         G = B * H
         dO4 = _heads(dO, B, Lq, H, Lqp)
@@ -160,28 +240,92 @@ class _Attn:
         dK4 = torch.empty(G, Lkp, 64, device=dev)                                   # dK = dS^T Q
         L_.gemm(dS.transpose(1, 2).contiguous(), self.q4.transpose(1, 2).contiguous(), dK4, Lkp, 64, Lqp, groups=G,
                 a_gstride=Lkp * Lqp, w_gstride=64 * Lqp, c_gstride=Lkp * 64)
-        return _merge(dQ4, B, Lq, H), _merge(dK4, B, Lk, H), _merge(dV4, B, Lk, H)
+        _merge_into(dq_out, dQ4, B, Lq, H)
+        _merge_into(dk_out, dK4, B, Lk, H)
+        _merge_into(dv_out, dV4, B, Lk, H)
 
 
 class TrainStep:
-    def __init__(self, diffusion_transformer, precision="fp32"):
+    def __init__(self, diffusion_transformer, precision="fp32", rescale_interval=100):
         assert precision in ("f16x2", "fp32")
         self.dt = diffusion_transformer
         self.tr = diffusion_transformer.transformer
         self.precision = precision
+        self.gemm = _SplitGemm() if precision == "f16x2" else _Fp32Gemm()
+        self.rescale_interval = rescale_interval
+        self.loss_scale_exp = None if precision == "f16x2" else 0    # k of the loss scale 2^k; None: calibrate first
+        self.calibrated_amax = None
+        self._steps = 0
+        self._capturing = False     # set by GraphedIteration while a hipGraph records the step: no host syncs then
+
+    # ---- the step's linears ------------------------------------------------------------------------------------------
+    def _linears(self):
+        """[(per-block dict), ..., logits]: fused weights are concatenated here once per step (query | key | value rows)."""
+        tr = self.tr
+        out = []
+        for li, blk in enumerate(tr.blocks):
+            a1, a2 = blk.attn1, blk.attn2
+            p = "b%d." % li
+            out.append({
+                "qkv1": _Linear(p + "qkv1", torch.cat((a1.query.weight, a1.key.weight, a1.value.weight)).detach(),
+                                torch.cat((a1.query.bias, a1.key.bias, a1.value.bias)).detach()),
+                "proj1": _Linear(p + "proj1", a1.proj.weight.detach(), a1.proj.bias.detach()),
+                "q2": _Linear(p + "q2", a2.query.weight.detach(), a2.query.bias.detach()),
+                "kv2": _Linear(p + "kv2", torch.cat((a2.key.weight, a2.value.weight)).detach(),
+                               torch.cat((a2.key.bias, a2.value.bias)).detach()),
+                "proj2": _Linear(p + "proj2", a2.proj.weight.detach(), a2.proj.bias.detach()),
+                "fc1": _Linear(p + "fc1", blk.mlp[0].weight.detach(), blk.mlp[0].bias.detach()),
+                "fc2": _Linear(p + "fc2", blk.mlp[2].weight.detach(), blk.mlp[2].bias.detach()),
+            })
+        lin = tr.to_logits[1]
+        return out, _Linear("logits", lin.weight.detach(), lin.bias.detach())
 
     @torch.no_grad()
     def loss_and_grads(self, x0, cond_emb, t, pt, noise):
         """x0 i64[B, L] clean tokens, cond_emb f32[B, 77, 512], t i64[B], pt f32[B] (sample_time's output), noise
         f32[B, K+1, L] uniforms for q_sample.  Returns (loss scalar as forward() reports it, {parameter name relative to
         the DiffusionTransformer: gradient}).  Gradients are those of that loss."""
-        dt, tr = self.dt, self.tr
-        _SPLIT[0] = self.precision == "f16x2"
+        if self.loss_scale_exp is None:
+            self.calibrate(x0, cond_emb, t, pt, noise)
+        return self._run(x0, cond_emb, t, pt, noise, calibrating=False)
+
+    @torch.no_grad()
+    def calibrate(self, x0, cond_emb, t, pt, noise):
+        """Loss scale of the "f16x2" backend from one unscaled backward on this batch: the largest |dY| that enters a GEMM
+        is put at 2^12..2^13 (fp16 overflows at 2^16; a split value keeps 2^-25 absolutely).  One host sync.  The
+        importance-sampling statistics (Lt_history / Lt_count) are not touched."""
+        if self.precision != "f16x2":
+            return 0
+        self.loss_scale_exp = 0
+        amax = torch.zeros(1, device=x0.device)
+        self._run(x0, cond_emb, t, pt, noise, calibrating=True, amax=amax)
+        m = float(amax.item())
+        self.calibrated_amax = m
+        self.loss_scale_exp = 0 if (m == 0.0 or not math.isfinite(m)) else 12 - math.floor(math.log2(m))
+        return self.loss_scale_exp
+
+    def _run(self, x0, cond_emb, t, pt, noise, calibrating, amax=None):
+        dt, tr, G_ = self.dt, self.tr, self.gemm
         dev = x0.device
         B, Lx = x0.shape
         D, H, K = tr.n_embd, tr.n_head, tr.num_codes
         M = B * Lx
         T = dt.num_timesteps
+        blocks, lin_logits = self._linears()
+        all_lins = [l for b in blocks for l in b.values()] + [lin_logits]
+        if self.precision == "f16x2" and (not G_.wexp or (self._steps % self.rescale_interval == 0 and not calibrating
+                                                           and not self._capturing)):
+            G_.refresh_scales(all_lins)
+        for l in all_lins:
+            G_.prepare(l)
+        scale = 2.0 ** self.loss_scale_exp
+        inv = 1.0 / scale
+
+        def seen(dy):                                   # calibration: every gradient that is about to enter a GEMM
+            if amax is not None:
+                L_.check(L_.lib().ds_amax(L_.ptr(dy), dy.numel(), L_.ptr(amax), L_.stream()))
+            return dy
+
         sched = dt._schedule_table()
         xt = dt.q_sample_tokens(x0.contiguous(), t, noise)
         emb = tr.content_emb
@@ -191,39 +335,36 @@ class TrainStep:
         cond = cond_emb.reshape(-1, cond_emb.shape[-1]).float().contiguous()
         Lc = cond_emb.shape[1]
         saved = []
-        for blk in tr.blocks:
+        for blk, ls in zip(tr.blocks, blocks):
             s = {"x0": x}
             s["tab1"] = blk.ln1.table()
             h = _norm_fwd(x, 0, Lx, table=s["tab1"], t=t)
-            a1 = blk.attn1
             s["h1"] = h
-            q, k, v = _lin_fwd(h, a1.query.weight, a1.query.bias), _lin_fwd(h, a1.key.weight, a1.key.bias), \
-                _lin_fwd(h, a1.value.weight, a1.value.bias)
-            s["att1"] = _Attn(q, k, v, B, Lx, Lx, H)
-            x = _lin_fwd(s["att1"].out, a1.proj.weight, a1.proj.bias, R=x)
+            qkv = G_.fwd(ls["qkv1"], h)                                             # [M][3D]: q | k | v
+            s["att1"] = _Attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, Lx, Lx, H)
+            x = G_.fwd(ls["proj1"], s["att1"].out, R=x)
             s["x1"] = x
             s["tab2"] = blk.ln1_1.table()
             h = _norm_fwd(x, 0, Lx, table=s["tab2"], t=t)
             s["h2"] = h
-            a2 = blk.attn2
-            q = _lin_fwd(h, a2.query.weight, a2.query.bias)
-            k, v = _lin_fwd(cond, a2.key.weight, a2.key.bias), _lin_fwd(cond, a2.value.weight, a2.value.bias)
-            s["att2"] = _Attn(q, k, v, B, Lx, Lc, H)
-            x = _lin_fwd(s["att2"].out, a2.proj.weight, a2.proj.bias, R=x)
+            q = G_.fwd(ls["q2"], h)
+            kv = G_.fwd(ls["kv2"], cond)                                            # [B*Lc][2D]: k | v
+            s["att2"] = _Attn(q, kv[:, :D], kv[:, D:], B, Lx, Lc, H)
+            x = G_.fwd(ls["proj2"], s["att2"].out, R=x)
             s["x2"] = x
             h = _norm_fwd(x, 1, Lx, gamma=blk.ln2.weight, beta=blk.ln2.bias)
             s["h3"] = h
-            u = _lin_fwd(h, blk.mlp[0].weight, blk.mlp[0].bias)
+            u = G_.fwd(ls["fc1"], h)
             s["u"] = u
             gact = torch.empty_like(u)
             L_.check(L_.lib().ds_gelu2(L_.ptr(u), None, L_.ptr(gact), u.numel(), L_.stream()))
             s["g"] = gact
-            x = _lin_fwd(gact, blk.mlp[2].weight, blk.mlp[2].bias, R=x)
+            x = G_.fwd(ls["fc2"], gact, R=x)
             saved.append(s)
         xf = x
-        lnf, lin = tr.to_logits[0], tr.to_logits[1]
+        lnf = tr.to_logits[0]
         hf = _norm_fwd(xf, 1, Lx, gamma=lnf.weight, beta=lnf.bias)
-        logits = _lin_fwd(hf, lin.weight, lin.bias)                                  # [M, K]
+        logits = G_.fwd(lin_logits, hf)                                             # [M, K]
         # ---- loss (forward value) and d loss / d logits
         kl, nll, kl_aux = (torch.empty(B, Lx, device=dev) for _ in range(3))
         L_.check(L_.lib().ds_loss_tail(L_.ptr(logits), L_.ptr(x0), L_.ptr(xt), L_.ptr(t), L_.ptr(sched), L_.ptr(kl), L_.ptr(nll),
@@ -232,9 +373,10 @@ class TrainStep:
         weight = mask_region * dt.mask_weight[0] + (1.0 - mask_region) * dt.mask_weight[1]
         is0 = (t == 0).float()
         kl_loss = is0 * nll.sum(-1) + (1.0 - is0) * (kl * weight).sum(-1)
-        lt2 = kl_loss.pow(2)                         # importance-sampling statistics of sample_time (:452-455)
-        dt.Lt_history.scatter_(dim=0, index=t, src=(0.1 * lt2 + 0.9 * dt.Lt_history.gather(dim=0, index=t)))
-        dt.Lt_count.scatter_add_(dim=0, index=t, src=torch.ones_like(lt2))
+        if not calibrating:
+            lt2 = kl_loss.pow(2)                     # importance-sampling statistics of sample_time (:452-455)
+            dt.Lt_history.scatter_(dim=0, index=t, src=(0.1 * lt2 + 0.9 * dt.Lt_history.gather(dim=0, index=t)))
+            dt.Lt_count.scatter_add_(dim=0, index=t, src=torch.ones_like(lt2))
         vb = kl_loss / pt
         if dt.auxiliary_loss_weight != 0:
             wa = t.float() / T + 1.0 if dt.adaptive_auxiliary_loss else 1.0
@@ -246,58 +388,76 @@ class TrainStep:
                                            L_.ptr(sched), L_.ptr(dlog), B, Lx, K, T, float(dt.mask_weight[0]),
                                            float(dt.mask_weight[1]), float(dt.auxiliary_loss_weight),
                                            int(bool(dt.adaptive_auxiliary_loss)), L_.stream()))
-        dlog.mul_(norm)                                                              # loss = sum(vb) / (B L)
-        # ---- backward
-        g = {}
-        dh, g["transformer.to_logits.1.weight"], g["transformer.to_logits.1.bias"] = _lin_bwd(hf, lin.weight, dlog)
-        dx, g["transformer.to_logits.0.weight"], g["transformer.to_logits.0.bias"] = \
-            (lambda r: (r[0], r[1][0], r[2][0]))(_norm_bwd(xf, dh, 1, Lx, gamma=lnf.weight))
+        dlog.mul_(norm * scale)                                                      # loss = sum(vb) / (B L); x loss scale
+        # ---- backward (every d* below carries the loss scale; `small` collects what one multiply un-scales at the end)
+        g, small = {}, []
+
+        def lin_bwd(lin, xin, dy, need_dx=True):
+            seen(dy)
+            dxo = G_.dx(lin, dy) if need_dx else None
+            dW = G_.dw(lin, xin, dy, inv)
+            db = _colsum(dy)[0]
+            small.append(db)
+            return dxo, dW, db
+
+        dh, g["transformer.to_logits.1.weight"], g["transformer.to_logits.1.bias"] = lin_bwd(lin_logits, hf, dlog)
+        dx, dgam, dbet = _norm_bwd(xf, dh, 1, Lx, gamma=lnf.weight)
+        g["transformer.to_logits.0.weight"], g["transformer.to_logits.0.bias"] = dgam[0], dbet[0]
+        small += [dgam, dbet]
 
         def axpy(y, x_):
             L_.check(L_.lib().ds_axpy(L_.ptr(y), L_.ptr(x_), 1.0, y.numel(), L_.stream()))
 
-        def adaln_param_grads(ln, table_rows_scale, table_rows_shift, pfx):
-            """d table[t_b] rows -> emb.weight / linear.{weight, bias} through table = Linear(SiLU(emb)) (weight prep)."""
+        Tp = _ceil(T, 32)
+
+        def adaln_param_grads(ln, d_scale, d_shift, pfx):
+            """d table[t_b] rows -> emb.weight / linear.{weight, bias} through  table = Linear(SiLU(emb))  (AdaLayerNorm,
+            transformer_utils.py:134-149): dW = dtab^T silu(e), db = column sums of dtab, de = (dtab W) silu'(e)."""
             dtab = torch.zeros(T, 2 * D, device=dev)
-            dtab.index_add_(0, t, torch.cat((table_rows_scale, table_rows_shift), dim=1))
-            with torch.enable_grad():
-                e = ln.emb.weight.detach().clone().requires_grad_(True)
-                w = ln.linear.weight.detach().clone().requires_grad_(True)
-                b = ln.linear.bias.detach().clone().requires_grad_(True)
-                tab = torch.nn.functional.linear(torch.nn.functional.silu(e), w, b)
-                tab.backward(dtab)
-            g[pfx + ".emb.weight"], g[pfx + ".linear.weight"], g[pfx + ".linear.bias"] = e.grad, w.grad, b.grad
+            dtab.index_add_(0, t, torch.cat((d_scale, d_shift), dim=1))
+            dtab.mul_(inv)
+            e, w = ln.emb.weight.detach(), ln.linear.weight.detach()
+            sg = torch.sigmoid(e)
+            s_ = e * sg
+            dtabT = _convert(dtab, T, 2 * D, 2 * D, 1, 1.0, torch.empty(2 * D, Tp, device=dev), Tp, 0, 0)
+            sT = _convert(s_, T, D, D, 1, 1.0, torch.empty(D, Tp, device=dev), Tp, 0, 0)
+            dw = L_.gemm(dtabT, sT, torch.empty(2 * D, D, device=dev), 2 * D, D, Tp)
+            wT = _convert(w, 2 * D, D, D, 1, 1.0, torch.empty(D, 2 * D, device=dev), 2 * D, 0, 0)
+            ds_ = L_.gemm(dtab, wT, torch.empty(T, D, device=dev), T, D, 2 * D)
+            g[pfx + ".emb.weight"] = ds_ * (sg * (1.0 + e * (1.0 - sg)))
+            g[pfx + ".linear.weight"], g[pfx + ".linear.bias"] = dw, _colsum(dtab)[0]
 
         for li in reversed(range(len(saved))):
-            s, blk = saved[li], tr.blocks[li]
+            s, blk, ls = saved[li], tr.blocks[li], blocks[li]
             p = "transformer.blocks.%d." % li
             # x3 = x2 + fc2(gelu(fc1(ln2(x2))))
-            dgact, g[p + "mlp.2.weight"], g[p + "mlp.2.bias"] = _lin_bwd(s["g"], blk.mlp[2].weight, dx)
+            dgact, g[p + "mlp.2.weight"], g[p + "mlp.2.bias"] = lin_bwd(ls["fc2"], s["g"], dx)
             du = torch.empty_like(dgact)
             L_.check(L_.lib().ds_gelu2(L_.ptr(s["u"]), L_.ptr(dgact), L_.ptr(du), du.numel(), L_.stream()))
-            dh, g[p + "mlp.0.weight"], g[p + "mlp.0.bias"] = _lin_bwd(s["h3"], blk.mlp[0].weight, du)
+            dh, g[p + "mlp.0.weight"], g[p + "mlp.0.bias"] = lin_bwd(ls["fc1"], s["h3"], du)
             dxn, dgam, dbet = _norm_bwd(s["x2"], dh, 1, Lx, gamma=blk.ln2.weight)
             g[p + "ln2.weight"], g[p + "ln2.bias"] = dgam[0], dbet[0]
+            small += [dgam, dbet]
             axpy(dx, dxn)
             # x2 = x1 + proj2(attn2(q(ln1_1(x1)), kv(cond)))
-            a2 = blk.attn2
-            dao, g[p + "attn2.proj.weight"], g[p + "attn2.proj.bias"] = _lin_bwd(s["att2"].out, a2.proj.weight, dx)
-            dq, dk, dv = s["att2"].backward(dao)
-            dh, g[p + "attn2.query.weight"], g[p + "attn2.query.bias"] = _lin_bwd(s["h2"], a2.query.weight, dq)
-            _, g[p + "attn2.key.weight"], g[p + "attn2.key.bias"] = _lin_bwd(cond, a2.key.weight, dk, need_dx=False)
-            _, g[p + "attn2.value.weight"], g[p + "attn2.value.bias"] = _lin_bwd(cond, a2.value.weight, dv, need_dx=False)
+            dao, g[p + "attn2.proj.weight"], g[p + "attn2.proj.bias"] = lin_bwd(ls["proj2"], s["att2"].out, dx)
+            dq = torch.empty(M, D, device=dev)
+            dkv = torch.empty(B * Lc, 2 * D, device=dev)
+            s["att2"].backward(dao, dq, dkv[:, :D], dkv[:, D:])
+            dh, g[p + "attn2.query.weight"], g[p + "attn2.query.bias"] = lin_bwd(ls["q2"], s["h2"], dq)
+            _, dWkv, dbkv = lin_bwd(ls["kv2"], cond, dkv, need_dx=False)
+            g[p + "attn2.key.weight"], g[p + "attn2.value.weight"] = dWkv[:D], dWkv[D:]
+            g[p + "attn2.key.bias"], g[p + "attn2.value.bias"] = dbkv[:D], dbkv[D:]
             dxn, dsc, dsh = _norm_bwd(s["x1"], dh, 0, Lx, table=s["tab2"], t=t)
             adaln_param_grads(blk.ln1_1, dsc, dsh, p + "ln1_1")
             axpy(dx, dxn)
             # x1 = x0 + proj1(attn1(qkv(ln1(x0))))
-            a1 = blk.attn1
-            dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = _lin_bwd(s["att1"].out, a1.proj.weight, dx)
-            dq, dk, dv = s["att1"].backward(dao)
-            dh, g[p + "attn1.query.weight"], g[p + "attn1.query.bias"] = _lin_bwd(s["h1"], a1.query.weight, dq)
-            dh2, g[p + "attn1.key.weight"], g[p + "attn1.key.bias"] = _lin_bwd(s["h1"], a1.key.weight, dk)
-            dh3, g[p + "attn1.value.weight"], g[p + "attn1.value.bias"] = _lin_bwd(s["h1"], a1.value.weight, dv)
-            axpy(dh, dh2)
-            axpy(dh, dh3)
+            dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["att1"].out, dx)
+            dqkv = torch.empty(M, 3 * D, device=dev)
+            s["att1"].backward(dao, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
+            dh, dWqkv, dbqkv = lin_bwd(ls["qkv1"], s["h1"], dqkv)
+            for j, nm in enumerate(("query", "key", "value")):
+                g[p + "attn1.%s.weight" % nm], g[p + "attn1.%s.bias" % nm] = dWqkv[j * D:(j + 1) * D], dbqkv[j * D:(j + 1) * D]
             dxn, dsc, dsh = _norm_bwd(s["x0"], dh, 0, Lx, table=s["tab1"], t=t)
             adaln_param_grads(blk.ln1, dsc, dsh, p + "ln1")
             axpy(dx, dxn)
@@ -309,15 +469,24 @@ class TrainStep:
         L_.check(L_.lib().ds_colsum(L_.ptr(dx), L_.ptr(dpos), Lx, B, D, Lx * D, D, 0, L_.stream()))
         Hh, Ww = emb.spatial_size
         dpos3 = dpos.view(Hh, Ww, D)
-        g["transformer.content_emb.height_emb.weight"] = _colsum(dpos3.reshape(Hh * Ww, D), Hh)       # sum over w
+        dhh = _colsum(dpos3.reshape(Hh * Ww, D), Hh)                                                    # sum over w
+        g["transformer.content_emb.height_emb.weight"] = dhh
         dw = torch.empty(Ww, D, device=dev)
         L_.check(L_.lib().ds_colsum(L_.ptr(dpos), L_.ptr(dw), Ww, Hh, D, Ww * D, D, 0, L_.stream()))   # sum over h
         g["transformer.content_emb.width_emb.weight"] = dw
+        small += [demb, dhh, dw]
+        if inv != 1.0:
+            torch._foreach_mul_(small, inv)
+        if not calibrating:
+            self._steps += 1
         return loss, g
 
+    # ---- optimizer -------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def adamw_step(self, grads, state, step, lr, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2):
-        """In-place AdamW on the parameters that have a gradient (state: dict name -> (m, v), created on first use)."""
+    def adamw_step(self, grads, state, step, lr, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, hyper=None):
+        """In-place AdamW on the parameters that have a gradient (state: dict name -> (m, v), created on first use).
+        hyper: optional f32[4] device tensor { lr, 1 - beta1^step, sqrt(1 - beta2^step), grad_scale } -- then `step` / `lr`
+        are ignored and the launch arguments do not depend on the iteration (captured graphs: `capture`)."""
         params = dict(self.dt.named_parameters())
         for name, gr in grads.items():
             p_ = params[name]
@@ -325,6 +494,96 @@ class TrainStep:
                 state[name] = (torch.zeros_like(p_), torch.zeros_like(p_))
             m, v = state[name]
             gr = gr.contiguous()
-            L_.check(L_.lib().ds_adamw(L_.ptr(p_.data), L_.ptr(gr), L_.ptr(m), L_.ptr(v), p_.numel(), lr, betas[0], betas[1],
-                                       eps, weight_decay, step, L_.stream()))
+            if hyper is None:
+                L_.check(L_.lib().ds_adamw(L_.ptr(p_.data), L_.ptr(gr), L_.ptr(m), L_.ptr(v), p_.numel(), lr, betas[0], betas[1],
+                                           eps, weight_decay, step, L_.stream()))
+            else:
+                L_.check(L_.lib().ds_adamw_dev(L_.ptr(p_.data), L_.ptr(gr), L_.ptr(m), L_.ptr(v), p_.numel(), L_.ptr(hyper),
+                                               betas[0], betas[1], eps, weight_decay, L_.stream()))
         self.tr.invalidate()       # cached weight packs / AdaLN tables are stale now (frees the native handle too)
+
+    # ---- the whole iteration as ONE hipGraph -----------------------------------------------------------------------------
+    def capture(self, x0, cond_emb, t, pt, noise, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, max_norm=None):
+        """Capture  loss_and_grads -> global-norm clip -> AdamW  (engine/solver_spec.py:308-331's order) on static copies of
+        the batch tensors into one hipGraph and return a `GraphedIteration`: `it(x0, cond_emb, t, pt, noise, lr)` copies
+        the batch in, refreshes the 4 device scalars of the update and replays -- one graph launch per training iteration.
+        Single-GPU form (the data-parallel step all-reduces between gradients and update: use the eager Solver there).
+        The loss scale and the weight pre-scales are the calibrated constants of capture time; `recapture()` refreshes them."""
+        return GraphedIteration(self, (x0, cond_emb, t, pt, noise), betas, eps, weight_decay, max_norm)
+
+
+class GraphedIteration:
+    def __init__(self, step, batch, betas, eps, weight_decay, max_norm):
+        self.step, self.betas, self.eps, self.weight_decay, self.max_norm = step, betas, eps, weight_decay, max_norm
+        self.static = [b.clone() for b in batch]
+        self.hyper = torch.zeros(4, device=batch[0].device)
+        self.opt_state = {}
+        self.iteration = 0
+        self.graph = None
+        self._capture()
+
+    @torch.no_grad()
+    def _capture(self):
+        st = self.step
+        dev = self.static[0].device
+        if st.loss_scale_exp is None:
+            st.calibrate(*self.static)
+        # warm-up on a side stream (lazy initialisation inside the library, allocator pools), with lr = 0 and every
+        # statistic restored afterwards so that the warm-up leaves no trace in the training state
+        dt = st.dt
+        keep = (dt.Lt_history.clone(), dt.Lt_count.clone(), st._steps)
+        self.hyper.copy_(torch.tensor([0.0, 1.0, 1.0, 0.0]))
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        for name, (m, v) in self.opt_state.items():
+            m.zero_()
+            v.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        st._capturing = True
+        try:
+            with torch.cuda.graph(self.graph):
+                self._body()
+        finally:
+            st._capturing = False
+        dt.Lt_history.copy_(keep[0])
+        dt.Lt_count.copy_(keep[1])
+        st._steps = keep[2]
+
+    def _body(self):
+        st = self.step
+        loss, grads = st._run(*self.static, calibrating=False)
+        tensors = list(grads.values())
+        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)))
+        if self.max_norm is not None:                  # torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), <= 1
+            self.hyper[3:4].copy_(torch.clamp(self.max_norm / (total + 1e-6), max=1.0).reshape(1))
+        st.adamw_step(grads, self.opt_state, 0, 0.0, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay,
+                      hyper=self.hyper)
+        self.loss, self.grad_norm, self.grads = loss, total, grads
+
+    def recapture(self):
+        """New calibration of the loss scale / weight pre-scales on the current static batch, then a new graph."""
+        self.step.loss_scale_exp = None
+        self.step.gemm.wexp.clear() if hasattr(self.step.gemm, "wexp") else None
+        keep_state = {k: (m.clone(), v.clone()) for k, (m, v) in self.opt_state.items()}
+        self._capture()
+        for k, (m, v) in keep_state.items():
+            self.opt_state[k][0].copy_(m)
+            self.opt_state[k][1].copy_(v)
+
+    @torch.no_grad()
+    def __call__(self, x0, cond_emb, t, pt, noise, lr):
+        for dst, src in zip(self.static, (x0, cond_emb, t, pt, noise)):
+            dst.copy_(src)
+        self.iteration += 1
+        b1, b2 = self.betas
+        self.hyper[:3].copy_(torch.tensor([lr, 1.0 - b1 ** self.iteration, math.sqrt(1.0 - b2 ** self.iteration)]))
+        if self.max_norm is None:
+            self.hyper[3:4].fill_(1.0)
+        self.graph.replay()
+        self.step._steps += 1
+        self.step.tr.invalidate()          # the replay updated the weights: cached inference packs are stale
+        return {"loss": self.loss, "grad_norm": self.grad_norm, "lr": lr}

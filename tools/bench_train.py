@@ -6,8 +6,10 @@ batch: q_sample -> 19-layer forward keeping activations -> loss -> hand-written 
   python tools/bench_train.py --batch 20 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py ...
 
-Prints one JSON line on rank 0: iterations/s, samples/s (whole job), ms per phase (loss+gradients / all-reduce / update).
-The training step is the exact-fp32, untuned first version: this tool exists to measure it.
+  python tools/bench_train.py --precision f16x2 --graph        (one GPU: the iteration replayed as one hipGraph)
+
+Prints one JSON line on rank 0: iterations/s, samples/s (whole job), ms per phase (loss+gradients / all-reduce / update;
+with --graph everything is one launch and only the total is meaningful).
 """
 import argparse
 import json
@@ -32,6 +34,7 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=("f16x2", "fp32"),
                     help="linear-layer GEMMs (forward, dX, dW): 3-pass fp16 split or exact-fp32 MFMA")
     ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
+    ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -79,12 +82,16 @@ def main():
                 times["grads"] += time.perf_counter() - t0
             return out
 
-    solver = Solver(Timed(dt, precision=args.precision), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
-                    scheduler=PlateauWarmupLR(3.0e-6, factor=0.5, patience=25000, min_lr=1.0e-6, threshold=1.0e-1,
-                                              warmup_lr=4.5e-4, warmup=1000),
-                    clip_grad_norm=GradClipWindow(0, 5000, 0.5),
-                    ema=EMA(dt, decay=0.99, update_interval=25, device=args.ema_device),
-                    allreduce=timed_allreduce if world > 1 else None)
+    sched = PlateauWarmupLR(3.0e-6, factor=0.5, patience=25000, min_lr=1.0e-6, threshold=1.0e-1, warmup_lr=4.5e-4, warmup=1000)
+    ema = EMA(dt, decay=0.99, update_interval=25, device=args.ema_device)
+    if args.graph and world == 1:
+        from text_to_sound_synthesis_amd.modeling.solver import GraphSolver
+        solver = GraphSolver(TrainStep(dt, precision=args.precision), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+                             scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema)
+    else:
+        solver = Solver(Timed(dt, precision=args.precision), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+                        scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
+                        allreduce=timed_allreduce if world > 1 else None)
 
     def one():
         t, pt = dt.sample_time(B, dev, "importance")
@@ -116,6 +123,8 @@ def main():
             "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
             "ms": {k: 1e3 * v / args.steps for k, v in times.items()},
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "graph": bool(args.graph and world == 1),
+            "loss_scale_exp": solver.train_step.loss_scale_exp,
             "config": {"workload": "BASELINE configs[4]: training step, B=%d per GPU, %d layers, K=%d" % (B, args.n_layer, args.codes),
                        "parallelism": "dp%d" % world}}))
     if world > 1:
