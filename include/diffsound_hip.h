@@ -205,6 +205,10 @@ int ds_layernorm_bwd(const float* x, const float* dy, float* dx, float* dyxn, in
 /* out[g][c] (+)= sum over R rows of x[(g*gstride) + r*ld + c]: bias / scale / per-sample AdaLN gradients */
 int ds_colsum(const float* x, float* out, int G, int R, int C, long long ld, long long gstride, int accumulate,
               ds_stream_t stream);
+/* the same sums for tall inputs (R in the thousands): rows are summed in up to 64 chunks by separate workgroups into
+ * `work` (>= G * 64 * C floats is always enough), then the chunks are added in a fixed order -- deterministic */
+int ds_colsum_ws(const float* x, float* out, int G, int R, int C, long long ld, long long gstride, int accumulate,
+                 float* work, long long work_floats, ds_stream_t stream);
 /* GELU2: dy == NULL -> out = x * sigmoid(1.702 x); else out = dy * d/dx of that */
 int ds_gelu2(const float* x, const float* dy, float* out, long long n, ds_stream_t stream);
 /* in place dS = scale * P * (dP - rowsum(dP * P)) over the first n columns of each row (attention backward) */

@@ -81,6 +81,10 @@ class Lib:
             of[g * C:(g + 1) * C] = of[g * C:(g + 1) * C] + s if accumulate else s
         return 0
 
+    def ds_colsum_ws(self, x, out, G, R, C, ld, gstride, accumulate, work, work_floats, stream):
+        assert work is not None and work_floats >= G * 64 * C          # the documented always-enough size
+        return self.ds_colsum(x, out, G, R, C, ld, gstride, accumulate, stream)
+
     def ds_convert_operand(self, src, rows, cols, ld_src, transpose, scale, dst, ld_dst, plane, dst_f16, stream):
         assert ld_dst % 8 == 0 and ld_dst >= (rows if transpose else cols) and ld_src >= cols
         v = _flat(src).as_strided((rows, cols), (ld_src, 1)) * scale

@@ -46,10 +46,16 @@ def _ceil(a, b):
 
 
 def _colsum(x, G=1, R=None, accumulate_into=None):
+    """out[g][c] = sum over the R rows of group g (tall inputs: chunked two-stage sum, ds_colsum_ws)"""
     M, C_ = x.shape
     R = M // G if R is None else R
     out = torch.empty(G, C_, device=x.device) if accumulate_into is None else accumulate_into
-    L_.check(L_.lib().ds_colsum(L_.ptr(x), L_.ptr(out), G, R, C_, C_, R * C_, int(accumulate_into is not None), L_.stream()))
+    if R >= 64:
+        work = torch.empty(G * 64 * C_, device=x.device)
+        L_.check(L_.lib().ds_colsum_ws(L_.ptr(x), L_.ptr(out), G, R, C_, C_, R * C_, int(accumulate_into is not None),
+                                       L_.ptr(work), work.numel(), L_.stream()))
+    else:
+        L_.check(L_.lib().ds_colsum(L_.ptr(x), L_.ptr(out), G, R, C_, C_, R * C_, int(accumulate_into is not None), L_.stream()))
     return out
 
 
