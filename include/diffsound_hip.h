@@ -213,6 +213,14 @@ int ds_colsum_ws(const float* x, float* out, int G, int R, int C, long long ld, 
 int ds_gelu2(const float* x, const float* dy, float* out, long long n, ds_stream_t stream);
 /* in place dS = scale * P * (dP - rowsum(dP * P)) over the first n columns of each row (attention backward) */
 int ds_softmax_bwd_rows(const float* P, float* dP, int rows, int n, int ld, float scale, ds_stream_t stream);
+/* Backward of ds_attention (FullAttention / CrossAttention cores, transformer_utils.py:43-58, :91-109) by tile-wise
+ * recomputation -- the probabilities are never stored: given Q, K, V, the forward's O and dO it writes dQ, dK, dV.
+ * Same addressing as ds_attention (rows b*L + pos, head h at columns h*64.., any row strides: column ranges of fused
+ * projections work in place); exact-fp32 MFMA; Lq, Lk <= 288.  stats: 2 * B * heads * ceil32(Lq) floats of workspace
+ * (per query: log-sum-exp of its scaled scores and delta = dO . O). */
+int ds_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                     const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                     float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
 /* d emb[tokens[m]] += dx[m] (atomic) */
 int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
 /* y += a * x, n % 4 == 0 */

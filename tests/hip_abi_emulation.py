@@ -153,6 +153,31 @@ class Lib:
         d[:, :n] = ds
         return 0
 
+    @staticmethod
+    def _heads(x, ld, B, L, H):
+        """flat storage starting at the operand's first column, row stride ld -> [B, H, L, 64] view"""
+        return _flat(x).as_strided((B, H, L, 64), (L * ld, 64, ld, 1))
+
+    def ds_attention(self, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Lq, Lk, scale, stream):
+        Q, K, V = self._heads(q, ldq, B, Lq, H), self._heads(k, ldk, B, Lk, H), self._heads(v, ldv, B, Lk, H)
+        P = torch.softmax(scale * (Q.double() @ K.double().transpose(-1, -2)), dim=-1)
+        self._heads(o, ldo, B, Lq, H).copy_((P @ V.double()).float())
+        return 0
+
+    def ds_attention_bwd(self, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, dq, lddq, dk, lddk, dv, lddv, stats, B, H, Lq, Lk,
+                         scale, stream):
+        assert stats.numel() >= 2 * B * H * ((Lq + 31) // 32 * 32)
+        with torch.enable_grad():
+            Q = self._heads(q, ldq, B, Lq, H).double().requires_grad_(True)
+            K = self._heads(k, ldk, B, Lk, H).double().requires_grad_(True)
+            V = self._heads(v, ldv, B, Lk, H).double().requires_grad_(True)
+            out = torch.softmax(scale * (Q @ K.transpose(-1, -2)), dim=-1) @ V
+            out.backward(self._heads(d_o, lddo, B, Lq, H).double())
+        self._heads(dq, lddq, B, Lq, H).copy_(Q.grad.float())
+        self._heads(dk, lddk, B, Lk, H).copy_(K.grad.float())
+        self._heads(dv, lddv, B, Lk, H).copy_(V.grad.float())
+        return 0
+
     def ds_embed(self, tok, emb, pos, out, M, L, D, stream):
         out.view(M, D).copy_(emb[tok.reshape(-1)] + pos.repeat(M // L, 1))
         return 0
@@ -214,6 +239,7 @@ def install(monkeypatch):
     fake = Lib()
     monkeypatch.setattr(_lib, "lib", lambda: fake)
     monkeypatch.setattr(_lib, "ptr", lambda t: t)
+    monkeypatch.setattr(_lib, "ptr_off", lambda t, elems: _flat(t)[elems:])
     monkeypatch.setattr(_lib, "stream", lambda: None)
     monkeypatch.setattr(_lib, "gemm", gemm)
     return fake

@@ -109,6 +109,50 @@ def test_softmax_backward_rows(L):
     assert close(dPc.cpu()[:, :n], s.grad) and (dPc[:, n:] == 0).all()
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,fusedkv", [(2, 16, 265, 265, 3), (2, 16, 265, 77, 2), (1, 2, 40, 33, 2), (3, 4, 288, 96, 2)])
+def test_attention_backward_recompute(L, B, H, Lq, Lk, fusedkv):
+    """ds_attention_bwd (two kernels, tile-wise recomputation, nothing stored between forward and backward but O):
+    dQ / dK / dV written in place into fused projection gradients, against float64 autograd of softmax(q k^T / 8) v;
+    the forward it differentiates is ds_attention on the same in-place operands."""
+    D = H * 64
+    if fusedkv == 3:            # self-attention: q | k | v columns of one [B*L][3D] buffer
+        qkv = rnd((B * Lq, 3 * D), "ab.qkv.%d" % Lq, 1.5)
+        srcs = [(qkv, 0, 3 * D), (qkv, D, 3 * D), (qkv, 2 * D, 3 * D)]
+    else:                       # cross-attention: q [B*Lq][D], k | v columns of [B*Lk][2D]
+        q, kv = rnd((B * Lq, D), "ab.q.%d" % Lq, 1.5), rnd((B * Lk, 2 * D), "ab.kv.%d" % Lk, 1.5)
+        srcs = [(q, 0, D), (kv, 0, 2 * D), (kv, D, 2 * D)]
+    dO = rnd((B * Lq, D), "ab.do.%d" % Lq, 0.7)
+
+    def heads(t, col, Lx):
+        return t[:, col:col + D].reshape(B, Lx, H, 64).permute(0, 2, 1, 3)
+    Q, K, V = (heads(t.double(), col, Lx).clone().requires_grad_(True) for (t, col, _), Lx in zip(srcs, (Lq, Lk, Lk)))
+    out = torch.softmax(0.125 * (Q @ K.transpose(-1, -2)), dim=-1) @ V
+    out.backward(heads(dO.double(), 0, Lq))
+    dev = {id(t): t.cuda() for t, _, _ in srcs}
+    ops = [(dev[id(t)], col, ld) for t, col, ld in srcs]
+    o = torch.empty(B * Lq, D, device="cuda")
+    L.check(L.lib().ds_attention(L.ptr_off(*ops[0][:2]), ops[0][2], L.ptr_off(*ops[1][:2]), ops[1][2], L.ptr_off(*ops[2][:2]),
+                                 ops[2][2], L.ptr(o), D, B, H, Lq, Lk, 0.125, L.stream()))
+    want_o = out.detach().permute(0, 2, 1, 3).reshape(B * Lq, D)
+    assert close(o.cpu(), want_o, 1e-5)
+    grads = {id(t): torch.full(t.shape, float("nan"), device="cuda") for t, _, _ in srcs}
+    gops = [(grads[id(t)], col, ld) for t, col, ld in srcs]
+    stats = torch.empty(2 * B * H * ((Lq + 31) // 32 * 32), device="cuda")
+    dOc = dO.cuda()
+    L.check(L.lib().ds_attention_bwd(
+        L.ptr_off(*ops[0][:2]), ops[0][2], L.ptr_off(*ops[1][:2]), ops[1][2], L.ptr_off(*ops[2][:2]), ops[2][2], L.ptr(o), D,
+        L.ptr(dOc), D, L.ptr_off(*gops[0][:2]), gops[0][2], L.ptr_off(*gops[1][:2]), gops[1][2], L.ptr_off(*gops[2][:2]), gops[2][2],
+        L.ptr(stats), B, H, Lq, Lk, 0.125, L.stream()))
+    for name, (gt, col, _), ref, Lx in zip("qkv", gops, (Q, K, V), (Lq, Lk, Lk)):
+        got = gt.cpu()[:, col:col + D]
+        want = ref.grad.permute(0, 2, 1, 3).reshape(B * Lx, D)
+        err = (got.double() - want).abs().max().item() / want.abs().max().item()
+        print("d%s: rel err %.2e" % (name, err))
+        assert err < 2e-5, (name, err)
+    for gt in grads.values():
+        assert not torch.isnan(gt).any()        # every column range of the fused gradient buffers was written
+
+
 def test_embedding_backward_and_colsum_strided(L):
     M, D, rows = 530, 1024, 257
     tok = synth.synth_tokens(2, 265, 256, mask_frac=0.3, key="eb.t").view(-1)
@@ -220,8 +264,8 @@ def test_amax_and_adamw_dev(L):
     assert close(pb.cpu(), pa.cpu(), 1e-6) and close(mb.cpu(), ma.cpu(), 1e-6)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
-def test_training_step_gradients_vs_oracle_autograd(precision):
+@pytest.mark.parametrize("precision,attention", [("fp32", "fused"), ("f16x2", "fused"), ("f16x2", "composed")])
+def test_training_step_gradients_vs_oracle_autograd(precision, attention):
     """The whole backward of the denoiser on the HIP kernels (modeling/train.py; linear layers on the exact-fp32 MFMA or
     on the 3-pass fp16 split GEMM incl. dX and dW, gradients rescaled by an exact power of two into fp16's range): loss and
     EVERY parameter gradient of the 2-layer model against autograd through the oracle (which the CPU suite pins to
@@ -247,7 +291,7 @@ def test_training_step_gradients_vs_oracle_autograd(precision):
     with torch.enable_grad():
         _, _, loss_ref, _ = O.train_loss(sd, x0, cond, t, pt, u)
         loss_ref.backward()
-    step = TrainStep(dt, precision=precision)
+    step = TrainStep(dt, precision=precision, attention=attention)
     loss, grads = step.loss_and_grads(x0.cuda(), cond.cuda(), t.cuda(), pt.cuda(), u.cuda())
     print("loss %.6f (oracle %.6f, reference %.6f)" % (loss.item(), loss_ref.item(), float(g["loss"])))
     assert abs(loss.item() - float(g["loss"])) < 2e-4 * float(g["loss"])

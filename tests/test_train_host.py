@@ -41,13 +41,13 @@ def oracle_grads():
                          if k.startswith("transformer.transformer.") and v.is_floating_point() and v.grad is not None}, lt2
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
-def test_training_step_host_composition(monkeypatch, oracle_grads, precision):
+@pytest.mark.parametrize("precision,attention", [("fp32", "fused"), ("f16x2", "fused"), ("f16x2", "composed")])
+def test_training_step_host_composition(monkeypatch, oracle_grads, precision, attention):
     from text_to_sound_synthesis_amd.modeling.train import TrainStep
     hip_abi_emulation.install(monkeypatch)
     loss_ref, want, lt2 = oracle_grads
     dt, _ = _model()
-    step = TrainStep(dt, precision=precision)
+    step = TrainStep(dt, precision=precision, attention=attention)
     batch = _batch()
     loss, grads = step.loss_and_grads(*batch)
     assert abs(loss.item() - loss_ref) < 2e-5 * loss_ref

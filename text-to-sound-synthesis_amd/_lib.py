@@ -89,6 +89,8 @@ _PROTOS = {
     "ds_colsum_ws": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _i64, C.c_int, _vp, _i64, _vp]),
     "ds_gelu2": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "ds_softmax_bwd_rows": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_attention_bwd": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                   _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_embed_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_axpy": (C.c_int, [_vp, _vp, _f, _i64, _vp]),
     "ds_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, C.c_int, _vp]),
@@ -158,6 +160,12 @@ def ptr(t):
     if not t.is_contiguous():
         raise DiffsoundHipError("tensor must be contiguous")
     return t.data_ptr()
+
+
+def ptr_off(t, elems):
+    """Device address `elems` elements into a contiguous tensor (a column range of a fused projection, addressed in place
+    with the tensor's row stride)."""
+    return ptr(t) + elems * t.element_size()
 
 
 def stream():

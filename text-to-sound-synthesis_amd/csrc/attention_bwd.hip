@@ -1,0 +1,345 @@
+// Backward of the fused multi-head attention (head dim 64, exact-fp32 MFMA) for the training step (scope row 8f-3):
+// what loss.backward() computes for FullAttention / CrossAttention (transformer_utils.py:43-58, :91-109)
+//     P = softmax(scale Q K^T),  O = P V
+//     dV = P^T dO,   dP = dO V^T,   dS = scale P (dP - delta),  delta_q = sum_d dO[q][d] O[q][d],
+//     dQ = dS K,     dK = dS^T Q
+// by TILE-WISE RECOMPUTATION: neither P nor dS ever exists in HBM (the composed version kept P [B*16][288][288] per
+// layer -- 106 MB -- and moved it, dP and two transposes of them through HBM for every layer).
+//
+// Same formulation as attention.hip: a wave owns a 32-row tile of one index and holds the OTHER index in registers
+// (transposed score tiles, 144 accumulator registers), all rows of the other operand sit in LDS (68-float rows).  The
+// MFMA contracts over the register index for free, never over the lane index -- hence two kernels:
+//   * ds_attn_bwd_q_kernel   wave = 32 queries, keys in registers:   S^T = K Q^T -> softmax (as the forward) -> row
+//                            statistics L_q = max + log(sum), delta_q -> dP^T = V dO^T -> dS -> dQ = dS K
+//   * ds_attn_bwd_kv_kernel  wave = 32 keys, queries in registers:   S = Q K^T -> P = exp(scale S - L_q) -> dV = P^T dO
+//                            -> dP = dO V^T -> dS = scale P (dP - delta_q) -> dK = dS^T Q
+// (7 tile products instead of the 5 of a formulation with cross-lane transposes; the exact-fp32 MFMA makes them the
+// cost of the kernels: 2 Lq Lk 64 flops each at 157 TFLOP/s peak.)  One LDS buffer per workgroup, re-staged between
+// the phases (K, V, K  /  Q, dO, Q), two workgroups per CU.
+#include "common.h"
+
+#define AB_LD 68
+#define AB_WAVES 3
+#define AB_NT (AB_WAVES * 64)
+#define AB_FENCE()                                                     \
+    do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// rows [0, valid) of a [rows][64] operand (row stride ld) -> lds[NT * 32][AB_LD]; rows past `valid` are zero
+template <int NT, int INFLIGHT>
+__device__ __forceinline__ void ab_stage(float* __restrict__ lds, const float* __restrict__ src, int ld, int valid, int tid) {
+    static_assert((NT * 32 * 16) % (AB_NT * INFLIGHT) == 0, "staging trip count");
+    // an opaque copy of the thread id: the addresses of one staging pass are re-derived in the next one instead of being
+    // kept live across the MFMA phases in between (they were spilled to scratch: the kernels run at the 256-register cap)
+    asm volatile("" : "+v"(tid));
+    for (int it0 = 0; it0 < NT * 32 * 16 / AB_NT; it0 += INFLIGHT) {
+        f32x4 t8[INFLIGHT];
+#pragma unroll
+        for (int u = 0; u < INFLIGHT; ++u) {
+            const int f = tid + (it0 + u) * AB_NT;
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            t8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < valid) t8[u] = *(const f32x4*)(src + (size_t)row * ld + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < INFLIGHT; ++u) {
+            const int f = tid + (it0 + u) * AB_NT;
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            *(f32x4*)(lds + row * AB_LD + c4) = t8[u];
+        }
+    }
+}
+
+// tile product with the register index on the ROWS of the result: acc[i = lds row (tile * 32 + lane & 31)][j = the
+// lane's own row of the register operand]:  acc += X_lds[tile rows][d] * Y_reg[d]   (attention.hip pass 1)
+__device__ __forceinline__ void ab_rows_times_reg(f32x16& acc, const float* __restrict__ lds, int tile, int l31, int hh,
+                                                  const f32x4 (&yf)[8]) {
+    const float* xr = lds + (tile * 32 + l31) * AB_LD + 4 * hh;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4 xf = *(const f32x4*)(xr + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[j], yf[c][j], acc, 0, 0, 0);
+    }
+}
+
+// out[i = lane's own index][d] += sum over the 32 register rows of `tile`:  W[i][row] * Z_lds[row][d]  (attention.hip
+// pass 2); o0: d = lane & 31, o1: d = 32 + lane & 31
+__device__ __forceinline__ void ab_reg_times_rows(f32x16& o0, f32x16& o1, const f32x16& w, const float* __restrict__ lds, int tile,
+                                                  int l31, int hh) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float* zr = lds + row * AB_LD + l31;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], zr[0], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], zr[32], o1, 0, 0, 0);
+    }
+}
+
+// lane (row = lane & 31, half hh) keeps X[row][8c + 4hh + j], c = 0..7, j = 0..3
+__device__ __forceinline__ void ab_load_frag(f32x4 (&f)[8], const float* __restrict__ rowp, int hh) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = *(const f32x4*)(rowp + 4 * hh + 8 * c);
+}
+
+// result tile [32 rows over registers][lane & 31 (+32) = d] -> dst rows row0 + .., for rows < limit
+__device__ __forceinline__ void ab_store_tile(float* __restrict__ dst, int ld, int row0, int limit, const f32x16& o0, const f32x16& o1,
+                                              int l31, int hh) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < limit) {
+            float* p = dst + (size_t)row * ld + l31;
+            p[0] = o0[r];
+            p[32] = o1[r];
+        }
+    }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
+                                                                int ldk, const float* __restrict__ Vp, int ldv,
+                                                                const float* __restrict__ O, int ldo, const float* __restrict__ dO,
+                                                                int lddo, float* __restrict__ dQ, int lddq, float* __restrict__ stats,
+                                                                int Lq, int Lk, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float kv[];  // [NKT*32][AB_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.x % heads, grp = blockIdx.x / heads, b = blockIdx.y;
+    const int q0 = (grp * AB_WAVES + wave) * 32;
+    const bool active = q0 < Lq;             // wave-uniform
+    const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
+    const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
+    int qr = q0 + l31;
+    if (qr >= Lq) qr = Lq - 1;
+    const size_t qrow = (size_t)b * Lq + qr;
+
+    ab_stage<NKT, 4>(kv, kb, ldk, Lk, tid);
+    f32x16 s[NKT];
+    {
+        f32x4 qf[8];
+        ab_load_frag(qf, Q + qrow * ldq + head * 64, hh);
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+                ab_rows_times_reg(s[kt], kv, kt, l31, hh, qf);          // S^T tile: rows = keys, lane = query
+            }
+        }
+    }
+    __syncthreads();                          // everyone is done reading K
+    ab_stage<NKT, 2>(kv, vb, ldv, Lk, tid);  // V into the same buffer (its latency runs under the softmax)
+
+    // softmax over the keys of query l31, exactly as the forward (attention.hip)
+    float Lrow = 0.f;
+    if (active) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = key < Lk ? s[kt][r] * scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+        Lrow = mx + logf(sum);
+    }
+    // dO fragment and delta_q = sum_d dO O  (loaded only now: with the Q fragment still live the kernel would not fit
+    // its 256 registers; the fence keeps the scheduler from hoisting the loads over the softmax)
+    AB_FENCE();
+    f32x4 dof[8];
+    ab_load_frag(dof, dO + qrow * lddo + head * 64, hh);
+    float delta = 0.f;
+    {
+        const float* op = O + qrow * ldo + head * 64 + 4 * hh;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 o4 = *(const f32x4*)(op + 8 * c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) delta += dof[c][j] * o4[j];
+        }
+        delta += __shfl_xor(delta, 32);
+    }
+    if (active && hh == 0 && q0 + l31 < Lq) {
+        const int lqs = ((Lq + 31) >> 5) << 5;
+        float* st = stats + ((size_t)b * heads + head) * lqs + q0 + l31;
+        st[0] = Lrow;
+        st[(size_t)gridDim.y * heads * lqs] = delta;
+    }
+    __syncthreads();                          // V is in LDS
+    if (active) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x16 dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+            ab_rows_times_reg(dp, kv, kt, l31, hh, dof);                // dP^T tile = V dO^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = scale * s[kt][r] * (dp[r] - delta);   // dS^T (0 for masked keys: P = 0)
+            AB_FENCE();                       // one dP tile live at a time
+        }
+    }
+    __syncthreads();
+    ab_stage<NKT, 2>(kv, kb, ldk, Lk, tid);  // K again
+    __syncthreads();
+    if (active) {
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) ab_reg_times_rows(o0, o1, s[kt], kv, kt, l31, hh);   // dQ = dS K
+        ab_store_tile(dQ + (size_t)b * Lq * lddq + head * 64, lddq, q0, Lq, o0, o1, l31, hh);
+    }
+}
+
+template <int NQT>
+__global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
+                                                                 int ldk, const float* __restrict__ Vp, int ldv,
+                                                                 const float* __restrict__ dO, int lddo, float* __restrict__ dK, int lddk,
+                                                                 float* __restrict__ dV, int lddv, const float* __restrict__ stats, int Lq,
+                                                                 int Lk, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQT*32][AB_LD] operand rows, then L[NQT*32], delta[NQT*32]
+    float* Ls = qs + NQT * 32 * AB_LD;
+    float* Ds = Ls + NQT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.x % heads, grp = blockIdx.x / heads, b = blockIdx.y;
+    const int k0 = (grp * AB_WAVES + wave) * 32;
+    const bool active = k0 < Lk;             // wave-uniform
+    const float* qb = Q + (size_t)b * Lq * ldq + head * 64;
+    const float* dob = dO + (size_t)b * Lq * lddo + head * 64;
+    int kr = k0 + l31;
+    const bool key_ok = kr < Lk;
+    if (kr >= Lk) kr = Lk - 1;
+    const size_t krow = (size_t)b * Lk + kr;
+
+    ab_stage<NQT, 4>(qs, qb, ldq, Lq, tid);
+    {
+        const int lqs = ((Lq + 31) >> 5) << 5;
+        const float* st = stats + ((size_t)b * heads + head) * lqs;
+        for (int i = tid; i < NQT * 32; i += AB_NT) {
+            Ls[i] = i < Lq ? st[i] : 0.f;
+            Ds[i] = i < Lq ? st[(size_t)gridDim.y * heads * lqs + i] : 0.f;
+        }
+    }
+    f32x16 t[NQT];
+    {
+        f32x4 kf[8];
+        ab_load_frag(kf, Kp + krow * ldk + head * 64, hh);
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[qt][r] = 0.f;
+                ab_rows_times_reg(t[qt], qs, qt, l31, hh, kf);          // S tile: rows = queries, lane = key
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    t[qt][r] = (q < Lq && key_ok) ? expf(t[qt][r] * scale - Ls[q]) : 0.f;      // P[q][key]
+                }
+            }
+        }
+    }
+    __syncthreads();                          // everyone is done reading Q
+    ab_stage<NQT, 2>(qs, dob, lddo, Lq, tid);
+    __syncthreads();
+    if (active) {
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows(o0, o1, t[qt], qs, qt, l31, hh);   // dV = P^T dO
+        ab_store_tile(dV + (size_t)b * Lk * lddv + head * 64, lddv, k0, Lk, o0, o1, l31, hh);
+        f32x4 vf[8];
+        ab_load_frag(vf, Vp + krow * ldv + head * 64, hh);
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            f32x16 dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+            ab_rows_times_reg(dp, qs, qt, l31, hh, vf);                 // dP tile = dO V^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                t[qt][r] = scale * t[qt][r] * (dp[r] - Ds[q]);          // dS (0 where P = 0)
+            }
+            AB_FENCE();
+        }
+    }
+    __syncthreads();
+    ab_stage<NQT, 2>(qs, qb, ldq, Lq, tid);   // Q again
+    __syncthreads();
+    if (active) {
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows(o0, o1, t[qt], qs, qt, l31, hh);   // dK = dS^T Q
+        ab_store_tile(dK + (size_t)b * Lk * lddk + head * 64, lddk, k0, Lk, o0, o1, l31, hh);
+    }
+}
+
+template <typename KernelT>
+static int ab_set_lds(KernelT kernel, size_t lds, bool& done) {
+    if (done) return 0;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        ds_set_error("attention backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return -2;
+    }
+    done = true;
+    return 0;
+}
+
+// Q / O / dO / dQ: [B*Lq][ld] (head h at columns h*64..), K / V / dK / dV: [B*Lk][ld]; any row strides (column ranges of
+// fused projections are addressed in place).  stats: 2 * B * heads * ceil32(Lq) floats of workspace.
+extern "C" int ds_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                                const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                                float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(q && k && v && o && d_o && dq && dk && dv && stats, "null pointer");
+    DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lq <= 288 && Lk <= 288, "at most 288 queries / keys are supported");
+    DS_CHECK_ARG(((ldq | ldk | ldv | ldo | lddo) & 3) == 0, "leading dims of the inputs must be multiples of 4");
+    DS_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "16-byte aligned inputs");
+    const int qgroups = ((Lq + 31) / 32 + AB_WAVES - 1) / AB_WAVES, kgroups = ((Lk + 31) / 32 + AB_WAVES - 1) / AB_WAVES;
+    static bool a3 = false, a9 = false, akv = false;
+    if (Lk <= 96) {
+        const size_t lds = 3 * 32 * AB_LD * sizeof(float);
+        if (ab_set_lds(ds_attn_bwd_q_kernel<3>, lds, a3)) return -2;
+        hipLaunchKernelGGL((ds_attn_bwd_q_kernel<3>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o, ldo,
+                           d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
+    } else {
+        const size_t lds = 9 * 32 * AB_LD * sizeof(float);
+        if (ab_set_lds(ds_attn_bwd_q_kernel<9>, lds, a9)) return -2;
+        hipLaunchKernelGGL((ds_attn_bwd_q_kernel<9>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o, ldo,
+                           d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
+    }
+    DS_CHECK_LAUNCH();
+    {
+        const size_t lds = (9 * 32 * AB_LD + 2 * 9 * 32) * sizeof(float);
+        if (ab_set_lds(ds_attn_bwd_kv_kernel<9>, lds, akv)) return -2;
+        hipLaunchKernelGGL((ds_attn_bwd_kv_kernel<9>), dim3(kgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, d_o,
+                           lddo, dk, lddk, dv, lddv, stats, Lq, Lk, heads, scale);
+    }
+    DS_CHECK_LAUNCH();
+    return 0;
+}

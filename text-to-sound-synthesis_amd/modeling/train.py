@@ -28,8 +28,11 @@ Two GEMM backends (`TrainStep(precision=...)`), both behind the same step:
            The step then has no host synchronisation at all and can be captured in a hipGraph (`capture`): one graph
            launch per iteration instead of ~3000 kernel launches from Python.
 
-Attention (scores, softmax, PV and their backward from the materialised probabilities), the norms and the loss tail are
-exact fp32 in both modes.  Worst per-tensor gradient error against autograd through the oracle, all 63 tensors of the
+Attention is exact fp32 in both modes: `attention="fused"` (default) = `ds_attention` forward + `ds_attention_bwd`, a
+backward by tile-wise recomputation that reads Q | K | V and writes dQ | dK | dV in place in the fused projection buffers
+and never stores the probabilities; `attention="composed"` = grouped fp32 GEMMs + row softmax with materialised
+probabilities and torch head split / merge / transposes (the first version, kept as a cross-check).  The norms and the
+loss tail are exact fp32 too.  Worst per-tensor gradient error against autograd through the oracle, all 63 tensors of the
 2-layer test model: see tests/test_hip_train_kernels.py.
 """
 import math
@@ -251,9 +254,30 @@ class _Attn:
         _merge_into(dv_out, dV4, B, Lk, H)
 
 
+class _FusedAttn:
+    """The same attention cores on the fused kernels: `ds_attention` forward and `ds_attention_bwd` (tile-wise
+    recomputation: the probabilities are never stored), reading Q / K / V and writing dQ / dK / dV IN PLACE in the fused
+    projection buffers -- an operand is (tensor, first column, row stride).  Exact-fp32 MFMA, like the composed version."""
+
+    def __init__(self, q, k, v, B, Lq, Lk, H):
+        self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H = q, k, v, B, Lq, Lk, H
+        self.out = torch.empty(B * Lq, H * 64, device=q[0].device)
+        L_.check(L_.lib().ds_attention(L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2],
+                                       L_.ptr(self.out), H * 64, B, H, Lq, Lk, 0.125, L_.stream()))
+
+    def backward(self, dO, dq, dk, dv):
+        q, k, v, B, Lq, Lk, H = self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H
+        stats = torch.empty(2 * B * H * _ceil(Lq, 32), device=dO.device)
+        L_.check(L_.lib().ds_attention_bwd(
+            L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2], L_.ptr(self.out), H * 64,
+            L_.ptr(dO), H * 64, L_.ptr_off(dq[0], dq[1]), dq[2], L_.ptr_off(dk[0], dk[1]), dk[2], L_.ptr_off(dv[0], dv[1]), dv[2],
+            L_.ptr(stats), B, H, Lq, Lk, 0.125, L_.stream()))
+
+
 class TrainStep:
-    def __init__(self, diffusion_transformer, precision="fp32", rescale_interval=100):
-        assert precision in ("f16x2", "fp32")
+    def __init__(self, diffusion_transformer, precision="fp32", rescale_interval=100, attention="fused"):
+        assert precision in ("f16x2", "fp32") and attention in ("fused", "composed")
+        self.attention = attention
         self.dt = diffusion_transformer
         self.tr = diffusion_transformer.transformer
         self.precision = precision
@@ -326,6 +350,7 @@ class TrainStep:
             G_.prepare(l)
         scale = 2.0 ** self.loss_scale_exp
         inv = 1.0 / scale
+        fused = self.attention == "fused"
 
         def seen(dy):                                   # calibration: every gradient that is about to enter a GEMM
             if amax is not None:
@@ -347,7 +372,10 @@ class TrainStep:
             h = _norm_fwd(x, 0, Lx, table=s["tab1"], t=t)
             s["h1"] = h
             qkv = G_.fwd(ls["qkv1"], h)                                             # [M][3D]: q | k | v
-            s["att1"] = _Attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, Lx, Lx, H)
+            if fused:
+                s["att1"] = _FusedAttn((qkv, 0, 3 * D), (qkv, D, 3 * D), (qkv, 2 * D, 3 * D), B, Lx, Lx, H)
+            else:
+                s["att1"] = _Attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, Lx, Lx, H)
             x = G_.fwd(ls["proj1"], s["att1"].out, R=x)
             s["x1"] = x
             s["tab2"] = blk.ln1_1.table()
@@ -355,7 +383,10 @@ class TrainStep:
             s["h2"] = h
             q = G_.fwd(ls["q2"], h)
             kv = G_.fwd(ls["kv2"], cond)                                            # [B*Lc][2D]: k | v
-            s["att2"] = _Attn(q, kv[:, :D], kv[:, D:], B, Lx, Lc, H)
+            if fused:
+                s["att2"] = _FusedAttn((q, 0, D), (kv, 0, 2 * D), (kv, D, 2 * D), B, Lx, Lc, H)
+            else:
+                s["att2"] = _Attn(q, kv[:, :D], kv[:, D:], B, Lx, Lc, H)
             x = G_.fwd(ls["proj2"], s["att2"].out, R=x)
             s["x2"] = x
             h = _norm_fwd(x, 1, Lx, gamma=blk.ln2.weight, beta=blk.ln2.bias)
@@ -449,7 +480,10 @@ class TrainStep:
             dao, g[p + "attn2.proj.weight"], g[p + "attn2.proj.bias"] = lin_bwd(ls["proj2"], s["att2"].out, dx)
             dq = torch.empty(M, D, device=dev)
             dkv = torch.empty(B * Lc, 2 * D, device=dev)
-            s["att2"].backward(dao, dq, dkv[:, :D], dkv[:, D:])
+            if fused:
+                s["att2"].backward(dao, (dq, 0, D), (dkv, 0, 2 * D), (dkv, D, 2 * D))
+            else:
+                s["att2"].backward(dao, dq, dkv[:, :D], dkv[:, D:])
             dh, g[p + "attn2.query.weight"], g[p + "attn2.query.bias"] = lin_bwd(ls["q2"], s["h2"], dq)
             _, dWkv, dbkv = lin_bwd(ls["kv2"], cond, dkv, need_dx=False)
             g[p + "attn2.key.weight"], g[p + "attn2.value.weight"] = dWkv[:D], dWkv[D:]
@@ -460,7 +494,10 @@ class TrainStep:
             # x1 = x0 + proj1(attn1(qkv(ln1(x0))))
             dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["att1"].out, dx)
             dqkv = torch.empty(M, 3 * D, device=dev)
-            s["att1"].backward(dao, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
+            if fused:
+                s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D))
+            else:
+                s["att1"].backward(dao, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
             dh, dWqkv, dbqkv = lin_bwd(ls["qkv1"], s["h1"], dqkv)
             for j, nm in enumerate(("query", "key", "value")):
                 g[p + "attn1.%s.weight" % nm], g[p + "attn1.%s.bias" % nm] = dWqkv[j * D:(j + 1) * D], dbqkv[j * D:(j + 1) * D]
