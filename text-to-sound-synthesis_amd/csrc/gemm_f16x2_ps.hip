@@ -80,6 +80,14 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
         tm_ = first + in % gsz;
         tn_ = in / gsz;
     }
+#ifdef PS_TIMING   // probe build only (tools/ps_timing.py): per-workgroup time stamps through the unused pro_scale pointer
+    unsigned long long ps_ts[8];
+#define PS_STAMP(i_) do { ps_ts[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    const unsigned long long ps_c0 = __builtin_amdgcn_s_memtime();
+    PS_STAMP(0);
+#else
+#define PS_STAMP(i_) do { } while (0)
+#endif
     const int row_lo = tm_ * L;                     // the sample's rows [row_lo, row_lo + L) are what this tile stores
     const int m0 = (row_lo >> 4) << 4, n0 = tn_ * BN;
     const int nk = p.K / 32;                        // even (K % 64 == 0)
@@ -225,6 +233,7 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     if (4 * nk >= LEAD) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PS_BAR();
+    PS_STAMP(1);
     if (wr == 1) PS_BAR();          // the second wave row runs one barrier behind the first
     for (int t = 0; t < nk; t += 2) {
         PS_PHASE(0, 0); PS_PHASE(1, 0); PS_PHASE(2, 0); PS_PHASE(3, 0);
@@ -234,6 +243,10 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     }
     if (wr == 0) PS_BAR();          // ... and the first row waits for it at the end
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PS_STAMP(2);
+#ifdef PS_TIMING
+    const unsigned long long ps_c1 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue -------------------------------------------------------------------------------------------------
     // One workgroup per CU: nothing else runs on the CU while a tile is written out, so the epilogue is on the critical
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
                     *(const f32x4*)(Tf + rl * BN + cc * 4) + (it < pf_ ? res[it < pf_ ? it : 0] : res2[it >= pf_ ? it - pf_ : 0]); \
         }                                                                                            \
     } while (0)
-        PS_ROW_SLAB(0); PS_ROW_SLAB(1); PS_ROW_SLAB(2);
+        PS_ROW_SLAB(0); PS_STAMP(3); PS_ROW_SLAB(1); PS_STAMP(4); PS_ROW_SLAB(2); PS_STAMP(5);
     } else {
         // fp16 split outputs: T[rows][256] of 32-bit (hi | lo << 16) (<= 128 KB); a thread reads 8 columns = 32 bytes
         // and writes one 16-byte store per plane
@@ -413,8 +426,19 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
             }                                                                                        \
         }                                                                                            \
     } while (0)
-        PS_SPLIT_SLAB(0); PS_SPLIT_SLAB(1); PS_SPLIT_SLAB(2);
+        PS_SPLIT_SLAB(0); PS_STAMP(3); PS_SPLIT_SLAB(1); PS_STAMP(4); PS_SPLIT_SLAB(2); PS_STAMP(5);
     }
+#ifdef PS_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tile's stores have left the wave's queue
+    PS_STAMP(6);
+    if (p.pro_scale && (tid_e == 0 || tid_e == 256)) {
+        unsigned long long* o = (unsigned long long*)p.pro_scale + ((size_t)blockIdx.x * 2 + (tid_e >> 8)) * 10;
+        for (int i = 0; i < 7; ++i) o[i] = ps_ts[i];
+        o[7] = ps_c1 - ps_c0;                               // shader cycles from entry to the end of the main loop
+        o[8] = (unsigned long long)(tm_ * 65536 + tn_);
+        o[9] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_ID: CU / XCC fields
+    }
+#endif
 }
 
 // Whether the per-sample program serves this problem, and pays: packed operands, sample-structured rows with
