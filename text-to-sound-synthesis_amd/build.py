@@ -18,17 +18,28 @@ NO_SCRATCH = ("ds_gemm_f16x2", "ds_gemm_bf16x3", "ds_attn_f16x2", "ds_gemm_kerne
               "ds_attn_bwd")
 
 
-def source_fingerprint():
-    """16 hex digits over every source the shared object is built from (csrc/*.hip, common.h, the public header).
-    Measurements that describe the kernels (profiles/*_pmc_*.json -> bench.py's roofline.traffic) carry it, and are
-    reported only while it still matches the sources in the tree."""
+def _code_only(text):
+    """C / C++ source with comments and all whitespace removed (string literals are kept as they are)."""
+    import re
+    out = re.sub(r'//[^\n]*|/\*.*?\*/|("(?:\\.|[^"\\])*")', lambda m: m.group(1) or "", text, flags=re.S)
+    return re.sub(r"\s+", "", out)
+
+
+# what the dominant kernel of the sampling path (ds_gemm_f16x2_ps_kernel, gemm_f16x2_ps.hip) is compiled from
+DOMINANT_KERNEL_SOURCES = ("gemm_f16x2_ps.hip", "common.h")
+
+
+def source_fingerprint(files=DOMINANT_KERNEL_SOURCES):
+    """16 hex digits over the CODE (comments and whitespace stripped) of the sources the dominant kernel is compiled from
+    (its .hip file and common.h; the public header only contributes enum values and grows with every new entry point, so
+    it is left out).  Measurements that describe that kernel
+    (profiles/*_pmc_*.json -> bench.py's roofline.traffic) carry it and are reported only while it still matches the
+    tree -- a comment edit or a change to another kernel's file does not make them stale, a change to this kernel does."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SOURCES) + ["common.h"]:
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
-    with open(os.path.join(ROOT, "include", "diffsound_hip.h"), "rb") as fh:
-        h.update(fh.read())
+    for f in sorted(files):
+        with open(os.path.join(CSRC, f), "r") as fh:
+            h.update(f.encode() + b"\0" + _code_only(fh.read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -1,11 +1,11 @@
 """Where the time of the per-sample ping-pong GEMM goes, measured INSIDE the kernel: a probe build of
-gemm_f16x2_ps.hip (-DPS_TIMING, tools/build_ps_timing.sh -> gpurun_ab_timing.so, loaded through DIFFSOUND_LIB) stamps
+gemm_f16x2_ps.hip (-DPS_TIMING, tools/build_ps_variant.sh timing -DPS_TIMING -> gpurun_ab_timing.so, loaded through DIFFSOUND_LIB) stamps
 s_memrealtime (100 MHz) per workgroup at entry / first operands landed / end of the main loop / after each epilogue slab /
 stores drained, plus the shader cycles of prologue + main loop.  Per denoiser GEMM (B = 64) this prints the mean, min
 and max of every segment over the workgroups, the launch's span from the first entry to the last drain, and the HIP-event
 time of the same launch.  Run on the GPU box:
 
-    bash tools/build_ps_timing.sh && DIFFSOUND_LIB=$PWD/gpurun_ab_timing.so python tools/ps_timing.py
+    bash tools/build_ps_variant.sh timing -DPS_TIMING && DIFFSOUND_LIB=$PWD/gpurun_ab_timing.so python tools/ps_timing.py
 """
 import os
 import sys
