@@ -101,3 +101,19 @@ def test_split_k_plan_and_padding():
         for M in (231, 795, 5300, 1540):
             Mp = _ceil(M, 32 * S)
             assert Mp >= M and (Mp // S) % 32 == 0 and Mp - M < 32 * S
+
+
+def test_loss_scale_guard():
+    """observe_grad_norm: the calibrated loss scale is kept inside a (1/64, 4) window of the gradient norm at calibration."""
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    dt, _ = _model()
+    step = TrainStep(dt, precision="f16x2")
+    step.loss_scale_exp = 17
+    assert not step.observe_grad_norm(3.0)             # first observation = the reference
+    assert not step.observe_grad_norm(11.0) and not step.observe_grad_norm(0.06) and step.loss_scale_exp == 17
+    assert step.observe_grad_norm(12.5) and step.loss_scale_exp is None       # > 4x: re-calibrate on the next step
+    step.loss_scale_exp = 15
+    assert not step.observe_grad_norm(12.5)            # new reference
+    assert step.observe_grad_norm(0.1) and step.loss_scale_exp is None        # < 1/64
+    fp = TrainStep(dt, precision="fp32")
+    assert not fp.observe_grad_norm(1.0) and not fp.observe_grad_norm(1e9) and fp.loss_scale_exp == 0

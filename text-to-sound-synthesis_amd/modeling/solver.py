@@ -203,6 +203,9 @@ class Solver:
                                    weight_decay=self.weight_decay)
         if self.scheduler is not None:
             self.lr = self.scheduler.step(loss)
+        if total is not None and self.last_iter % 16 == 0 and hasattr(self.train_step, "observe_grad_norm"):
+            self.train_step.observe_grad_norm(float(total))      # guard of the split backend's loss scale (a host float:
+                                                                 # one extra sync every 16 iterations)
         if self.ema is not None:
             self.ema.update(iteration=self.last_iter)
         return {"loss": loss, "lr": self.lr, "grad_norm": total}
@@ -251,6 +254,7 @@ class GraphSolver:
         self.last_iter += 1
         if self.scheduler is not None:
             self.lr = self.scheduler.step(out["loss"])
+        self.iteration_graph.check_loss_scale()        # re-calibrates and re-captures if the gradients left the window
         if self.ema is not None:
             self.ema.update(iteration=self.last_iter)
         return {"loss": out["loss"], "lr": self.lr, "grad_norm": out["grad_norm"]}

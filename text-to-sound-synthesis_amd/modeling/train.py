@@ -287,6 +287,23 @@ class TrainStep:
         self.calibrated_amax = None
         self._steps = 0
         self._capturing = False     # set by GraphedIteration while a hipGraph records the step: no host syncs then
+        self._calib_norm = None     # global gradient norm at calibration time (observe_grad_norm)
+
+    def observe_grad_norm(self, norm):
+        """Guard of the calibrated loss scale ("f16x2" backend): the calibration leaves 8x of headroom below fp16's range
+        (largest |dY| at 2^12..2^13, saturation at 2^16) and ~2^9 below it before the smallest interesting values lose
+        fp32-class precision.  Gradients grow and shrink together, so the global gradient norm the solver computes anyway
+        is the monitor: once it has moved by more than 4x up or 64x down from its value at calibration time, the next
+        step re-calibrates (returns True then).  Call it with a HOST float (the solvers do, next to float(loss))."""
+        if self.precision != "f16x2" or not math.isfinite(norm) or norm <= 0.0:
+            return False
+        if self._calib_norm is None:
+            self._calib_norm = norm
+            return False
+        if norm > 4.0 * self._calib_norm or norm < self._calib_norm / 64.0:
+            self.loss_scale_exp, self._calib_norm = None, None
+            return True
+        return False
 
     # ---- the step's linears ------------------------------------------------------------------------------------------
     def _linears(self):
@@ -610,7 +627,8 @@ class GraphedIteration:
     def recapture(self):
         """New calibration of the loss scale / weight pre-scales on the current static batch, then a new graph."""
         self.step.loss_scale_exp = None
-        self.step.gemm.wexp.clear() if hasattr(self.step.gemm, "wexp") else None
+        if hasattr(self.step.gemm, "wexp"):
+            self.step.gemm.wexp.clear()
         keep_state = {k: (m.clone(), v.clone()) for k, (m, v) in self.opt_state.items()}
         self._capture()
         for k, (m, v) in keep_state.items():
@@ -630,3 +648,10 @@ class GraphedIteration:
         self.step._steps += 1
         self.step.tr.invalidate()          # the replay updated the weights: cached inference packs are stale
         return {"loss": self.loss, "grad_norm": self.grad_norm, "lr": lr}
+
+    def check_loss_scale(self):
+        """Host-side guard (one sync): re-calibrate + re-capture when the gradient norm has left the calibrated window."""
+        if self.step.observe_grad_norm(float(self.grad_norm)):
+            self.recapture()
+            return True
+        return False
