@@ -879,7 +879,10 @@ static void run_pp(const char* name, const _Float16* A, const _Float16* W, float
 // Block 8 is read and multiplied in phase 3 (which reads nothing in pp_kernel): its quarter (type 3 of tile t) is retired
 // by the wait of phase 4t + 1, and the region is re-staged by quarter 4t + 11, issued in phase 4t + 5 -- two phases
 // after the last read (pp_kernel's WAR rule).
-template <int GM>
+// EX: MFMA cost model of the ninth block row (timing only -- EX < 2 computes wrong values for rows 256..): 2 = the 32-row
+// block of the product kernel (6 MFMAs 32x32x16 per k-tile and wave), 1 = half of it (= what a 16-row block on
+// v_mfma_f32_16x16x32_f16 would issue if samples were aligned to 16-row groups: 272-row tiles), 0 = none (256 rows)
+template <int GM, int EX = 2>
 __global__ __launch_bounds__(512, 1) void ps_kernel(const _Float16* A, long long a_plane, const _Float16* W,
                                                     long long w_plane, float* C, int M, int N, int K,
                                                     unsigned long long* clk) {
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(512, 1) void ps_kernel(const _Float16* A, long long
     } while (0)
 #define PS_EXTRA(sb_)                                                                                \
     do {                                                                                             \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+        _Pragma("unroll") for (int ks = 0; ks < EX; ++ks) {                                          \
             acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1[ks], b0[sb_][ks], acc8, 0, 0, 0);       \
             acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0[ks], b1[sb_][ks], acc8, 0, 0, 0);       \
             acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0[ks], b0[sb_][ks], acc8, 0, 0, 0);       \
@@ -1074,20 +1077,20 @@ __global__ __launch_bounds__(512, 1) void ps_kernel(const _Float16* A, long long
     }
 }
 
-template <int GM>
+template <int GM, int EX = 2>
 static void run_ps(const char* name, const _Float16* A, const _Float16* W, float* C, int M, int N, int K,
                    unsigned long long* clk) {
     const size_t lds = (size_t)2 * 2 * (288 + 256) * HLD * 2;
-    hipFuncSetAttribute((const void*)ps_kernel<GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)ps_kernel<GM, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (M / 265) * ((N + 255) / 256);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL((ps_kernel<GM>), dim3(tiles), dim3(512), lds, 0, A, (long long)M * K, W, (long long)N * K, C, M, N, K, clk);
+        hipLaunchKernelGGL((ps_kernel<GM, EX>), dim3(tiles), dim3(512), lds, 0, A, (long long)M * K, W, (long long)N * K, C, M, N, K, clk);
     const int reps = 30;
     hipEventRecord(e0, 0);
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL((ps_kernel<GM>), dim3(tiles), dim3(512), lds, 0, A, (long long)M * K, W, (long long)N * K, C, M, N, K, clk);
+        hipLaunchKernelGGL((ps_kernel<GM, EX>), dim3(tiles), dim3(512), lds, 0, A, (long long)M * K, W, (long long)N * K, C, M, N, K, clk);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -1230,6 +1233,18 @@ int main() {
     QCASE(16384, 3072, 1024)
     QCASE(16384, 1024, 4096)
     QCASE(16960, 1024, 1024)
+    }
+    if (getenv("PROBE_PS_EXTRA")) {      // what the 23 padding rows of the 288-row tile cost (timing model, see ps_kernel)
+#define ECASE(MM, N, K)                                                                             \
+    run_ps<4, 2>("per-sample, 288 rows", A, W, C2, MM, N, K, clk);                                   \
+    run_ps<4, 1>("per-sample, 272-row model", A, W, C2, MM, N, K, clk);                              \
+    run_ps<4, 0>("per-sample, 256-row model", A, W, C2, MM, N, K, clk);                              \
+    run_ps<4, 2>("per-sample, 288 rows", A, W, C2, MM, N, K, clk);
+    ECASE(16960, 1024, 1024)
+    ECASE(16960, 3072, 1024)
+    ECASE(16960, 4096, 1024)
+    ECASE(16960, 1024, 4096)
+    return 0;
     }
     if (getenv("PROBE_PS")) {
 #define SCASE(MM, N, K)                                                                             \
