@@ -428,3 +428,28 @@ def test_graphed_iteration_matches_eager():
         assert d.mean().item() < 1e-7 and (d > 1e-6).float().mean().item() < 1e-4, (d.mean().item(), d.max().item())
     assert torch.equal(dt_e.Lt_count.cpu(), dt_g.Lt_count.cpu())
     assert graph.train_step.loss_scale_exp == eager.train_step.loss_scale_exp
+
+
+def test_overlapped_weight_gradients_identical():
+    """TrainStep(overlap_dw=True): the dW / db work of the backward on a second HIP stream (events order it against the
+    in-place updates of the residual gradient) must give bit-identical gradients, twice in a row (allocator reuse)."""
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    m = build_model(default_config(n_layer=2, diffusion_step=100))
+    m.load_state_dict({**dict(synth_sd("dalle", 2)), **synth_sd("encoder")}, strict=False)
+    dt = m.cuda().eval().transformer
+    dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]
+    batch = (synth.synth_tokens(3, mask_frac=0.0, key="tl.x0").cuda(), synth.synth_cond_emb(3, key="tl.c").cuda(),
+             torch.tensor([57, 0, 93]).cuda(), (torch.ones(3) / 100).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u").cuda())
+    ref_step = TrainStep(dt, precision="f16x2")
+    loss0, g0 = ref_step.loss_and_grads(*batch)
+    g0 = {k: v.clone() for k, v in g0.items()}
+    ov = TrainStep(dt, precision="f16x2", overlap_dw=True)
+    for rep in range(2):
+        loss1, g1 = ov.loss_and_grads(*batch)
+        torch.cuda.synchronize()
+        assert loss1.item() == loss0.item()
+        skip = ("emb.weight",)          # atomics (embedding / AdaLN index_add): order-dependent in the last bit either way
+        bad = [k for k in g0 if not k.endswith(skip) and not torch.equal(g0[k], g1[k])]
+        assert not bad, (rep, bad[:5])

@@ -275,9 +275,11 @@ class _FusedAttn:
 
 
 class TrainStep:
-    def __init__(self, diffusion_transformer, precision="fp32", rescale_interval=100, attention="fused"):
+    def __init__(self, diffusion_transformer, precision="fp32", rescale_interval=100, attention="fused", overlap_dw=False):
         assert precision in ("f16x2", "fp32") and attention in ("fused", "composed")
         self.attention = attention
+        self.overlap_dw = overlap_dw      # weight-gradient GEMMs on a second HIP stream, beside the dX / attention chain
+        self._side = None
         self.dt = diffusion_transformer
         self.tr = diffusion_transformer.transformer
         self.precision = precision
@@ -288,6 +290,11 @@ class TrainStep:
         self._steps = 0
         self._capturing = False     # set by GraphedIteration while a hipGraph records the step: no host syncs then
         self._calib_norm = None     # global gradient norm at calibration time (observe_grad_norm)
+
+    def _side_stream(self, dev):
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        return self._side
 
     def observe_grad_norm(self, norm):
         """Guard of the calibrated loss scale ("f16x2" backend): the calibration leaves 8x of headroom below fp16's range
@@ -446,13 +453,41 @@ class TrainStep:
         # ---- backward (every d* below carries the loss scale; `small` collects what one multiply un-scales at the end)
         g, small = {}, []
 
-        def lin_bwd(lin, xin, dy, need_dx=True):
+        side = self._side_stream(dev) if (self.overlap_dw and dev.type == "cuda") else None
+        reads_dx = []               # side-stream work that still reads the residual gradient `dx` (updated in place below)
+
+        def lin_bwd(lin, xin, dy, need_dx=True, dy_is_dx=False):
+            """dX on the current stream; dW / db -- off the critical path of the backward, nothing downstream needs them
+            before the clip -- on the side stream when `overlap_dw` is set (the MFMA-bound weight-gradient GEMMs then
+            run beside the latency-bound attention backward / norm kernels of the main chain)."""
             seen(dy)
-            dxo = G_.dx(lin, dy) if need_dx else None
-            dW = G_.dw(lin, xin, dy, inv)
-            db = _colsum(dy)[0]
+            if side is None:
+                dxo = G_.dx(lin, dy) if need_dx else None
+                dW = G_.dw(lin, xin, dy, inv)
+                db = _colsum(dy)[0]
+            else:
+                main = torch.cuda.current_stream(dev)
+                ready = torch.cuda.Event()
+                ready.record(main)                          # dy and xin are complete at this point of the main stream
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    dW = G_.dw(lin, xin, dy, inv)
+                    db = _colsum(dy)[0]
+                    if dy_is_dx:
+                        done = torch.cuda.Event()
+                        done.record(side)
+                        reads_dx.append(done)
+                dy.record_stream(side)                      # (allocator: not to be reused before the side stream is done)
+                xin.record_stream(side)
+                dxo = G_.dx(lin, dy) if need_dx else None
             small.append(db)
             return dxo, dW, db
+
+        def dx_readers_done():
+            """before `dx` is modified in place: the weight-gradient GEMMs that read it as their dY have finished"""
+            for ev in reads_dx:
+                torch.cuda.current_stream(dev).wait_event(ev)
+            reads_dx.clear()
 
         dh, g["transformer.to_logits.1.weight"], g["transformer.to_logits.1.bias"] = lin_bwd(lin_logits, hf, dlog)
         dx, dgam, dbet = _norm_bwd(xf, dh, 1, Lx, gamma=lnf.weight)
@@ -460,6 +495,7 @@ class TrainStep:
         small += [dgam, dbet]
 
         def axpy(y, x_):
+            dx_readers_done()
             L_.check(L_.lib().ds_axpy(L_.ptr(y), L_.ptr(x_), 1.0, y.numel(), L_.stream()))
 
         Tp = _ceil(T, 32)
@@ -485,7 +521,7 @@ class TrainStep:
             s, blk, ls = saved[li], tr.blocks[li], blocks[li]
             p = "transformer.blocks.%d." % li
             # x3 = x2 + fc2(gelu(fc1(ln2(x2))))
-            dgact, g[p + "mlp.2.weight"], g[p + "mlp.2.bias"] = lin_bwd(ls["fc2"], s["g"], dx)
+            dgact, g[p + "mlp.2.weight"], g[p + "mlp.2.bias"] = lin_bwd(ls["fc2"], s["g"], dx, dy_is_dx=True)
             du = torch.empty_like(dgact)
             L_.check(L_.lib().ds_gelu2(L_.ptr(s["u"]), L_.ptr(dgact), L_.ptr(du), du.numel(), L_.stream()))
             dh, g[p + "mlp.0.weight"], g[p + "mlp.0.bias"] = lin_bwd(ls["fc1"], s["h3"], du)
@@ -494,7 +530,7 @@ class TrainStep:
             small += [dgam, dbet]
             axpy(dx, dxn)
             # x2 = x1 + proj2(attn2(q(ln1_1(x1)), kv(cond)))
-            dao, g[p + "attn2.proj.weight"], g[p + "attn2.proj.bias"] = lin_bwd(ls["proj2"], s["att2"].out, dx)
+            dao, g[p + "attn2.proj.weight"], g[p + "attn2.proj.bias"] = lin_bwd(ls["proj2"], s["att2"].out, dx, dy_is_dx=True)
             dq = torch.empty(M, D, device=dev)
             dkv = torch.empty(B * Lc, 2 * D, device=dev)
             if fused:
@@ -509,7 +545,7 @@ class TrainStep:
             adaln_param_grads(blk.ln1_1, dsc, dsh, p + "ln1_1")
             axpy(dx, dxn)
             # x1 = x0 + proj1(attn1(qkv(ln1(x0))))
-            dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["att1"].out, dx)
+            dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["att1"].out, dx, dy_is_dx=True)
             dqkv = torch.empty(M, 3 * D, device=dev)
             if fused:
                 s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D))
@@ -535,6 +571,8 @@ class TrainStep:
         L_.check(L_.lib().ds_colsum(L_.ptr(dpos), L_.ptr(dw), Ww, Hh, D, Ww * D, D, 0, L_.stream()))   # sum over h
         g["transformer.content_emb.width_emb.weight"] = dw
         small += [demb, dhh, dw]
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)      # every dW / db is complete from here on
         if inv != 1.0:
             torch._foreach_mul_(small, inv)
         if not calibrating:

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
     ap.add_argument("--attention", default="fused", choices=("fused", "composed"),
                     help="fused: ds_attention + ds_attention_bwd (recompute); composed: grouped GEMMs with stored probabilities")
+    ap.add_argument("--overlap-dw", action="store_true", help="weight-gradient GEMMs on a second HIP stream")
     ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,10 +89,10 @@ def main():
     ema = EMA(dt, decay=0.99, update_interval=25, device=args.ema_device)
     if args.graph and world == 1:
         from text_to_sound_synthesis_amd.modeling.solver import GraphSolver
-        solver = GraphSolver(TrainStep(dt, precision=args.precision, attention=args.attention), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = GraphSolver(TrainStep(dt, precision=args.precision, attention=args.attention, overlap_dw=args.overlap_dw), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                              scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema)
     else:
-        solver = Solver(Timed(dt, precision=args.precision, attention=args.attention), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = Solver(Timed(dt, precision=args.precision, attention=args.attention, overlap_dw=args.overlap_dw), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                         scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
                         allreduce=timed_allreduce if world > 1 else None)
 
@@ -125,7 +126,7 @@ def main():
             "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
             "ms": {k: 1e3 * v / args.steps for k, v in times.items()},
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-            "graph": bool(args.graph and world == 1), "attention": args.attention,
+            "graph": bool(args.graph and world == 1), "attention": args.attention, "overlap_dw": args.overlap_dw,
             "loss_scale_exp": solver.train_step.loss_scale_exp,
             "config": {"workload": "BASELINE configs[4]: training step, B=%d per GPU, %d layers, K=%d" % (B, args.n_layer, args.codes),
                        "parallelism": "dp%d" % world}}))
