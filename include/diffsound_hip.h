@@ -283,6 +283,13 @@ int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B);
 enum { DS_SPLIT_NONE = 0, DS_SPLIT_BF16X3 = 1, DS_SPLIT_F16X2 = 2 };
 int ds_denoiser_set_split_weights(ds_denoiser* h, int mode, const void* const* split, const float* out_scales,
                                   const void* w_logits_split, float logits_scale);
+/* Padded-row mode of ds_denoiser_step(_ex) (default on): in f16x2 mode, at batch sizes whose GEMMs run the per-sample
+ * program (B = 64), every sample occupies 272 rows = 17 packed row groups of the step's activation matrices instead of
+ * seq_len = 265 -- tiles start on a group boundary and their ninth block row is 16 rows on the 16x16x32 MFMA (-5 % MFMA
+ * work).  The 7 extra rows per sample are zero embeddings that stay finite, are never attention keys, and are skipped by
+ * the sampler.  Tokens agree with the unpadded step except on exact near-ties (rows 256..264 of a sample are summed in
+ * another order: ~1e-7 relative).  0 switches it off (A/B, bit-for-bit comparisons across batch sizes). */
+int ds_denoiser_set_row_padding(ds_denoiser* h, int on);
 /* cross-attention K/V depend only on the caption: computed once per batch (CrossAttention.key/value,
  * transformer_utils.py:96,98).  cond [B][Lc][Dc] -> kv [n_layer][B*Lc][2D] */
 int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int B, float* kv, ds_stream_t stream);

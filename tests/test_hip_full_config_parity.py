@@ -109,6 +109,37 @@ def test_teacher_forced_100_steps_19_layers(model, g, mode):
     assert len(flips) <= MAX_FLIPS, "%d teacher-forced disagreements in %d decisions" % (len(flips), 100 * B * 265)
 
 
+def test_teacher_forced_batch64_padded_rows(model, g):
+    """The same 100 teacher-forced steps AT THE BENCHMARKED BATCH SIZE, where the step runs in padded-row mode (272 rows
+    per sample, per-sample GEMM program with a 16-row ninth block: csrc/api.hip rows_per_sample): the 8 reference captions
+    replicated 8 times = 64 clips.  Every replica must reproduce the reference's tokens (disagreements only at the
+    reference's own near-ties, at most MAX_FLIPS per replica set), and the 8 replicas of a caption must agree."""
+    set_precision(model, "f16x2")
+    dt = model.transformer
+    assert dt.transformer.row_padding
+    R = 8
+    cond = g["cond_emb"].float().cuda().repeat(R, 1, 1)
+    trace = g["step_tokens"].long()
+    B0 = trace.shape[1]
+    B = R * B0
+    kv = dt.transformer.condition_kv(cond, dt._schedule_table())
+    flips, replica_mismatch = [], 0
+    for i in range(100):
+        t = 99 - i
+        x_t = (torch.full((B0, 265), 256, dtype=torch.long) if i == 0 else trace[i - 1]).repeat(R, 1)
+        u = noise(t, (B0, 257, 265)).repeat(R, 1, 1)
+        tok = dt.p_sample_tokens(x_t.cuda(), kv, torch.full((B,), t, dtype=torch.long).cuda(), u.cuda(), initial=(i == 0)).cpu()
+        replica_mismatch += int((tok.view(R, B0, 265) != tok.view(R, B0, 265)[:1]).sum())
+        for b, p in (tok != trace[i].repeat(R, 1)).nonzero().tolist():
+            flips.append({"t": t, "clip": b % B0, "replica": b // B0, "pos": p, "gap": float(g["gap"][i, b % B0, p]),
+                          "tmargin": float(g["tmargin"][i, b % B0, p])})
+    report("f16x2", "teacher_forced_batch64_padded_rows", {"decisions": 100 * B * 265, "flips": len(flips),
+                                                           "replica_mismatches": replica_mismatch, "detail": flips[:16]})
+    unexplained = [f for f in flips if not (f["tmargin"] < CUT_TIE or f["gap"] < GAP_TIE)]
+    assert not unexplained, "token disagreements away from any near-tie: %s" % unexplained[:4]
+    assert len(flips) <= MAX_FLIPS * R and replica_mismatch == 0
+
+
 @pytest.mark.parametrize("mode", ["fp32", "f16x2"])
 def test_free_running_tokens_mel_wave(model, voc, g, mode):
     set_precision(model, mode)

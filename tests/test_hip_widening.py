@@ -149,6 +149,91 @@ def test_f16x2_per_sample_program_attention_store_bit_identical(B):
         assert img is None or torch.equal(img, img_ref)
 
 
+@pytest.mark.parametrize("B,N,K", [(5, 1024, 1024), (3, 1024, 4096), (2, 4096, 1024), (7, 256, 128)])
+def test_f16x2_per_sample_program_272_row_samples(B, N, K):
+    """Samples of 272 rows (17 packed row groups: the denoiser's padded-row mode): the tile's ninth block row is the 16
+    rows 256..271 on v_mfma_f32_16x16x32_f16.  Rows 0..255 of every sample keep the bits of the 4-wave programs; rows
+    256..271 sum the same products in another order (one 32-k MFMA instead of two 16-k ones) and are compared with
+    float64.  Row-major + bias + residual in place, and packed split output with GELU2."""
+    from test_hip_split_gemm import relerr, rnd, torch_split
+    from text_to_sound_synthesis_amd import _lib as L
+    Lp = 272
+    M = B * Lp
+    A, W, b, R = rnd((M, K), "p272.A", 2.0).cuda(), rnd((N, K), "p272.W", 0.05).cuda(), rnd((N,), "p272.b").cuda(), \
+        rnd((M, N), "p272.R").cuda()
+    W2, sc = L.split_f16x2(W)
+    W2p, _ = L.split_f16x2(W, packed=True)
+    A2p = L.pack_planes(torch_split(A))
+    ref = torch.empty(M, N, device="cuda")
+    L.gemm(A, W2, ref, M, N, K, bias=b, R=R, split2=sc)
+    refg = torch.empty(M, N, device="cuda")
+    L.gemm(A, W2, refg, M, N, K, bias=b, act=L.ACT_GELU2, split2=sc)
+    exact = (A.double() @ W.double().t() + b.double())
+    low = (torch.arange(M, device="cuda") % Lp) < 256            # rows computed by the 32x32x16 blocks
+    try:
+        L.lib().ds_gemm_f16x2_force_tile(PS)
+        out = R.clone()
+        L.gemm(A2p, W2p, out, M, N, K, bias=b, R=out, split2=sc, a_plane=M * K, rows_per_sample=Lp)
+        assert torch.equal(out[low], ref[low])
+        assert relerr((out - R)[~low].cpu(), exact[~low].float().cpu()) < 2e-6
+        guard = torch.full((M + 64, N), float("nan"), device="cuda")
+        L.gemm(A2p, W2p, guard, M, N, K, bias=b, split2=sc, a_plane=M * K, rows_per_sample=Lp)
+        assert torch.isnan(guard[M:]).all() and not torch.isnan(guard[:M]).any()
+        outs = torch.zeros(2, M * N, device="cuda", dtype=torch.float16)
+        L.gemm(A2p, W2p, outs, M, N, K, bias=b, act=L.ACT_GELU2, split2=sc, a_plane=M * K, c_plane=M * N,
+               rows_per_sample=Lp)
+        got = L.unpack_planes(outs, M, N)
+        want = torch_split(refg)
+        assert torch.equal(got[:, low], want[:, low])
+        gv = got[0].float() + got[1].float()
+        eg = exact * torch.sigmoid(1.702 * exact)
+        assert relerr(gv[~low].cpu(), eg[~low].float().cpu()) < 4e-6
+    finally:
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_f16x2_per_sample_program_272_row_attention_store(B):
+    """The attention-ready stores for 272-row samples: Q planes [B][heads][272][64], K / V^T images with 272 keys (the
+    denoiser masks keys 265.. in the attention kernel).  Positions 0..255 bit-identical to the 4-wave programs, 256..271
+    compared as values."""
+    from test_hip_split_gemm import rnd, torch_split
+    from text_to_sound_synthesis_amd import _lib as L
+    Lp, H, D = 272, 16, 1024
+    M, K = B * Lp, D
+    A = rnd((M, K), "pa272.A", 2.0).cuda()
+    A2p = L.pack_planes(torch_split(A))
+    for N in (3 * D, D):
+        W, b = rnd((N, K), "pa272.W%d" % N, 0.05).cuda(), rnd((N,), "pa272.b%d" % N).cuda()
+        W2p, sc = L.split_f16x2(W, packed=True)
+
+        def run():
+            qh = torch.full((2, B, H, Lp, 64), float("nan"), device="cuda", dtype=torch.float16)
+            img = torch.zeros(B, H, 4, 288 * 64, device="cuda", dtype=torch.float16) if N == 3 * D else None
+            L.gemm(A2p, W2p, qh, M, N, K, bias=b, split2=sc, a_plane=M * K, store=L.STORE_ATTN, rows_per_sample=Lp,
+                   attn=(img, H, 288, B * H * Lp * 64))
+            return qh, img
+        L.lib().ds_gemm_f16x2_force_tile(2 if B == 1 else 1)
+        try:
+            q_ref, img_ref = run()
+            L.lib().ds_gemm_f16x2_force_tile(PS)
+            qh, img = run()
+        finally:
+            L.lib().ds_gemm_f16x2_force_tile(-1)
+        assert torch.equal(qh[:, :, :, :256], q_ref[:, :, :, :256])
+        val = lambda x: x[0].float() + x[1].float()
+        assert not torch.isnan(qh.float()).any()
+        assert (val(qh) - val(q_ref)).abs().max().item() < 2e-5 * val(q_ref).abs().max().item()
+        if img is not None:
+            kk = lambda im: im[:, :, 0].float() + im[:, :, 1].float()      # K image: hi + lo, [B][H][288*64]
+            vv = lambda im: im[:, :, 2].float() + im[:, :, 3].float()
+            assert (kk(img) - kk(img_ref)).abs().max().item() < 2e-5 * kk(img_ref).abs().max().item()
+            assert (vv(img) - vv(img_ref)).abs().max().item() < 2e-5 * vv(img_ref).abs().max().item()
+            # key slots 272.. stay zero; most of the image (keys < 256) is bit-identical
+            same = (img == img_ref).float().mean().item()
+            assert same > 0.9, same
+
+
 def test_denoiser_step_with_per_sample_program_gives_the_same_tokens():
     """A whole sampling step of the 19-layer denoiser at B = 8 with every eligible GEMM forced onto the per-sample
     program: logits and tokens equal the 4-wave programs'."""
@@ -172,6 +257,44 @@ def test_denoiser_step_with_per_sample_program_gives_the_same_tokens():
         assert torch.equal(dt.transformer(x, cond, t), want_logits)
     finally:
         L.lib().ds_gemm_f16x2_force_tile(-1)
+
+
+def test_padded_row_mode_of_the_sampling_step():
+    """B = 64, 19 layers: the sampling step in padded-row mode (272 rows per sample, the per-sample GEMM program with a
+    16-row ninth block, 7 zero-embedded extra rows per sample that are queries but never keys) against the same step on
+    265 rows: the same tokens up to exact near-ties, from a mixed state and from the all-[MASK] start; then five chained
+    steps.  (Rows 256..264 of a sample are summed in another order: logits agree to ~1e-6, not bit for bit.)"""
+    from test_hip_split_gemm import build
+    m = build(19, mode="f16x2")
+    dt = m.transformer
+    dt.truncation_r = 0.85
+    tr = dt.transformer
+    B = 64
+    cond = synth.synth_cond_emb(B, key="pad.cond").cuda()
+    kv = tr.condition_kv(cond, dt._schedule_table())
+    u = synth.synth_uniform((B, 257, 265), key="pad.u").cuda()
+
+    def step(x, t, initial, pad):
+        tr.row_padding = pad
+        return dt.p_sample_tokens(x, kv, torch.full((B,), t, device="cuda", dtype=torch.long), u, initial).clone()
+    try:
+        x = synth.synth_tokens(B, mask_frac=0.6, key="pad.x").cuda()
+        a, b = step(x, 41, False, True), step(x, 41, False, False)
+        diff = int((a != b).sum())
+        print("mixed state, t = 41: %d of %d tokens differ between 272- and 265-row steps" % (diff, a.numel()))
+        assert diff <= 2
+        x0 = torch.full((B, 265), 256, dtype=torch.long, device="cuda")
+        a, b = step(x0, 99, True, True), step(x0, 99, True, False)
+        assert int((a != b).sum()) <= 2
+        xa = xb = x0
+        for i, t in enumerate((99, 98, 97, 96, 95)):
+            xa, xb = step(xa, t, i == 0, True), step(xb, t, i == 0, False)
+        same_clips = int((xa == xb).all(dim=1).sum())
+        print("five chained steps: %d of %d clips identical" % (same_clips, B))
+        assert same_clips >= B - 2 and int((xa == 256).sum()) == int((xb == 256).sum()) or same_clips >= B - 2
+        assert int(xa.max()) <= 256 and int(xa.min()) >= 0
+    finally:
+        tr.row_padding = True
 
 
 # ---- loss settings the golden vector does not cover (other mask weights / auxiliary weights / timesteps) --------------

@@ -99,6 +99,7 @@ struct ds_denoiser {
     const void* w_logits3 = nullptr;
     float logits_osc = 1.f;
     int split_mode = DS_SPLIT_NONE;
+    int pad_rows = 1;              // padded-row mode allowed (ds_denoiser_set_row_padding; see rows_per_sample())
     float S3(int layer, int slot) const { return osc.empty() ? 1.f : osc[(size_t)layer * DS_LP_COUNT + slot]; }
     const float* P(int layer, int slot) const { return lp[(size_t)layer * DS_LP_COUNT + slot]; }
     const void* P3(int layer, int slot) const { return lp3.empty() ? nullptr : lp3[(size_t)layer * DS_LP_COUNT + slot]; }
@@ -155,8 +156,29 @@ struct Carve {
 };
 // floats occupied by the K / V^T images of one attention over Lk keys (4 fp16 planes of nkey*64 per sample and head)
 static size_t attn_img_floats(int B, int heads, int Lk) { return (size_t)B * heads * 4 * ds_attn_nkey(Lk) * 64 / 2; }
-static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c) {
-    const size_t M = (size_t)B * h->d.seq_len, D = h->d.n_embd;
+// Rows per sample of the activation matrices.  PADDED-ROW MODE (sampling steps in f16x2 mode at batch sizes whose GEMMs
+// take the per-sample program, i.e. B = 64): every sample occupies PS_ROWS = 272 rows = 17 packed 16-row groups instead
+// of L = 265, so a sample's tile starts on a packed group, and the tile's ninth block row is the 16 rows 256..271 on the
+// 16x16x32 MFMA instead of 32 rows (gemm_f16x2_ps.hip NB16: -5 % MFMA work).  The 7 extra rows per sample start as zeros
+// (ds_embed_rows), stay finite through every layer (LayerNorm of a constant row = its shift), are extra QUERIES of the
+// attention (the ninth query tile exists anyway) but never keys (Lk = L masks them), and the sampler reads the L real
+// rows of each sample (ds_sample_tail_rows).  Rows 256..264 of a sample are then summed in another order than by the
+// 4-wave programs (same products): equal to ~1e-7 relative, not bit-identical across batch sizes.
+static const int PS_ROWS = 272;
+static int rows_per_sample(const ds_denoiser* h, int B) {
+    const int L = h->d.seq_len;
+    if (!h->pad_rows || h->split_mode != DS_SPLIT_F16X2 || L > PS_ROWS || L <= PS_ROWS - 16) return L;
+    const long tiles = (long)B * (h->d.n_embd / 256), rounds = (tiles + 255) / 256;    // the N = 1024 GEMMs' grid
+    return (tiles >= 192 && tiles * 100 >= rounds * 256 * 85) ? PS_ROWS : L;         // = ds_gemm_f16x2_ps_applies
+}
+extern "C" int ds_denoiser_set_row_padding(ds_denoiser* h, int on) {
+    DS_CHECK_ARG(h, "null handle");
+    h->pad_rows = on != 0;
+    return 0;
+}
+
+static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c, int Lp = 0) {
+    const size_t M = (size_t)B * (Lp > 0 ? Lp : PS_ROWS > h->d.seq_len ? PS_ROWS : h->d.seq_len), D = h->d.n_embd;
     const size_t M16 = (M + 15) & ~(size_t)15;   // hn / att / fc double as packed split planes (rows padded to 16)
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -168,7 +190,7 @@ static size_t carve(const ds_denoiser* h, int B, void* ws, Carve* c) {
     t.x = take(M * D);
     t.hn = take(M16 * D);
     // fp32 modes: [M][3D] rows.  f16x2 mode: Q planes (M*D floats) + the K / V^T images (padded to nkey key slots)
-    const size_t qkv_ready = M * D + attn_img_floats(B, h->d.n_head, h->d.seq_len);
+    const size_t qkv_ready = M * D + attn_img_floats(B, h->d.n_head, h->d.seq_len);   // (nkey covers 272 rows too)
     t.qkv = take(qkv_ready > M * 3 * D ? qkv_ready : M * 3 * D);
     t.kvimg = t.qkv ? t.qkv + M * D : nullptr;
     t.att = take(M16 * D);
@@ -195,6 +217,7 @@ extern "C" int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B) {
 struct ProfRec { hipEvent_t a, b; double flops; int tile; };
 extern int g_last_tile;  // gemm_f32.hip
 static bool g_prof = false;
+static double g_prof_row_frac = 1.0;   // real rows / launched rows of the GEMMs being recorded (padded-row mode: 265 / 272)
 static std::vector<ProfRec> g_recs;
 
 extern "C" int ds_profile_enable(int on) {
@@ -245,7 +268,7 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
     };
     if (!g_prof) return launch();
     ProfRec r;
-    r.flops = 2.0 * M * N * K;
+    r.flops = 2.0 * M * N * K * g_prof_row_frac;   // algorithmic: the padding rows of the padded-row mode do not count
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
         ds_set_error("profile: hipEventCreate failed");
         return -2;
@@ -283,10 +306,13 @@ extern "C" int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int 
     return 0;
 }
 
+// Lp: rows per sample of every activation matrix (d.seq_len, or PS_ROWS in padded-row mode: layout 0 only)
 static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64_t* t, const float* kv, int B,
-                        const Carve& w, float* logits, int layout, hipStream_t s) {
+                        const Carve& w, float* logits, int layout, hipStream_t s, int Lp) {
     const ds_denoiser_desc& d = h->d;
-    const int D = d.n_embd, L = d.seq_len, M = B * L, Mc = B * d.cond_len, F = D * d.mlp_mult;
+    const int D = d.n_embd, Lv = d.seq_len, L = Lp, M = B * L, Mc = B * d.cond_len, F = D * d.mlp_mult;
+    DS_CHECK_ARG(Lp == Lv || (layout == 0 && Lp > Lv), "padded rows need the row-major logits layout");
+    g_prof_row_frac = (double)Lv / Lp;
     const float scale = 0.125f;  // 1/sqrt(64), transformer_utils.py:48
     // f16x2 mode: attention follows the GEMM arithmetic, and every GEMM input is produced as PACKED SPLIT PLANES
     // (common.h ds_packed_off; two fp16 planes in the bytes of the fp32 buffer, rows padded to 16) by the kernel
@@ -330,16 +356,16 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
         return dense(A, lda, h->P(l, slot), h->P(l, bslot), R, C, N, M, N, K, act, s, DS_STORE_ROW, L, h->P3(l, slot),
                      h->split_mode, h->S3(l, slot), ap, cp);
     };
-    TRY(ds_embed(tokens, d.tok_emb, d.pos_emb, w.x, M, L, D, s));
+    TRY(ds_embed_rows(tokens, d.tok_emb, d.pos_emb, w.x, B, Lv, L, D, s));
     for (int l = 0; l < d.n_layer; ++l) {
         // x += attn1(ln1(x, t))
         TRY(adaln(l, DS_LP_ADALN1));
         if (f16) {
             TRY(lin_attn(l, DS_LP_W_QKV, DS_LP_B_QKV, 3 * D, 3 * D, w.kvimg));   // Q planes + K / V^T images
-            TRY(attn_ready(w.kvimg, L));
+            TRY(attn_ready(w.kvimg, Lv));                                          // padded rows are queries, never keys
         } else {
             TRY(lin(l, DS_LP_W_QKV, DS_LP_B_QKV, w.hn, D, pD, nullptr, w.qkv, 3 * D, D, DS_ACT_NONE, 0));
-            TRY(attn(w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, L));
+            TRY(attn(w.qkv, 3 * D, w.qkv + D, w.qkv + 2 * D, 3 * D, Lv));
         }
         TRY(lin(l, DS_LP_W_PROJ1, DS_LP_B_PROJ1, w.att, D, pD, w.x, w.x, D, D, DS_ACT_NONE, 0));
         // x += attn2(ln1_1(x, t), cond)
@@ -372,8 +398,8 @@ extern "C" int ds_denoiser_forward(const ds_denoiser* h, const int64_t* tokens, 
                                    int B, void* workspace, float* logits, int logits_layout, ds_stream_t stream) {
     DS_CHECK_ARG(h && tokens && t && kv && workspace && logits && B > 0, "bad arguments");
     Carve w;
-    carve(h, B, workspace, &w);
-    return forward_impl(h, tokens, t, kv, B, w, logits, logits_layout, (hipStream_t)stream);
+    carve(h, B, workspace, &w, h->d.seq_len);
+    return forward_impl(h, tokens, t, kv, B, w, logits, logits_layout, (hipStream_t)stream, h->d.seq_len);
 }
 
 // t drives the network (AdaLN), t_post the posterior: they differ only for the skip-step sampler
@@ -384,10 +410,11 @@ extern "C" int ds_denoiser_step_ex(const ds_denoiser* h, const int64_t* tokens_i
                                    ds_stream_t stream) {
     DS_CHECK_ARG(h && tokens_in && t && kv && u && workspace && tokens_out && B > 0, "bad arguments");
     Carve w;
-    carve(h, B, workspace, &w);
-    TRY(forward_impl(h, tokens_in, t, kv, B, w, w.logits, 0, (hipStream_t)stream));
-    return ds_sample_tail_ex(w.logits, tokens_in, t_post ? t_post : t, u, h->d.sched, tokens_out, nullptr, nullptr,
-                             nullptr, B, h->d.seq_len, h->d.n_codes, h->d.n_steps, initial, trunc_r, trunc_k, stream);
+    const int Lp = rows_per_sample(h, B);
+    carve(h, B, workspace, &w, Lp);
+    TRY(forward_impl(h, tokens_in, t, kv, B, w, w.logits, 0, (hipStream_t)stream, Lp));
+    return ds_sample_tail_rows(w.logits, Lp, tokens_in, t_post ? t_post : t, u, h->d.sched, tokens_out, nullptr, nullptr,
+                               nullptr, B, h->d.seq_len, h->d.n_codes, h->d.n_steps, initial, trunc_r, trunc_k, stream);
 }
 
 extern "C" int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const float* kv,

@@ -56,7 +56,14 @@ typedef __attribute__((address_space(3))) void* ds_lptr;
 
 enum { PS_EPI_ROW = 0, PS_EPI_SPLIT = 1, PS_EPI_ATTN = 2 };
 
-template <int EPI>
+// NB16: the sample has L = 272 rows (a whole number of 16-row packed groups: the denoiser's padded-row mode, api.hip), so
+// the tile's ninth block row is the 16 rows 256..271 and runs on v_mfma_f32_16x16x32_f16 -- 6 MFMAs of half the cost per
+// k-tile and wave instead of 6 of 32x32x16 (measured with a timing model in the probe: -4.6..5.4 % per launch).  The wave
+// (wr, wc) owns the two 16 x 16 tiles at columns (2 wc + wr) 32 + {0, 16}; its B fragments in that instruction's layout are
+// read in phase 1 (B-sub0 is re-staged from phase 3 on, B-sub1 from the next phase 0), the sixteen A rows in phase 2 (their
+// quarter is retired in phase 1), and the MFMAs run in phase 2: 15 / 12 MFMA-equivalents in phases 2 / 3 instead of 12 / 18.
+// One 32-k MFMA per product and k-tile instead of two 16-k ones: rows 256.. are NOT bit-identical to the 4-wave programs.
+template <int EPI, bool NB16>
 __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int BM = PS_BM, BN = PS_BN, HLD = PS_HLD, LEAD = PS_LEAD;
@@ -142,8 +149,11 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     do { PS_FENCE(); __builtin_amdgcn_s_barrier(); PS_FENCE(); } while (0)
     const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
     f32x16 acc[4][2], acc8;
+    f32x4 acc9[2];                  // NB16: the two 16 x 16 tiles of the ninth block row
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc8[r] = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) acc9[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -153,6 +163,9 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     h8 a0[2][2], a1[2][2];          // [ks][row block of the current A-sub]: hi, lo planes
     h8 b0[2][2], b1[2][2];          // [B-sub][ks]: hi, lo planes
     h8 e0[2], e1[2];                // block 8 [ks]: hi, lo planes
+    h8 ea0, ea1, eb0[2], eb1[2];    // NB16: A rows 256..271 and the wave's two 16-column B tiles, 16x16x32 operand layout
+    const int l15 = lane & 15;
+    const int swzq = ((lane >> 4) ^ ((l15 >> 2) & 3)) * 8;     // lane group kq = lane >> 4 holds k = 8 kq .. 8 kq + 7
 #define PS_READ_A(buf_, s_)                                                                          \
     do {                                                                                             \
         const _Float16* Ac = smem + (buf_) * STAGE + (wr * 128 + (s_) * 64 + l31) * HLD;             \
@@ -198,13 +211,35 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
             acc8 = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0[ks], b0[sb_][ks], acc8, 0, 0, 0);       \
         }                                                                                            \
     } while (0)
+#define PS_READ_EB16(buf_)                                                                           \
+    do {                                                                                             \
+        const _Float16* Bc = smem + (buf_) * STAGE + 2 * APL + ((2 * wc + wr) * 32 + l15) * HLD;     \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                           \
+            eb0[tt] = *(const h8*)(Bc + tt * 16 * HLD + swzq);                                       \
+            eb1[tt] = *(const h8*)(Bc + BPL + tt * 16 * HLD + swzq);                                 \
+        }                                                                                            \
+    } while (0)
+#define PS_READ_EA16(buf_)                                                                           \
+    do {                                                                                             \
+        const _Float16* Ec = smem + (buf_) * STAGE + (256 + l15) * HLD;                              \
+        ea0 = *(const h8*)(Ec + swzq);                                                               \
+        ea1 = *(const h8*)(Ec + APL + swzq);                                                         \
+    } while (0)
+#define PS_EXTRA16()                                                                                 \
+    do {                                                                                             \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                           \
+            acc9[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea1, eb0[tt], acc9[tt], 0, 0, 0);      \
+            acc9[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea0, eb1[tt], acc9[tt], 0, 0, 0);      \
+            acc9[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea0, eb0[tt], acc9[tt], 0, 0, 0);      \
+        }                                                                                            \
+    } while (0)
     // one phase: P = phase within the k-tile (compile time), BUF = parity of the k-tile t (compile time)
 #define PS_PHASE(P, BUF)                                                                             \
     do {                                                                                             \
         if (P == 0) { PS_READ_A(BUF, 0); PS_READ_B(BUF, 0); }                                        \
-        if (P == 1) PS_READ_B(BUF, 1);                                                               \
-        if (P == 2) PS_READ_A(BUF, 1);                                                               \
-        if (P == 3) PS_READ_E(BUF);                                                                  \
+        if (P == 1) { PS_READ_B(BUF, 1); if (NB16) PS_READ_EB16(BUF); }                              \
+        if (P == 2) { PS_READ_A(BUF, 1); if (NB16) PS_READ_EA16(BUF); }                              \
+        if (P == 3 && !NB16) PS_READ_E(BUF);                                                         \
         PS_FENCE();                                                                                  \
         {                                                                                            \
             constexpr int dq = (P) + LEAD;                     /* quarter 4 t + dq */                \
@@ -220,8 +255,8 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
         __builtin_amdgcn_s_setprio(1);                                                               \
         if (P == 0) PS_QUAD(0, 0);                                                                   \
         if (P == 1) PS_QUAD(0, 1);                                                                   \
-        if (P == 2) PS_QUAD(1, 1);                                                                   \
-        if (P == 3) { PS_QUAD(1, 0); if (wr == 0) PS_EXTRA(0); else PS_EXTRA(1); }                   \
+        if (P == 2) { PS_QUAD(1, 1); if (NB16) PS_EXTRA16(); }                                       \
+        if (P == 3) { PS_QUAD(1, 0); if (!NB16) { if (wr == 0) PS_EXTRA(0); else PS_EXTRA(1); } }    \
         __builtin_amdgcn_s_setprio(0);                                                               \
         PS_BAR();                                                                                    \
     } while (0)
@@ -282,6 +317,17 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
                             STORE(rl, cl, v);                                                        \
                         }                                                                            \
                     }                                                                                \
+            }                                                                                        \
+        } else if (NB16) {              /* 16 x 16 tiles: column = lane & 15, row = 4 (lane >> 4) + r; rows 16.. of the */ \
+            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {   /* slab are never stored (vhi = 272)            */ \
+                const int cl = (wce * 2 + wre) * 32 + tt * 16 + (tid_e & 15);                        \
+                const float bv = p.bias ? p.bias[n0 + cl] : 0.f;                                     \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                      \
+                    const int rl = 4 * ((tid_e >> 4) & 3) + r;                                       \
+                    float v = acc9[tt][r] * osc + bv;                                                \
+                    if (p.act == DS_ACT_GELU2) v = ds_gelu2_fast(v);                                 \
+                    STORE(rl, cl, v);                                                                \
+                }                                                                                    \
             }                                                                                        \
         } else {                                                                                     \
             const int cl = (wce * 2 + wre) * 32 + l31e;                                              \
@@ -467,11 +513,11 @@ bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid) {
     return tiles >= 192 && tiles * 100 >= rounds * 256 * 85;     // >= 85 % of the CU-rounds it occupies do work
 }
 
-template <int EPI>
+template <int EPI, bool NB16>
 static int launch_ps(const GemmParams& p, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_ps_kernel<EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_ps_kernel<EPI, NB16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2_ps: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -480,12 +526,15 @@ static int launch_ps(const GemmParams& p, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = (p.M / p.rows_per_sample) * (p.N / PS_BN);
-    hipLaunchKernelGGL((ds_gemm_f16x2_ps_kernel<EPI>), dim3(tiles), dim3(512), PS_LDS_BYTES, s, p);
+    hipLaunchKernelGGL((ds_gemm_f16x2_ps_kernel<EPI, NB16>), dim3(tiles), dim3(512), PS_LDS_BYTES, s, p);
     DS_CHECK_LAUNCH();
     return 0;
 }
 
 int ds_launch_gemm_f16x2_ps(const GemmParams& p, hipStream_t s) {
-    if (p.store == DS_STORE_ATTN) return launch_ps<PS_EPI_ATTN>(p, s);
-    return p.c_split ? launch_ps<PS_EPI_SPLIT>(p, s) : launch_ps<PS_EPI_ROW>(p, s);
+    // 272-row samples (16-row aligned, 17 packed groups): the ninth block row is 16 rows on the 16x16x32 MFMA
+    const bool nb16 = p.rows_per_sample == PS_BM - 16;
+    if (p.store == DS_STORE_ATTN) return nb16 ? launch_ps<PS_EPI_ATTN, true>(p, s) : launch_ps<PS_EPI_ATTN, false>(p, s);
+    if (p.c_split) return nb16 ? launch_ps<PS_EPI_SPLIT, true>(p, s) : launch_ps<PS_EPI_SPLIT, false>(p, s);
+    return nb16 ? launch_ps<PS_EPI_ROW, true>(p, s) : launch_ps<PS_EPI_ROW, false>(p, s);
 }

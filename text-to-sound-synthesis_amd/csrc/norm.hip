@@ -20,18 +20,25 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // x[m][:] = emb[tok[m]][:] + pos[m % L][:]          D = 1024
+// Lp >= L: output rows per sample (the denoiser's padded-row mode: sample b occupies rows b Lp .. b Lp + Lp - 1, the rows
+// past position L - 1 are written as zeros); tokens stay [B][L]
 __global__ __launch_bounds__(256) void ds_embed_kernel(const int64_t* __restrict__ tok,
                                                        const float* __restrict__ emb,
                                                        const float* __restrict__ pos,
-                                                       float* __restrict__ out, int M, int L, int D, int f16) {
+                                                       float* __restrict__ out, int M, int L, int D, int f16, int Lp) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int lane = threadIdx.x & 63;
-    long long t = tok[row];
+    const int b = row / Lp, ps = row - b * Lp;
+    float* o = out + (size_t)row * D;
+    if (ps >= L) {
+        for (int c = lane * 4; c < D; c += 256) *(f32x4*)(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    long long t = tok[(size_t)b * L + ps];
     if (t < 0) t = 0;  // index[index < 0] = 0, dalle_mask_image_embedding.py:41
     const float* e = emb + (size_t)t * D;
-    const float* p = pos + (size_t)(row % L) * D;
-    float* o = out + (size_t)row * D;
+    const float* p = pos + (size_t)ps * D;
     for (int c = lane * 4; c < D; c += 256) {
         const f32x4 a = *(const f32x4*)(e + c), b = *(const f32x4*)(p + c);
         f32x4 r = a + b;
@@ -181,7 +188,19 @@ extern "C" int ds_embed(const int64_t* tokens, const float* emb, const float* po
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(tokens && emb && pos && out, "null pointer");
     DS_CHECK_ARG(M > 0 && L > 0 && D % 4 == 0, "bad shape");
-    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D, 0);
+    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D, 0, L);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same with Lp >= L output rows per sample (rows past position L - 1 are zeros): x [B * Lp][D]
+int ds_embed_rows(const int64_t* tokens, const float* emb, const float* pos, float* out, int B, int L, int Lp,
+                             int D, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(tokens && emb && pos && out, "null pointer");
+    DS_CHECK_ARG(B > 0 && L > 0 && Lp >= L && D % 4 == 0, "bad shape");
+    const int M = B * Lp;
+    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D, 0, Lp);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -232,7 +251,7 @@ extern "C" int ds_embed_f16(const int64_t* tokens, const float* emb, const float
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(tokens && emb && pos && out, "null pointer");
     DS_CHECK_ARG(M > 0 && L > 0 && D % 4 == 0, "bad shape");
-    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D, 1);
+    hipLaunchKernelGGL(ds_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tokens, emb, pos, out, M, L, D, 1, L);
     DS_CHECK_LAUNCH();
     return 0;
 }

@@ -56,6 +56,7 @@ struct SampleParams {
     int initial;              // 1: x_t is the all-[MASK] start state (log one-hot = 0 / -inf)
     float trunc_r;            // < 0: no top-r truncation
     int trunc_k;              // > 0: top-k truncation instead ('top{k}p', dalle_spec.py:147-157)
+    int lrows;                // rows of `logits` per sample (>= L: the denoiser's padded-row mode), L by default
 };
 
 template <int NPL>
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
 
     // ---- predict_start: float64 log-softmax over the K real classes ----
     float v[NPL];
-    const float* lg = p.logits + (size_t)col * K;
+    const float* lg = p.logits + ((size_t)b * p.lrows + pos) * K;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) v[j] = lg[j * 64 + lane];
     float mx = v[0];
@@ -508,16 +509,17 @@ extern "C" int ds_q_sample(const int64_t* x0, const int64_t* t, const float* u, 
     return 0;
 }
 
-extern "C" int ds_sample_tail_ex(const float* logits, const int64_t* xt, const int64_t* t, const float* u,
-                                 const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc,
-                                 float* dbg_post, int B, int L, int K, int T, int initial, float trunc_r,
-                                 int trunc_k, ds_stream_t stream_) {
+// logits_rows >= L: rows of `logits` per sample ([B * logits_rows][K]; the denoiser's padded-row mode, api.hip)
+int ds_sample_tail_rows(const float* logits, int logits_rows, const int64_t* xt, const int64_t* t, const float* u,
+                        const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc, float* dbg_post,
+                        int B, int L, int K, int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(logits && xt && t && u && sched && out_tokens, "null pointer");
     DS_CHECK_ARG(K == 256 || K == 512, "codebook size must be 256 or 512");
     DS_CHECK_ARG(trunc_k >= 0 && !(trunc_k > 0 && trunc_r >= 0.f), "top-k and top-r truncation are exclusive");
+    DS_CHECK_ARG(logits_rows >= L, "logits rows per sample");
     SampleParams p{logits, xt, t, u, sched, out_tokens, dbg_log_pred, dbg_trunc, dbg_post, B, L, T, initial, trunc_r,
-                   trunc_k};
+                   trunc_k, logits_rows};
     const int cols = B * L;
     if (K == 256)
         hipLaunchKernelGGL((ds_sample_tail_kernel<4>), dim3((cols + 3) / 4), dim3(256), 0, stream, p);
@@ -525,6 +527,14 @@ extern "C" int ds_sample_tail_ex(const float* logits, const int64_t* xt, const i
         hipLaunchKernelGGL((ds_sample_tail_kernel<8>), dim3((cols + 3) / 4), dim3(256), 0, stream, p);
     DS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ds_sample_tail_ex(const float* logits, const int64_t* xt, const int64_t* t, const float* u,
+                                 const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc,
+                                 float* dbg_post, int B, int L, int K, int T, int initial, float trunc_r,
+                                 int trunc_k, ds_stream_t stream) {
+    return ds_sample_tail_rows(logits, L, xt, t, u, sched, out_tokens, dbg_log_pred, dbg_trunc, dbg_post, B, L, K, T, initial,
+                               trunc_r, trunc_k, stream);
 }
 
 extern "C" int ds_sample_tail(const float* logits, const int64_t* xt, const int64_t* t, const float* u,

@@ -135,6 +135,7 @@ class Text2ImageTransformer(nn.Module):
         #   "bf16x3" 3-way bf16 split, 6 bf16-MFMA passes (csrc/gemm_bf16x3.hip)
         #   "fp32"   v_mfma_f32_32x32x2_f32, the exact fp32 FMA chain (csrc/gemm_f32.hip)
         self.precision = os.environ.get("DIFFSOUND_GEMM", "f16x2")
+        self.row_padding = os.environ.get("DIFFSOUND_PAD_ROWS", "1") != "0"
         self._packed = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: self.invalidate())
 
@@ -169,6 +170,9 @@ class Text2ImageTransformer(nn.Module):
         """Device-side packed weights + ds_denoiser handle (built once, on first use)."""
         if self._packed is not None and (sched is None or self._packed["sched_src"] is sched) \
                 and self._packed.get("precision") == self.precision:
+            if self._packed.get("row_padding") != self.row_padding:      # a switch on the handle, no re-packing
+                _lib.check(_lib.lib().ds_denoiser_set_row_padding(self._packed["handle"], int(self.row_padding)))
+                self._packed["row_padding"] = self.row_padding
             return self._packed
         self.invalidate()
         dev = self.to_logits[1].weight.device
@@ -240,8 +244,11 @@ class Text2ImageTransformer(nn.Module):
             _lib.check(_lib.lib().ds_denoiser_set_split_weights(h, mode, ptrs3, scales, wl3.data_ptr(), lsc))
         elif self.precision != "fp32":
             raise ValueError("precision must be 'fp32', 'bf16x3' or 'f16x2', got %r" % (self.precision,))
+        # padded-row mode of the sampling step (272 rows per sample at batch sizes served by the per-sample GEMM program,
+        # csrc/api.hip rows_per_sample): on by default; `row_padding = False` / DIFFSOUND_PAD_ROWS=0 keeps 265 rows
+        _lib.check(_lib.lib().ds_denoiser_set_row_padding(h, int(self.row_padding)))
         self._packed = {"handle": h, "keep": keep, "sched_src": sched, "ws": {}, "device": dev,
-                        "precision": self.precision}
+                        "precision": self.precision, "row_padding": self.row_padding}
         return self._packed
 
     def workspace(self, B, sched=None, slot=0):
