@@ -14,9 +14,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from text_to_sound_synthesis_amd import _lib as L
 
-B, Lq, H = 64, 265, 16
+B, H = 64, 16
+Lq = int(sys.argv[1]) if len(sys.argv) > 1 else 265     # rows per sample: 265, or 272 = the padded-row mode's 16-row ninth block
 M = B * Lq
 M16 = (M + 15) // 16 * 16
+print("rows per sample: %d" % Lq)
 
 
 def split(a):
