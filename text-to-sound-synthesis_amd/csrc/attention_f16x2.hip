@@ -58,6 +58,13 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
 
     const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
     const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
+#ifdef AH_TIMING   // probe build only (tools/attn_timing.py): per-workgroup s_memrealtime stamps through the unused V pointer
+    unsigned long long ah_ts[6];
+#define AH_STAMP(i_) do { ah_ts[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    AH_STAMP(0);
+#else
+#define AH_STAMP(i_) do { } while (0)
+#endif
 
     // READY: this (sample, head)'s image  K hi | K lo | V^T hi | V^T lo  (bytes), NKEY/4 KB per operand
     const unsigned char* img = (const unsigned char*)Kp + ((size_t)b * heads + head) * (size_t)(8 * KPL);
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
     // (explicit: hipcc does not reliably add the vmcnt(0) an in-flight LDS-DMA needs before a barrier, see gemm_f16x2.hip)
     if constexpr (READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // K is in LDS
+    AH_STAMP(1);
 
     f32x16 s[NKT];
     if (active) {
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
             }
         }
     }
+    AH_STAMP(2);
     __syncthreads();  // everyone is done reading K
 
     if constexpr (READY) {   // the V^T image replaces K in the same buffer; the transfer runs under the softmax
@@ -198,39 +207,45 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
     }
 
     // ---- softmax over keys (fp32, in registers) ----
+    // The longest VALU stretch of a wave (measured in-kernel: 5.9 of 23 us), so it is kept to 4 operations per score:
+    // the row maximum is taken on the RAW scores (scale > 0), keys past Lk are masked only in the tiles that contain
+    // them, each exponential is one v_fma (scale into the log2 domain and subtract the maximum) + one v_exp, and the
+    // division by the row sum is applied to the 32 output values after P V instead of to the 144 probabilities (the
+    // unnormalised e <= 1 splits into fp16 planes exactly as well).
+    float inv = 1.f;
     if (active) {
-        // exp(x) = 2^(x log2 e): the scores are scaled into the log2 domain once and each exponential is one
-        // v_exp_f32 (expf costs ~6 VALU per element; the softmax is the longest stretch of a workgroup's life)
-        const float sl = scale * 1.4426950408889634f;
+        const float sl = scale * 1.4426950408889634f;   // exp(x) = 2^(x log2 e)
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt * 32 + 32 > Lk) {                    // wave-uniform: this tile holds keys >= Lk
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hh + 16 * (r >> 3);   // pi(MFMA row)
-                const float v = key < Lk ? s[kt][r] * sl : -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hh + 16 * (r >> 3);   // pi(MFMA row)
+                    s[kt][r] = key < Lk ? s[kt][r] : -INFINITY;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float msl = mx * sl;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sl, -msl));   // masked: 2^-inf = 0
                 s[kt][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 32);
-        const float inv = 1.f / sum;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+        inv = 1.f / sum;
     }
+    AH_STAMP(3);
     if constexpr (READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // V^T is in LDS
+    AH_STAMP(4);
 
     f32x16 o0, o1;
 #pragma unroll
@@ -261,6 +276,15 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, vb0, o1, 0, 0, 0);
             }
     }
+    if (active) {   // normalise: output register r holds query (r & 3) + 8 (r >> 2) + 4 hh, whose 1 / sum sits in that lane
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float iq = __shfl(inv, (r & 3) + 8 * (r >> 2) + 4 * hh);
+            o0[r] *= iq;
+            o1[r] *= iq;
+        }
+    }
+    AH_STAMP(5);
     if (o_plane > 0) {
         // packed split planes for the f16x2 projection GEMM (K = ldo): each wave stages its 32 x 64 tile (hi, lo) in
         // the now free LDS and stores 16-byte chunks (8 d of one row) instead of 2-byte pieces
@@ -298,6 +322,15 @@ __global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const f
             }
         }
     }
+#ifdef AH_TIMING
+    if (READY && Vp && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = (unsigned long long*)Vp + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * AH_WAVES + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = ah_ts[i];
+        o[6] = __builtin_amdgcn_s_memrealtime();
+        o[7] = active;
+    }
+#endif
 }
 
 template <bool READY>
@@ -359,12 +392,19 @@ extern "C" int ds_attn_nkey(int Lk) { return Lk <= 96 ? 96 : (Lk <= 288 ? 288 : 
 // Attention on attention-ready operands (common.h): qh = Q planes [2][B][heads][Lq][64] (q_plane halves apart),
 // kv_img = [B][heads][4][nkey*64] halves (K hi | K lo | V^T hi | V^T lo, rows of keys >= Lk zero), output as in
 // ds_attention_f16x2_split.  Bit-identical to ds_attention_f16x2_split on the same values.
+#ifdef AH_TIMING
+static const float* g_ah_timing_buf = nullptr;       // probe build: 8 x u64 per wave (ds_attn_timing_buffer)
+extern "C" void ds_attn_timing_buffer(void* p) { g_ah_timing_buf = (const float*)p; }
+#define AH_TIMING_V g_ah_timing_buf
+#else
+#define AH_TIMING_V nullptr
+#endif
 extern "C" int ds_attention_f16x2_ready(const void* qh, long long q_plane, const void* kv_img, void* oh, int ldo, int B,
                                         int heads, int Lq, int Lk, float scale, ds_stream_t stream) {
     DS_CHECK_ARG(ldo % 32 == 0 && ldo >= heads * 64, "packed output needs ldo % 32 == 0");
     DS_CHECK_ARG(q_plane >= (long long)B * heads * Lq * 64 && q_plane % 8 == 0, "Q plane stride");
     DS_CHECK_ARG(((uintptr_t)qh & 15) == 0 && ((uintptr_t)kv_img & 15) == 0, "operands must be 16-byte aligned");
-    return attn_f16x2_launch<true>((const float*)qh, 0, (const float*)kv_img, 0, nullptr, 0, (float*)oh, ldo, B, heads,
+    return attn_f16x2_launch<true>((const float*)qh, 0, (const float*)kv_img, 0, AH_TIMING_V, 0, (float*)oh, ldo, B, heads,
                                    Lq, Lk, scale, (long long)((B * Lq + 15) & ~15) * ldo, q_plane, (hipStream_t)stream);
 }
 
