@@ -290,6 +290,8 @@ int ds_denoiser_set_split_weights(ds_denoiser* h, int mode, const void* const* s
  * the sampler.  Tokens agree with the unpadded step except on exact near-ties (rows 256..264 of a sample are summed in
  * another order: ~1e-7 relative).  0 switches it off (A/B, bit-for-bit comparisons across batch sizes). */
 int ds_denoiser_set_row_padding(ds_denoiser* h, int on);
+/* rows per sample of the activation matrices ds_denoiser_step(_ex) would use at batch B: seq_len, or 272 in padded-row mode */
+int ds_denoiser_rows_per_sample(const ds_denoiser* h, int B);
 /* cross-attention K/V depend only on the caption: computed once per batch (CrossAttention.key/value,
  * transformer_utils.py:96,98).  cond [B][Lc][Dc] -> kv [n_layer][B*Lc][2D] */
 int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int B, float* kv, ds_stream_t stream);

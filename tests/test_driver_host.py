@@ -69,3 +69,40 @@ def test_dalle_sample_control_flow_with_stub_backends():
         m.sample(batch, return_att_weight=True)
     with pytest.raises(NotImplementedError):
         m.sample(batch, sample_type="debug")
+
+
+def test_padded_row_mode_selection_and_workspace():
+    """Host logic of the native denoiser handle (csrc/api.hip rows_per_sample / carve; no device work, runs without a GPU):
+    the sampling step pads every sample to 272 rows exactly where the per-sample GEMM program serves the batch -- f16x2
+    mode, row padding on, grids of whole CU rounds (B = 64, 128; not 8, 32, 48) -- and the workspace query covers it."""
+    import ctypes as C
+
+    import torch
+    from text_to_sound_synthesis_amd import _lib as L
+    lib = L.lib()
+    d = L.DenoiserDesc()
+    d.n_layer, d.n_embd, d.n_head, d.seq_len, d.cond_len, d.cond_dim = 2, 1024, 16, 265, 77, 512
+    d.n_codes, d.n_steps, d.mlp_mult = 256, 100, 4
+    dummy = torch.zeros(64)                       # host memory: the handle only stores pointers
+    for f in ("tok_emb", "pos_emb", "lnf_g", "lnf_b", "w_logits", "b_logits", "sched"):
+        setattr(d, f, dummy.data_ptr())
+    n = 2 * L.LP_COUNT
+    ptrs = (C.c_void_p * n)(*([dummy.data_ptr()] * n))
+    h = C.c_void_p()
+    L.check(lib.ds_denoiser_create(C.byref(d), ptrs, C.byref(h)))
+    try:
+        assert [lib.ds_denoiser_rows_per_sample(h, B) for B in (1, 32, 64)] == [265, 265, 265]       # fp32 mode: never
+        scales = (C.c_float * n)(*([1.0] * n))
+        L.check(lib.ds_denoiser_set_split_weights(h, 2, ptrs, scales, dummy.data_ptr(), 1.0))        # f16x2 mode
+        got = {B: lib.ds_denoiser_rows_per_sample(h, B) for B in (1, 8, 32, 48, 55, 64, 100, 128)}
+        assert got == {1: 265, 8: 265, 32: 265, 48: 265, 55: 272, 64: 272, 100: 265, 128: 272}, got
+        ws = {B: lib.ds_denoiser_workspace_bytes(h, B) for B in (8, 64)}
+        assert ws[64] >= 64 * 272 * 1024 * 4 * (1 + 1 + 3 + 1 + 4) and ws[64] > 8 * ws[8] * 0.99
+        L.check(lib.ds_denoiser_set_row_padding(h, 0))
+        assert lib.ds_denoiser_rows_per_sample(h, 64) == 265
+        L.check(lib.ds_denoiser_set_row_padding(h, 1))
+        assert lib.ds_denoiser_rows_per_sample(h, 64) == 272
+        L.check(lib.ds_denoiser_set_split_weights(h, 1, ptrs, scales, dummy.data_ptr(), 1.0))        # bf16x3 mode: never
+        assert lib.ds_denoiser_rows_per_sample(h, 64) == 265
+    finally:
+        lib.ds_denoiser_destroy(h)

@@ -100,6 +100,7 @@ _PROTOS = {
     "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),
     "ds_denoiser_destroy": (None, [_vp]),
     "ds_denoiser_set_row_padding": (C.c_int, [_vp, C.c_int]),
+    "ds_denoiser_rows_per_sample": (C.c_int, [_vp, C.c_int]),
     "ds_denoiser_workspace_bytes": (_i64, [_vp, C.c_int]),
     "ds_denoiser_kv_bytes": (_i64, [_vp, C.c_int]),
     "ds_denoiser_cond_kv": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),

@@ -171,6 +171,7 @@ static int rows_per_sample(const ds_denoiser* h, int B) {
     const long tiles = (long)B * (h->d.n_embd / 256), rounds = (tiles + 255) / 256;    // the N = 1024 GEMMs' grid
     return (tiles >= 192 && tiles * 100 >= rounds * 256 * 85) ? PS_ROWS : L;         // = ds_gemm_f16x2_ps_applies
 }
+extern "C" int ds_denoiser_rows_per_sample(const ds_denoiser* h, int B) { return h && B > 0 ? rows_per_sample(h, B) : -1; }
 extern "C" int ds_denoiser_set_row_padding(ds_denoiser* h, int on) {
     DS_CHECK_ARG(h, "null handle");
     h->pad_rows = on != 0;
