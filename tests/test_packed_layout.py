@@ -283,6 +283,125 @@ def test_per_sample_tile_data_path_emulation():
     assert np.array_equal(C, A1 @ W0.T + A0 @ W1.T + A0 @ W0.T)
 
 
+def test_ping_pong_schedule_hazards_16_row_ninth_block():
+    """The same happens-before model for the NB16 variant of the per-sample program (272-row samples): the wave's B
+    fragments for the ninth block row are read in PHASE 1 (so quarter type 1, B-sub0, is last read in phase 1 instead of 0)
+    and the sixteen ninth-block A rows in PHASE 2 (type 3 is last read in phase 2 instead of 3).  LEAD 6 stays legal."""
+    def hazards(LEAD, read_off, first_off, nk=6):
+        b1 = lambda row, g: 2 * g + 2 + row
+        b2 = lambda row, g: 2 * g + 3 + row
+        before_read = lambda row, g: b2(row, g - 1) if g > 0 else 1 + row
+        bad = []
+        for q in range(4 * nk):
+            tile, ty = divmod(q, 4)
+            g_read = 4 * tile + first_off[ty]
+            w = max(q - 2, -1)
+            for reader in (0, 1):
+                for waiter in (0, 1):
+                    if (b1(waiter, w) if w >= 0 else 1) > before_read(reader, max(g_read, 0)):
+                        bad.append(("RAW", q, reader, waiter))
+            g_issue = q - LEAD
+            if g_issue < 0 or tile < 2:
+                continue
+            g_prev = 4 * (tile - 2) + read_off[ty]
+            for reader in (0, 1):
+                for issuer in (0, 1):
+                    if b2(reader, g_prev) > before_read(issuer, g_issue):
+                        bad.append(("WAR", q, reader, issuer))
+            if g_prev == g_issue:
+                bad.append(("WAR-own-phase", q))
+        return bad
+    assert hazards(6, (0, 1, 1, 2), (0, 0, 1, 2)) == []
+    # reading the B fragments as late as the 32-row variant reads its ninth block (phase 3) would race with the re-staging
+    assert any(h[0].startswith("WAR") for h in hazards(6, (0, 3, 3, 3), (0, 0, 1, 2)))
+
+
+def test_per_sample_tile_16_row_ninth_block_emulation():
+    """Index plumbing of the NB16 variant (csrc/gemm_f16x2_ps.hip, samples of 272 rows = 17 packed groups): blocks 0..7 as
+    in the 32-row variant; the ninth block row = rows 256..271, two 16 x 16 tiles per wave at columns (2 wc + wr) 32 + 16 tt
+    on v_mfma_f32_16x16x32_f16 -- operand lane l holds row / column l & 15 and the 8 k values 8 (l >> 4) .., read from the
+    stage image at chunk (l >> 4) ^ ((l & 15) >> 2 & 3); result lane l holds column l & 15, rows 4 (l >> 4) + r."""
+    import numpy as np
+    from text_to_sound_synthesis_amd import _lib as L
+    rng = np.random.default_rng(5)
+    Ls, B = 272, 2
+    M, N, K, nk = B * Ls, 256, 64, 2
+    Ah = rng.integers(-8, 9, size=(2, M, K)).astype(np.float16)
+    Wh = rng.integers(-8, 9, size=(2, N, K)).astype(np.float16)
+    Ap = L.pack_planes(torch.from_numpy(Ah)).numpy().reshape(2, -1)
+    Wp = L.pack_planes(torch.from_numpy(Wh)).numpy().reshape(2, -1)
+    BM, BN, HLD = 288, 256, 32
+    APL, BPL = BM * HLD, BN * HLD
+    STAGE = 2 * (APL + BPL)
+    rgsA = (M + 15) >> 4
+    C = np.zeros((M, N))
+    done = np.zeros((M, N), dtype=np.int32)
+    lane = np.arange(64)
+    l31, hh, l15, kq = lane & 31, lane >> 5, lane & 15, lane >> 4
+
+    def mat32(f):                      # 32x32x16 operand: lane l -> row l & 31, k = 8 (l >> 5) + e
+        m = np.zeros((32, 16))
+        for l in range(64):
+            m[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = f[l]
+        return m
+
+    def mat16(f):                      # 16x16x32 operand: lane l -> row l & 15, k = 8 (l >> 4) + e
+        m = np.zeros((16, 32))
+        for l in range(64):
+            m[l & 15, 8 * (l >> 4):8 * (l >> 4) + 8] = f[l]
+        return m
+    for b in range(B):
+        m0 = b * Ls
+        assert m0 % 16 == 0
+        acc = np.zeros((BM, BN))
+        for t in range(nk):
+            lds = np.full(STAGE, np.nan, dtype=np.float32)
+            for ty in range(4):
+                for wave in range(8):
+                    for k in range(2):
+                        idx = 2 * wave + k
+                        plane, r = idx >> 3, idx & 7
+                        isA = ty in (0, 3)
+                        sub = (ty == 3) if isA else (ty == 2)
+                        gip = (r >> 2) * 8 + sub * 4 + (r & 3) if isA else (r >> 1) * 4 + sub * 2 + (r & 1)
+                        rg = min(((m0 if isA else 0) >> 4) + gip, (rgsA if isA else N // 16) - 1)
+                        src = (Ap if isA else Wp)[plane]
+                        l_off = (plane * 18 + gip if isA else 36 + plane * 16 + gip) * 512
+                        lds[l_off:l_off + 512] = src[rg * nk * 512 + t * 512:rg * nk * 512 + t * 512 + 512]
+                    if ty == 3:
+                        e = wave & 3
+                        plane, gip = e >> 1, 16 + (e & 1)
+                        rg = min((m0 >> 4) + gip, rgsA - 1)
+                        l_off = (plane * 18 + gip) * 512
+                        lds[l_off:l_off + 512] = Ap[plane][rg * nk * 512 + t * 512:rg * nk * 512 + t * 512 + 512]
+            for wave in range(8):
+                wr, wc = wave >> 2, wave & 3
+                for ks in range(2):
+                    swz = ((2 * ks + hh) ^ ((l31 >> 2) & 3)) * 8
+                    frag = lambda base_row, plane_off: mat32(np.stack(
+                        [lds[plane_off + (base_row + l31) * HLD + swz + e] for e in range(8)], axis=1))
+                    for i in range(4):
+                        a0, a1 = frag(wr * 128 + i * 32, 0), frag(wr * 128 + i * 32, APL)
+                        for sb in (0, 1):
+                            b0, b1 = frag(wc * 64 + sb * 32, 2 * APL), frag(wc * 64 + sb * 32, 2 * APL + BPL)
+                            acc[wr * 128 + i * 32:wr * 128 + i * 32 + 32, wc * 64 + sb * 32:wc * 64 + sb * 32 + 32] += \
+                                a1 @ b0.T + a0 @ b1.T + a0 @ b0.T
+                swzq = (kq ^ ((l15 >> 2) & 3)) * 8
+                f16 = lambda base_row, plane_off: mat16(np.stack(
+                    [lds[plane_off + (base_row + l15) * HLD + swzq + e] for e in range(8)], axis=1))
+                ea0, ea1 = f16(256, 0), f16(256, APL)
+                for tt in range(2):
+                    col = (2 * wc + wr) * 32 + tt * 16
+                    eb0, eb1 = f16(col, 2 * APL), f16(col, 2 * APL + BPL)
+                    acc[256:272, col:col + 16] += ea1 @ eb0.T + ea0 @ eb1.T + ea0 @ eb0.T      # one 32-k MFMA per product
+        for trow in range(0, Ls):
+            C[m0 + trow] += acc[trow]
+            done[m0 + trow] += 1
+    assert (done == 1).all()
+    A0, A1, W0, W1 = (x.astype(np.float64) for x in (Ah[0], Ah[1], Wh[0], Wh[1]))
+    assert np.array_equal(C, A1 @ W0.T + A0 @ W1.T + A0 @ W0.T)
+
+
 def test_generic_tile_data_path_emulation():
     """The same emulation for the generic staging of ds_gemm_f16x2_body (AMODE 2: wave w owns the 16-row groups
     w + NW i of the stage image, one DMA instruction each) over every tile geometry the library instantiates."""
