@@ -155,3 +155,25 @@ def test_boundary_signatures_match_reference():
         if any(w[2] == "VAR_KEYWORD" for w in want) and not any(g[2] == "VAR_KEYWORD" for g in got):
             problems.append("%s: reference accepts **kwargs, ours does not" % name)
     assert not problems, "\n".join(problems)
+
+
+def test_kernel_source_fingerprint_ignores_comments_only():
+    """build.source_fingerprint (guards bench.py's roofline.traffic): comments and whitespace do not change it, code does;
+    it covers the dominant kernel's own sources and matches the newest committed PMC summary when that was measured on
+    this tree's kernel."""
+    import glob
+    import json
+    import os
+    from text_to_sound_synthesis_amd import build as B
+    a = "int f(int x) { return x + 1; }  // add one\n/* block\n comment */ const char* s = \"a // not a comment\";\n"
+    b = "int f(int x){return x+1;}\nconst char*s=\"a // not a comment\";"
+    assert B._code_only(a) == B._code_only(b)
+    assert B._code_only(a) != B._code_only(a.replace("x + 1", "x + 2"))
+    assert "gemm_f16x2_ps.hip" in B.DOMINANT_KERNEL_SOURCES
+    fp = B.source_fingerprint()
+    assert len(fp) == 16 and fp == B.source_fingerprint()
+    files = sorted(glob.glob(os.path.join(B.ROOT, "profiles", "r*_pmc_denoiser_step_b64.json")))
+    assert files, "no PMC summary committed"
+    meta = json.load(open(files[-1])).get("_meta", {})
+    assert meta.get("source_sha16") == fp, ("the newest PMC summary %s was measured on other kernel sources: re-run "
+                                            "tools/profile_round.sh" % os.path.basename(files[-1]))
