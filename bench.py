@@ -43,7 +43,11 @@ def parse():
     ap.add_argument("--n-layer", type=int, default=19)
     ap.add_argument("--codes", type=int, default=256)
     ap.add_argument("--precision", default=os.environ.get("DIFFSOUND_GEMM", "f16x2"), choices=("fp32", "bf16x3", "f16x2"),
-                    help="denoiser GEMM arithmetic: fp32 MFMA, or the fp32-accurate 3-way bf16 split")
+                    help="denoiser GEMM arithmetic: exact-fp32 MFMA, or an fp32-class split on the 16-bit matrix cores -- "
+                         "f16x2 (default): 2 fp16 planes per operand, 3 MFMA passes; bf16x3: 3 bf16 planes, 6 passes")
+    ap.add_argument("--rng", default="philox", choices=("philox", "torch"),
+                    help="philox (default): Gumbel noise drawn in the sampler kernel, keyed by the global caption index -- "
+                         "the same clips at every world size; torch: torch.rand per step, the reference's own draw")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFSOUND_STREAMS", "1")), choices=(1, 2),
                     help="2: the sampling loop runs the batch as two half-batches on two HIP streams")
     ap.add_argument("--transformer-only", action="store_true",
@@ -232,6 +236,8 @@ def result_line(args, world, elapsed, n_total):
                                 "codebook %d: CLIP text tower -> 19-layer denoiser -> SpecVQGAN decode -> MelGAN "
                                 "22 kHz") % (B, T, args.codes),
                    "global_batch": n_total, "n_layer": args.n_layer, "parallelism": "caption-sharded x%d" % world,
+                   "noise": ("in-kernel Philox4x32-10 keyed by (seed, global caption id, step, position, class)"
+                             if getattr(args, "rng", "philox") == "philox" else "torch.rand per step"),
                    "denoiser_tflops_effective": round(value * GFLOP_PER_SAMPLE_STEP * T / 1e3, 2)},
     }
 
@@ -265,13 +271,15 @@ def main():
     n_total = B * world
     # rank 0 owns the captions: synthetic caption STRINGS, tokenised inside the timed region by
     # the package's BPE tokenizer (clip.tokenize semantics: <SOT> word pieces <EOT>, context 77) on the closed-vocabulary
-    # merge table tests/golden/bpe_closed_vocab.json -- the part of CLIP's table these captions exercise, ids checked
+    # merge table text-to-sound-synthesis_amd/data/bpe_closed_vocab.json (tokenizer.CLOSED_VOCAB_PATH) -- the part of CLIP's table these captions exercise, ids checked
     # against the reference's tokenizer when the file was made (the 1.3 MB full table is not on the GPU box).  Every
     # rank gets a slice of the ids and runs the CLIP text tower on it.
     from text_to_sound_synthesis_amd import tokenizer as tz
     captions = synth.synth_captions(n_total, seed=7) if rank == 0 else None
-    bpe = tz.SimpleTokenizer(bpe_path=os.path.join(ROOT, "tests", "golden", "bpe_closed_vocab.json")) if rank == 0 else None
+    bpe = tz.SimpleTokenizer(bpe_path=tz.CLOSED_VOCAB_PATH) if rank == 0 else None
     torch.manual_seed(1234 + rank)
+    lo_id, hi_id = shard.shard_bounds(n_total, world, rank)
+    my_ids = torch.arange(lo_id, hi_id, device=dev, dtype=torch.long)
     stage = {"scatter": 0.0, "kv": 0.0, "sample": 0.0, "decode": 0.0, "vocode": 0.0, "gather": 0.0}
 
     def one_step(timed_stages=False):
@@ -284,7 +292,9 @@ def main():
             if rank == 0 else None
         toks = shard.scatter_conditions(tok_all, n_total, (77,), dev, dtype=torch.long)
         t1 = mark()
-        out = dt.sample(condition_token=toks, condition_mask=None, condition_embed=None, filter_ratio=0)
+        # per-caption in-kernel noise keyed by the GLOBAL caption index: a caption's clip is the same at every world size
+        out = dt.sample(condition_token=toks, condition_mask=None, condition_embed=None, filter_ratio=0,
+                        caption_ids=None if args.rng == "torch" else my_ids, seed=1234)
         t2 = mark()
         if args.transformer_only:
             tok = out["content_token"]

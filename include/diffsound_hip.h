@@ -182,17 +182,37 @@ int ds_sample_tail_ex(const float* logits, const int64_t* xt, const int64_t* t, 
 int ds_q_sample(const int64_t* x0, const int64_t* t, const float* u, const float* sched, int64_t* out_tokens, int B,
                 int L, int K, int T, ds_stream_t stream);
 
+/* ---- the same samplers with the noise drawn INSIDE the kernel -----------------------------------------------------
+ * The reference draws torch.rand_like(logits) per step (log_sample_categorical, diffusion_transformer.py:359-368), so
+ * what a caption draws depends on the batch it is in.  SURVEY.md section 8(e) asks for per-sample noise keyed by the
+ * global caption index so that a shard reproduces the single-GPU draw (pattern: Codebook/evaluation/
+ * generate_samples_caps.py:153,306 -- rank-sharded sampler, nothing collective in the loop).  These entries draw from a
+ * counter-based Philox4x32-10 stream: the uniform of class c = 64 j + lane (the [MASK] class K is j = K / 64, lane 0)
+ * at grid position pos of caption gids[b] in sampler call `call` is word (j & 3) of
+ *     Philox(counter = (64 (j >> 2) + lane, pos | rng_stream << 16, call, gids[b]), key = (seed lo, seed hi))
+ * mapped to [0, 1) as (word >> 8) * 2^-24; rng_stream = 0 for reverse steps, 1 for q_sample.  gids [B] (device, each
+ * < 2^32), L < 65536.  ds_philox_uniforms writes that stream out as u [B][K+1][L] (tests: *_rng(...) == the u-path fed
+ * with it).  Host mirror (numpy): text_to_sound_synthesis_amd.shard.caption_uniforms. */
+int ds_philox_uniforms(const int64_t* gids, unsigned long long seed, int call, int rng_stream, float* u, int B, int L,
+                       int K, ds_stream_t stream);
+int ds_sample_tail_rng(const float* logits, const int64_t* xt, const int64_t* t, const int64_t* gids,
+                       unsigned long long seed, int call, const float* sched, int64_t* out_tokens, int B, int L, int K,
+                       int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream);
+int ds_q_sample_rng(const int64_t* x0, const int64_t* t, const int64_t* gids, unsigned long long seed, int call,
+                    const float* sched, int64_t* out_tokens, int B, int L, int K, int T, ds_stream_t stream);
+
 /* forward terms of the training loss (DiffusionTransformer._train_loss, diffusion_transformer.py:408-476), one value
  * per grid position [B][L]: kl = KL(true posterior || model posterior) (:439-440), nll = the t == 0 decoder term
  * (:446), kl_aux = KL(x_0 || p(x_0|x_t)) over the K classes (:462); logits [B*L][K] of the network at (x_t, t),
- * dbg_model_log_prob optional [B][K+1][L].  Forward only: no gradients are produced anywhere in this library. */
+ * dbg_model_log_prob optional [B][K+1][L].  Forward value only; its gradient is ds_loss_tail_bwd below. */
 int ds_loss_tail(const float* logits, const int64_t* x0, const int64_t* xt, const int64_t* t, const float* sched,
                  float* kl, float* nll, float* kl_aux, float* dbg_model_log_prob, int B, int L, int K, int T,
                  ds_stream_t stream);
 
 /* d(sum over samples of vb_loss) / d logits for the loss above (pt [B] = the sampling probabilities of t; mask
  * weights for masked / unmasked x_t positions; auxiliary loss weight and its adaptive flag): dlogits [B*L][K].  The
- * first backward kernel of the training step; the rest of the backward does not exist yet. */
+ * first kernel of the training step's backward (modeling/train.py composes the rest from the entries below, the GEMMs
+ * and ds_attention_bwd). */
 int ds_loss_tail_bwd(const float* logits, const int64_t* x0, const int64_t* xt, const int64_t* t, const float* pt,
                      const float* sched, float* dlogits, int B, int L, int K, int T, float mask_weight_masked,
                      float mask_weight_other, float aux_weight, int adaptive, ds_stream_t stream);
@@ -308,6 +328,19 @@ int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64
 int ds_denoiser_step_ex(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const int64_t* t_post,
                         const float* kv, const float* u, int B, int initial, float trunc_r, int trunc_k,
                         void* workspace, int64_t* tokens_out, ds_stream_t stream);
+
+/* ds_denoiser_step_ex with the noise drawn in the sampler kernel (ds_sample_tail_rng): Philox call index `call` */
+int ds_denoiser_step_rng(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const int64_t* t_post,
+                         const float* kv, const int64_t* gids, unsigned long long seed, int call, int B, int initial,
+                         float trunc_r, int trunc_k, void* workspace, int64_t* tokens_out, ds_stream_t stream);
+
+/* A whole reverse chain (DiffusionTransformer.sample's loop, diffusion_transformer.py:639-641; sample_fast's, :790-804)
+ * enqueued without returning to the host: n_calls steps, t_steps = DEVICE i64[n_calls][2][B] (per call the network's
+ * timestep vector, then the posterior's), tokens [B][seq_len] in: start state / out: result, tokens_tmp same size,
+ * call k draws Philox call index call0 + k, initial != 0: the start state is all-[MASK]. */
+int ds_denoiser_sample_rng(const ds_denoiser* h, int64_t* tokens, int64_t* tokens_tmp, const int64_t* t_steps,
+                           int n_calls, const float* kv, const int64_t* gids, unsigned long long seed, int call0, int B,
+                           int initial, float trunc_r, int trunc_k, void* workspace, ds_stream_t stream);
 
 /* per-launch HIP-event timing of the denoiser's GEMM launches (measurement only, bench.py) */
 int ds_profile_enable(int on);

@@ -404,7 +404,8 @@ def signatures():
 
 
 def bpe_closed_vocab():
-    """tests/golden/bpe_closed_vocab.json: the part of CLIP's merge table that the synthetic-caption word list
+    """text-to-sound-synthesis_amd/data/bpe_closed_vocab.json (package data, not a golden vector: it is input of the
+    tokenizer, consumed by bench.py's timed region): the part of CLIP's merge table that the synthetic-caption word list
     (text_to_sound_synthesis_amd.synth._WORDS) exercises -- every merge the FULL table applies to one of those words, with
     its original rank, plus the ids of the resulting tokens and the two specials.  Checked here against the reference's
     own tokenizer on 3000 random captions over the word list.  (The GPU box has no copy of the full table.)"""
@@ -434,7 +435,7 @@ def bpe_closed_vocab():
     enc = {t: full.encoder[t] for t in sorted(tokens)}
     for sp in ("<|startoftext|>", "<|endoftext|>"):
         enc[sp] = full.encoder[sp]
-    path = os.path.join(OUT, "bpe_closed_vocab.json")
+    path = tz.CLOSED_VOCAB_PATH
     with open(path, "w") as f:
         json.dump({"words": words, "merges": sorted(merges, key=lambda m: m[2]), "encoder": enc}, f)
     closed = tz.SimpleTokenizer(bpe_path=path)

@@ -1,0 +1,219 @@
+"""Sharding-invariant sampling: the *_rng entries draw the Gumbel noise inside the sampler kernel
+from a Philox stream keyed by (seed, global caption id, call, position, class).  Checked here on the GPU:
+  * the device stream == its numpy mirror (shard.caption_uniforms, itself pinned to the Random123 known answers on the
+    CPU, tests/test_philox.py), bit for bit;
+  * every *_rng entry == the `u`-pointer entry fed with those uniforms (so the reference-parity tests of the `u` path
+    carry over);
+  * the property itself: 8 captions as one batch == two batches of 4 == any order == one at a time, tokens identical;
+  * the whole chain enqueued from C++ (ds_denoiser_sample_rng) == the host-stepped loop.
+GPU only (-m gpu)."""
+import random
+
+import pytest
+import torch
+
+from conftest import synth_sd
+from text_to_sound_synthesis_amd import _lib, shard, synth
+
+pytestmark = pytest.mark.gpu
+NO_GRAD = True
+
+SEED = (0x9e37 << 32) | 20240926
+
+
+def build(n_layer=2, T=10, mode="f16x2", codes=256):
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    m = build_model(default_config(n_layer=n_layer, diffusion_step=T, n_embed=codes))
+    sd = dict(synth_sd("dalle", n_layer))
+    if T != 100:
+        sd = {k: (v[:T] if k.endswith(("ln1.emb.weight", "ln1_1.emb.weight")) else v) for k, v in sd.items()}
+    if codes == 256:
+        m.load_state_dict(sd, strict=False)
+    else:
+        synth.synth_init_(m, seed=0)
+    m.transformer.transformer.precision = mode
+    m = m.cuda().eval()
+    m.transformer.truncation_r = 0.85
+    return m
+
+
+@pytest.mark.parametrize("K", [256, 512])
+def test_device_stream_equals_host_mirror(K):
+    L = 265
+    ids = [0, 1, 77, 123456789, 2 ** 32 - 1]
+    gids = torch.tensor(ids, dtype=torch.long, device="cuda")
+    for call, stream in ((0, 0), (99, 0), (5, 1)):
+        u = torch.empty(len(ids), K + 1, L, device="cuda")
+        _lib.check(_lib.lib().ds_philox_uniforms(_lib.ptr(gids), SEED, call, stream, _lib.ptr(u), len(ids), L, K, _lib.stream()))
+        want = shard.caption_uniforms(ids, call, K, L, SEED, rng_stream=stream)
+        assert torch.equal(u.cpu(), want), "device Philox stream differs from the host mirror (K=%d call=%d)" % (K, call)
+
+
+@pytest.mark.parametrize("K", [256, 512])
+def test_sample_tail_rng_equals_u_path(K):
+    """ds_sample_tail_rng == ds_sample_tail_ex fed with the mirror's uniforms, incl. the all-[MASK] start state, top-k
+    truncation and ragged batch sizes (dead waves in the last workgroup)."""
+    L, T = 265, 100
+    m = build(1, T=T, codes=K)
+    sched = m.transformer._schedule_table()      # the [8][T+1] table as the product builds it
+    g = torch.Generator().manual_seed(K)
+    for B, initial, tr, tk in ((3, 0, 0.85, 0), (5, 1, 0.85, 0), (2, 0, -1.0, 30), (1, 0, -1.0, 0)):
+        logits = (torch.randn(B * L, K, generator=g) * 2.0).cuda()
+        xt = torch.randint(0, K + 1, (B, L), generator=g).cuda()
+        if initial:
+            xt.fill_(K)
+        t = torch.randint(1, T, (B,), generator=g).cuda()
+        ids = [int(v) for v in torch.randint(0, 2 ** 31, (B,), generator=g)]
+        gids = torch.tensor(ids, dtype=torch.long, device="cuda")
+        call = 17
+        out_rng = torch.empty(B, L, dtype=torch.long, device="cuda")
+        _lib.check(_lib.lib().ds_sample_tail_rng(_lib.ptr(logits), _lib.ptr(xt), _lib.ptr(t), _lib.ptr(gids), SEED, call,
+                                                 _lib.ptr(sched), _lib.ptr(out_rng), B, L, K, T, initial, tr, tk, _lib.stream()))
+        u = shard.caption_uniforms(ids, call, K, L, SEED).cuda()
+        out_u = torch.empty_like(out_rng)
+        _lib.check(_lib.lib().ds_sample_tail_ex(_lib.ptr(logits), _lib.ptr(xt), _lib.ptr(t), _lib.ptr(u), _lib.ptr(sched),
+                                                _lib.ptr(out_u), None, None, None, B, L, K, T, initial, tr, tk, _lib.stream()))
+        assert torch.equal(out_rng, out_u)
+    del m
+
+
+def test_q_sample_rng_equals_u_path():
+    m = build(1, T=100)
+    dt = m.transformer
+    K, L, B = 256, 265, 4
+    x0 = synth.synth_tokens(B, mask_frac=0.0, key="rng.q.x0").cuda()
+    t = torch.tensor([0, 37, 80, 99], device="cuda")
+    ids = [9, 3, 1000000, 4]
+    gids = torch.tensor(ids, dtype=torch.long, device="cuda")
+    out = torch.empty_like(x0)
+    _lib.check(_lib.lib().ds_q_sample_rng(_lib.ptr(x0), _lib.ptr(t), _lib.ptr(gids), SEED, 0, _lib.ptr(dt._schedule_table()),
+                                          _lib.ptr(out), B, L, K, 100, _lib.stream()))
+    want = dt.q_sample_tokens(x0, t, shard.caption_uniforms(ids, 0, K, L, SEED, rng_stream=1).cuda())
+    assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "fp32"])
+def test_captions_draw_the_same_clip_in_any_batch(mode):
+    """The property SURVEY.md section 8(e) asks for.  8 captions: as one batch, as two batches of 4, in another order,
+    one at a time -- the 10-step chain must end on identical tokens for every caption.  (Batch sizes below the padded-row
+    mode's threshold: every GEMM program is bit-identical across those, tests/test_hip_split_gemm.py.)"""
+    m = build(2, T=10, mode=mode)
+    dt = m.transformer
+    n = 8
+    cond = synth.synth_cond_emb(n, key="rng.inv.cond").cuda()
+    ids = torch.tensor([40, 41, 42, 43, 1000, 7, 99999, 3], dtype=torch.long)
+
+    def run(sel):
+        sel = list(sel)
+        out = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond[sel].contiguous(), filter_ratio=0,
+                        caption_ids=ids[sel], seed=SEED)
+        return out["content_token"].cpu()
+
+    whole = run(range(n))
+    assert int(whole.max()) < 256                                          # no [MASK] left at t = 0
+    assert not torch.equal(whole[0], whole[1])
+    halves = torch.cat([run(range(0, 4)), run(range(4, 8))])
+    assert torch.equal(halves, whole), "two batches of 4 differ from one batch of 8"
+    perm = [5, 2, 7, 0, 3, 6, 1, 4]
+    assert torch.equal(run(perm), whole[perm]), "a permuted batch differs"
+    singles = torch.cat([run([i]) for i in range(n)])
+    assert torch.equal(singles, whole), "single-caption batches differ"
+    ragged = torch.cat([run(range(0, 3)), run(range(3, 8))])
+    assert torch.equal(ragged, whole)
+    # another seed, another draw
+    other = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, caption_ids=ids,
+                      seed=SEED + 1)["content_token"].cpu()
+    assert not torch.equal(other, whole)
+    # rng_mode = "philox" without ids: ids default to 0 .. B-1
+    dt.rng_mode = "philox"
+    try:
+        a = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, seed=SEED)
+        b = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0,
+                      caption_ids=torch.arange(n), seed=SEED)
+        assert torch.equal(a["content_token"], b["content_token"])
+    finally:
+        dt.rng_mode = "torch"
+
+
+def test_chain_from_cpp_equals_host_stepped_loop():
+    """ds_denoiser_sample_rng (all steps enqueued by one C call) == the Python loop over ds_denoiser_step_ex fed with the
+    host mirror's uniforms (the path the reference-parity tests pin), for the plain, the skip-step and the repeat-step
+    samplers and for the filter_ratio > 0 re-sampling branch."""
+    m = build(2, T=10)
+    dt = m.transformer
+    B, K, L = 3, 256, 265
+    cond = synth.synth_cond_emb(B, key="rng.chain.cond").cuda()
+    ids = [12, 500, 13]
+
+    def nf_reverse(call, shp):
+        return shard.caption_uniforms(ids, call, K, L, SEED)
+
+    # plain chain: noise_fn's first argument is the timestep; call index = T - 1 - t
+    a = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, caption_ids=ids, seed=SEED)
+    b = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0,
+                  noise_fn=lambda t, shp: nf_reverse(9 - t, shp))
+    assert torch.equal(a["content_token"], b["content_token"])
+    # skip-step sampler (timesteps 9, 6, 3, 0 for skip_step 2): calls 0, 1, 2, 3
+    a = dt.sample_fast(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, skip_step=2,
+                       caption_ids=ids, seed=SEED)
+    order = {9: 0, 6: 1, 3: 2, 0: 3}
+    b = dt.sample_fast(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, skip_step=2,
+                       noise_fn=lambda t, shp: nf_reverse(order[t], shp))
+    assert torch.equal(a["content_token"], b["content_token"])
+    # 'q' repeat-step sampler: Python's `random` decides the repeats (as the reference's wrapper); with it active the
+    # noise_fn argument is the running call index
+    dt.repeat_rate = 0.5
+    try:
+        random.seed(5)
+        a = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, caption_ids=ids, seed=SEED)
+        random.seed(5)
+        b = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, noise_fn=nf_reverse)
+        assert torch.equal(a["content_token"], b["content_token"])
+    finally:
+        dt.repeat_rate = None
+    # partial re-sampling: q_sample on stream 1 (call 0), then the reverse chain from t = 4 on stream 0
+    x0 = synth.synth_tokens(B, mask_frac=0.0, key="rng.chain.x0").cuda()
+    a = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, content_token=x0, filter_ratio=0.5,
+                  caption_ids=ids, seed=SEED)
+
+    def nf_partial(call, shp):      # call 0 = q_sample's draw, 1.. = the reverse steps
+        return shard.caption_uniforms(ids, 0, K, L, SEED, rng_stream=1) if call == 0 else nf_reverse(call - 1, shp)
+    b = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, content_token=x0, filter_ratio=0.5,
+                  noise_fn=nf_partial)
+    assert torch.equal(a["content_token"], b["content_token"])
+
+
+def test_generate_content_with_caption_ids_and_replicates():
+    """DALLE.generate_content: ids ride in the batch dict (the method's signature is the reference's); replicate r of
+    caption i draws as id + r * 2^24, so replicates differ from each other and a caption's replicate 0 equals its
+    un-replicated clip."""
+    m = build(1, T=6)
+    cond = synth.synth_cond_emb(2, key="rng.gc.cond").cuda()
+    one = m.generate_content(batch={"condition_embed_token": cond, "caption_ids": [5, 6], "seed": SEED}, filter_ratio=0,
+                             replicate=1, content_ratio=1, sample_type="top0.85r")["content_token"]
+    two = m.generate_content(batch={"condition_embed_token": cond, "caption_ids": [5, 6], "seed": SEED}, filter_ratio=0,
+                             replicate=2, content_ratio=1, sample_type="top0.85r")["content_token"]
+    assert torch.equal(two[:2], one)
+    assert not torch.equal(two[2:], one)
+    solo = m.generate_content(batch={"condition_embed_token": cond[1:], "caption_ids": [6], "seed": SEED}, filter_ratio=0,
+                              replicate=1, content_ratio=1, sample_type="top0.85r")["content_token"]
+    assert torch.equal(solo[0], one[1])
+
+
+def test_full_batch_padded_rows_with_in_kernel_noise():
+    """B = 64 (padded-row mode, the per-sample GEMM program): captions 0..7 replicated 8 times with the SAME ids draw the
+    same tokens in all replicas, and agree with the B = 8 run of the same captions except where a decision sits on a
+    near-tie (rows 256..264 of a sample are summed in another order in this mode: ~1e-7 relative on the logits)."""
+    m = build(2, T=10)
+    dt = m.transformer
+    c8 = synth.synth_cond_emb(8, key="rng.b64.cond").cuda()
+    ids8 = torch.arange(100, 108)
+    small = dt.sample(condition_token=None, condition_mask=None, condition_embed=c8, filter_ratio=0, caption_ids=ids8,
+                      seed=SEED)["content_token"]
+    big = dt.sample(condition_token=None, condition_mask=None, condition_embed=c8.repeat(8, 1, 1), filter_ratio=0,
+                    caption_ids=ids8.repeat(8), seed=SEED)["content_token"].view(8, 8, 265)
+    for r in range(1, 8):
+        assert torch.equal(big[r], big[0]), "replica %d differs inside one batch" % r
+    differing = int((big[0] != small).any(1).sum())
+    print("B=64 (272-row tiles) vs B=8: %d of 8 clips differ" % differing)
+    assert differing <= 1

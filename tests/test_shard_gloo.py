@@ -31,7 +31,7 @@ def _worker(rank, world, port, n_items, q):
         assert mine.shape == (hi - lo, 2, 3)
         # stand-in for the per-caption pipeline: a function of the caption's conditioning and of
         # noise keyed by the GLOBAL caption index (independent of rank / batch position)
-        noise = shard.per_caption_noise(range(lo, hi), step=7, shape_tail=(4,), device=torch.device("cpu"))
+        noise = shard.per_caption_noise(range(lo, hi), step=7, shape_tail=(5, 3), device=torch.device("cpu")).flatten(1)
         local = mine.sum((1, 2))[:, None] + noise
         out = shard.gather_outputs(local, n_items)
         if rank == 0:
@@ -55,7 +55,7 @@ def test_scatter_compute_gather(world, n_items):
         p.join(timeout=60)
         assert p.exitcode == 0
     cond_all = torch.arange(n_items * 6, dtype=torch.float32).view(n_items, 2, 3)
-    noise = shard.per_caption_noise(range(n_items), step=7, shape_tail=(4,), device=torch.device("cpu"))
+    noise = shard.per_caption_noise(range(n_items), step=7, shape_tail=(5, 3), device=torch.device("cpu")).flatten(1)
     want = cond_all.sum((1, 2))[:, None] + noise          # what a single process would produce
     assert torch.equal(out, want)
 

@@ -100,7 +100,7 @@ def test_tokenizer_matches_live_reference_on_random_captions():
 
 
 def test_closed_vocabulary_merge_table_matches_goldens_and_refuses_other_words():
-    """tests/golden/bpe_closed_vocab.json (what bench.py tokenises with on the GPU box): ids equal the reference's for
+    """data/bpe_closed_vocab.json (package data; what bench.py tokenises with on the GPU box): ids equal the reference's for
     captions over its word list (oracle/make_golden.py checked 3000 of them against the reference's tokenizer when the
     file was written; here: the committed golden captions that stay inside the word list), and a word outside the list
     raises instead of producing wrong ids."""
@@ -108,7 +108,7 @@ def test_closed_vocabulary_merge_table_matches_goldens_and_refuses_other_words()
     import pytest
     from conftest import GOLDEN
     from text_to_sound_synthesis_amd import synth, tokenizer as tz
-    closed = tz.SimpleTokenizer(bpe_path=os.path.join(GOLDEN, "bpe_closed_vocab.json"))
+    closed = tz.SimpleTokenizer(bpe_path=tz.CLOSED_VOCAB_PATH)
     caps = synth.synth_captions(64, seed=7)
     tok = tz.tokenize(caps, context_length=77, add_start_and_end=True, tokenizer=closed)["token"]
     assert tok.shape == (64, 77) and (tok[:, 0] == 49406).all()

@@ -80,6 +80,10 @@ _PROTOS = {
     "ds_sample_tail_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f, C.c_int, _vp]),
     "ds_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_philox_uniforms": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_sample_tail_rng": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, _f, C.c_int, _vp]),
+    "ds_q_sample_rng": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_vq_argmin": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_loss_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f,
@@ -107,6 +111,10 @@ _PROTOS = {
     "ds_denoiser_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "ds_denoiser_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f, _vp, _vp, _vp]),
     "ds_denoiser_step_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f, C.c_int, _vp, _vp, _vp]),
+    "ds_denoiser_step_rng": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int, _f, C.c_int,
+                                       _vp, _vp, _vp]),
+    "ds_denoiser_sample_rng": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int, _f,
+                                         C.c_int, _vp, _vp]),
     "ds_profile_enable": (C.c_int, [C.c_int]),
     "ds_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ds_codebook_gather": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

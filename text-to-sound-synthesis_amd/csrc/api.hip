@@ -405,17 +405,65 @@ extern "C" int ds_denoiser_forward(const ds_denoiser* h, const int64_t* tokens, 
 
 // t drives the network (AdaLN), t_post the posterior: they differ only for the skip-step sampler
 // (sample_fast, diffusion_transformer.py:796-803 calls q_posterior with t - skip_step)
-extern "C" int ds_denoiser_step_ex(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t,
-                                   const int64_t* t_post, const float* kv, const float* u, int B, int initial,
-                                   float trunc_r, int trunc_k, void* workspace, int64_t* tokens_out,
-                                   ds_stream_t stream) {
-    DS_CHECK_ARG(h && tokens_in && t && kv && u && workspace && tokens_out && B > 0, "bad arguments");
+static int step_impl(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const int64_t* t_post,
+                     const float* kv, const float* u, const int64_t* gids, unsigned long long seed, int call, int B,
+                     int initial, float trunc_r, int trunc_k, void* workspace, int64_t* tokens_out, ds_stream_t stream) {
     Carve w;
     const int Lp = rows_per_sample(h, B);
     carve(h, B, workspace, &w, Lp);
     TRY(forward_impl(h, tokens_in, t, kv, B, w, w.logits, 0, (hipStream_t)stream, Lp));
     return ds_sample_tail_rows(w.logits, Lp, tokens_in, t_post ? t_post : t, u, h->d.sched, tokens_out, nullptr, nullptr,
-                               nullptr, B, h->d.seq_len, h->d.n_codes, h->d.n_steps, initial, trunc_r, trunc_k, stream);
+                               nullptr, B, h->d.seq_len, h->d.n_codes, h->d.n_steps, initial, trunc_r, trunc_k, stream,
+                               gids, seed, call);
+}
+
+extern "C" int ds_denoiser_step_ex(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t,
+                                   const int64_t* t_post, const float* kv, const float* u, int B, int initial,
+                                   float trunc_r, int trunc_k, void* workspace, int64_t* tokens_out,
+                                   ds_stream_t stream) {
+    DS_CHECK_ARG(h && tokens_in && t && kv && u && workspace && tokens_out && B > 0, "bad arguments");
+    return step_impl(h, tokens_in, t, t_post, kv, u, nullptr, 0ull, 0, B, initial, trunc_r, trunc_k, workspace, tokens_out,
+                     stream);
+}
+
+// the same step with the noise drawn inside the sampler kernel (sampler.hip: Philox keyed by seed, counter = global
+// caption id gids[b], sampler call index, grid position, class): what a caption draws does not depend on the batch it is
+// in, on its position in it, or on the rank that runs it
+extern "C" int ds_denoiser_step_rng(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t,
+                                    const int64_t* t_post, const float* kv, const int64_t* gids,
+                                    unsigned long long seed, int call, int B, int initial, float trunc_r, int trunc_k,
+                                    void* workspace, int64_t* tokens_out, ds_stream_t stream) {
+    DS_CHECK_ARG(h && tokens_in && t && kv && gids && workspace && tokens_out && B > 0, "bad arguments");
+    return step_impl(h, tokens_in, t, t_post, kv, nullptr, gids, seed, call, B, initial, trunc_r, trunc_k, workspace,
+                     tokens_out, stream);
+}
+
+// A whole reverse chain enqueued from C++ (DiffusionTransformer.sample's loop, diffusion_transformer.py:639-641, and
+// sample_fast's, :790-804): n_calls steps; t_steps is a DEVICE array i64[n_calls][2][B] -- per call the network's
+// timestep vector and the posterior's (equal except for the skip-step sampler).  tokens (in: the start state, out: the
+// result) and tokens_tmp ([B][seq_len] each) are the two ends of the ping-pong; call k uses Philox call index
+// call0 + k; `initial` marks the first call's state as the all-[MASK] start.  Nothing returns to the host between steps.
+extern "C" int ds_denoiser_sample_rng(const ds_denoiser* h, int64_t* tokens, int64_t* tokens_tmp, const int64_t* t_steps,
+                                      int n_calls, const float* kv, const int64_t* gids, unsigned long long seed,
+                                      int call0, int B, int initial, float trunc_r, int trunc_k, void* workspace,
+                                      ds_stream_t stream) {
+    DS_CHECK_ARG(h && tokens && tokens_tmp && t_steps && kv && gids && workspace && B > 0 && n_calls >= 0, "bad arguments");
+    int64_t *cur = tokens, *nxt = tokens_tmp;
+    for (int k = 0; k < n_calls; ++k) {
+        const int64_t* tk = t_steps + (size_t)k * 2 * B;
+        TRY(step_impl(h, cur, tk, tk + B, kv, nullptr, gids, seed, call0 + k, B, initial && k == 0, trunc_r, trunc_k,
+                      workspace, nxt, stream));
+        int64_t* sw = cur; cur = nxt; nxt = sw;
+    }
+    if (cur != tokens) {
+        hipError_t e = hipMemcpyAsync(tokens, cur, (size_t)B * h->d.seq_len * sizeof(int64_t), hipMemcpyDeviceToDevice,
+                                      (hipStream_t)stream);
+        if (e != hipSuccess) {
+            ds_set_error("ds_denoiser_sample_rng: hipMemcpyAsync: %s", hipGetErrorString(e));
+            return -2;
+        }
+    }
+    return 0;
 }
 
 extern "C" int ds_denoiser_step(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const float* kv,

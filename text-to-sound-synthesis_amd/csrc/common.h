@@ -117,9 +117,11 @@ struct GemmParams {
 // padded-row forms used by the native denoiser driver (api.hip): Lp / logits_rows >= L rows per sample
 int ds_embed_rows(const int64_t* tokens, const float* emb, const float* pos, float* out, int B, int L, int Lp, int D,
                   ds_stream_t stream);                                                                  // norm.hip
+// u == nullptr: the uniforms are drawn in the kernel from the Philox stream of (seed; gids[b], call) (sampler.hip)
 int ds_sample_tail_rows(const float* logits, int logits_rows, const int64_t* xt, const int64_t* t, const float* u,
                         const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc, float* dbg_post,
-                        int B, int L, int K, int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream);  // sampler.hip
+                        int B, int L, int K, int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream,
+                        const int64_t* gids = nullptr, unsigned long long seed = 0ull, int call = 0);  // sampler.hip
 
 int ds_launch_gemm(const GemmParams& p, hipStream_t stream, int loader);
 int ds_launch_gemm_bf16x3(const GemmParams& p, hipStream_t stream);  // gemm_bf16x3.hip

@@ -42,6 +42,14 @@
 
 #include "common.h"
 
+// Probe builds only (tools/probe/probe_ceiling.hip includes this file with -DPS_ABLATE=bits): take one ingredient out of the
+// main loop so that the launch time and the shader clock show what it costs.  1 = no LDS-DMA inside the loop, 2 = no
+// fragment reads inside the loop (the registers keep k-tile 0's fragments), 4 = no MFMAs, 8 = no epilogue, 16 = no
+// barriers inside the loop.  The product is built with PS_ABLATE = 0: none of this changes its code.
+#ifndef PS_ABLATE
+#define PS_ABLATE 0
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* ds_gptr;
@@ -147,6 +155,8 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PS_BAR()                                                                                     \
     do { PS_FENCE(); __builtin_amdgcn_s_barrier(); PS_FENCE(); } while (0)
+#define PS_LBAR()                                                                                    \
+    do { if (!(PS_ABLATE & 16)) PS_BAR(); else PS_FENCE(); } while (0)
     const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
     f32x16 acc[4][2], acc8;
     f32x4 acc9[2];                  // NB16: the two 16 x 16 tiles of the ninth block row
@@ -236,49 +246,77 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     // one phase: P = phase within the k-tile (compile time), BUF = parity of the k-tile t (compile time)
 #define PS_PHASE(P, BUF)                                                                             \
     do {                                                                                             \
-        if (P == 0) { PS_READ_A(BUF, 0); PS_READ_B(BUF, 0); }                                        \
-        if (P == 1) { PS_READ_B(BUF, 1); if (NB16) PS_READ_EB16(BUF); }                              \
-        if (P == 2) { PS_READ_A(BUF, 1); if (NB16) PS_READ_EA16(BUF); }                              \
-        if (P == 3 && !NB16) PS_READ_E(BUF);                                                         \
+        if (!(PS_ABLATE & 2)) {                                                                      \
+            if (P == 0) { PS_READ_A(BUF, 0); PS_READ_B(BUF, 0); }                                    \
+            if (P == 1) { PS_READ_B(BUF, 1); if (NB16) PS_READ_EB16(BUF); }                          \
+            if (P == 2) { PS_READ_A(BUF, 1); if (NB16) PS_READ_EA16(BUF); }                          \
+            if (P == 3 && !NB16) PS_READ_E(BUF);                                                     \
+        }                                                                                            \
         PS_FENCE();                                                                                  \
         {                                                                                            \
             constexpr int dq = (P) + LEAD;                     /* quarter 4 t + dq */                \
             const int tq = t + (dq >> 2);                                                            \
-            if (tq < nk) {                                                                           \
+            if (tq < nk && !(PS_ABLATE & 1)) {                                                       \
                 PS_ISSUE(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                       \
                 asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   /* the 4 youngest quarters: 2+2+2+3 */ \
             } else {                                                                                 \
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* tail: nothing younger to count */ \
             }                                                                                        \
         }                                                                                            \
-        PS_BAR();                                                                                    \
+        PS_LBAR();                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                               \
-        if (P == 0) PS_QUAD(0, 0);                                                                   \
-        if (P == 1) PS_QUAD(0, 1);                                                                   \
-        if (P == 2) { PS_QUAD(1, 1); if (NB16) PS_EXTRA16(); }                                       \
-        if (P == 3) { PS_QUAD(1, 0); if (!NB16) { if (wr == 0) PS_EXTRA(0); else PS_EXTRA(1); } }    \
+        if (!(PS_ABLATE & 4)) {                                                                      \
+            if (P == 0) PS_QUAD(0, 0);                                                               \
+            if (P == 1) PS_QUAD(0, 1);                                                               \
+            if (P == 2) { PS_QUAD(1, 1); if (NB16) PS_EXTRA16(); }                                   \
+            if (P == 3) { PS_QUAD(1, 0); if (!NB16) { if (wr == 0) PS_EXTRA(0); else PS_EXTRA(1); } } \
+        } else {                                               /* probe: the fragment reads stay live */ \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                            \
+                _Pragma("unroll") for (int y = 0; y < 2; ++y)                                        \
+                    asm volatile("" :: "v"(a0[x][y]), "v"(a1[x][y]), "v"(b0[x][y]), "v"(b1[x][y]));  \
+            asm volatile("" :: "v"(ea0), "v"(ea1), "v"(eb0[0]), "v"(eb1[0]), "v"(eb0[1]), "v"(eb1[1])); \
+        }                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                               \
-        PS_BAR();                                                                                    \
+        PS_LBAR();                                                                                   \
     } while (0)
     // prologue: quarters 0 .. 5 (k-tile 0 and types 0, 1 of k-tile 1) = 13 instructions per wave; quarters 0 and 1 have
     // landed once only the 4 youngest (2 + 3 + 2 + 2 = 9) are outstanding
 #pragma unroll
-    for (int q = 0; q < LEAD; ++q)
+    for (int q = 0; q < ((PS_ABLATE & 1) ? 8 : LEAD); ++q)        // (probe without DMA in the loop: both stages filled here)
         if ((q >> 2) < nk) PS_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
-    if (4 * nk >= LEAD) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    if (4 * nk >= LEAD && !(PS_ABLATE & 3)) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PS_BAR();
     PS_STAMP(1);
-    if (wr == 1) PS_BAR();          // the second wave row runs one barrier behind the first
+    if (PS_ABLATE & 2) {            // probe: the only fragment reads of the launch
+        PS_READ_A(0, 0); PS_READ_B(0, 0); PS_READ_B(0, 1); PS_READ_E(0);
+        if (NB16) { PS_READ_EB16(0); PS_READ_EA16(0); }
+        PS_BAR();
+    }
+    if (wr == 1) PS_LBAR();         // the second wave row runs one barrier behind the first
     for (int t = 0; t < nk; t += 2) {
         PS_PHASE(0, 0); PS_PHASE(1, 0); PS_PHASE(2, 0); PS_PHASE(3, 0);
         ++t;
         PS_PHASE(0, 1); PS_PHASE(1, 1); PS_PHASE(2, 1); PS_PHASE(3, 1);
         --t;
     }
-    if (wr == 0) PS_BAR();          // ... and the first row waits for it at the end
+    if (wr == 0) PS_LBAR();         // ... and the first row waits for it at the end
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PS_STAMP(2);
+    if (PS_ABLATE & 8) {            // probe: no epilogue (the accumulators stay live through a store that never runs)
+        if (p.M == -12345) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p.C[(i * 2 + j) * 16 + r + tid * 256] = acc[i][j][r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p.C[r + tid * 256 + 128] = acc8[r];
+            p.C[tid * 256 + 150] = acc9[0][0] + acc9[1][1];
+        }
+        return;
+    }
 #ifdef PS_TIMING
     const unsigned long long ps_c1 = __builtin_amdgcn_s_memtime();
 #endif

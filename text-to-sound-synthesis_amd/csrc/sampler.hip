@@ -16,8 +16,35 @@
 // is an O(K^2/64) compare-and-add per lane against an LDS copy of the column -- 66k flops per
 // column, nothing next to the 155 GFLOP transformer step, and no sort network.
 // Noise is read in the reference's own [B, K+1, L] layout so that torch.rand_like on the same
-// shape reproduces the reference's RNG stream.
+// shape reproduces the reference's RNG stream -- or (the *_rng entries) drawn inside the kernel from a counter-based
+// Philox4x32-10 stream keyed by (seed; global caption id, sampler call, grid position, class): the draw of a caption
+// then depends neither on the batch it is in, nor on its position in it, nor on the rank that runs it (SURVEY.md
+// section 8e: "generate the noise per sample, seeded by global caption index"), no [B][K+1][L] tensor of uniforms
+// exists, and a whole reverse chain can be enqueued without returning to the host (api.hip ds_denoiser_sample_rng).
 #include "common.h"
+
+// ---- Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 constants) ----
+// counter (c0, c1, c2, c3), key (k0, k1) -> four 32-bit words.  Host mirror: text_to_sound_synthesis_amd/shard.py
+// philox4x32_10 / caption_uniforms (numpy), checked against the published known-answer vectors in tests/.
+typedef unsigned ds_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ds_u32x4 ds_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                                      unsigned k1) {
+    asm volatile("" : "+v"(k0), "+v"(k1), "+v"(c1), "+v"(c2), "+v"(c3));   // everything in VGPRs: scalar rounds push the sampler kernel past its SGPRs
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+        const unsigned lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return ds_u32x4{c0, c1, c2, c3};
+}
+// The uniform of class c = 64 j + lane (j = c >> 6; the [MASK] class K is j = K / 64, lane 0) at grid position pos of
+// caption gid in sampler call `call` of stream `sid` (0: reverse steps, 1: q_sample) is word (j & 3) of
+//   Philox(counter = (64 (j >> 2) + lane, pos | sid << 16, call, gid), key = seed)  ->  (word >> 8) * 2^-24  in [0, 1):
+// the lane that owns classes 64 j + lane runs one Philox per four of them and uses every word.
+__device__ __forceinline__ float ds_u01(unsigned w) { return (float)(w >> 8) * 5.9604644775390625e-8f; }
 
 #define LOG_ZERO_F (-69.07755278982137f)  // logf(1e-30f)
 
@@ -58,9 +85,16 @@ struct SampleParams {
     int trunc_k;              // > 0: top-k truncation instead ('top{k}p', dalle_spec.py:147-157)
     int lrows;                // rows of `logits` per sample (>= L: the denoiser's padded-row mode), L by default
 };
+// u == nullptr: the uniforms come from the Philox stream of (seed; gid[b], call) instead (see ds_u01 above).  (A separate
+// kernel argument: with these fields inside SampleParams hipcc reserves 68 bytes of -- unused -- private segment.)
+struct SampleRng {
+    const int64_t* gid;       // [B] global caption ids (< 2^32)
+    unsigned seed_lo, seed_hi;
+    int call;
+};
 
-template <int NPL>
-__global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams p) {
+template <int NPL, bool RNG>
+__global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams p, const SampleRng g) {
     constexpr int K = NPL * 64;
     __shared__ float s_lp[4][K];
     __shared__ float s_pr[4][K];
@@ -204,19 +238,32 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
     }
 
     // ---- Gumbel-argmax (first index wins ties, as torch.argmax) ----
-    const float* up = p.u + dbg_base;
+    float un[NPL], un_m;            // this lane's uniforms (classes 64 j + lane) and the [MASK] class's
+    if (!RNG) {
+        const float* up = p.u + dbg_base;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) un[j] = up[(size_t)(j * 64 + lane) * p.L];
+        un_m = up[(size_t)K * p.L];
+    } else {
+        const unsigned gid = (unsigned)g.gid[b];
+#pragma unroll
+        for (int q = 0; q < NPL / 4; ++q) {
+            const ds_u32x4 w4 = ds_philox4x32_10(q * 64 + lane, pos, g.call, gid, g.seed_lo, g.seed_hi);
+            un[4 * q + 0] = ds_u01(w4.x); un[4 * q + 1] = ds_u01(w4.y);
+            un[4 * q + 2] = ds_u01(w4.z); un[4 * q + 3] = ds_u01(w4.w);
+        }
+        un_m = ds_u01(ds_philox4x32_10((NPL / 4) * 64, pos, g.call, gid, g.seed_lo, g.seed_hi).x);
+    }
     float best = -INFINITY;
     int bidx = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
         const int c = j * 64 + lane;
-        const float uu = up[(size_t)c * p.L];
-        const float gsc = -logf(-logf(uu + 1e-30f) + 1e-30f) + post[j];
+        const float gsc = -logf(-logf(un[j] + 1e-30f) + 1e-30f) + post[j];
         if (gsc > best) { best = gsc; bidx = c; }  // ascending c within a lane keeps the first max
     }
     if (lane == 0) {
-        const float uu = up[(size_t)K * p.L];
-        const float gsc = -logf(-logf(uu + 1e-30f) + 1e-30f) + post_m;
+        const float gsc = -logf(-logf(un_m + 1e-30f) + 1e-30f) + post_m;
         if (gsc > best) { best = gsc; bidx = K; }
     }
 #pragma unroll
@@ -473,7 +520,9 @@ extern "C" int ds_loss_tail(const float* logits, const int64_t* x0, const int64_
 // log_add_exp(log_onehot(x_0)[K] + log_1_min_cumprod_ct[t], log_cumprod_ct[t]) for [MASK]  (q_pred, :253-267)
 __global__ __launch_bounds__(256) void ds_q_sample_kernel(const int64_t* __restrict__ x0, const int64_t* __restrict__ t,
                                                           const float* __restrict__ u, const float* __restrict__ sched,
-                                                          int64_t* __restrict__ out, int B, int L, int K, int T) {
+                                                          int64_t* __restrict__ out, int B, int L, int K, int T,
+                                                          const int64_t* __restrict__ gid, unsigned seed_lo,
+                                                          unsigned seed_hi, int call) {
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= B * L) return;
     const int lane = threadIdx.x & 63;
@@ -483,12 +532,21 @@ __global__ __launch_bounds__(256) void ds_q_sample_kernel(const int64_t* __restr
                 l1mcct = sched[7 * T1 + tt];
     const int x = (int)x0[col];
     const float hit = lae(0.f + lcat, lcbt), off = lae(LOG_ZERO_F + lcat, lcbt);
-    const float* up = u + (size_t)b * (K + 1) * L + pos;
+    const float* up = u ? u + (size_t)b * (K + 1) * L + pos : nullptr;
     float best = -INFINITY;
     int bi = 0x7fffffff;
+    ds_u32x4 w4 = {0u, 0u, 0u, 0u};
     for (int c = lane; c <= K; c += 64) {
         const float lq = c < K ? (c == x ? hit : off) : lae((x == K ? 0.f : LOG_ZERO_F) + l1mcct, lcct);
-        const float g = -logf(-logf(up[(size_t)c * L] + 1e-30f) + 1e-30f) + lq;
+        float uu;
+        if (up) {
+            uu = up[(size_t)c * L];
+        } else {                                   // stream 1 of the caption's Philox draws (ds_u01 above)
+            const int j = c >> 6;
+            if ((j & 3) == 0) w4 = ds_philox4x32_10((j >> 2) * 64 + (c & 63), pos | (1u << 16), call, (unsigned)gid[b], seed_lo, seed_hi);
+            uu = ds_u01((j & 3) == 0 ? w4.x : (j & 3) == 1 ? w4.y : (j & 3) == 2 ? w4.z : w4.w);
+        }
+        const float g = -logf(-logf(uu + 1e-30f) + 1e-30f) + lq;
         if (g > best) { best = g; bi = c; }
     }
 #pragma unroll
@@ -504,7 +562,50 @@ extern "C" int ds_q_sample(const int64_t* x0, const int64_t* t, const float* u, 
                            int B, int L, int K, int T, ds_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(x0 && t && u && sched && out && B > 0 && L > 0 && K > 0 && T > 0, "bad arguments");
-    hipLaunchKernelGGL(ds_q_sample_kernel, dim3((B * L + 3) / 4), dim3(256), 0, stream, x0, t, u, sched, out, B, L, K, T);
+    hipLaunchKernelGGL(ds_q_sample_kernel, dim3((B * L + 3) / 4), dim3(256), 0, stream, x0, t, u, sched, out, B, L, K, T,
+                       (const int64_t*)nullptr, 0u, 0u, 0);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_q_sample_rng(const int64_t* x0, const int64_t* t, const int64_t* gids, unsigned long long seed, int call,
+                               const float* sched, int64_t* out, int B, int L, int K, int T, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(x0 && t && gids && sched && out && B > 0 && L > 0 && K > 0 && T > 0, "bad arguments");
+    DS_CHECK_ARG(K % 256 == 0 && L < 65536, "codebook size must be a multiple of 256, L < 65536");
+    hipLaunchKernelGGL(ds_q_sample_kernel, dim3((B * L + 3) / 4), dim3(256), 0, stream, x0, t, (const float*)nullptr, sched,
+                       out, B, L, K, T, gids, (unsigned)seed, (unsigned)(seed >> 32), call);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// the uniforms the *_rng entries draw, written out in the reference's [B][K+1][L] layout (tests; same-noise comparisons
+// of the two paths).  rng_stream 0: reverse steps, 1: q_sample.
+__global__ __launch_bounds__(256) void ds_philox_uniforms_kernel(const int64_t* __restrict__ gid, unsigned seed_lo,
+                                                                 unsigned seed_hi, int call, unsigned sid,
+                                                                 float* __restrict__ u, int B, int L, int K) {
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= B * L) return;
+    const int lane = threadIdx.x & 63;
+    const int b = col / L, pos = col - b * L;
+    float* up = u + (size_t)b * (K + 1) * L + pos;
+    for (int g = 0; g <= K / 256; ++g) {
+        const ds_u32x4 w4 = ds_philox4x32_10(g * 64 + lane, pos | (sid << 16), call, (unsigned)gid[b], seed_lo, seed_hi);
+        const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (4 * g + e) * 64 + lane;
+            if (c <= K) up[(size_t)c * L] = ds_u01(w[e]);
+        }
+    }
+}
+extern "C" int ds_philox_uniforms(const int64_t* gids, unsigned long long seed, int call, int rng_stream, float* u, int B,
+                                  int L, int K, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(gids && u && B > 0 && L > 0 && L < 65536 && K > 0 && K % 256 == 0, "bad arguments");
+    DS_CHECK_ARG(rng_stream == 0 || rng_stream == 1, "rng_stream is 0 (reverse steps) or 1 (q_sample)");
+    hipLaunchKernelGGL(ds_philox_uniforms_kernel, dim3((B * L + 3) / 4), dim3(256), 0, stream, gids, (unsigned)seed,
+                       (unsigned)(seed >> 32), call, (unsigned)rng_stream, u, B, L, K);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -512,19 +613,22 @@ extern "C" int ds_q_sample(const int64_t* x0, const int64_t* t, const float* u, 
 // logits_rows >= L: rows of `logits` per sample ([B * logits_rows][K]; the denoiser's padded-row mode, api.hip)
 int ds_sample_tail_rows(const float* logits, int logits_rows, const int64_t* xt, const int64_t* t, const float* u,
                         const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc, float* dbg_post,
-                        int B, int L, int K, int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream_) {
+                        int B, int L, int K, int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream_,
+                        const int64_t* gids, unsigned long long seed, int call) {
     hipStream_t stream = (hipStream_t)stream_;
-    DS_CHECK_ARG(logits && xt && t && u && sched && out_tokens, "null pointer");
+    DS_CHECK_ARG(logits && xt && t && (u || gids) && sched && out_tokens, "null pointer");
     DS_CHECK_ARG(K == 256 || K == 512, "codebook size must be 256 or 512");
     DS_CHECK_ARG(trunc_k >= 0 && !(trunc_k > 0 && trunc_r >= 0.f), "top-k and top-r truncation are exclusive");
-    DS_CHECK_ARG(logits_rows >= L, "logits rows per sample");
+    DS_CHECK_ARG(logits_rows >= L && L < 65536, "logits rows per sample");
     SampleParams p{logits, xt, t, u, sched, out_tokens, dbg_log_pred, dbg_trunc, dbg_post, B, L, T, initial, trunc_r,
                    trunc_k, logits_rows};
+    const SampleRng g{gids, (unsigned)seed, (unsigned)(seed >> 32), call};
     const int cols = B * L;
-    if (K == 256)
-        hipLaunchKernelGGL((ds_sample_tail_kernel<4>), dim3((cols + 3) / 4), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((ds_sample_tail_kernel<8>), dim3((cols + 3) / 4), dim3(256), 0, stream, p);
+    const dim3 grid((cols + 3) / 4);
+    if (K == 256 && u) hipLaunchKernelGGL((ds_sample_tail_kernel<4, false>), grid, dim3(256), 0, stream, p, g);
+    else if (K == 256) hipLaunchKernelGGL((ds_sample_tail_kernel<4, true>), grid, dim3(256), 0, stream, p, g);
+    else if (u) hipLaunchKernelGGL((ds_sample_tail_kernel<8, false>), grid, dim3(256), 0, stream, p, g);
+    else hipLaunchKernelGGL((ds_sample_tail_kernel<8, true>), grid, dim3(256), 0, stream, p, g);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -533,8 +637,17 @@ extern "C" int ds_sample_tail_ex(const float* logits, const int64_t* xt, const i
                                  const float* sched, int64_t* out_tokens, float* dbg_log_pred, float* dbg_trunc,
                                  float* dbg_post, int B, int L, int K, int T, int initial, float trunc_r,
                                  int trunc_k, ds_stream_t stream) {
+    DS_CHECK_ARG(u, "null pointer");
     return ds_sample_tail_rows(logits, L, xt, t, u, sched, out_tokens, dbg_log_pred, dbg_trunc, dbg_post, B, L, K, T, initial,
-                               trunc_r, trunc_k, stream);
+                               trunc_r, trunc_k, stream, nullptr, 0ull, 0);
+}
+
+extern "C" int ds_sample_tail_rng(const float* logits, const int64_t* xt, const int64_t* t, const int64_t* gids,
+                                  unsigned long long seed, int call, const float* sched, int64_t* out_tokens, int B,
+                                  int L, int K, int T, int initial, float trunc_r, int trunc_k, ds_stream_t stream) {
+    DS_CHECK_ARG(gids, "null pointer");
+    return ds_sample_tail_rows(logits, L, xt, t, nullptr, sched, out_tokens, nullptr, nullptr, nullptr, B, L, K, T, initial,
+                               trunc_r, trunc_k, stream, gids, seed, call);
 }
 
 extern "C" int ds_sample_tail(const float* logits, const int64_t* xt, const int64_t* t, const float* u,

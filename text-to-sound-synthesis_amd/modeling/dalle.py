@@ -117,6 +117,12 @@ class DALLE(nn.Module):
                   condition_embed=condition.get("condition_embed_token"), content_token=None,
                   filter_ratio=filter_ratio, temperature=temperature, return_att_weight=return_att_weight,
                   return_logits=False, print_log=False, sample_type=sample_type)
+        if batch.get("caption_ids") is not None:             # per-caption in-kernel noise (diffusion.py rng_mode)
+            ids = torch.as_tensor(batch["caption_ids"], dtype=torch.long)
+            kw["caption_ids"] = torch.cat([ids for _ in range(replicate)]) + \
+                torch.arange(replicate).repeat_interleave(ids.numel()) * int(batch.get("caption_id_stride", 1 << 24))
+        if batch.get("seed") is not None:
+            kw["seed"] = int(batch["seed"])
         if len(parts) == 2 and parts[1][:4] == "fast":       # skip-step sampler (:211-222)
             trans_out = tr.sample_fast(skip_step=int(parts[1][4:]), **kw)
         else:

@@ -72,6 +72,14 @@ class DiffusionTransformer(nn.Module):
         # Measured at B=64: 15.4 clips/s vs 15.9-16.7 on one stream -- no gain (the half-size GEMMs quantise worse
         # than the overlap recovers), so the default stays 1.
         self.sample_streams = int(os.environ.get("DIFFSOUND_STREAMS", "1"))
+        # Noise source of the samplers.  "torch" (default): torch.rand((B, K+1, L)) per call on the model's device, the
+        # reference's own draw (log_sample_categorical, :359-368) -- same seed, same device => same stream, but what a
+        # caption draws depends on the batch around it.  "philox" (or passing caption_ids to sample()): the uniforms are
+        # drawn inside the sampler kernel from a counter-based stream keyed by (sample_seed, global caption id, call,
+        # position, class) -- a caption's clip no longer depends on batch size, batch position or rank (SURVEY.md
+        # section 8e), no noise tensor exists, and the whole chain is enqueued by one C call (ds_denoiser_sample_rng).
+        self.rng_mode = os.environ.get("DIFFSOUND_RNG", "torch")
+        self.sample_seed = 1234
         assert alpha_init_type == "alpha1", "Diffsound uses alpha_init_type='alpha1'"
         at, bt, ct, att, btt, ctt = alpha_schedule(self.num_timesteps, N=self.num_classes)
         f64 = lambda x: torch.tensor(x.astype("float64"))
@@ -177,6 +185,33 @@ class DiffusionTransformer(nn.Module):
                                                   _lib.ptr(tr.workspace(B, sched, slot)), _lib.ptr(out), _lib.stream()))
         return out
 
+    @torch.no_grad()
+    def p_sample_tokens_rng(self, x_t, kv, t, caption_ids, call, initial, out=None, t_post=None, slot=0, seed=None):
+        """p_sample_tokens with the noise drawn in the kernel: Philox stream of (seed, caption_ids[b], call)."""
+        tr = self.transformer
+        sched = self._schedule_table()
+        p = tr.packed(sched)
+        B = x_t.shape[0]
+        if out is None:
+            out = torch.empty_like(x_t)
+        r, k = self._truncation()
+        _lib.check(_lib.lib().ds_denoiser_step_rng(
+            p["handle"], _lib.ptr(x_t), _lib.ptr(t), _lib.ptr(t_post), _lib.ptr(kv), _lib.ptr(caption_ids),
+            int(self.sample_seed if seed is None else seed), int(call), B, int(initial), r, k,
+            _lib.ptr(tr.workspace(B, sched, slot)), _lib.ptr(out), _lib.stream()))
+        return out
+
+    def _caption_ids(self, caption_ids, B, device):
+        """i64[B] global caption ids on the device (default: 0 .. B-1)."""
+        if caption_ids is None:
+            return torch.arange(B, device=device, dtype=torch.long)
+        ids = torch.as_tensor(caption_ids, dtype=torch.long).to(device).contiguous()
+        if ids.shape != (B,):
+            raise ValueError("caption_ids must have one entry per caption: got %s for a batch of %d" % (tuple(ids.shape), B))
+        if int(ids.min()) < 0 or int(ids.max()) >= 2 ** 32:
+            raise ValueError("caption ids must be in [0, 2^32)")
+        return ids
+
     def _cond(self, condition_token, condition_embed):
         if self.condition_emb is not None and condition_token is not None:
             return self.condition_emb(condition_token).float()          # CLIP text tower (:619-621)
@@ -184,7 +219,7 @@ class DiffusionTransformer(nn.Module):
             raise ValueError("pass condition_token (with a condition_emb module) or condition_embed [B,77,512]")
         return condition_embed.float()
 
-    # ---- training loss, FORWARD VALUE only (no backward kernels exist yet) ----------------
+    # ---- training loss: the forward value (the step with gradients is modeling/train.py) ----
     def sample_time(self, b, device, method="uniform"):
         """Timesteps for a batch and their sampling probabilities (:379-406): importance sampling by sqrt(Lt_history)
         once every timestep has been seen more than 10 times, uniform before."""
@@ -278,7 +313,7 @@ class DiffusionTransformer(nn.Module):
         oh = torch.nn.functional.one_hot(xt, self.num_classes).permute(0, 2, 1).float()
         return torch.log(oh.clamp(min=1e-30))
 
-    def _reverse(self, cond_emb, steps, noise_fn, return_logits, start_tokens=None):
+    def _reverse(self, cond_emb, steps, noise_fn, return_logits, start_tokens=None, caption_ids=None, seed=None):
         """steps: list of (t, t_post) pairs, first one from the all-[MASK] state (or from start_tokens, already
         diffused to the first t).  The 'q' repeat sampler
         (dalle_spec.py:135-143: with probability `repeat_rate` a step is applied twice at the same t) draws from
@@ -292,6 +327,28 @@ class DiffusionTransformer(nn.Module):
             x = torch.full((B, L), K1 - 1, device=device, dtype=torch.long)  # all [MASK]
         else:
             x = start_tokens.to(device).clone()
+        if noise_fn is None and (caption_ids is not None or self.rng_mode == "philox"):
+            # in-kernel noise: the whole chain is one C call, nothing returns to Python between steps
+            calls = []
+            for step, step_post in steps:
+                reps = 2 if (self.repeat_rate is not None and random.random() < self.repeat_rate) else 1
+                calls += [(step, step_post)] * reps
+            sched = self._schedule_table()
+            tr = self.transformer
+            p = tr.packed(sched)
+            kv = tr.condition_kv(cond_emb.contiguous(), sched)
+            gids = self._caption_ids(caption_ids, B, device)
+            t_steps = torch.tensor(calls, dtype=torch.long, device=device).view(-1, 2, 1).expand(-1, 2, B).contiguous()
+            tmp = torch.empty_like(x)
+            r, k = self._truncation()
+            _lib.check(_lib.lib().ds_denoiser_sample_rng(
+                p["handle"], _lib.ptr(x), _lib.ptr(tmp), _lib.ptr(t_steps), len(calls), _lib.ptr(kv), _lib.ptr(gids),
+                int(self.sample_seed if seed is None else seed), 0, B, int(start_tokens is None), r, k,
+                _lib.ptr(tr.workspace(B, sched, 0)), _lib.stream()))
+            out = {"content_token": x}
+            if return_logits:
+                out["logits"] = torch.nn.functional.one_hot(x, K1).permute(0, 2, 1).float()
+            return out
         # sub-batches: one (the whole batch on the current stream) or two halves on two side streams
         two = self.sample_streams == 2 and B >= 2 and device.type == "cuda"
         bounds = [(0, B // 2), (B // 2, B)] if two else [(0, B)]
@@ -337,16 +394,18 @@ class DiffusionTransformer(nn.Module):
     @torch.no_grad()
     def sample(self, condition_token, condition_mask, condition_embed, content_token=None, filter_ratio=0.5,
                temperature=1.0, return_att_weight=False, return_logits=False, content_logits=None,
-               print_log=True, noise_fn=None, **kwargs):
+               print_log=True, noise_fn=None, caption_ids=None, seed=None, **kwargs):
         """Reverse diffusion from the all-[MASK] state (:587-659, filter_ratio == 0 branch).
 
         noise_fn(step, shape) may supply the uniforms (tests inject the oracle's noise; with the 'q' repeat sampler
-        active the first argument is the running p_sample call index instead of the timestep)."""
+        active the first argument is the running p_sample call index instead of the timestep).  caption_ids (i64[B],
+        global caption indices) selects the in-kernel per-caption noise (see rng_mode); seed overrides sample_seed."""
         cond_emb = self._cond(condition_token, condition_embed)
         T = self.num_timesteps
         start_step = int(T * filter_ratio)
         if start_step == 0:
-            return self._reverse(cond_emb, [(s_, s_) for s_ in range(T - 1, -1, -1)], noise_fn, return_logits)
+            return self._reverse(cond_emb, [(s_, s_) for s_ in range(T - 1, -1, -1)], noise_fn, return_logits,
+                                 caption_ids=caption_ids, seed=seed)
         # partial re-sampling (:643-651): diffuse the given tokens (e.g. DALLE.get_tokens of a mel) forward to
         # t = start_step - 1, then run the reverse chain from there.  With noise_fn, call 0 is q_sample's draw and
         # the reverse steps get the running call index 1.. instead of the timestep.
@@ -355,9 +414,20 @@ class DiffusionTransformer(nn.Module):
         device, B = self.device, cond_emb.shape[0]
         shape = (B, self.num_classes, self.content_seq_len)
         t = torch.full((B,), start_step - 1, device=device, dtype=torch.long)
+        steps = list(range(start_step - 1, -1, -1))
+        if noise_fn is None and (caption_ids is not None or self.rng_mode == "philox"):
+            # forward diffusion on stream 1 of each caption's Philox draws (call 0), the reverse chain on stream 0
+            x0 = content_token.to(device).contiguous()
+            gids = self._caption_ids(caption_ids, B, device)
+            x = torch.empty_like(x0)
+            _lib.check(_lib.lib().ds_q_sample_rng(_lib.ptr(x0), _lib.ptr(t), _lib.ptr(gids),
+                                                  int(self.sample_seed if seed is None else seed), 0,
+                                                  _lib.ptr(self._schedule_table()), _lib.ptr(x), B, self.content_seq_len,
+                                                  self.num_classes - 1, self.num_timesteps, _lib.stream()))
+            return self._reverse(cond_emb, [(s_, s_) for s_ in steps], None, return_logits, start_tokens=x,
+                                 caption_ids=gids, seed=seed)
         u = noise_fn(0, shape).to(device) if noise_fn is not None else torch.rand(shape, device=device)
         x = self.q_sample_tokens(content_token.to(device), t, u)
-        steps = list(range(start_step - 1, -1, -1))
         nf = None if noise_fn is None else (lambda st, shp: noise_fn(1 + steps.index(st), shp)) \
             if self.repeat_rate is None else (lambda c, shp: noise_fn(1 + c, shp))
         return self._reverse(cond_emb, [(s_, s_) for s_ in steps], nf, return_logits, start_tokens=x)
@@ -365,7 +435,7 @@ class DiffusionTransformer(nn.Module):
     @torch.no_grad()
     def sample_fast(self, condition_token, condition_mask, condition_embed, content_token=None, filter_ratio=0.5,
                     temperature=1.0, return_att_weight=False, return_logits=False, content_logits=None,
-                    print_log=True, skip_step=1, noise_fn=None, **kwargs):
+                    print_log=True, skip_step=1, noise_fn=None, caption_ids=None, seed=None, **kwargs):
         """Skip-step sampler (:748-812): timesteps T-1, T-2-skip, ... (0 appended), the network sees t, the
         posterior t - skip_step while t > skip_step.  The reference calls p_pred's pieces directly, so the 'q'
         wrapper on p_sample never applies here."""
@@ -377,6 +447,6 @@ class DiffusionTransformer(nn.Module):
         keep, self.repeat_rate = self.repeat_rate, None
         try:
             return self._reverse(cond_emb, [(s_, s_ - skip_step if s_ > skip_step else s_) for s_ in lst], noise_fn,
-                                 return_logits)
+                                 return_logits, caption_ids=caption_ids, seed=seed)
         finally:
             self.repeat_rate = keep

@@ -46,17 +46,25 @@ class Diffsound:
             p.requires_grad = False
 
     @torch.no_grad()
-    def generate_sample_with_condition(self, cond, truncation_rate=0.85, replicate=1, fast=False):
+    def generate_sample_with_condition(self, cond, truncation_rate=0.85, replicate=1, fast=False, caption_ids=None,
+                                       seed=None):
         """Captions -> (mel01 f32[B,80,848], wave f32[B,1,217088], tokens), everything left on the GPU.
         `cond` is a list of caption strings (needs the text stage: tokenizer + CLIP in the config),
         token ids i64[B,77], or caption embeddings f32[B,77,512].  fast=n selects the skip-step sampler with
-        skip_step n-1, spelled like the reference's drivers (generate_samples_batch.py:100-103,148-151)."""
+        skip_step n-1, spelled like the reference's drivers (generate_samples_batch.py:100-103,148-151).
+        caption_ids (one global index per caption) switches the sampler to per-caption in-kernel noise: a caption's clip
+        then does not depend on the batch it is generated in (DiffusionTransformer.rng_mode); replicate r of caption i
+        draws as caption id ids[i] + r * 2^24."""
         if isinstance(cond, (list, tuple, str)):
             batch = {"text": [cond] if isinstance(cond, str) else list(cond)}
         elif cond.dtype == torch.long:
             batch = {"condition_token": cond}
         else:
             batch = {"condition_embed_token": cond}
+        if caption_ids is not None:
+            batch["caption_ids"] = caption_ids
+        if seed is not None:
+            batch["seed"] = seed
         out = self.model.generate_content(batch=batch, filter_ratio=0, replicate=replicate, content_ratio=1,
                                           return_att_weight=False,
                                           sample_type="top" + str(truncation_rate) + ("r,fast" + str(fast - 1) if fast else "r"))
@@ -105,9 +113,14 @@ class Diffsound:
         import numpy as np
         os.makedirs(save_root, exist_ok=True)
         written = []
+        n_seen = 0                       # running caption index over the whole table = the global caption id
+        philox = self.model.transformer.rng_mode == "philox"
         for key, captions in self.read_tsv(val_path).items():
             base = key.split(".")[0] + "_mel_sample_"
-            mel01, wave, _ = self.generate_sample_with_condition(list(captions), truncation_rate, replicate, fast=fast)
+            ids = list(range(n_seen, n_seen + len(captions))) if philox else None
+            n_seen += len(captions)
+            mel01, wave, _ = self.generate_sample_with_condition(list(captions), truncation_rate, replicate, fast=fast,
+                                                                 caption_ids=ids)
             mel01, wave = mel01.cpu().numpy(), wave[:, 0].cpu().numpy()
             for i in range(mel01.shape[0]):
                 path = os.path.join(save_root, base + str(i))

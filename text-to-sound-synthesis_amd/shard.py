@@ -70,14 +70,52 @@ def gather_outputs(local, n_items, group=None):
     return None
 
 
+# ---- per-caption noise: host mirror of the sampler's in-kernel Philox stream (csrc/sampler.hip) ------------------------
+# The product draws the Gumbel noise of a reverse step INSIDE ds_sample_tail (ds_denoiser_step_rng / _sample_rng): the
+# uniform of class c at grid position pos of global caption id gid in sampler call `call` is a pure function of
+# (seed, gid, call, pos, c) -- independent of batch composition, batch position and rank.  The functions below restate
+# that function in numpy; they are what tests and the oracle-driven parity checks feed to the `u` path to reproduce a
+# device draw on the host (and are checked against the Random123 known-answer vectors in tests/test_philox.py).
+_PHILOX_M0, _PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+_PHILOX_W0, _PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11): counter words c0..c3 and key words k0, k1 (numpy-broadcastable unsigned
+    32-bit values) -> the four output words, uint32 arrays."""
+    import numpy as np
+    c0, c1, c2, c3, k0, k1 = (np.asarray(v).astype(np.uint64) & 0xFFFFFFFF for v in (c0, c1, c2, c3, k0, k1))
+    c0, c1, c2, c3, k0, k1 = np.broadcast_arrays(c0, c1, c2, c3, k0, k1)
+    for _ in range(10):
+        p0, p1 = c0 * _PHILOX_M0, c2 * _PHILOX_M1
+        hi0, lo0, hi1, lo1 = p0 >> 32, p0 & 0xFFFFFFFF, p1 >> 32, p1 & 0xFFFFFFFF
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + _PHILOX_W0) & 0xFFFFFFFF, (k1 + _PHILOX_W1) & 0xFFFFFFFF
+    return tuple(v.astype(np.uint32) for v in (c0, c1, c2, c3))
+
+
+def caption_uniforms(global_ids, call, n_codes, seq_len, seed, rng_stream=0):
+    """f32[n, n_codes + 1, seq_len] (the reference's rand_like(logits) layout): the uniforms ds_sample_tail_rng
+    (rng_stream 0) / ds_q_sample_rng (1) draw for captions `global_ids` in sampler call `call`.  Class c = 64 j + lane
+    takes word j & 3 of Philox(counter = (64 (j >> 2) + lane, pos | rng_stream << 16, call, gid), key = seed), mapped to
+    [0, 1) as (word >> 8) * 2^-24 (include/diffsound_hip.h)."""
+    import numpy as np
+    gid = np.asarray(list(global_ids), dtype=np.uint64).reshape(-1, 1, 1)
+    c = np.arange(n_codes + 1, dtype=np.uint64).reshape(1, -1, 1)
+    pos = np.arange(seq_len, dtype=np.uint64).reshape(1, 1, -1)
+    j, lane = c >> 6, c & 63
+    words = philox4x32_10((j >> 2) * 64 + lane, pos | (int(rng_stream) << 16), int(call), gid,
+                          int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    sel = np.broadcast_to(j & 3, words[0].shape)
+    w = np.choose(sel.astype(np.int64), words)
+    return torch.from_numpy(((w >> 8).astype(np.float32) * np.float32(2.0 ** -24)))
+
+
 def per_caption_noise(global_ids, step, shape_tail, device, base_seed=1234):
-    """Uniform noise [n, *shape_tail] where row i depends only on (base_seed, global_ids[i], step)."""
-    out = torch.empty((len(global_ids),) + tuple(shape_tail), device=device, dtype=torch.float32)
-    g = torch.Generator(device=device)
-    for i, gid in enumerate(global_ids):
-        g.manual_seed((base_seed * 1000003 + int(gid)) * 1009 + int(step))
-        out[i] = torch.rand(shape_tail, device=device, generator=g)
-    return out
+    """Uniform noise [n, K + 1, L] where row i depends only on (base_seed, global_ids[i], step): the host mirror of
+    the product's in-kernel draw (caption_uniforms above), kept under its round-1 name for callers that inject noise."""
+    k1, length = shape_tail
+    return caption_uniforms(global_ids, step, k1 - 1, length, base_seed).to(device)
 
 
 def allreduce_gradients(grads, bucket_bytes=256 << 20, group=None, average=True):

@@ -26,6 +26,12 @@ except ImportError:  # pragma: no cover
                        _re.IGNORECASE | _re.UNICODE)
 
 
+# The part of CLIP's merge table that the synthetic benchmark / test captions exercise (synth._WORDS), with the original
+# ranks and token ids: written by oracle/make_golden.py from the reference's bpe_simple_vocab_16e6.txt.gz and checked there
+# against the reference's tokenizer on 3000 captions.  Package data: bench.py tokenises with it inside the timed region.
+CLOSED_VOCAB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "bpe_closed_vocab.json")
+
+
 def find_bpe_file(bpe_path=None):
     for c in (bpe_path, os.environ.get("DIFFSOUND_BPE_PATH"),
               os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "bpe_simple_vocab_16e6.txt.gz")):
@@ -75,7 +81,7 @@ class SimpleTokenizer:
         self._cache = {}
 
     def _init_closed(self, path):
-        """Closed-vocabulary table (tests/golden/bpe_closed_vocab.json, written by oracle/make_golden.py from the full
+        """Closed-vocabulary table (data/bpe_closed_vocab.json = CLOSED_VOCAB_PATH, written by oracle/make_golden.py from the full
         CLIP table): for a fixed word list it holds exactly the merges the full table applies to those words, with
         their ORIGINAL ranks, and the ids of the resulting tokens -- so encoding any text over that word list runs the
         same greedy algorithm and yields the same ids as the full table.  Any other word raises (never a silent
