@@ -186,6 +186,67 @@ def codebook512():
          post=post[:, :, s], tokens=toks, kept=(trunc > -70).sum(1), mel0=mel[0])
 
 
+def trained_like():
+    """Off the N(0, 0.02) manifold (synth.py profile="trained": LayerNorm gains over two decades, hot residual-stream
+    channels, heavy-tailed weights, one MLP unit driving GELU2 outputs into the 1e4s -- fp16 tops out at 65504): the
+    19-layer denoiser's logits from the reference in fp32 (as shipped) AND in float64 (the same modules after .double():
+    the yardstick that says how far fp32 itself is from the exact result on these weights), one teacher-forced step with
+    injected noise, and the Gumbel-argmax margin of every decision of that step."""
+    torch.manual_seed(0)
+    m = rh.build_dalle(n_layer=19, diffusion_step=100, n_embed=256)
+    synth.synth_init_(m, seed=0, skip=("content_codec.",), profile="trained")
+    from sound_synthesis.modeling.transformers.diffusion_transformer import index_to_log_onehot
+    dt = m.transformer
+    tok = synth.synth_tokens(2, mask_frac=0.5, key="tl19.tokens")
+    cond = synth.synth_cond_emb(2, key="tl19.cond")
+    t = torch.tensor([63, 7])
+    amax = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            amax[name] = max(amax.get(name, 0.0), float(out.abs().max()))
+        return f
+    hs = []
+    for blk in dt.transformer.blocks:
+        hs += [blk.mlp[1].register_forward_hook(hook("gelu2_out")), blk.ln2.register_forward_hook(hook("ln2_out")),
+               blk.register_forward_hook(lambda mod, inp, out: amax.__setitem__("block_out", max(amax.get("block_out", 0.0),
+                                                                                 float(out[0].abs().max()))))]
+    logits32 = dt.transformer(tok, cond, t)
+    for h in hs:
+        h.remove()
+    # one teacher-forced step (B = 1) with the reference's truncation wrapper and injected noise
+    x1 = synth.synth_tokens(1, mask_frac=0.55, key="tl19.step.xt")
+    c1 = synth.synth_cond_emb(1, key="tl19.step.cond")
+    tv = torch.tensor([50])
+    log_z = index_to_log_onehot(x1, 257)
+    trunc = m.predict_start_with_truncation(dt.predict_start, "top0.85r")(log_z, c1, tv)
+    post = dt.q_posterior(log_x_start=trunc, log_x_t=log_z, t=tv)
+    u = synth.synth_uniform((1, 257, 265), key="tl19.step.u")
+    gum = -torch.log(-torch.log(u + 1e-30) + 1e-30) + post
+    top2 = gum.topk(2, dim=1).values
+    with InjectNoise(lambda shp: u):
+        toks = dt.log_sample_categorical(post).argmax(1)
+    logits64 = m.double().transformer.transformer(tok, cond.double(), t)
+    s = slice(None, None, POS_STRIDE)
+    save("transformer_L19_trainedlike", pos_stride=POS_STRIDE, logits=logits32[:, :, s], logits64=logits64[:, :, s],
+         fp32_vs_fp64=float((logits32.double() - logits64).abs().max()), tokens=toks, margin=(top2[:, 0] - top2[:, 1]),
+         kept=(trunc > -70).sum(1), amax_gelu2=amax["gelu2_out"], amax_ln2=amax["ln2_out"], amax_block=amax["block_out"])
+    print("trained-like: logits |max| %.2f, reference fp32 vs float64 %.2e, GELU2 out |max| %.0f, residual |max| %.0f"
+          % (float(logits64.abs().max()), float((logits32.double() - logits64).abs().max()), amax["gelu2_out"],
+             amax["block_out"]))
+
+
+def codebook512_L19():
+    """The benchmarked K = 512 leg (BASELINE configs[3]) runs 19 layers: its logits from the reference (k512_L2.npz pins the
+    2-layer build only)."""
+    torch.manual_seed(0)
+    m = rh.build_dalle(n_layer=19, diffusion_step=100, n_embed=512)
+    x = synth.synth_tokens(2, 265, 512, mask_frac=0.4, key="k512.x")
+    cond = synth.synth_cond_emb(2, key="k512.c")
+    logits = m.transformer.transformer(x, cond, torch.tensor([61, 12]))
+    save("k512_L19", pos_stride=POS_STRIDE, logits=logits[:, :, ::POS_STRIDE])
+
+
 GRAD_PROBES = ("transformer.to_logits.1.weight", "transformer.to_logits.0.weight", "transformer.blocks.1.mlp.2.weight",
                "transformer.blocks.1.mlp.0.bias", "transformer.blocks.0.attn1.query.weight",
                "transformer.blocks.0.attn2.key.weight", "transformer.blocks.0.ln1.linear.weight",
@@ -465,6 +526,9 @@ def main():
         return train_loss()
     if "--k512-only" in sys.argv:
         return codebook512()
+    if "--trained-only" in sys.argv:
+        trained_like()
+        return codebook512_L19()
     if "--encoder-only" in sys.argv:
         return encoder()
     if "--samplers-only" in sys.argv:
@@ -550,6 +614,8 @@ def main():
     samplers()
     encoder()
     codebook512()
+    trained_like()
+    codebook512_L19()
     train_loss()
     solver_schedule()
     dalle_sample()

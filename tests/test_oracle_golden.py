@@ -49,6 +49,35 @@ def test_transformer_L19(sd_dalle_l19):
     assert (out - ref).abs().max().item() < 1e-4
 
 
+def test_transformer_L19_trained_like_statistics():
+    """Off the initialiser manifold (synth.py profile="trained": LayerNorm gains over two decades, hot channels,
+    heavy-tailed weights, GELU2 outputs in the 1e4s).  The golden holds the reference's logits in fp32 AND in float64;
+    the distance between those two is how far fp32 itself is from the exact result on these weights (1.6e-3 -- against
+    2.4e-6 on the initialiser-like weights), and the yardstick for every implementation."""
+    from conftest import synth_sd
+    g = golden("transformer_L19_trainedlike")
+    ref_err = float(g["fp32_vs_fp64"])
+    assert 1e4 < float(g["amax_gelu2"]) < 65504 and float(g["amax_block"]) > 1e3      # the stress is real, and representable
+    assert 1e-4 < ref_err < 1e-2
+    sd = synth_sd("dalle", 19, profile="trained")
+    tok = synth.synth_tokens(2, mask_frac=0.5, key="tl19.tokens")
+    cond = synth.synth_cond_emb(2, key="tl19.cond")
+    out = O.transformer_forward(sd, tok, cond, torch.tensor([63, 7]))[:, :, ::int(g["pos_stride"])]
+    assert (out.double() - g["logits64"]).abs().max().item() <= 2 * ref_err
+    assert (out - g["logits"]).abs().max().item() <= 2 * ref_err
+
+
+def test_codebook_512_L19_logits():
+    from conftest import synth_sd
+    g = golden("k512_L19")
+    sd = synth_sd("dalle_k512", 19)
+    x = synth.synth_tokens(2, 265, 512, mask_frac=0.4, key="k512.x")
+    cond = synth.synth_cond_emb(2, key="k512.c")
+    logits = O.transformer_forward(sd, x, cond, torch.tensor([61, 12]))
+    assert logits.shape == (2, 512, 265)
+    assert (logits[:, :, ::int(g["pos_stride"])] - g["logits"]).abs().max() < 1e-4
+
+
 def test_teacher_forced_steps(sd_dalle_l2):
     g = golden("steps_L2")
     ps = int(g["pos_stride"])

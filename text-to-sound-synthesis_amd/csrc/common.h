@@ -19,6 +19,10 @@ __device__ __forceinline__ _Float16 ds_split_hi(float a) {
     return (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);  // saturate instead of overflowing to inf
 }
 __device__ __forceinline__ _Float16 ds_split_lo(float a, _Float16 hi) {
+    // contraction off: when `a` is a bare product of the caller (GELU2's v * sigmoid(..) under a compile-time-true branch),
+    // hipcc's default -ffp-contract=fast would fuse it into fma(v, s, -hi) -- the residual of the UNROUNDED product, a
+    // different lo plane than every other producer writes (found by the bit-identity tests, round 3)
+#pragma clang fp contract(off)
     return (_Float16)__builtin_amdgcn_fmed3f(a - (float)hi, -65504.f, 65504.f);  // a - hi is exact in fp32
 }
 

@@ -45,7 +45,8 @@
 // Probe builds only (tools/probe/probe_ceiling.hip includes this file with -DPS_ABLATE=bits): take one ingredient out of the
 // main loop so that the launch time and the shader clock show what it costs.  1 = no LDS-DMA inside the loop, 2 = no
 // fragment reads inside the loop (the registers keep k-tile 0's fragments), 4 = no MFMAs, 8 = no epilogue, 16 = no
-// barriers inside the loop.  The product is built with PS_ABLATE = 0: none of this changes its code.
+// barriers inside the loop, 32 = epilogue without its global loads / stores (LDS staging only), 64 = epilogue without the
+// LDS staging (global loads / stores only).  The product is built with PS_ABLATE = 0: none of this changes its code.
 #ifndef PS_ABLATE
 #define PS_ABLATE 0
 #endif
@@ -60,7 +61,15 @@ typedef __attribute__((address_space(3))) void* ds_lptr;
 #define PS_BN 256
 #define PS_LEAD 6
 #define PS_GM 4            // raster: groups of 4 sample tiles x all column tiles (measured: 4 beats 2 and 8 by ~10 %)
-#define PS_LDS_BYTES (2 * 2 * (PS_BM + PS_BN) * PS_HLD * 2)   // two stages of 68 KB
+#define PS_STAGE_BYTES (2 * 2 * (PS_BM + PS_BN) * PS_HLD * 2)   // the main loop's two operand stages of 68 KB
+#define PS_VT_BYTES (2 * 2 * PS_BN * 36 * 4)                    // the epilogue's transposed V^T staging: two buffers of 72 KB
+#define PS_LDS_BYTES (PS_VT_BYTES > PS_STAGE_BYTES ? PS_VT_BYTES : PS_STAGE_BYTES)
+// NB16 operands: lane quad q of the 16-row MFMA operand reads tile-row quad PS_SIG(q) = {0, 2, 3, 1}[q].  With the natural
+// order the 16-lane service groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...) hit each 16-byte slot of the packed image
+// twice (rows 0-3 and 4-7 of k-chunks 0 and 1 share a slot: SQ_LDS_BANK_CONFLICT = 17 % of the loop's LDS cycles, round-3
+// PMC pass); with this order every group covers the 16 slots once.  A permutation of the operand's ROWS only: each
+// output element is the same sum in the same order, it just lives in another lane (the epilogue applies PS_SIG again).
+#define PS_SIG(q_) ((0x78 >> (2 * (q_))) & 3)
 
 enum { PS_EPI_ROW = 0, PS_EPI_SPLIT = 1, PS_EPI_ATTN = 2 };
 
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     h8 b0[2][2], b1[2][2];          // [B-sub][ks]: hi, lo planes
     h8 e0[2], e1[2];                // block 8 [ks]: hi, lo planes
     h8 ea0, ea1, eb0[2], eb1[2];    // NB16: A rows 256..271 and the wave's two 16-column B tiles, 16x16x32 operand layout
-    const int l15 = lane & 15;
+    const int l15 = PS_SIG((lane >> 2) & 3) * 4 + (lane & 3);   // the tile row / column this lane's operand row is (see PS_SIG)
     const int swzq = ((lane >> 4) ^ ((l15 >> 2) & 3)) * 8;     // lane group kq = lane >> 4 holds k = 8 kq .. 8 kq + 7
 #define PS_READ_A(buf_, s_)                                                                          \
     do {                                                                                             \
@@ -323,13 +332,23 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
 
     // ---- epilogue -------------------------------------------------------------------------------------------------
     // One workgroup per CU: nothing else runs on the CU while a tile is written out, so the epilogue is on the critical
-    // path (a first version with exact expf + IEEE division in GELU2, 2-byte LDS stores and latency-serialised residual
-    // loads cost 20-60k cycles per tile against ~140k of main loop).  Hence: GELU2 by v_exp / v_rcp (ds_gelu2_fast, shared
-    // with gemm_f16x2.hip so both programs stay bit-identical), hi | lo staged as ONE 32-bit LDS store per value, read
-    // back 32 bytes at a time (both planes of 8 columns), constant trip counts so that the residual loads of several
-    // iterations are in flight together, no integer divisions.
-    // The lane / wave indices are re-derived from an opaque copy of the thread id so that none of them stays live
-    // across the main loop (which runs at the 256-register cap: one of them used to be spilled to scratch).
+    // path.  Round-3 measurements (tools/probe/probe_ceiling.hip, profiles/r03b_*): at 32 CUs the epilogue takes the
+    // same ~38k cycles per tile as at 256 -- it is bound inside the CU, not by HBM -- and for the fp16-plane families 70 to
+    // 100 % of it was the STAGING (accumulators -> LDS), not the global stores: the first version staged in three row slabs
+    // of which only one wave row (4 of 8 waves, one per SIMD) produced values, re-loaded the bias in every slab behind a
+    // full memory latency, and wrote V^T with 64 different cache lines per store instruction.  Hence this structure:
+    //   * five STEPS: step s = 0..3 is block row s of BOTH wave rows (tile rows s 32 + [0, 32) and 128 + s 32 + [0, 32):
+    //     every wave stages 32 values per lane), step 4 the ninth block row;
+    //   * two LDS buffers: step s stages into buffer s & 1, ONE barrier, then all 512 threads read the step back in
+    //     16-byte pieces and store it -- the global stores (and residual loads) of step s run under the staging of step
+    //     s + 1 (a buffer is re-written two steps later, behind the barrier of the step in between);
+    //   * the bias values of a lane's columns are loaded once, before step 0;
+    //   * V^T tiles are staged TRANSPOSED ([column][32 keys + 4]: four consecutive keys of a lane's column are one
+    //     ds_write_b128), so a thread reads the 8 keys of its 16-byte store with two ds_read_b128 and consecutive lanes
+    //     write consecutive 16-byte pieces of one d (64-byte runs instead of 64 scattered pieces per instruction).
+    // GELU2 by v_exp / v_rcp (ds_gelu2_fast, shared with gemm_f16x2.hip so both programs stay bit-identical), hi | lo
+    // staged as ONE 32-bit value, no integer divisions.  The lane / wave indices are re-derived from an opaque copy of the
+    // thread id so that none of them stays live across the main loop (which runs at the 256-register cap).
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));
     const int l31e = tid_e & 31, hhe = (tid_e >> 5) & 1, wre = tid_e >> 8, wce = (tid_e >> 6) & 3;
@@ -338,94 +357,90 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     int vhi = off + L;
     if (vhi > p.M - m0) vhi = p.M - m0;
     const float osc = p.out_scale;
-    // every value of slab SL (0: wave row 0's rows, 1: wave row 1's, 2: the ninth block of every wave) with its
-    // slab-local row `rl` and tile column `cl`; STORE(rl, cl, v) writes it to the staging buffer
-#define PS_SLAB_VALUES(SL, STORE)                                                                    \
+    // this lane's columns: the two 32-column blocks of the wave tile, and its column(s) of the ninth block row
+    //   NB16: lane (q = lane >> 4, n = lane & 15) of a 16 x 16 tile holds rows 4 sigma(q) + r, column pi(n) (see PS_SIG)
+    const int qe = (tid_e >> 4) & 3, ne = tid_e & 15;
+    const int cl0 = (wce * 2 + 0) * 32 + l31e, cl1 = (wce * 2 + 1) * 32 + l31e;
+    const int cl9 = (wce * 2 + wre) * 32 + (NB16 ? PS_SIG(ne >> 2) * 4 + (ne & 3) : l31e);   // NB16: + 16 for the second tile
+    float bv0 = 0.f, bv1 = 0.f, bv9a = 0.f, bv9b = 0.f;
+    if (p.bias) {
+        bv0 = p.bias[n0 + cl0]; bv1 = p.bias[n0 + cl1]; bv9a = p.bias[n0 + cl9];
+        if (NB16) bv9b = p.bias[n0 + cl9 + 16];
+    }
+    constexpr int EBUF = 64 * BN;                 // 32-bit words per staging buffer: 64 rows x 256 columns (64 KB)
+    // the tile row of step-local row `rs` (0..63: two groups of 32; step 4: 0..15 / 0..31)
+#define PS_TROW(S, rs_) ((S) < 4 ? ((rs_) >> 5) * 128 + (S) * 32 + ((rs_) & 31) : 256 + (rs_))
+    // every value this wave stages in step S: STORE(step-local row, tile column, value)
+#define PS_STEP_VALUES(S, GELU, STORE)                                                               \
     do {                                                                                             \
-        if ((SL) < 2) {                                                                              \
-            if (wre == (SL)) {                                                                       \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
-                    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                  \
-                        const int cl = (wce * 2 + j) * 32 + l31e;                                    \
-                        const float bv = p.bias ? p.bias[n0 + cl] : 0.f;                             \
-                        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                             \
-                            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hhe;                \
-                            float v = acc[i][j][r] * osc + bv;                                       \
-                            if (p.act == DS_ACT_GELU2) v = ds_gelu2_fast(v);                         \
-                            STORE(rl, cl, v);                                                        \
-                        }                                                                            \
-                    }                                                                                \
-            }                                                                                        \
-        } else if (NB16) {              /* 16 x 16 tiles: column = lane & 15, row = 4 (lane >> 4) + r; rows 16.. of the */ \
-            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {   /* slab are never stored (vhi = 272)            */ \
-                const int cl = (wce * 2 + wre) * 32 + tt * 16 + (tid_e & 15);                        \
-                const float bv = p.bias ? p.bias[n0 + cl] : 0.f;                                     \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                      \
-                    const int rl = 4 * ((tid_e >> 4) & 3) + r;                                       \
-                    float v = acc9[tt][r] * osc + bv;                                                \
-                    if (p.act == DS_ACT_GELU2) v = ds_gelu2_fast(v);                                 \
-                    STORE(rl, cl, v);                                                                \
+        if ((S) < 4) {                                                                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
+                const int cl = j ? cl1 : cl0;                                                        \
+                const float bv = j ? bv1 : bv0;                                                      \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
+                    float v = acc[(S) < 4 ? (S) : 0][j][r] * osc + bv;                               \
+                    if (GELU) v = ds_gelu2_fast(v);                                                  \
+                    STORE(wre * 32 + (r & 3) + 8 * (r >> 2) + 4 * hhe, cl, v);                       \
                 }                                                                                    \
             }                                                                                        \
+        } else if (NB16) {                                                                           \
+            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                         \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                      \
+                    float v = acc9[tt][r] * osc + (tt ? bv9b : bv9a);                                \
+                    if (GELU) v = ds_gelu2_fast(v);                                                  \
+                    STORE(4 * PS_SIG(qe) + r, cl9 + tt * 16, v);                                     \
+                }                                                                                    \
         } else {                                                                                     \
-            const int cl = (wce * 2 + wre) * 32 + l31e;                                              \
-            const float bv = p.bias ? p.bias[n0 + cl] : 0.f;                                         \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hhe;                                     \
-                float v = acc8[r] * osc + bv;                                                        \
-                if (p.act == DS_ACT_GELU2) v = ds_gelu2_fast(v);                                     \
-                STORE(rl, cl, v);                                                                    \
+                float v = acc8[r] * osc + bv9a;                                                      \
+                if (GELU) v = ds_gelu2_fast(v);                                                      \
+                STORE((r & 3) + 8 * (r >> 2) + 4 * hhe, cl9, v);                                     \
             }                                                                                        \
         }                                                                                            \
     } while (0)
+    const bool gelu = p.act == DS_ACT_GELU2;
+    __syncthreads();                               // every wave is out of the main loop: the operand stages are free
 
     if constexpr (EPI == PS_EPI_ROW) {
-        // row-major fp32 (+ residual): T[rows][256] floats (<= 128 KB), 16-byte residual loads and stores
-        float* Tf = (float*)smem_raw;
-#define PS_ST_F32(rl_, cl_, v_) Tf[(rl_) * BN + (cl_)] = (v_)
-#define PS_ROW_SLAB(SL)                                                                              \
+        // row-major fp32 (+ residual): 16-byte residual loads and stores, one row of the tile per wave and iteration
+#define PS_ST_F32(rs_, cl_, v_) Tf[(rs_) * BN + (cl_)] = (v_)
+#define PS_ROW_STEP(S)                                                                               \
     do {                                                                                             \
-        constexpr int rows_ = (SL) < 2 ? 128 : 32;                                                   \
-        constexpr int iters_ = rows_ * (BN / 4) / 512;          /* 16 or 4: every thread, every iteration */ \
-        constexpr int pf_ = iters_ < 8 ? iters_ : 8;            /* iterations whose residual is prefetched */ \
-        const int cc = tid_e & (BN / 4 - 1);                                                         \
-        const int col = n0 + cc * 4;                                                                 \
-        /* part of the slab's residual values is requested BEFORE the staging barriers (32 registers; all 144 */ \
-        /* accumulators are still live in slab 0): their HBM latency runs under the accumulator -> LDS pass */ \
-        f32x4 res[pf_];                                                                              \
-        _Pragma("unroll") for (int it = 0; it < pf_; ++it) {                                         \
-            const int trow = (SL) * 128 + (tid_e >> 6) + 8 * it;                                     \
+        constexpr int rows_ = (S) < 4 ? 64 : (NB16 ? 16 : 32);                                       \
+        constexpr int iters_ = rows_ / 8;                       /* 8, or 2 / 4 */                    \
+        float* Tf = (float*)smem_raw + ((S) & 1) * EBUF;                                             \
+        const int cc = tid_e & 63, col = n0 + cc * 4;                                                \
+        f32x4 res[iters_];                  /* requested before the staging: their latency runs under it */ \
+        _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                      \
+            const int trow = PS_TROW(S, (tid_e >> 6) + 8 * it);                                      \
             res[it] = f32x4{0.f, 0.f, 0.f, 0.f};                                                     \
-            if (p.R && trow >= off && trow < vhi) res[it] = *(const f32x4*)(p.R + (size_t)(m0 + trow) * p.ldr + col); \
+            if (!(PS_ABLATE & 32) && p.R && trow >= off && trow < vhi) res[it] = *(const f32x4*)(p.R + (size_t)(m0 + trow) * p.ldr + col); \
         }                                                                                            \
-        __syncthreads();                    /* the operand stages / the previous slab are free */    \
-        PS_SLAB_VALUES(SL, PS_ST_F32);                                                               \
-        __syncthreads();                                                                             \
-        f32x4 res2[iters_ - pf_ > 0 ? iters_ - pf_ : 1];                                             \
-        _Pragma("unroll") for (int it = pf_; it < iters_; ++it) {                                    \
-            const int trow = (SL) * 128 + (tid_e >> 6) + 8 * it;                                     \
-            res2[it - pf_] = f32x4{0.f, 0.f, 0.f, 0.f};                                              \
-            if (p.R && trow >= off && trow < vhi) res2[it - pf_] = *(const f32x4*)(p.R + (size_t)(m0 + trow) * p.ldr + col); \
+        if (!(PS_ABLATE & 64)) {                                                                     \
+            if (gelu) PS_STEP_VALUES(S, true, PS_ST_F32); else PS_STEP_VALUES(S, false, PS_ST_F32);  \
+            __syncthreads();                                                                         \
         }                                                                                            \
         _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                      \
-            const int rl = (tid_e >> 6) + 8 * it, trow = (SL) * 128 + rl;                            \
-            if (trow >= off && trow < vhi)                                                           \
-                *(f32x4*)(p.C + (size_t)(m0 + trow) * p.ldc + col) =                                 \
-                    *(const f32x4*)(Tf + rl * BN + cc * 4) + (it < pf_ ? res[it < pf_ ? it : 0] : res2[it >= pf_ ? it - pf_ : 0]); \
+            const int rs = (tid_e >> 6) + 8 * it, trow = PS_TROW(S, rs);                             \
+            if (trow >= off && trow < vhi) {                                                         \
+                const f32x4 vv_ = (PS_ABLATE & 64) ? res[it] + osc : *(const f32x4*)(Tf + rs * BN + cc * 4) + res[it]; \
+                if (PS_ABLATE & 32) asm volatile("" :: "v"(vv_));                                    \
+                else *(f32x4*)(p.C + (size_t)(m0 + trow) * p.ldc + col) = vv_;                       \
+            }                                                                                        \
         }                                                                                            \
     } while (0)
-        PS_ROW_SLAB(0); PS_STAMP(3); PS_ROW_SLAB(1); PS_STAMP(4); PS_ROW_SLAB(2); PS_STAMP(5);
+        PS_ROW_STEP(0); PS_ROW_STEP(1); PS_STAMP(3); PS_ROW_STEP(2); PS_ROW_STEP(3); PS_STAMP(4); PS_ROW_STEP(4); PS_STAMP(5);
     } else {
-        // fp16 split outputs: T[rows][256] of 32-bit (hi | lo << 16) (<= 128 KB); a thread reads 8 columns = 32 bytes
-        // and writes one 16-byte store per plane
-        unsigned* T = (unsigned*)smem_raw;
-#define PS_ST_SPLIT(rl_, cl_, v_)                                                                    \
+        // fp16 split outputs: staged as 32-bit (hi | lo << 16); a thread reads 8 values = 32 bytes and writes one 16-byte
+        // store per plane
+#define PS_PACK(v_, dst_)                                                                            \
     do {                                                                                             \
         const _Float16 hi_ = ds_split_hi(v_);                                                        \
         const _Float16 lo_ = ds_split_lo(v_, hi_);                                                   \
-        T[(rl_) * BN + (cl_)] = (unsigned)__builtin_bit_cast(unsigned short, hi_) |                  \
-                                ((unsigned)__builtin_bit_cast(unsigned short, lo_) << 16);           \
+        dst_ = (unsigned)__builtin_bit_cast(unsigned short, hi_) |                                   \
+               ((unsigned)__builtin_bit_cast(unsigned short, lo_) << 16);                            \
     } while (0)
+#define PS_ST_SPLIT(rs_, cl_, v_) PS_PACK(v_, T[(rs_) * BN + (cl_)])
         // 8 packed values -> the 8 halves of plane 0 (low halves) and of plane 1 (high halves)
 #define PS_UNZIP(x_, hi_, lo_)                                                                       \
     do {                                                                                             \
@@ -437,80 +452,160 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
         const int hw = p.attn_heads * 64;
         const int which = EPI == PS_EPI_ATTN ? n0 / hw : 0;            // block-uniform: Q, K or V columns
         const int b = tm_;                                               // the sample of this tile
-#define PS_SPLIT_SLAB(SL)                                                                            \
+        // row-major step: packed planes (EPI_SPLIT), or the Q planes / K images of the attention-ready store
+#define PS_SPLIT_STEP(S)                                                                             \
     do {                                                                                             \
-        constexpr int SR = (SL) < 2 ? 128 : 32;                                                      \
-        __syncthreads();                                                                             \
-        PS_SLAB_VALUES(SL, PS_ST_SPLIT);                                                             \
-        __syncthreads();                                                                             \
-        if (EPI == PS_EPI_SPLIT || which < 2) {           /* 8 consecutive columns of a row per thread */ \
-            constexpr int iters_ = SR * (BN / 8) / 512;       /* 8 or 2 */                           \
-            const int cc = tid_e & (BN / 8 - 1);                                                     \
-            const int col = n0 + cc * 8;                                                             \
-            _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                  \
-                const int rl = (tid_e >> 5) + 16 * it, trow = (SL) * 128 + rl;                       \
-                if (trow >= off && trow < vhi) {                                                     \
-                    const int row = m0 + trow;                                                       \
-                    unsigned x[8];                                                                   \
-                    *(u32x4*)(x) = *(const u32x4*)(T + rl * BN + cc * 8);                            \
-                    *(u32x4*)(x + 4) = *(const u32x4*)(T + rl * BN + cc * 8 + 4);                    \
-                    u32x4 vh, vl;                                                                    \
-                    PS_UNZIP(x, vh, vl);                                                             \
-                    _Float16 *d0, *d1;                                                               \
-                    if (EPI == PS_EPI_SPLIT) {                                                       \
-                        d0 = (_Float16*)p.C + ds_packed_off(row, col, p.ldc >> 5);                   \
-                        d1 = d0 + p.c_plane;                                                         \
-                    } else {                                                                         \
-                        const int pos = trow - off;                                                  \
-                        const int hc = col - which * hw, head = hc >> 6, d = hc & 63;                \
-                        const size_t bh = (size_t)b * p.attn_heads + head;                           \
-                        if (which == 0) {                                                            \
-                            d0 = (_Float16*)p.C + (bh * L + pos) * 64 + d;                           \
-                            d1 = d0 + p.attn_qplane;                                                 \
-                        } else {                                                                     \
-                            d0 = (_Float16*)p.attn_kv + (bh * 4) * ((size_t)p.attn_nkey * 64) + ds_attn_k_off(pos, d); \
-                            d1 = d0 + (size_t)p.attn_nkey * 64;                                      \
-                        }                                                                            \
-                    }                                                                                \
-                    *(u32x4*)d0 = vh;                                                                \
-                    *(u32x4*)d1 = vl;                                                                \
-                }                                                                                    \
-            }                                                                                        \
-        } else {                                          /* V^T: 8 consecutive keys of one d per store */ \
-            /* valid tile rows of this slab [lo, hi); key = tile row - off; units of 8 keys are aligned in the   */ \
-            /* sample's own key index, so a unit that straddles a slab edge is written in two parts (2-byte stores) */ \
-            const int lo = (SL) * 128 > off ? (SL) * 128 : off;                                      \
-            const int hi = (SL) * 128 + SR < vhi ? (SL) * 128 + SR : vhi;                            \
-            const int u_first = lo < hi ? (lo - off) >> 3 : 0;                                       \
-            const int units = lo < hi ? ((hi - off + 7) >> 3) - u_first : 0;                         \
-            const int pln = p.attn_nkey * 64;                                                        \
-            const int rlo = lo - (SL) * 128, rhi = hi - (SL) * 128;                                  \
-            const int cl = tid_e & (BN - 1);              /* this thread's column (d), units u = tid / 256, + 2, ... */ \
-            const int hc = n0 + cl - 2 * hw, head = hc >> 6, d = hc & 63;                            \
-            _Float16* img = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2) * (size_t)pln; \
-            for (int u = tid_e >> 8; u < units; u += 2) {                                            \
-                const int k0 = (u_first + u) * 8;                   /* first key of the unit */      \
-                const int r0 = k0 + off - (SL) * 128;               /* its slab-local row (may be < 0) */ \
-                _Float16* dst = img + ds_attn_vt_off(k0, d, p.attn_nkey);                            \
-                if (r0 >= rlo && r0 + 8 <= rhi) {                                                    \
-                    unsigned x[8];                                                                   \
-                    _Pragma("unroll") for (int e = 0; e < 8; ++e) x[e] = T[(r0 + e) * BN + cl];      \
-                    u32x4 vh, vl;                                                                    \
-                    PS_UNZIP(x, vh, vl);                                                             \
-                    *(u32x4*)dst = vh;                                                               \
-                    *(u32x4*)(dst + pln) = vl;                                                       \
+        constexpr int rows_ = (S) < 4 ? 64 : (NB16 ? 16 : 32);                                       \
+        constexpr int iters_ = rows_ / 16;                      /* 4, or 1 / 2 */                    \
+        unsigned* T = (unsigned*)smem_raw + ((S) & 1) * EBUF;                                        \
+        if (!(PS_ABLATE & 64)) {                                                                     \
+            if (gelu) PS_STEP_VALUES(S, true, PS_ST_SPLIT); else PS_STEP_VALUES(S, false, PS_ST_SPLIT); \
+            __syncthreads();                                                                         \
+        }                                                                                            \
+        const int cc = tid_e & 31, col = n0 + cc * 8;                                                \
+        _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                      \
+            const int rs = (tid_e >> 5) + 16 * it, trow = PS_TROW(S, rs);                            \
+            if (trow >= off && trow < vhi) {                                                         \
+                const int row = m0 + trow;                                                           \
+                unsigned x[8];                                                                       \
+                u32x4 vh, vl;                                                                        \
+                if (PS_ABLATE & 64) {                                                                \
+                    vh = u32x4{(unsigned)row, (unsigned)col, 1u, 2u}; vl = vh + 7u;                  \
                 } else {                                                                             \
-                    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                    \
-                        if (r0 + e >= rlo && r0 + e < rhi) {                                         \
-                            const unsigned x1 = T[(r0 + e) * BN + cl];                               \
-                            dst[e] = __builtin_bit_cast(_Float16, (unsigned short)(x1 & 0xffffu));   \
-                            dst[pln + e] = __builtin_bit_cast(_Float16, (unsigned short)(x1 >> 16)); \
-                        }                                                                            \
+                    *(u32x4*)(x) = *(const u32x4*)(T + rs * BN + cc * 8);                            \
+                    *(u32x4*)(x + 4) = *(const u32x4*)(T + rs * BN + cc * 8 + 4);                    \
+                    PS_UNZIP(x, vh, vl);                                                             \
+                }                                                                                    \
+                _Float16 *d0, *d1;                                                                   \
+                if (EPI == PS_EPI_SPLIT) {                                                           \
+                    d0 = (_Float16*)p.C + ds_packed_off(row, col, p.ldc >> 5);                       \
+                    d1 = d0 + p.c_plane;                                                             \
+                } else {                                                                             \
+                    const int pos = trow - off;                                                      \
+                    const int hc = col - which * hw, head = hc >> 6, d = hc & 63;                    \
+                    const size_t bh = (size_t)b * p.attn_heads + head;                               \
+                    if (which == 0) {                                                                \
+                        d0 = (_Float16*)p.C + (bh * L + pos) * 64 + d;                               \
+                        d1 = d0 + p.attn_qplane;                                                     \
+                    } else {                                                                         \
+                        d0 = (_Float16*)p.attn_kv + (bh * 4) * ((size_t)p.attn_nkey * 64) + ds_attn_k_off(pos, d); \
+                        d1 = d0 + (size_t)p.attn_nkey * 64;                                          \
+                    }                                                                                \
+                }                                                                                    \
+                if (PS_ABLATE & 32) { asm volatile("" :: "v"(vh), "v"(vl), "v"(d0), "v"(d1)); }      \
+                else { *(u32x4*)d0 = vh; *(u32x4*)d1 = vl; }                                         \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+        // V^T step: transposed staging, per group of 32 tile rows T2[group][column][36] (32 keys + 4 words of padding:
+        // the 144-byte column stride spreads the eight lanes of a ds_write_b128 group over all banks).  The values of a
+        // lane come four consecutive rows at a time (registers 4 q .. 4 q + 3 of a 32 x 32 block, 0 .. 3 of a 16 x 16 tile).
+        constexpr int VLD = 36, VGRP = BN * VLD;              // words per column / per group (36 KB)
+#define PS_VT_STAGE(S, GELU)                                                                         \
+    do {                                                                                             \
+        unsigned* T2 = (unsigned*)smem_raw + ((S) & 1) * (2 * VGRP);                                 \
+        if ((S) < 4) {                                                                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                            \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                      \
+                    u32x4 w;                                                                         \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                  \
+                        float v = acc[(S) < 4 ? (S) : 0][j][4 * q + e] * osc + (j ? bv1 : bv0);      \
+                        if (GELU) v = ds_gelu2_fast(v);                                              \
+                        PS_PACK(v, w[e]);                                                            \
+                    }                                                                                \
+                    *(u32x4*)(T2 + wre * VGRP + (j ? cl1 : cl0) * VLD + 8 * q + 4 * hhe) = w;        \
+                }                                                                                    \
+        } else if (NB16) {                                                                           \
+            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                       \
+                u32x4 w;                                                                             \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
+                    float v = acc9[tt][e] * osc + (tt ? bv9b : bv9a);                                \
+                    if (GELU) v = ds_gelu2_fast(v);                                                  \
+                    PS_PACK(v, w[e]);                                                                \
+                }                                                                                    \
+                *(u32x4*)(T2 + (cl9 + tt * 16) * VLD + 4 * PS_SIG(qe)) = w;                          \
+            }                                                                                        \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+                u32x4 w;                                                                             \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
+                    float v = acc8[4 * q + e] * osc + bv9a;                                          \
+                    if (GELU) v = ds_gelu2_fast(v);                                                  \
+                    PS_PACK(v, w[e]);                                                                \
+                }                                                                                    \
+                *(u32x4*)(T2 + cl9 * VLD + 8 * q + 4 * hhe) = w;                                     \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+        // ... and its stores: per group, the valid tile rows [lo, hi) are keys [lo - off, hi - off); 16-byte units of 8
+        // keys are aligned in the sample's own key index.  A group whose rows are whole units (the padded-row mode: off = 0)
+        // is written 4 units per column with consecutive lanes on consecutive units; otherwise a unit that straddles the
+        // group's edge is written in parts (2-byte stores), one column per thread as the first version did.
+#define PS_VT_STEP(S)                                                                                \
+    do {                                                                                             \
+        constexpr int ngrp_ = (S) < 4 ? 2 : 1;                                                       \
+        constexpr int grows_ = (S) < 4 ? 32 : (NB16 ? 16 : 32);                                      \
+        const unsigned* T2 = (const unsigned*)smem_raw + ((S) & 1) * (2 * VGRP);                     \
+        if (!(PS_ABLATE & 64)) {                                                                     \
+            if (gelu) PS_VT_STAGE(S, true); else PS_VT_STAGE(S, false);                              \
+            __syncthreads();                                                                         \
+        }                                                                                            \
+        const int pln = p.attn_nkey * 64;                                                            \
+        _Pragma("unroll") for (int g = 0; g < ngrp_; ++g) {                                          \
+            const int G0 = (S) < 4 ? g * 128 + (S) * 32 : 256;      /* first tile row of the group */ \
+            const int lo = G0 > off ? G0 : off;                                                      \
+            const int hi = G0 + grows_ < vhi ? G0 + grows_ : vhi;                                    \
+            if (lo >= hi) continue;                                                                  \
+            const unsigned* Tg = T2 + g * VGRP;                                                      \
+            if (lo == G0 && hi == G0 + grows_ && ((G0 - off) & 7) == 0) {                            \
+                constexpr int upc_ = grows_ / 8;                    /* units per column: 4 (2) */    \
+                constexpr int iters_ = BN * upc_ / 512;             /* 2 (1) */                      \
+                _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                              \
+                    const int task = tid_e + 512 * it, cl = task / upc_, u = task % upc_;            \
+                    const int hc = n0 + cl - 2 * hw, head = hc >> 6, d = hc & 63;                    \
+                    _Float16* img = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2) * (size_t)pln; \
+                    unsigned x[8];                                                                   \
+                    *(u32x4*)(x) = *(const u32x4*)(Tg + cl * VLD + 8 * u);                           \
+                    *(u32x4*)(x + 4) = *(const u32x4*)(Tg + cl * VLD + 8 * u + 4);                   \
+                    u32x4 vh, vl;                                                                    \
+                    PS_UNZIP(x, vh, vl);                                                             \
+                    _Float16* dst = img + ds_attn_vt_off(G0 - off + 8 * u, d, p.attn_nkey);          \
+                    if (PS_ABLATE & 32) { asm volatile("" :: "v"(vh), "v"(vl), "v"(dst)); }          \
+                    else { *(u32x4*)dst = vh; *(u32x4*)(dst + pln) = vl; }                           \
+                }                                                                                    \
+            } else {                                                                                 \
+                const int u_first = (lo - off) >> 3, units = ((hi - off + 7) >> 3) - u_first;        \
+                const int cl = tid_e & (BN - 1);                                                     \
+                const int hc = n0 + cl - 2 * hw, head = hc >> 6, d = hc & 63;                        \
+                _Float16* img = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2) * (size_t)pln; \
+                for (int u = tid_e >> 8; u < units; u += 2) {                                        \
+                    const int k0 = (u_first + u) * 8;               /* first key of the unit */      \
+                    const int r0 = k0 + off - G0;                   /* its group-local row (may be < 0) */ \
+                    _Float16* dst = img + ds_attn_vt_off(k0, d, p.attn_nkey);                        \
+                    if (r0 >= lo - G0 && r0 + 8 <= hi - G0) {       /* a whole unit inside the group */ \
+                        unsigned x[8];                                                               \
+                        _Pragma("unroll") for (int e = 0; e < 8; ++e) x[e] = Tg[cl * VLD + r0 + e];  \
+                        u32x4 vh, vl;                                                                \
+                        PS_UNZIP(x, vh, vl);                                                         \
+                        *(u32x4*)dst = vh;                                                           \
+                        *(u32x4*)(dst + pln) = vl;                                                   \
+                    } else {                                                                         \
+                        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                \
+                            if (r0 + e >= lo - G0 && r0 + e < hi - G0) {                             \
+                                const unsigned x1 = Tg[cl * VLD + r0 + e];                           \
+                                dst[e] = __builtin_bit_cast(_Float16, (unsigned short)(x1 & 0xffffu)); \
+                                dst[pln + e] = __builtin_bit_cast(_Float16, (unsigned short)(x1 >> 16)); \
+                            }                                                                        \
+                    }                                                                                \
                 }                                                                                    \
             }                                                                                        \
         }                                                                                            \
     } while (0)
-        PS_SPLIT_SLAB(0); PS_STAMP(3); PS_SPLIT_SLAB(1); PS_STAMP(4); PS_SPLIT_SLAB(2); PS_STAMP(5);
+        if (EPI == PS_EPI_ATTN && which == 2) {
+            PS_VT_STEP(0); PS_VT_STEP(1); PS_STAMP(3); PS_VT_STEP(2); PS_VT_STEP(3); PS_STAMP(4); PS_VT_STEP(4); PS_STAMP(5);
+        } else {
+            PS_SPLIT_STEP(0); PS_SPLIT_STEP(1); PS_STAMP(3); PS_SPLIT_STEP(2); PS_SPLIT_STEP(3); PS_STAMP(4); PS_SPLIT_STEP(4); PS_STAMP(5);
+        }
     }
 #ifdef PS_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tile's stores have left the wave's queue

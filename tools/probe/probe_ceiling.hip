@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -66,6 +67,16 @@ namespace v13 {
 #undef PS_ABLATE
 #define PS_ABLATE 14
 namespace v14 {
+#include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
+}
+#undef PS_ABLATE
+#define PS_ABLATE 32
+namespace v32 {
+#include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
+}
+#undef PS_ABLATE
+#define PS_ABLATE 64
+namespace v64 {
 #include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
 }
 
@@ -153,6 +164,8 @@ int main(int argc, char** argv) {
                             {"qkv  N=3072 K=1024 (Q / K / V^T)", 3072, 1024, 2}, {"fc2  N=1024 K=4096 (row + residual)", 1024, 4096, 0}};
     struct Var { const char* name; launch_fn fn; };
     const Var vars[] = {{"product kernel", v0::ds_launch_gemm_f16x2_ps},
+                        {"epilogue: LDS staging only", v32::ds_launch_gemm_f16x2_ps},
+                        {"epilogue: global ld/st only", v64::ds_launch_gemm_f16x2_ps},
                         {"no epilogue", v8::ds_launch_gemm_f16x2_ps},
                         {"no epilogue, no DMA", v9::ds_launch_gemm_f16x2_ps},
                         {"MFMA + barriers only", v11::ds_launch_gemm_f16x2_ps},
@@ -195,7 +208,15 @@ int main(int argc, char** argv) {
         if (sh.epi == 2) { p.store = DS_STORE_ATTN; p.attn_kv = img; p.attn_heads = H; p.attn_nkey = 288; p.attn_qplane = (long long)B * H * L * 64; }
         printf("B = %d: %s   %d tiles = %.2f per CU%s\n", B, sh.name, B * N / 256, B * N / 256 / 256.0,
                zero_lo == 2 ? "   [all operands zero]" : zero_lo ? "   [lo planes zero]" : "");
+        int vi = -1;
         for (const Var& v : vars) {
+            ++vi;
+            if (const char* sel = getenv("PROBE_VARIANTS")) {
+                char key[8];
+                snprintf(key, sizeof(key), ",%d,", vi);
+                std::string hay = std::string(",") + sel + ",";
+                if (hay.find(key) == std::string::npos) continue;
+            }
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             // settle for half the duration, then measure the second half
