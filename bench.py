@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
+    ap.add_argument("--roofline-steps", type=int, default=12,
+                    help="denoiser steps of the profiled roofline leg (HIP events around every GEMM launch)")
+    ap.add_argument("--roofline-warm", type=int, default=10, help="un-profiled steps before them")
     return ap.parse_args()
 
 
@@ -149,13 +152,14 @@ def cpu_baseline(n_layer, codes, T):
                          best_n, bB, T, res[bB][1], res[bB][2], res[bB][3], T)}
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary over one denoiser step at
-    B=64 (profiles/r*_pmc_denoiser_step_b64.json, made on the GPU box by tools/profile_round.sh: tools/pmc_step.py under
+def pmc_traffic(kernel, template_tail, algorithmic_mb):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary over denoiser sampling steps
+    at B=64 (profiles/r*_pmc_denoiser_step_b64.json, made on the GPU box by tools/profile_round.sh: tools/pmc_step.py under
     separate --pmc passes, tools/pmc_summarize.py with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).
-    PMC counters cannot be read inside this process, so the number is a committed measurement -- and it is reported
-    ONLY while the kernel sources still hash to what was measured (`_meta.source_sha16`); otherwise traffic is null
-    and the note says the profile is stale."""
+    PMC counters cannot be read inside this process, so the number is a committed measurement -- reported ONLY while
+    (a) the kernel sources still hash to what was measured (`_meta.source_sha16`) and (b) the summary lists the very
+    instantiations this run timed: the FULL symbol must match, template arguments included (`template_tail`, e.g.
+    ",true>" for the 272-row program of the padded-row mode).  Otherwise traffic is null and the note says why."""
     import glob
     from text_to_sound_synthesis_amd.build import source_fingerprint
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_denoiser_step_b64.json")))
@@ -169,21 +173,33 @@ def pmc_traffic(kernel):
         return None, ("stale: %s was measured on kernel sources %s, the tree is %s -- re-run tools/profile_round.sh"
                       % (os.path.basename(path), meta.get("source_sha16", "(unrecorded)"), now))
     want = kernel.split(" (")[0].replace(" ", "")
-    want = want[:-1] if want.endswith(">") else want     # "<128,128" also matches "<128,128,2>"
-    # every instantiation of the program (e.g. the three epilogue families of ds_gemm_f16x2_ps_kernel), weighted by launches
-    hit = [r for name, r in table.items() if name != "_meta" and name.replace(" ", "").startswith(want)
-           and r.get("hbm_read_MB_per_launch") is not None]
-    if hit:
-        n = sum(r["dispatches"] for r in hit)
-        rd = sum(r["hbm_read_MB_per_launch"] * r["dispatches"] for r in hit) / n
-        wr = sum((r["hbm_write_MB_per_launch"] or 0.0) * r["dispatches"] for r in hit) / n
-        l2 = sum(r["l2_hit_rate"] * r["dispatches"] for r in hit) / n
-        return round((rd + wr) * 1e6), ("bytes per launch = %.0f MB read (2 x FETCH_SIZE; Infinity-Cache hits included) + %.0f MB "
-                                        "written (WRITE_SIZE), mean of %d dispatches of %d kernel symbols, L2 hit rate %.2f; "
-                                        "algorithmic operand + residual + result bytes of the same launches average 276 MB "
-                                        "(DESIGN.md section 3); source profiles/%s (kernel sources %s)"
-                                        % (rd, wr, n, len(hit), l2, os.path.basename(path), now))
-    return None, "kernel not in %s" % os.path.basename(path)
+    hit = {name: r for name, r in table.items() if name != "_meta" and name.replace(" ", "").startswith(want + "<")
+           and name.replace(" ", "").endswith(template_tail) and r.get("hbm_read_MB_per_launch") is not None}
+    if not hit:
+        return None, ("%s lists no %s<...%s instantiation (it has: %s)"
+                      % (os.path.basename(path), want, template_tail, meta.get("gemm_instantiations", "?")))
+    n = sum(r["dispatches"] for r in hit.values())
+    rd = sum(r["hbm_read_MB_per_launch"] * r["dispatches"] for r in hit.values()) / n
+    wr = sum((r["hbm_write_MB_per_launch"] or 0.0) * r["dispatches"] for r in hit.values()) / n
+    l2 = sum(r["l2_hit_rate"] * r["dispatches"] for r in hit.values()) / n
+    return round((rd + wr) * 1e6), (
+        "bytes per launch = %.0f MB read (2 x FETCH_SIZE; Infinity-Cache hits included) + %.0f MB written (WRITE_SIZE), mean "
+        "of %d dispatches of %s, L2 hit rate %.2f; algorithmic operand + residual + result bytes of the same launches average "
+        "%.0f MB -> traffic / algorithmic = %.2f; source profiles/%s (kernel sources %s)"
+        % (rd, wr, n, sorted(hit), l2, algorithmic_mb, (rd + wr) / algorithmic_mb, os.path.basename(path), now))
+
+
+def gemm_algorithmic_mb(B, rows, D=1024, mlp=4):
+    """Mean over the six GEMM launches of a block of operand + residual + result bytes (packed fp16 planes = 4 bytes per
+    element, like fp32): what one launch of the per-sample program has to move at least, in MB."""
+    M = B * rows
+    a, o = M * D * 4.0, M * D * 4.0
+    qkv = a + 3 * D * D * 4.0 + 3 * o
+    proj = a + D * D * 4.0 + 2 * o                      # result + residual
+    crossq = a + D * D * 4.0 + o
+    fc1 = a + mlp * D * D * 4.0 + mlp * o
+    fc2 = mlp * a + mlp * D * D * 4.0 + 2 * o
+    return (qkv + 2 * proj + crossq + fc1 + fc2) / 6.0 / 1e6
 
 
 def timed_loop(one_step, warmup, steps, device, world):
@@ -335,10 +351,12 @@ def main():
             u = torch.rand((B, args.codes + 1, 265), device=dev)
             t = torch.full((B,), T - 1, device=dev, dtype=torch.long)
             x = dt.p_sample_tokens(x, kv, t, u, initial=True)            # warm-up (also builds the pack)
+            for i in range(args.roofline_warm):                          # bring the board to the timed loop's thermal state
+                x = dt.p_sample_tokens(x, kv, t, u, initial=False)
             torch.cuda.synchronize()
             L.ds_profile_enable(1)
-            for i in range(3):
-                t = torch.full((B,), T - 2 - i, device=dev, dtype=torch.long)
+            for i in range(args.roofline_steps):
+                t = torch.full((B,), max(T - 2 - i, 0), device=dev, dtype=torch.long)
                 x = dt.p_sample_tokens(x, kv, t, u, initial=False)
             L.ds_profile_enable(0)
             ms, fl, n = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
@@ -352,8 +370,13 @@ def main():
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             peak = mfma_peak / passes                  # ceiling in algorithmic (2MNK) flops of this formulation
             # the committed PMC passes ran the default f16x2 step at B=64; other legs / sizes have no measurement
-            measured = precision == "f16x2" and (B, args.n_layer, args.codes) == (64, 19, 256)
-            traffic, traffic_note = pmc_traffic(names[dom]) if measured else (None, None)
+            measured = precision == "f16x2" and dom == 3 and (B, args.n_layer, args.codes) == (64, 19, 256)
+            traffic, traffic_note = None, None
+            if measured:
+                h = dt.transformer.packed(dt._schedule_table())["handle"]
+                rows = L.ds_denoiser_rows_per_sample(h, B)
+                traffic, traffic_note = pmc_traffic(names[dom], ",true>" if rows == 272 else ",false>",
+                                                    gemm_algorithmic_mb(B, rows))
             return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": "%s (%s, dense loader)" % (names[dom], what), "launches": int(n[dom]),

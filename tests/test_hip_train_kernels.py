@@ -430,6 +430,51 @@ def test_graphed_iteration_matches_eager():
     assert graph.train_step.loss_scale_exp == eager.train_step.loss_scale_exp
 
 
+def test_graph_solver_resumes_from_its_state_dict():
+    """a run trained with GraphSolver can be checkpointed and resumed -- two iterations, state_dict + the
+    weights into a fresh model / solver, a third iteration there == the third iteration of the uninterrupted run (loss, the
+    AdamW moments inside the graph, the bias-correction counter), and the saturation monitor saw real gradients."""
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.solver import GradClipWindow, GraphSolver
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+
+    def make():
+        m = build_model(default_config(n_layer=2, diffusion_step=100))
+        m.load_state_dict({**dict(synth_sd("dalle", 2)), **synth_sd("encoder")}, strict=False)
+        m = m.cuda().eval()
+        dt = m.transformer
+        dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]
+        return dt
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0").cuda()
+    cond = synth.synth_cond_emb(3, key="tl.c").cuda()
+    pt = (torch.ones(3) / 100).cuda()
+    batches = [(torch.tensor([57, 0, 93]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u").cuda()),
+               (torch.tensor([3, 99, 41]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u2").cuda()),
+               (torch.tensor([12, 12, 70]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u3").cuda())]
+    dt_a, dt_b = make(), make()
+    a = GraphSolver(TrainStep(dt_a, precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5))
+    for t, u in batches[:2]:
+        a.step(x0, cond, t, pt, u)
+    assert float(a.train_step._amax_live) > 0.0            # the monitor accumulates max |scaled dY| on the device
+    state = a.state_dict()
+    weights = {k: v.detach().clone() for k, v in dt_a.state_dict().items()}
+    oa = a.step(x0, cond, batches[2][0], pt, batches[2][1])
+    dt_b.load_state_dict(weights)
+    b = GraphSolver(TrainStep(dt_b, precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5))
+    b.load_state_dict(state)
+    ob = b.step(x0, cond, batches[2][0], pt, batches[2][1])
+    assert b.iteration_graph.iteration == a.iteration_graph.iteration == 3 and b.clip_grad_norm.last_epoch == 2
+    la, lb = float(oa["loss"]), float(ob["loss"])
+    assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+    key = "transformer.blocks.1.mlp.0.weight"
+    ma, mb = a.iteration_graph.opt_state[key][0], b.iteration_graph.opt_state[key][0]
+    assert (ma - mb).abs().max().item() <= 1e-5 * ma.abs().max().item()
+    wa, wb = dict(dt_a.named_parameters())[key].detach(), dict(dt_b.named_parameters())[key].detach()
+    d = (wa - wb).abs()
+    assert d.mean().item() < 1e-7 and (d > 1e-6).float().mean().item() < 1e-4
+
+
 def test_overlapped_weight_gradients_identical():
     """TrainStep(overlap_dw=True): the dW / db work of the backward on a second HIP stream (events order it against the
     in-place updates of the residual gradient) must give bit-identical gradients, twice in a row (allocator reuse)."""

@@ -252,10 +252,18 @@ def test_denoiser_step_with_per_sample_program_gives_the_same_tokens():
     want_logits = dt.transformer(x, cond, t).clone()
     try:
         L.lib().ds_gemm_f16x2_force_tile(PS)
+        # the driver sizes its rows with the same rule that dispatches the program (ds_gemm_f16x2_ps_taken, forced tile
+        # included): forced, the step runs in padded-row mode unless that is switched off
+        assert L.lib().ds_denoiser_rows_per_sample(dt.transformer.packed(dt._schedule_table())["handle"], B) == 272
+        dt.transformer.row_padding = False
         got = dt.p_sample_tokens(x, kv, t, u, False)
-        assert torch.equal(got, want)
+        assert torch.equal(got, want)                                  # 265-row tiles: the bits of the 4-wave programs
         assert torch.equal(dt.transformer(x, cond, t), want_logits)
+        dt.transformer.row_padding = True
+        got = dt.p_sample_tokens(x, kv, t, u, False)                   # 272-row tiles: rows 256..264 summed in another order
+        assert int((got != want).sum()) <= 2
     finally:
+        dt.transformer.row_padding = True
         L.lib().ds_gemm_f16x2_force_tile(-1)
 
 

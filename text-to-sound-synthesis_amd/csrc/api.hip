@@ -165,11 +165,11 @@ static size_t attn_img_floats(int B, int heads, int Lk) { return (size_t)B * hea
 // rows of each sample (ds_sample_tail_rows).  Rows 256..264 of a sample are then summed in another order than by the
 // 4-wave programs (same products): equal to ~1e-7 relative, not bit-identical across batch sizes.
 static const int PS_ROWS = 272;
+bool ds_gemm_f16x2_ps_taken(int B, int N);   // gemm_f16x2.hip: the dispatch rule of the per-sample program, forced tile included
 static int rows_per_sample(const ds_denoiser* h, int B) {
     const int L = h->d.seq_len;
     if (!h->pad_rows || h->split_mode != DS_SPLIT_F16X2 || L > PS_ROWS || L <= PS_ROWS - 16) return L;
-    const long tiles = (long)B * (h->d.n_embd / 256), rounds = (tiles + 255) / 256;    // the N = 1024 GEMMs' grid
-    return (tiles >= 192 && tiles * 100 >= rounds * 256 * 85) ? PS_ROWS : L;         // = ds_gemm_f16x2_ps_applies
+    return ds_gemm_f16x2_ps_taken(B, h->d.n_embd) ? PS_ROWS : L;    // the N = 1024 GEMMs' grid decides (gemm_f16x2.hip)
 }
 extern "C" int ds_denoiser_rows_per_sample(const ds_denoiser* h, int B) { return h && B > 0 ? rows_per_sample(h, B) : -1; }
 extern "C" int ds_denoiser_set_row_padding(ds_denoiser* h, int on) {

@@ -339,6 +339,8 @@ static int attn_f16x2_launch(const float* q, int ldq, const float* k, int ldk, c
                              long long q_plane, hipStream_t stream) {
     DS_CHECK_ARG(q && k && (READY || v) && o, "null pointer");
     DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "bad shape");
+    // the softmax takes the row maximum on the RAW scores and folds `scale` into the exp2 FMA: correct for scale > 0 only
+    DS_CHECK_ARG(scale > 0.f, "scale must be positive");
     DS_CHECK_ARG(READY || (ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0), "leading dims must be multiples of 4");
     const int qtiles = (Lq + 31) / 32;
     const int groups = (qtiles + AH_WAVES - 1) / AH_WAVES;

@@ -516,6 +516,15 @@ static int launch_h(const GemmParams& p, hipStream_t s) {
 
 extern int g_last_tile;
 extern "C" void ds_gemm_f16x2_force_tile(int t) { g_force_tile_h = t; }
+bool ds_gemm_f16x2_ps_grid_pays(long tiles);                                  // gemm_f16x2_ps.hip
+// Whether ds_launch_gemm_f16x2 would run the per-sample program for a packed-operand GEMM over B samples and N columns
+// (every other precondition met): the forced tile decides first, then the grid rule.  The denoiser driver sizes its
+// activation rows with this (padded-row mode), so it cannot drift from the dispatch below.
+bool ds_gemm_f16x2_ps_taken(int B, int N) {
+    if (g_force_tile_h == 9) return true;
+    if (g_force_tile_h >= 0) return false;
+    return ds_gemm_f16x2_ps_grid_pays((long)B * (N / 256));
+}
 bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid);   // gemm_f16x2_ps.hip
 int ds_launch_gemm_f16x2_ps(const GemmParams& p, hipStream_t s);
 

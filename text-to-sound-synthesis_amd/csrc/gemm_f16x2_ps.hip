@@ -623,6 +623,7 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
 // Whether the per-sample program serves this problem, and pays: packed operands, sample-structured rows with
 // 256 < L + 15 <= 288, N in whole 256-column tiles, an even number of k-tiles, 16-byte-aligned row stores, and a grid
 // that fills the 256 CUs in (nearly) whole rounds.
+bool ds_gemm_f16x2_ps_grid_pays(long tiles);
 bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid) {
     const int L = p.rows_per_sample;
     if (!p.a_split || L <= 0 || L > PS_BM - 15 || L <= 240 || p.M % L != 0) return false;
@@ -637,10 +638,15 @@ bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid) {
         return false;
     }
     if (!need_full_grid) return true;
-    const long tiles = (long)(p.M / L) * (p.N / PS_BN);
+    return ds_gemm_f16x2_ps_grid_pays((long)(p.M / L) * (p.N / PS_BN));
+}
+
+// THE grid rule of the per-sample program (one copy: ds_launch_gemm_f16x2 dispatches on it, and the denoiser driver's
+// padded-row mode -- api.hip rows_per_sample -- asks ds_gemm_f16x2_ps_taken, which also knows the forced tile): the
+// program pays when its tiles fill the 256 CUs in (nearly) whole rounds.
+bool ds_gemm_f16x2_ps_grid_pays(long tiles) {
     const long rounds = (tiles + 255) / 256;
-    // measurement hook: DIFFSOUND_PS_MIN_TILES=n takes the program for every grid of >= n tiles (two half-batches on two
-    // streams share the chip: 128-tile grids then run side by side)
+    // measurement hook: DIFFSOUND_PS_MIN_TILES=n takes the program for every grid of >= n tiles
     static const int env_min = getenv("DIFFSOUND_PS_MIN_TILES") ? atoi(getenv("DIFFSOUND_PS_MIN_TILES")) : 0;
     if (env_min > 0) return tiles >= env_min;
     return tiles >= 192 && tiles * 100 >= rounds * 256 * 85;     // >= 85 % of the CU-rounds it occupies do work

@@ -171,12 +171,23 @@ def _model_device(m):
 
 
 def _invalidate(m):
-    """Weight packs cached by the HIP modules (split fp16 planes, AdaLN tables) are stale after a weight swap."""
+    """Weight packs cached by the HIP modules (split fp16 planes, AdaLN tables) are stale after a weight swap -- and so
+    are the per-matrix pre-scales 2^s and the loss scale a TrainStep derived from the old weights (it registers itself on
+    its DiffusionTransformer as a `_scale_clients` weak reference)."""
     for sub in m.modules():
         if hasattr(sub, "invalidate"):
             sub.invalidate()           # also destroys the native handle that points at the old packs
         elif hasattr(sub, "_packed"):
             sub._packed = None
+        for ref in getattr(sub, "_scale_clients", ()):
+            client = ref()
+            if client is not None:
+                client.reset_scales()
+
+
+def _window_always_clips(clip):
+    """ClipGradNorm's window test (clip_grad_norm.py:21-28) is true for every iteration >= 0?"""
+    return clip.start_iteration <= 0 or (clip.end_iteration > 0 and clip.end_iteration >= clip.start_iteration)
 
 
 class Solver:
@@ -203,9 +214,13 @@ class Solver:
                                    weight_decay=self.weight_decay)
         if self.scheduler is not None:
             self.lr = self.scheduler.step(loss)
+        # guards of the split backend's loss scale: the device-side saturation monitor (max |scaled dY| of every GEMM
+        # input; works without clipping, one host sync every `monitor_interval` iterations), and -- when a norm exists --
+        # its drift since calibration
+        if hasattr(self.train_step, "check_loss_scale"):
+            self.train_step.check_loss_scale()
         if total is not None and self.last_iter % 16 == 0 and hasattr(self.train_step, "observe_grad_norm"):
-            self.train_step.observe_grad_norm(float(total))      # guard of the split backend's loss scale (a host float:
-                                                                 # one extra sync every 16 iterations)
+            self.train_step.observe_grad_norm(float(total))
         if self.ema is not None:
             self.ema.update(iteration=self.last_iter)
         return {"loss": loss, "lr": self.lr, "grad_norm": total}
@@ -228,6 +243,8 @@ class Solver:
             self.clip_grad_norm.load_state_dict(state["clip_grad_norm"])
         if self.ema is not None and "ema" in state:
             self.ema.load_state_dict(state["ema"])
+        if hasattr(self.train_step, "reset_scales"):      # a resumed run usually follows a weight load: re-derive the scales
+            self.train_step.reset_scales()
 
 
 class GraphSolver:
@@ -242,7 +259,14 @@ class GraphSolver:
         self.train_step, self.lr = train_step, float(lr)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.scheduler, self.clip_grad_norm, self.ema = scheduler, clip_grad_norm, ema
+        # the clip coefficient is computed inside the captured graph on every replay: a window that skips iterations
+        # cannot be honoured there (the shipped configs/caps.yaml window -- start_iteration 0 -- clips always)
+        if clip_grad_norm is not None and not _window_always_clips(clip_grad_norm):
+            raise NotImplementedError("GraphSolver clips on every iteration: a ClipGradNorm window that skips iterations "
+                                      "(start_iteration %r, end_iteration %r) needs the eager Solver"
+                                      % (clip_grad_norm.start_iteration, clip_grad_norm.end_iteration))
         self.iteration_graph = None
+        self._pending_state = None          # load_state_dict before the first batch: applied right after the capture
         self.last_iter = -1
 
     def step(self, *batch):
@@ -250,11 +274,48 @@ class GraphSolver:
             max_norm = self.clip_grad_norm.max_norm if self.clip_grad_norm is not None else None
             self.iteration_graph = self.train_step.capture(*batch, betas=self.betas, eps=self.eps,
                                                            weight_decay=self.weight_decay, max_norm=max_norm)
+            if self._pending_state is not None:
+                self.iteration_graph.load_state_dict(self._pending_state)
+                self._pending_state = None
         out = self.iteration_graph(*batch, lr=self.lr)
         self.last_iter += 1
+        if self.clip_grad_norm is not None:
+            self.clip_grad_norm.last_epoch += 1        # the window's counter advances as in the eager solver (state_dict parity)
         if self.scheduler is not None:
             self.lr = self.scheduler.step(out["loss"])
-        self.iteration_graph.check_loss_scale()        # re-calibrates and re-captures if the gradients left the window
+        self.iteration_graph.check_loss_scale()        # periodic re-capture / sampled saturation monitor (no sync in between)
         if self.ema is not None:
             self.ema.update(iteration=self.last_iter)
         return {"loss": out["loss"], "lr": self.lr, "grad_norm": out["grad_norm"]}
+
+    def state_dict(self):
+        """Same layout as Solver.state_dict (a run can move between the two): the optimizer moments come out of the
+        graph's static tensors, the bias-correction counter rides along as `graph_iteration`."""
+        g = self.iteration_graph.state_dict() if self.iteration_graph is not None else \
+            (self._pending_state or {"iteration": 0, "optimizer": {}})
+        out = {"last_iter": self.last_iter, "lr": self.lr, "optimizer": g["optimizer"], "graph_iteration": g["iteration"]}
+        if self.scheduler is not None:
+            out["scheduler"] = self.scheduler.state_dict()
+        if self.clip_grad_norm is not None:
+            out["clip_grad_norm"] = self.clip_grad_norm.state_dict()
+        if self.ema is not None:
+            out["ema"] = self.ema.state_dict()
+        return out
+
+    def load_state_dict(self, state):
+        self.last_iter, self.lr = state["last_iter"], state["lr"]
+        g = {"iteration": state.get("graph_iteration", state["last_iter"] + 1), "optimizer": state["optimizer"]}
+        if self.iteration_graph is not None:
+            self.iteration_graph.load_state_dict(g)       # in place, into the tensors the captured graph updates
+        else:
+            self._pending_state = g
+        if self.scheduler is not None and "scheduler" in state:
+            self.scheduler.load_state_dict(state["scheduler"])
+        if self.clip_grad_norm is not None and "clip_grad_norm" in state:
+            self.clip_grad_norm.load_state_dict(state["clip_grad_norm"])
+        if self.ema is not None and "ema" in state:
+            self.ema.load_state_dict(state["ema"])
+        if hasattr(self.train_step, "reset_scales"):
+            self.train_step.reset_scales()
+            if self.iteration_graph is not None:
+                self.iteration_graph._replays = 1 << 30    # frozen constants of the old weights: re-capture at the next check

@@ -290,11 +290,50 @@ class TrainStep:
         self._steps = 0
         self._capturing = False     # set by GraphedIteration while a hipGraph records the step: no host syncs then
         self._calib_norm = None     # global gradient norm at calibration time (observe_grad_norm)
+        # Saturation monitor of the split backend (ds_split_hi / _lo SATURATE at 65504 -- no inf / NaN ever shows that a
+        # gradient left the calibrated window): every step folds max |scaled dY| over all GEMM inputs into this device
+        # scalar (ds_amax, the calibration's own probe; captured into the graph like any other launch), and
+        # check_loss_scale() reads it on the host every `monitor_interval` steps -- whether or not clipping is configured.
+        self.monitor_interval = 16
+        self._amax_live = None
+        self._since_check = 0
+        # weight swaps outside this class (checkpoint / EMA loads: solver._invalidate) must drop the cached pre-scales
+        import weakref
+        diffusion_transformer.__dict__.setdefault("_scale_clients", []).append(weakref.ref(self))
 
     def _side_stream(self, dev):
         if self._side is None:
             self._side = torch.cuda.Stream(dev)
         return self._side
+
+    def reset_scales(self):
+        """Forget the per-matrix weight pre-scales 2^s and the loss scale: the next step re-derives both (one calibration
+        backward).  Called after the weights were replaced behind this object's back (solver._invalidate)."""
+        if hasattr(self.gemm, "wexp"):
+            self.gemm.wexp.clear()
+        if self.precision == "f16x2":
+            self.loss_scale_exp = None
+        self._calib_norm = None
+        if self._amax_live is not None:
+            self._amax_live.zero_()
+
+    def check_loss_scale(self, force=False):
+        """Host side of the saturation monitor: every `monitor_interval` calls (or when forced) read max |scaled dY| since
+        the last check (one sync) and drop the calibration when it has left [2^6, 2^15) -- fp16 saturates at 2^16, and below
+        2^6 the smallest interesting gradients fall under the split's absolute resolution.  Returns True when the next step
+        must re-calibrate (a captured iteration must then be re-captured)."""
+        if self.precision != "f16x2" or self._amax_live is None:
+            return False
+        self._since_check += 1
+        if not force and self._since_check < self.monitor_interval:
+            return False
+        self._since_check = 0
+        m = float(self._amax_live.item())
+        self._amax_live.zero_()
+        if math.isfinite(m) and m > 0.0 and 2.0 ** 6 <= m < 2.0 ** 15:
+            return False
+        self.loss_scale_exp, self._calib_norm = None, None
+        return True
 
     def observe_grad_norm(self, norm):
         """Guard of the calibrated loss scale ("f16x2" backend): the calibration leaves 8x of headroom below fp16's range
@@ -376,7 +415,12 @@ class TrainStep:
         inv = 1.0 / scale
         fused = self.attention == "fused"
 
-        def seen(dy):                                   # calibration: every gradient that is about to enter a GEMM
+        if amax is None and self.precision == "f16x2":  # the saturation monitor (check_loss_scale)
+            if self._amax_live is None or self._amax_live.device != dev:
+                self._amax_live = torch.zeros(1, device=dev)
+            amax = self._amax_live
+
+        def seen(dy):                                   # every gradient that is about to enter a GEMM: calibration / monitor
             if amax is not None:
                 L_.check(L_.lib().ds_amax(L_.ptr(dy), dy.numel(), L_.ptr(amax), L_.stream()))
             return dy
@@ -664,12 +708,28 @@ class GraphedIteration:
 
     def recapture(self):
         """New calibration of the loss scale / weight pre-scales on the current static batch, then a new graph."""
-        self.step.loss_scale_exp = None
-        if hasattr(self.step.gemm, "wexp"):
-            self.step.gemm.wexp.clear()
+        self.step.reset_scales()
         keep_state = {k: (m.clone(), v.clone()) for k, (m, v) in self.opt_state.items()}
         self._capture()
         for k, (m, v) in keep_state.items():
+            self.opt_state[k][0].copy_(m)
+            self.opt_state[k][1].copy_(v)
+        self._replays = 0
+
+    def state_dict(self):
+        """What a resumed run needs of the captured iteration: the AdamW moments (they live in the graph's static tensors)
+        and the bias-correction counter."""
+        return {"iteration": self.iteration, "optimizer": {k: (m.clone(), v.clone()) for k, (m, v) in self.opt_state.items()}}
+
+    @torch.no_grad()
+    def load_state_dict(self, state):
+        """In place into the tensors the graph updates (no re-capture needed)."""
+        self.iteration = int(state["iteration"])
+        missing = [k for k in self.opt_state if k not in state["optimizer"]]
+        extra = [k for k in state["optimizer"] if k not in self.opt_state]
+        if missing or extra:
+            raise RuntimeError("GraphedIteration.load_state_dict: missing %s, unexpected %s" % (missing, extra))
+        for k, (m, v) in state["optimizer"].items():
             self.opt_state[k][0].copy_(m)
             self.opt_state[k][1].copy_(v)
 
@@ -684,12 +744,18 @@ class GraphedIteration:
             self.hyper[3:4].fill_(1.0)
         self.graph.replay()
         self.step._steps += 1
+        self._replays = getattr(self, "_replays", 0) + 1
         self.step.tr.invalidate()          # the replay updated the weights: cached inference packs are stale
         return {"loss": self.loss, "grad_norm": self.grad_norm, "lr": lr}
 
     def check_loss_scale(self):
-        """Host-side guard (one sync): re-calibrate + re-capture when the gradient norm has left the calibrated window."""
-        if self.step.observe_grad_norm(float(self.grad_norm)):
+        """Host-side guards of the frozen constants of a captured iteration.  (1) The weight pre-scales 2^s and the loss
+        scale are those of capture time -- the eager step refreshes the pre-scales every `rescale_interval` steps, a
+        replay cannot: re-capture after that many replays (one calibration backward + one capture).  (2) The saturation
+        monitor (max |scaled dY|, TrainStep.check_loss_scale) is read every `monitor_interval` replays -- one host sync
+        then, none in between -- and re-captures when the gradients have left the calibrated window."""
+        st = self.step
+        if getattr(self, "_replays", 0) >= max(1, st.rescale_interval) or st.check_loss_scale():
             self.recapture()
             return True
         return False

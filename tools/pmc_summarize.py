@@ -43,7 +43,10 @@ with open(out_csv, "w", newline="") as f:
     w.writerows(rows)
 table = {r["kernel"]: r for r in rows}
 # bench.py reports roofline.traffic from this file only while the kernel sources are the ones that were measured
-table["_meta"] = {"source_sha16": source_fingerprint(), "workload": "tools/pmc_step.py: two B=64 denoiser forwards, default precision"}
+table["_meta"] = {"source_sha16": source_fingerprint(),
+                  "workload": "tools/pmc_step.py: two B=64 denoiser sampling steps (ds_denoiser_step_rng, padded-row mode), "
+                              "default precision",
+                  "gemm_instantiations": sorted(k for k in table if "ds_gemm" in k)}
 json.dump(table, open(out_json, "w"), indent=1)
 for r in rows[:8]:
     print(r)
