@@ -359,14 +359,15 @@ def main():
                 t = torch.full((B,), max(T - 2 - i, 0), device=dev, dtype=torch.long)
                 x = dt.p_sample_tokens(x, kv, t, u, initial=False)
             L.ds_profile_enable(0)
-            ms, fl, n = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
-            _lib.check(L.ds_profile_collect(ms, fl, n))
+            ms, fl, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+            _lib.check(L.ds_profile_collect_n(ms, fl, n, 5))
             fmt, passes, mfma_peak, what = KIND[precision]
-            names = [fmt % bb for bb in ((128, 128), (128, 64), (64, 64))] + ["(unused)"]
+            names = [fmt % bb for bb in ((128, 128), (128, 64), (64, 64))] + ["(unused)", "(unused)"]
             if precision == "f16x2":   # packed-operand launches of the 128x128 config go through the balanced kernel
                 names[0] = "ds_gemm_f16x2_hybrid_kernel (128x128 tiles + 64x64 tail tiles)"
-                names[3] = "ds_gemm_f16x2_ps_kernel (per-sample 288x256 tiles, 8-phase ping-pong main loop)"
-            dom = max(range(4), key=lambda c: ms[c])   # the kernel symbol with the largest total time
+                names[3] = "ds_gemm_f16x2_ps_kernel (per-sample 272x256 tiles, 8-phase ping-pong main loop)"
+                names[4] = "ds_gemm_f16x2_ph_kernel (half-sample 144|128x256 tiles, 3 stages, 2 phases per k-tile)"
+            dom = max(range(5), key=lambda c: ms[c])   # the kernel symbol with the largest total time
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             peak = mfma_peak / passes                  # ceiling in algorithmic (2MNK) flops of this formulation
             # the committed PMC passes ran the default f16x2 step at B=64; other legs / sizes have no measurement
@@ -386,7 +387,7 @@ def main():
                     "all_gemm_tiles": {names[c]: {"launches": int(n[c]),
                                                   "avg_launch_us": round(ms[c] * 1e3 / max(1, n[c]), 2),
                                                   "tflops": round(fl[c] / max(ms[c], 1e-9) / 1e9, 2)}
-                                       for c in range(4) if n[c]},
+                                       for c in range(5) if n[c]},
                     "all_gemm_tflops": round(sum(fl) / (sum(ms) * 1e-3) / 1e12, 2)}
         roof = leg(args.precision)
         if args.precision != "fp32":                   # the exact-fp32 MFMA kernel on the same shapes, for reference

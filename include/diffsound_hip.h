@@ -347,6 +347,9 @@ int ds_profile_enable(int on);
 /* arrays of 4, indexed by GEMM program (0: 128x128, 1: 128x64, 2: 64x64 tiles; 3: the per-sample 288x256 ping-pong
    program of the f16x2 mode) */
 int ds_profile_collect(double* ms, double* flops, int64_t* launches);
+/* the same for the first n <= 5 programs: 4 = the per-sample program on HALF tiles (144 | 128 x 256: the grids full tiles
+   cannot fill, e.g. batch 32); ds_profile_collect folds it into entry 3 */
+int ds_profile_collect_n(double* ms, double* flops, int64_t* launches, int n);
 
 /* ---- SpecVQGAN decoder / MelGAN helpers ------------------------------------------------------- */
 /* ColumnMajor(reverse) + get_codebook_entry (permuter.py:31-55, quantize.py:88-103) -> [B][H][W][C] */

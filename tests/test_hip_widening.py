@@ -149,12 +149,25 @@ def test_f16x2_per_sample_program_attention_store_bit_identical(B):
         assert img is None or torch.equal(img, img_ref)
 
 
-@pytest.mark.parametrize("B,N,K", [(5, 1024, 1024), (3, 1024, 4096), (2, 4096, 1024), (7, 256, 128)])
-def test_f16x2_per_sample_program_272_row_samples(B, N, K):
+HALF = 10          # ds_gemm_f16x2_force_tile(10): the half-tile program (a 272-row sample = a 144-row + a 128-row tile)
+
+
+def _exact_rows(M, Lp, prog):
+    """Rows whose bits equal the 4-wave programs': all but the 16-row block on the 16x16x32 MFMA (rows 256..271 of a
+    sample for full tiles, rows 128..143 for half tiles)."""
+    r = torch.arange(M, device="cuda") % Lp
+    return r < 256 if prog == PS else (r < 128) | (r >= 144)
+
+
+@pytest.mark.parametrize("prog", [PS, HALF])
+@pytest.mark.parametrize("B,N,K", [(5, 1024, 1024), (3, 1024, 4096), (2, 4096, 1024), (7, 256, 128), (4, 512, 64)])
+def test_f16x2_per_sample_program_272_row_samples(B, N, K, prog):
     """Samples of 272 rows (17 packed row groups: the denoiser's padded-row mode): the tile's ninth block row is the 16
     rows 256..271 on v_mfma_f32_16x16x32_f16.  Rows 0..255 of every sample keep the bits of the 4-wave programs; rows
     256..271 sum the same products in another order (one 32-k MFMA instead of two 16-k ones) and are compared with
-    float64.  Row-major + bias + residual in place, and packed split output with GELU2."""
+    float64.  Row-major + bias + residual in place, and packed split output with GELU2.  prog = HALF: the same through the
+    half-tile program (three LDS stages, two phases per k-tile; k-tile counts 2, 4, 32 and 128 cover every remainder of its
+    3-k-tile loop): there the 16-row block is rows 128..143 of a sample."""
     from test_hip_split_gemm import relerr, rnd, torch_split
     from text_to_sound_synthesis_amd import _lib as L
     Lp = 272
@@ -169,9 +182,9 @@ def test_f16x2_per_sample_program_272_row_samples(B, N, K):
     refg = torch.empty(M, N, device="cuda")
     L.gemm(A, W2, refg, M, N, K, bias=b, act=L.ACT_GELU2, split2=sc)
     exact = (A.double() @ W.double().t() + b.double())
-    low = (torch.arange(M, device="cuda") % Lp) < 256            # rows computed by the 32x32x16 blocks
+    low = _exact_rows(M, Lp, prog)                               # rows computed by the 32x32x16 blocks
     try:
-        L.lib().ds_gemm_f16x2_force_tile(PS)
+        L.lib().ds_gemm_f16x2_force_tile(prog)
         out = R.clone()
         L.gemm(A2p, W2p, out, M, N, K, bias=b, R=out, split2=sc, a_plane=M * K, rows_per_sample=Lp)
         assert torch.equal(out[low], ref[low])
@@ -192,8 +205,9 @@ def test_f16x2_per_sample_program_272_row_samples(B, N, K):
         L.lib().ds_gemm_f16x2_force_tile(-1)
 
 
+@pytest.mark.parametrize("prog", [PS, HALF])
 @pytest.mark.parametrize("B", [1, 4])
-def test_f16x2_per_sample_program_272_row_attention_store(B):
+def test_f16x2_per_sample_program_272_row_attention_store(B, prog):
     """The attention-ready stores for 272-row samples: Q planes [B][heads][272][64], K / V^T images with 272 keys (the
     denoiser masks keys 265.. in the attention kernel).  Positions 0..255 bit-identical to the 4-wave programs, 256..271
     compared as values."""
@@ -216,11 +230,13 @@ def test_f16x2_per_sample_program_272_row_attention_store(B):
         L.lib().ds_gemm_f16x2_force_tile(2 if B == 1 else 1)
         try:
             q_ref, img_ref = run()
-            L.lib().ds_gemm_f16x2_force_tile(PS)
+            L.lib().ds_gemm_f16x2_force_tile(prog)
             qh, img = run()
         finally:
             L.lib().ds_gemm_f16x2_force_tile(-1)
-        assert torch.equal(qh[:, :, :, :256], q_ref[:, :, :, :256])
+        keep = torch.arange(Lp, device="cuda")
+        keep = keep < 256 if prog == PS else (keep < 128) | (keep >= 144)       # positions outside the 16-row block
+        assert torch.equal(qh[:, :, :, keep], q_ref[:, :, :, keep])
         val = lambda x: x[0].float() + x[1].float()
         assert not torch.isnan(qh.float()).any()
         assert (val(qh) - val(q_ref)).abs().max().item() < 2e-5 * val(q_ref).abs().max().item()
@@ -229,7 +245,7 @@ def test_f16x2_per_sample_program_272_row_attention_store(B):
             vv = lambda im: im[:, :, 2].float() + im[:, :, 3].float()
             assert (kk(img) - kk(img_ref)).abs().max().item() < 2e-5 * kk(img_ref).abs().max().item()
             assert (vv(img) - vv(img_ref)).abs().max().item() < 2e-5 * vv(img_ref).abs().max().item()
-            # key slots 272.. stay zero; most of the image (keys < 256) is bit-identical
+            # key slots 272.. stay zero; most of the image (keys outside the 16-row block) is bit-identical
             same = (img == img_ref).float().mean().item()
             assert same > 0.9, same
 
@@ -301,6 +317,45 @@ def test_padded_row_mode_of_the_sampling_step():
         print("five chained steps: %d of %d clips identical" % (same_clips, B))
         assert same_clips >= B - 2 and int((xa == 256).sum()) == int((xb == 256).sum()) or same_clips >= B - 2
         assert int(xa.max()) <= 256 and int(xa.min()) >= 0
+    finally:
+        tr.row_padding = True
+
+
+def test_batch_32_sampling_step_on_half_tiles():
+    """BASELINE configs[1]'s batch: at B = 32 the N = 1024 GEMMs are 128 full tiles (half the CUs) and the QKV GEMM 1.5
+    rounds, so the dispatch takes the HALF-tile program there (256 / 768 tiles) and full tiles for FC1 (512), all in
+    padded-row mode.  The step must give the tokens of the 265-row step (4-wave programs for the GEMMs full tiles cannot
+    fill) up to exact near-ties, from a mixed state, from the all-[MASK] start and over five chained steps."""
+    from test_hip_split_gemm import build
+    from text_to_sound_synthesis_amd import _lib as L
+    m = build(19, mode="f16x2")
+    dt = m.transformer
+    dt.truncation_r = 0.85
+    tr = dt.transformer
+    B = 32
+    cond = synth.synth_cond_emb(B, key="b32.cond").cuda()
+    kv = tr.condition_kv(cond, dt._schedule_table())
+    u = synth.synth_uniform((B, 257, 265), key="b32.u").cuda()
+    h = tr.packed(dt._schedule_table())["handle"]
+    assert L.lib().ds_denoiser_rows_per_sample(h, B) == 272 and L.lib().ds_denoiser_rows_per_sample(h, 16) == 265
+
+    def step(x, t, initial, pad):
+        tr.row_padding = pad
+        return dt.p_sample_tokens(x, kv, torch.full((B,), t, device="cuda", dtype=torch.long), u, initial).clone()
+    try:
+        x = synth.synth_tokens(B, mask_frac=0.6, key="b32.x").cuda()
+        a, b = step(x, 41, False, True), step(x, 41, False, False)
+        diff = int((a != b).sum())
+        print("B = 32, mixed state, t = 41: %d of %d tokens differ between the half-tile (272-row) and the 265-row step"
+              % (diff, a.numel()))
+        assert diff <= 2
+        x0 = torch.full((B, 265), 256, dtype=torch.long, device="cuda")
+        xa = xb = x0
+        for i, t in enumerate((99, 98, 97, 96, 95)):
+            xa, xb = step(xa, t, i == 0, True), step(xb, t, i == 0, False)
+        same_clips = int((xa == xb).all(dim=1).sum())
+        print("B = 32, five chained steps: %d of %d clips identical" % (same_clips, B))
+        assert same_clips >= B - 2 and int(xa.max()) <= 256 and int(xa.min()) >= 0
     finally:
         tr.row_padding = True
 

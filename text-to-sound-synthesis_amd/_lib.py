@@ -117,6 +117,7 @@ _PROTOS = {
                                          C.c_int, _vp, _vp]),
     "ds_profile_enable": (C.c_int, [C.c_int]),
     "ds_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "ds_profile_collect_n": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64), C.c_int]),
     "ds_codebook_gather": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_groupnorm_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "ds_softmax_rows": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f, _vp]),

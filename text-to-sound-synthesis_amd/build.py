@@ -26,7 +26,7 @@ def _code_only(text):
 
 
 # what the dominant kernel of the sampling path (ds_gemm_f16x2_ps_kernel, gemm_f16x2_ps.hip) is compiled from
-DOMINANT_KERNEL_SOURCES = ("gemm_f16x2_ps.hip", "common.h")
+DOMINANT_KERNEL_SOURCES = ("gemm_f16x2_ps.hip", "gemm_f16x2_ps_epilogue.inc", "common.h")
 
 
 def source_fingerprint(files=DOMINANT_KERNEL_SOURCES):
@@ -73,7 +73,8 @@ def _check_scratch(src, remarks):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "diffsound_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_f16x2_ps_epilogue.inc"),
+               os.path.join(ROOT, "include", "diffsound_hip.h")]
     hipcc = _hipcc()
 
     def compile_one(src):

@@ -226,21 +226,25 @@ extern "C" int ds_profile_enable(int on) {
     return 0;
 }
 // Waits for the recorded launches; per GEMM program c (0: 128x128, 1: 128x64, 2: 64x64 tiles, 3: the per-sample
-// ping-pong program -- each is its own kernel symbol) returns summed duration ms[c], algorithmic flops[c] (2MNK) and
-// launches[c].
-extern "C" int ds_profile_collect(double* ms, double* flops, int64_t* launches) {
-    DS_CHECK_ARG(ms && flops && launches, "null pointer");
-    for (int c = 0; c < 4; ++c) { ms[c] = 0.0; flops[c] = 0.0; launches[c] = 0; }
+// ping-pong program on full tiles, 4: on half tiles -- each is its own kernel symbol) returns summed duration ms[c],
+// algorithmic flops[c] (2MNK) and launches[c] for the first n <= 5 programs; the four-program form folds 4 into 3.
+extern "C" int ds_profile_collect_n(double* ms, double* flops, int64_t* launches, int n) {
+    DS_CHECK_ARG(ms && flops && launches && n >= 4 && n <= 5, "bad arguments");
+    for (int c = 0; c < n; ++c) { ms[c] = 0.0; flops[c] = 0.0; launches[c] = 0; }
     for (auto& r : g_recs) {
+        const int c = r.tile < n ? r.tile : n - 1;
         float e = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&e, r.a, r.b) == hipSuccess) ms[r.tile] += e;
-        flops[r.tile] += r.flops;
-        launches[r.tile] += 1;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&e, r.a, r.b) == hipSuccess) ms[c] += e;
+        flops[c] += r.flops;
+        launches[c] += 1;
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     g_recs.clear();
     return 0;
+}
+extern "C" int ds_profile_collect(double* ms, double* flops, int64_t* launches) {
+    return ds_profile_collect_n(ms, flops, launches, 4);
 }
 
 static int dense(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int ldc,

@@ -516,17 +516,20 @@ static int launch_h(const GemmParams& p, hipStream_t s) {
 
 extern int g_last_tile;
 extern "C" void ds_gemm_f16x2_force_tile(int t) { g_force_tile_h = t; }
-bool ds_gemm_f16x2_ps_grid_pays(long tiles);                                  // gemm_f16x2_ps.hip
-// Whether ds_launch_gemm_f16x2 would run the per-sample program for a packed-operand GEMM over B samples and N columns
-// (every other precondition met): the forced tile decides first, then the grid rule.  The denoiser driver sizes its
-// activation rows with this (padded-row mode), so it cannot drift from the dispatch below.
+int ds_gemm_f16x2_ps_choice(long B, long N, bool half_ok);                   // gemm_f16x2_ps.hip: the grid rule
+// Whether ds_launch_gemm_f16x2 would run a per-sample program (full or half tiles) for a packed-operand GEMM over B samples
+// of 272 rows and N columns (every other precondition met): the forced tile decides first, then the grid rule.  The
+// denoiser driver sizes its activation rows with this (padded-row mode), so it cannot drift from the dispatch below.
 bool ds_gemm_f16x2_ps_taken(int B, int N) {
-    if (g_force_tile_h == 9) return true;
+    if (g_force_tile_h == 9 || g_force_tile_h == 10) return true;
     if (g_force_tile_h >= 0) return false;
-    return ds_gemm_f16x2_ps_grid_pays((long)B * (N / 256));
+    return ds_gemm_f16x2_ps_choice(B, N, true) != 0;
 }
 bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid);   // gemm_f16x2_ps.hip
+bool ds_gemm_f16x2_ph_applies(const GemmParams& p);
+int ds_gemm_f16x2_ps_pick(const GemmParams& p);
 int ds_launch_gemm_f16x2_ps(const GemmParams& p, hipStream_t s);
+int ds_launch_gemm_f16x2_ph(const GemmParams& p, hipStream_t s);
 
 // resident 128x128 workgroups on the chip (256 CUs x 2); a test hook shrinks it so small shapes take the hybrid path
 static int g_balance_slots = 512;
@@ -604,10 +607,19 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     // Full-batch denoiser GEMMs (packed operands, one sample = 265 rows, N in 256-column tiles, a grid of whole
     // rounds of the 256 CUs): the per-sample ping-pong program of gemm_f16x2_ps.hip.  force_tile(9) takes it for
     // every shape it can compute (tests: small batches), force_tile(0 / 1 / 2) never.
-    if ((g_force_tile_h < 0 && ds_gemm_f16x2_ps_applies(p, true)) ||
-        (g_force_tile_h == 9 && ds_gemm_f16x2_ps_applies(p, false))) {
-        g_last_tile = 3;
-        return ds_launch_gemm_f16x2_ps(p, stream);
+    // force_tile(10): the half-tile program (272-row samples).
+    {
+        const int pick = g_force_tile_h < 0 ? ds_gemm_f16x2_ps_pick(p)
+                       : g_force_tile_h == 9 ? (ds_gemm_f16x2_ps_applies(p, false) ? 1 : 0)
+                       : g_force_tile_h == 10 ? (ds_gemm_f16x2_ph_applies(p) ? 2 : 0) : 0;
+        if (pick == 1) {
+            g_last_tile = 3;
+            return ds_launch_gemm_f16x2_ps(p, stream);
+        }
+        if (pick == 2) {
+            g_last_tile = 4;
+            return ds_launch_gemm_f16x2_ph(p, stream);
+        }
     }
     // Tile choice from the measured sweep (profiles/r01_gemm_tile_sweep_f16x2.txt, B=64): 128x128 reaches
     // ~235-250 TF-eq once the grid has >= 3 rounds of 512 resident blocks; below that 128x64 (3 blocks/CU,

@@ -330,283 +330,11 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     const unsigned long long ps_c1 = __builtin_amdgcn_s_memtime();
 #endif
 
-    // ---- epilogue -------------------------------------------------------------------------------------------------
-    // One workgroup per CU: nothing else runs on the CU while a tile is written out, so the epilogue is on the critical
-    // path.  Round-3 measurements (tools/probe/probe_ceiling.hip, profiles/r03b_*): at 32 CUs the epilogue takes the
-    // same ~38k cycles per tile as at 256 -- it is bound inside the CU, not by HBM -- and for the fp16-plane families 70 to
-    // 100 % of it was the STAGING (accumulators -> LDS), not the global stores: the first version staged in three row slabs
-    // of which only one wave row (4 of 8 waves, one per SIMD) produced values, re-loaded the bias in every slab behind a
-    // full memory latency, and wrote V^T with 64 different cache lines per store instruction.  Hence this structure:
-    //   * five STEPS: step s = 0..3 is block row s of BOTH wave rows (tile rows s 32 + [0, 32) and 128 + s 32 + [0, 32):
-    //     every wave stages 32 values per lane), step 4 the ninth block row;
-    //   * two LDS buffers: step s stages into buffer s & 1, ONE barrier, then all 512 threads read the step back in
-    //     16-byte pieces and store it -- the global stores (and residual loads) of step s run under the staging of step
-    //     s + 1 (a buffer is re-written two steps later, behind the barrier of the step in between);
-    //   * the bias values of a lane's columns are loaded once, before step 0;
-    //   * V^T tiles are staged TRANSPOSED ([column][32 keys + 4]: four consecutive keys of a lane's column are one
-    //     ds_write_b128), so a thread reads the 8 keys of its 16-byte store with two ds_read_b128 and consecutive lanes
-    //     write consecutive 16-byte pieces of one d (64-byte runs instead of 64 scattered pieces per instruction).
-    // GELU2 by v_exp / v_rcp (ds_gelu2_fast, shared with gemm_f16x2.hip so both programs stay bit-identical), hi | lo
-    // staged as ONE 32-bit value, no integer divisions.  The lane / wave indices are re-derived from an opaque copy of the
-    // thread id so that none of them stays live across the main loop (which runs at the 256-register cap).
-    int tid_e = tid;
-    asm volatile("" : "+v"(tid_e));
-    const int l31e = tid_e & 31, hhe = (tid_e >> 5) & 1, wre = tid_e >> 8, wce = (tid_e >> 6) & 3;
-    // valid tile rows [off, vhi): the sample's rows (and not past the matrix)
-    const int off = row_lo - m0;
-    int vhi = off + L;
-    if (vhi > p.M - m0) vhi = p.M - m0;
-    const float osc = p.out_scale;
-    // this lane's columns: the two 32-column blocks of the wave tile, and its column(s) of the ninth block row
-    //   NB16: lane (q = lane >> 4, n = lane & 15) of a 16 x 16 tile holds rows 4 sigma(q) + r, column pi(n) (see PS_SIG)
-    const int qe = (tid_e >> 4) & 3, ne = tid_e & 15;
-    const int cl0 = (wce * 2 + 0) * 32 + l31e, cl1 = (wce * 2 + 1) * 32 + l31e;
-    const int cl9 = (wce * 2 + wre) * 32 + (NB16 ? PS_SIG(ne >> 2) * 4 + (ne & 3) : l31e);   // NB16: + 16 for the second tile
-    float bv0 = 0.f, bv1 = 0.f, bv9a = 0.f, bv9b = 0.f;
-    if (p.bias) {
-        bv0 = p.bias[n0 + cl0]; bv1 = p.bias[n0 + cl1]; bv9a = p.bias[n0 + cl9];
-        if (NB16) bv9b = p.bias[n0 + cl9 + 16];
-    }
-    constexpr int EBUF = 64 * BN;                 // 32-bit words per staging buffer: 64 rows x 256 columns (64 KB)
-    // the tile row of step-local row `rs` (0..63: two groups of 32; step 4: 0..15 / 0..31)
-#define PS_TROW(S, rs_) ((S) < 4 ? ((rs_) >> 5) * 128 + (S) * 32 + ((rs_) & 31) : 256 + (rs_))
-    // every value this wave stages in step S: STORE(step-local row, tile column, value)
-#define PS_STEP_VALUES(S, GELU, STORE)                                                               \
-    do {                                                                                             \
-        if ((S) < 4) {                                                                               \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
-                const int cl = j ? cl1 : cl0;                                                        \
-                const float bv = j ? bv1 : bv0;                                                      \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
-                    float v = acc[(S) < 4 ? (S) : 0][j][r] * osc + bv;                               \
-                    if (GELU) v = ds_gelu2_fast(v);                                                  \
-                    STORE(wre * 32 + (r & 3) + 8 * (r >> 2) + 4 * hhe, cl, v);                       \
-                }                                                                                    \
-            }                                                                                        \
-        } else if (NB16) {                                                                           \
-            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                         \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                      \
-                    float v = acc9[tt][r] * osc + (tt ? bv9b : bv9a);                                \
-                    if (GELU) v = ds_gelu2_fast(v);                                                  \
-                    STORE(4 * PS_SIG(qe) + r, cl9 + tt * 16, v);                                     \
-                }                                                                                    \
-        } else {                                                                                     \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
-                float v = acc8[r] * osc + bv9a;                                                      \
-                if (GELU) v = ds_gelu2_fast(v);                                                      \
-                STORE((r & 3) + 8 * (r >> 2) + 4 * hhe, cl9, v);                                     \
-            }                                                                                        \
-        }                                                                                            \
-    } while (0)
-    const bool gelu = p.act == DS_ACT_GELU2;
-    __syncthreads();                               // every wave is out of the main loop: the operand stages are free
-
-    if constexpr (EPI == PS_EPI_ROW) {
-        // row-major fp32 (+ residual): 16-byte residual loads and stores, one row of the tile per wave and iteration
-#define PS_ST_F32(rs_, cl_, v_) Tf[(rs_) * BN + (cl_)] = (v_)
-#define PS_ROW_STEP(S)                                                                               \
-    do {                                                                                             \
-        constexpr int rows_ = (S) < 4 ? 64 : (NB16 ? 16 : 32);                                       \
-        constexpr int iters_ = rows_ / 8;                       /* 8, or 2 / 4 */                    \
-        float* Tf = (float*)smem_raw + ((S) & 1) * EBUF;                                             \
-        const int cc = tid_e & 63, col = n0 + cc * 4;                                                \
-        f32x4 res[iters_];                  /* requested before the staging: their latency runs under it */ \
-        _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                      \
-            const int trow = PS_TROW(S, (tid_e >> 6) + 8 * it);                                      \
-            res[it] = f32x4{0.f, 0.f, 0.f, 0.f};                                                     \
-            if (!(PS_ABLATE & 32) && p.R && trow >= off && trow < vhi) res[it] = *(const f32x4*)(p.R + (size_t)(m0 + trow) * p.ldr + col); \
-        }                                                                                            \
-        if (!(PS_ABLATE & 64)) {                                                                     \
-            if (gelu) PS_STEP_VALUES(S, true, PS_ST_F32); else PS_STEP_VALUES(S, false, PS_ST_F32);  \
-            __syncthreads();                                                                         \
-        }                                                                                            \
-        _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                      \
-            const int rs = (tid_e >> 6) + 8 * it, trow = PS_TROW(S, rs);                             \
-            if (trow >= off && trow < vhi) {                                                         \
-                const f32x4 vv_ = (PS_ABLATE & 64) ? res[it] + osc : *(const f32x4*)(Tf + rs * BN + cc * 4) + res[it]; \
-                if (PS_ABLATE & 32) asm volatile("" :: "v"(vv_));                                    \
-                else *(f32x4*)(p.C + (size_t)(m0 + trow) * p.ldc + col) = vv_;                       \
-            }                                                                                        \
-        }                                                                                            \
-    } while (0)
-        PS_ROW_STEP(0); PS_ROW_STEP(1); PS_STAMP(3); PS_ROW_STEP(2); PS_ROW_STEP(3); PS_STAMP(4); PS_ROW_STEP(4); PS_STAMP(5);
-    } else {
-        // fp16 split outputs: staged as 32-bit (hi | lo << 16); a thread reads 8 values = 32 bytes and writes one 16-byte
-        // store per plane
-#define PS_PACK(v_, dst_)                                                                            \
-    do {                                                                                             \
-        const _Float16 hi_ = ds_split_hi(v_);                                                        \
-        const _Float16 lo_ = ds_split_lo(v_, hi_);                                                   \
-        dst_ = (unsigned)__builtin_bit_cast(unsigned short, hi_) |                                   \
-               ((unsigned)__builtin_bit_cast(unsigned short, lo_) << 16);                            \
-    } while (0)
-#define PS_ST_SPLIT(rs_, cl_, v_) PS_PACK(v_, T[(rs_) * BN + (cl_)])
-        // 8 packed values -> the 8 halves of plane 0 (low halves) and of plane 1 (high halves)
-#define PS_UNZIP(x_, hi_, lo_)                                                                       \
-    do {                                                                                             \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
-            hi_[e] = ((x_)[2 * e] & 0xffffu) | ((x_)[2 * e + 1] << 16);                              \
-            lo_[e] = ((x_)[2 * e] >> 16) | ((x_)[2 * e + 1] & 0xffff0000u);                          \
-        }                                                                                            \
-    } while (0)
-        const int hw = p.attn_heads * 64;
-        const int which = EPI == PS_EPI_ATTN ? n0 / hw : 0;            // block-uniform: Q, K or V columns
-        const int b = tm_;                                               // the sample of this tile
-        // row-major step: packed planes (EPI_SPLIT), or the Q planes / K images of the attention-ready store
-#define PS_SPLIT_STEP(S)                                                                             \
-    do {                                                                                             \
-        constexpr int rows_ = (S) < 4 ? 64 : (NB16 ? 16 : 32);                                       \
-        constexpr int iters_ = rows_ / 16;                      /* 4, or 1 / 2 */                    \
-        unsigned* T = (unsigned*)smem_raw + ((S) & 1) * EBUF;                                        \
-        if (!(PS_ABLATE & 64)) {                                                                     \
-            if (gelu) PS_STEP_VALUES(S, true, PS_ST_SPLIT); else PS_STEP_VALUES(S, false, PS_ST_SPLIT); \
-            __syncthreads();                                                                         \
-        }                                                                                            \
-        const int cc = tid_e & 31, col = n0 + cc * 8;                                                \
-        _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                                      \
-            const int rs = (tid_e >> 5) + 16 * it, trow = PS_TROW(S, rs);                            \
-            if (trow >= off && trow < vhi) {                                                         \
-                const int row = m0 + trow;                                                           \
-                unsigned x[8];                                                                       \
-                u32x4 vh, vl;                                                                        \
-                if (PS_ABLATE & 64) {                                                                \
-                    vh = u32x4{(unsigned)row, (unsigned)col, 1u, 2u}; vl = vh + 7u;                  \
-                } else {                                                                             \
-                    *(u32x4*)(x) = *(const u32x4*)(T + rs * BN + cc * 8);                            \
-                    *(u32x4*)(x + 4) = *(const u32x4*)(T + rs * BN + cc * 8 + 4);                    \
-                    PS_UNZIP(x, vh, vl);                                                             \
-                }                                                                                    \
-                _Float16 *d0, *d1;                                                                   \
-                if (EPI == PS_EPI_SPLIT) {                                                           \
-                    d0 = (_Float16*)p.C + ds_packed_off(row, col, p.ldc >> 5);                       \
-                    d1 = d0 + p.c_plane;                                                             \
-                } else {                                                                             \
-                    const int pos = trow - off;                                                      \
-                    const int hc = col - which * hw, head = hc >> 6, d = hc & 63;                    \
-                    const size_t bh = (size_t)b * p.attn_heads + head;                               \
-                    if (which == 0) {                                                                \
-                        d0 = (_Float16*)p.C + (bh * L + pos) * 64 + d;                               \
-                        d1 = d0 + p.attn_qplane;                                                     \
-                    } else {                                                                         \
-                        d0 = (_Float16*)p.attn_kv + (bh * 4) * ((size_t)p.attn_nkey * 64) + ds_attn_k_off(pos, d); \
-                        d1 = d0 + (size_t)p.attn_nkey * 64;                                          \
-                    }                                                                                \
-                }                                                                                    \
-                if (PS_ABLATE & 32) { asm volatile("" :: "v"(vh), "v"(vl), "v"(d0), "v"(d1)); }      \
-                else { *(u32x4*)d0 = vh; *(u32x4*)d1 = vl; }                                         \
-            }                                                                                        \
-        }                                                                                            \
-    } while (0)
-        // V^T step: transposed staging, per group of 32 tile rows T2[group][column][36] (32 keys + 4 words of padding:
-        // the 144-byte column stride spreads the eight lanes of a ds_write_b128 group over all banks).  The values of a
-        // lane come four consecutive rows at a time (registers 4 q .. 4 q + 3 of a 32 x 32 block, 0 .. 3 of a 16 x 16 tile).
-        constexpr int VLD = 36, VGRP = BN * VLD;              // words per column / per group (36 KB)
-#define PS_VT_STAGE(S, GELU)                                                                         \
-    do {                                                                                             \
-        unsigned* T2 = (unsigned*)smem_raw + ((S) & 1) * (2 * VGRP);                                 \
-        if ((S) < 4) {                                                                               \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                            \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                      \
-                    u32x4 w;                                                                         \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                  \
-                        float v = acc[(S) < 4 ? (S) : 0][j][4 * q + e] * osc + (j ? bv1 : bv0);      \
-                        if (GELU) v = ds_gelu2_fast(v);                                              \
-                        PS_PACK(v, w[e]);                                                            \
-                    }                                                                                \
-                    *(u32x4*)(T2 + wre * VGRP + (j ? cl1 : cl0) * VLD + 8 * q + 4 * hhe) = w;        \
-                }                                                                                    \
-        } else if (NB16) {                                                                           \
-            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                       \
-                u32x4 w;                                                                             \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
-                    float v = acc9[tt][e] * osc + (tt ? bv9b : bv9a);                                \
-                    if (GELU) v = ds_gelu2_fast(v);                                                  \
-                    PS_PACK(v, w[e]);                                                                \
-                }                                                                                    \
-                *(u32x4*)(T2 + (cl9 + tt * 16) * VLD + 4 * PS_SIG(qe)) = w;                          \
-            }                                                                                        \
-        } else {                                                                                     \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
-                u32x4 w;                                                                             \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
-                    float v = acc8[4 * q + e] * osc + bv9a;                                          \
-                    if (GELU) v = ds_gelu2_fast(v);                                                  \
-                    PS_PACK(v, w[e]);                                                                \
-                }                                                                                    \
-                *(u32x4*)(T2 + cl9 * VLD + 8 * q + 4 * hhe) = w;                                     \
-            }                                                                                        \
-        }                                                                                            \
-    } while (0)
-        // ... and its stores: per group, the valid tile rows [lo, hi) are keys [lo - off, hi - off); 16-byte units of 8
-        // keys are aligned in the sample's own key index.  A group whose rows are whole units (the padded-row mode: off = 0)
-        // is written 4 units per column with consecutive lanes on consecutive units; otherwise a unit that straddles the
-        // group's edge is written in parts (2-byte stores), one column per thread as the first version did.
-#define PS_VT_STEP(S)                                                                                \
-    do {                                                                                             \
-        constexpr int ngrp_ = (S) < 4 ? 2 : 1;                                                       \
-        constexpr int grows_ = (S) < 4 ? 32 : (NB16 ? 16 : 32);                                      \
-        const unsigned* T2 = (const unsigned*)smem_raw + ((S) & 1) * (2 * VGRP);                     \
-        if (!(PS_ABLATE & 64)) {                                                                     \
-            if (gelu) PS_VT_STAGE(S, true); else PS_VT_STAGE(S, false);                              \
-            __syncthreads();                                                                         \
-        }                                                                                            \
-        const int pln = p.attn_nkey * 64;                                                            \
-        _Pragma("unroll") for (int g = 0; g < ngrp_; ++g) {                                          \
-            const int G0 = (S) < 4 ? g * 128 + (S) * 32 : 256;      /* first tile row of the group */ \
-            const int lo = G0 > off ? G0 : off;                                                      \
-            const int hi = G0 + grows_ < vhi ? G0 + grows_ : vhi;                                    \
-            if (lo >= hi) continue;                                                                  \
-            const unsigned* Tg = T2 + g * VGRP;                                                      \
-            if (lo == G0 && hi == G0 + grows_ && ((G0 - off) & 7) == 0) {                            \
-                constexpr int upc_ = grows_ / 8;                    /* units per column: 4 (2) */    \
-                constexpr int iters_ = BN * upc_ / 512;             /* 2 (1) */                      \
-                _Pragma("unroll") for (int it = 0; it < iters_; ++it) {                              \
-                    const int task = tid_e + 512 * it, cl = task / upc_, u = task % upc_;            \
-                    const int hc = n0 + cl - 2 * hw, head = hc >> 6, d = hc & 63;                    \
-                    _Float16* img = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2) * (size_t)pln; \
-                    unsigned x[8];                                                                   \
-                    *(u32x4*)(x) = *(const u32x4*)(Tg + cl * VLD + 8 * u);                           \
-                    *(u32x4*)(x + 4) = *(const u32x4*)(Tg + cl * VLD + 8 * u + 4);                   \
-                    u32x4 vh, vl;                                                                    \
-                    PS_UNZIP(x, vh, vl);                                                             \
-                    _Float16* dst = img + ds_attn_vt_off(G0 - off + 8 * u, d, p.attn_nkey);          \
-                    if (PS_ABLATE & 32) { asm volatile("" :: "v"(vh), "v"(vl), "v"(dst)); }          \
-                    else { *(u32x4*)dst = vh; *(u32x4*)(dst + pln) = vl; }                           \
-                }                                                                                    \
-            } else {                                                                                 \
-                const int u_first = (lo - off) >> 3, units = ((hi - off + 7) >> 3) - u_first;        \
-                const int cl = tid_e & (BN - 1);                                                     \
-                const int hc = n0 + cl - 2 * hw, head = hc >> 6, d = hc & 63;                        \
-                _Float16* img = (_Float16*)p.attn_kv + (((size_t)b * p.attn_heads + head) * 4 + 2) * (size_t)pln; \
-                for (int u = tid_e >> 8; u < units; u += 2) {                                        \
-                    const int k0 = (u_first + u) * 8;               /* first key of the unit */      \
-                    const int r0 = k0 + off - G0;                   /* its group-local row (may be < 0) */ \
-                    _Float16* dst = img + ds_attn_vt_off(k0, d, p.attn_nkey);                        \
-                    if (r0 >= lo - G0 && r0 + 8 <= hi - G0) {       /* a whole unit inside the group */ \
-                        unsigned x[8];                                                               \
-                        _Pragma("unroll") for (int e = 0; e < 8; ++e) x[e] = Tg[cl * VLD + r0 + e];  \
-                        u32x4 vh, vl;                                                                \
-                        PS_UNZIP(x, vh, vl);                                                         \
-                        *(u32x4*)dst = vh;                                                           \
-                        *(u32x4*)(dst + pln) = vl;                                                   \
-                    } else {                                                                         \
-                        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                \
-                            if (r0 + e >= lo - G0 && r0 + e < hi - G0) {                             \
-                                const unsigned x1 = Tg[cl * VLD + r0 + e];                           \
-                                dst[e] = __builtin_bit_cast(_Float16, (unsigned short)(x1 & 0xffffu)); \
-                                dst[pln + e] = __builtin_bit_cast(_Float16, (unsigned short)(x1 >> 16)); \
-                            }                                                                        \
-                    }                                                                                \
-                }                                                                                    \
-            }                                                                                        \
-        }                                                                                            \
-    } while (0)
-        if (EPI == PS_EPI_ATTN && which == 2) {
-            PS_VT_STEP(0); PS_VT_STEP(1); PS_STAMP(3); PS_VT_STEP(2); PS_VT_STEP(3); PS_STAMP(4); PS_VT_STEP(4); PS_STAMP(5);
-        } else {
-            PS_SPLIT_STEP(0); PS_SPLIT_STEP(1); PS_STAMP(3); PS_SPLIT_STEP(2); PS_SPLIT_STEP(3); PS_STAMP(4); PS_SPLIT_STEP(4); PS_STAMP(5);
-        }
-    }
+    constexpr int WROW = 128, EROW0 = 256;         // tile geometry of the full tile (gemm_f16x2_ps_epilogue.inc)
+    constexpr bool HALF_TILE = false;
+    const bool hasE = true;
+    const int pos0 = 0, tile_rows = L;
+#include "gemm_f16x2_ps_epilogue.inc"
 #ifdef PS_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tile's stores have left the wave's queue
     PS_STAMP(6);
@@ -620,13 +348,225 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
 #endif
 }
 
-// Whether the per-sample program serves this problem, and pays: packed operands, sample-structured rows with
-// 256 < L + 15 <= 288, N in whole 256-column tiles, an even number of k-tiles, 16-byte-aligned row stores, and a grid
-// that fills the 256 CUs in (nearly) whole rounds.
-bool ds_gemm_f16x2_ps_grid_pays(long tiles);
-bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid) {
+// ---- half tiles: the same program for grids that full tiles cannot fill ------------------------------------------------
+// BASELINE configs[1] runs 32 captions: the N = 1024 GEMMs are then 128 full tiles -- half of the CUs idle -- and the QKV
+// GEMM 384 = 1.5 rounds (the round-2 build fell back to the 4-wave programs there: 0.29 of the pipe against 0.44 at batch
+// 64).  A sample of 272 rows (padded-row mode) is cut into a 144-row tile (128 + the 16-row block on the 16x16x32 MFMA) and
+// a 128-row tile: 2 B N / 256 tiles of HALF the accumulators (72 registers) -- whole rounds again at B = 32 (256 / 768).
+// Same arithmetic, same MFMA order per accumulator as the full tile (rows 0..127 and 144..271 of a sample keep the bits of
+// the 4-wave programs, rows 128..143 are the 16-row block).  What changes:
+//   * a wave row is 64 tile rows (two 32-row blocks): ONE A sub-tile, so a k-tile is two phases -- (A, B-sub0) and
+//     (A, B-sub1) + the 16-row block -- of 12 (+3) MFMAs, still alternating between the two wave rows;
+//   * a stage is 144 + 256 rows = 50 KB, so THREE stages fit: the LDS-DMA of a k-tile is issued in two halves, H0 =
+//     A + B-sub0 (4 instructions per wave) in phase 0 and H1 = B-sub1 + the 16 extra A rows (3) in phase 1, two k-tiles
+//     ahead.  Hazards (phase g = 2 tile + p reads half g): RAW  the wait of phase g (after issuing half g + 4) is
+//     vmcnt(11 / 10) = the instructions of halves g + 2 .. g + 4, so half g + 1 has landed a phase before it is read;
+//     WAR  half g + 4 lands on the region of half g - 2, last read two phases earlier;
+//   * the second tile of a sample has no 16-row block: it still issues (and never reads) the seventh DMA of H1 so that
+//     every wave of every tile counts the same instructions, and skips the 16x16 MFMAs;
+//   * more operand traffic per MFMA (the B tile is re-staged for 144 rows instead of 272: x1.46 L2 -> LDS bytes, x1.3
+//     fragment reads) -- which is why full tiles keep every grid they can fill.
+#define PH_AROWS 144
+#define PH_STAGE_BYTES (2 * (PH_AROWS + PS_BN) * PS_HLD * 2)    // 50 KB
+#define PH_LDS_BYTES (3 * PH_STAGE_BYTES > PS_VT_BYTES ? 3 * PH_STAGE_BYTES : PS_VT_BYTES)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ph_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr bool NB16 = true;
+    constexpr int BN = PS_BN, HLD = PS_HLD;
+    constexpr int APL = PH_AROWS * HLD, BPL = BN * HLD, STAGE = 2 * (APL + BPL);   // halves
+    _Float16* smem = (_Float16*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int L = p.rows_per_sample;                // 272
+    const int tiles_n = p.N / BN, nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {   // each XCD works a contiguous run of tiles
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int th_, tn_;
+    {
+        const int tiles_m = 2 * (p.M / L);
+        const int per = PS_GM * tiles_n, grp = bid / per, first = grp * PS_GM;
+        const int gsz = tiles_m - first < PS_GM ? tiles_m - first : PS_GM;
+        const int in = bid - grp * per;
+        th_ = first + in % gsz;
+        tn_ = in / gsz;
+    }
+    const int tm_ = th_ >> 1;                       // the sample
+    const bool hasE = (th_ & 1) == 0;               // first half: rows 0..143 (128 + the 16-row block); second: 144..271
+    const int pos0 = hasE ? 0 : PH_AROWS, tile_rows = hasE ? PH_AROWS : 128;
+    const int row_lo = tm_ * L + pos0;              // a multiple of 16
+    const int m0 = row_lo, n0 = tn_ * BN;
+    const int nk = p.K / 32;
+    const _Float16* Ap = (const _Float16*)p.A;
+    const _Float16* Wp = (const _Float16*)p.W;
+    unsigned long long srcA[2], srcB[2][2], srcE;
+    int offA[2], offB[2][2], offE;
+    const unsigned lane16 = lane * 16;
+    const int rgsA = (p.M + 15) >> 4, rgsB = (p.N + 15) >> 4;
+#define PH_BASE(dst_, ptr_)                                                                          \
+    do {                                                                                             \
+        const unsigned long long a_ = (unsigned long long)(ptr_);                                    \
+        dst_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) | \
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);           \
+    } while (0)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = 2 * wave + k, plane = idx >> 3, r = idx & 7;
+        int rg = (m0 >> 4) + r;                                        // the 8 row groups of the tile's 128 main rows
+        if (rg >= rgsA) rg = rgsA - 1;
+        PH_BASE(srcA[k], Ap + plane * p.a_plane + (size_t)rg * nk * 512);
+        offA[k] = __builtin_amdgcn_readfirstlane((plane * 9 + r) * 1024);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int gip = (r >> 1) * 4 + s * 2 + (r & 1);            // wave column r >> 1, B-sub s, 16-row group r & 1
+            int rb = (n0 >> 4) + gip;
+            if (rb >= rgsB) rb = rgsB - 1;
+            PH_BASE(srcB[s][k], Wp + plane * p.w3_plane + (size_t)rb * nk * 512);
+            offB[s][k] = __builtin_amdgcn_readfirstlane((18 + plane * 16 + gip) * 1024);
+        }
+    }
+    {   // the 16 extra A rows (group 8 of both planes): wave w loads plane w & 1; a tile without them re-reads group 7
+        const int plane = wave & 1;
+        int rg = (m0 >> 4) + (hasE ? 8 : 7);
+        if (rg >= rgsA) rg = rgsA - 1;
+        PH_BASE(srcE, Ap + plane * p.a_plane + (size_t)rg * nk * 512);
+        offE = __builtin_amdgcn_readfirstlane((plane * 9 + 8) * 1024);
+    }
+#define PH_DMA(src_, off_, tile_, st_)                                                               \
+    __builtin_amdgcn_global_load_lds((ds_gptr)((const unsigned char*)((src_) + (unsigned long long)(tile_) * 1024) + lane16), \
+                                     (ds_lptr)(smem_raw + (st_) * (STAGE * 2) + (off_)), 16, 0, 0)
+#define PH_ISSUE(tile_, half_, st_)                                                                  \
+    do {                                                                                             \
+        if ((half_) == 0) {                                                                          \
+            PH_DMA(srcA[0], offA[0], tile_, st_); PH_DMA(srcA[1], offA[1], tile_, st_);              \
+            PH_DMA(srcB[0][0], offB[0][0], tile_, st_); PH_DMA(srcB[0][1], offB[0][1], tile_, st_);  \
+        } else {                                                                                     \
+            PH_DMA(srcB[1][0], offB[1][0], tile_, st_); PH_DMA(srcB[1][1], offB[1][1], tile_, st_);  \
+            PH_DMA(srcE, offE, tile_, st_);                                                          \
+        }                                                                                            \
+    } while (0)
+    const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
+    const int l15 = PS_SIG((lane >> 2) & 3) * 4 + (lane & 3);
+    const int swzq = ((lane >> 4) ^ ((l15 >> 2) & 3)) * 8;
+    f32x16 acc[2][2], acc8;             // acc8: the 32-row ninth block of the full tile (named by the shared epilogue, unused)
+    f32x4 acc9[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) acc9[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc8[r] = 0.f;
+    h8 a0[2][2], a1[2][2];              // [ks][row block]: hi, lo planes
+    h8 b0[2][2], b1[2][2];              // [B-sub][ks]
+    h8 ea0, ea1, eb0[2], eb1[2];        // the 16 extra A rows and the wave's two 16-column B tiles, 16x16x32 operand layout
+#define PH_READ_A(st_)                                                                               \
+    do {                                                                                             \
+        const _Float16* Ac = smem + (st_) * STAGE + (wr * 64 + l31) * HLD;                           \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib) {                                       \
+                a0[ks][ib] = *(const h8*)(Ac + ib * 32 * HLD + swz[ks]);                             \
+                a1[ks][ib] = *(const h8*)(Ac + APL + ib * 32 * HLD + swz[ks]);                       \
+            }                                                                                        \
+    } while (0)
+#define PH_READ_B(st_, s_)                                                                           \
+    do {                                                                                             \
+        const _Float16* Bc = smem + (st_) * STAGE + 2 * APL + (wc * 64 + (s_) * 32 + l31) * HLD;     \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            b0[s_][ks] = *(const h8*)(Bc + swz[ks]);                                                 \
+            b1[s_][ks] = *(const h8*)(Bc + BPL + swz[ks]);                                           \
+        }                                                                                            \
+    } while (0)
+#define PH_READ_EB16(st_)                                                                            \
+    do {                                                                                             \
+        const _Float16* Bc = smem + (st_) * STAGE + 2 * APL + ((2 * wc + wr) * 32 + l15) * HLD;      \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                           \
+            eb0[tt] = *(const h8*)(Bc + tt * 16 * HLD + swzq);                                       \
+            eb1[tt] = *(const h8*)(Bc + BPL + tt * 16 * HLD + swzq);                                 \
+        }                                                                                            \
+    } while (0)
+#define PH_READ_EA16(st_)                                                                            \
+    do {                                                                                             \
+        const _Float16* Ec = smem + (st_) * STAGE + (128 + l15) * HLD;                               \
+        ea0 = *(const h8*)(Ec + swzq);                                                               \
+        ea1 = *(const h8*)(Ec + APL + swzq);                                                         \
+    } while (0)
+    // per accumulator ks 0 {a1 b0, a0 b1, a0 b0}, ks 1 {...}: the order of every f16x2 program
+#define PH_QUAD(sb_)                                                                                 \
+    do {                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                           \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks][ib], b0[sb_][ks], acc[ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b1[sb_][ks], acc[ib][sb_], 0, 0, 0); \
+            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                         \
+                acc[ib][sb_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks][ib], b0[sb_][ks], acc[ib][sb_], 0, 0, 0); \
+        }                                                                                            \
+    } while (0)
+#define PH_EXTRA16()                                                                                 \
+    do {                                                                                             \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                           \
+            acc9[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea1, eb0[tt], acc9[tt], 0, 0, 0);      \
+            acc9[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea0, eb1[tt], acc9[tt], 0, 0, 0);      \
+            acc9[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea0, eb0[tt], acc9[tt], 0, 0, 0);      \
+        }                                                                                            \
+    } while (0)
+    // one phase of k-tile `tt` (run time) in stage ST = tt % 3 (compile time): P = 0: (A, B-sub0), P = 1: (A, B-sub1) + block
+#define PH_PHASE(P, ST)                                                                              \
+    do {                                                                                             \
+        if (P == 0) { PH_READ_A(ST); PH_READ_B(ST, 0); if (hasE && wr == 0) PH_READ_EB16(ST); }      \
+        else { PH_READ_B(ST, 1); if (hasE) { PH_READ_EA16(ST); if (wr == 1) PH_READ_EB16(ST); } }    \
+        PS_FENCE();                                                                                  \
+        if (tt + 2 < nk) {                                                                           \
+            PH_ISSUE(tt + 2, P, ((ST) + 2) % 3);                                                     \
+            if (P == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   /* halves g + 2 .. g + 4: 4 + 3 + 4 */ \
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          /*                        3 + 4 + 3 */ \
+        } else {                                                                                     \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* tail: nothing younger to count */  \
+        }                                                                                            \
+        PS_BAR();                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        if (P == 0) PH_QUAD(0);                                                                      \
+        else { PH_QUAD(1); if (hasE) PH_EXTRA16(); }                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+        PS_BAR();                                                                                    \
+    } while (0)
+    // prologue: k-tiles 0 and 1 (halves 0 .. 3 = 14 instructions per wave); half 0 has landed once only halves 1 .. 3
+    // (3 + 4 + 3) are outstanding
+    PH_ISSUE(0, 0, 0); PH_ISSUE(0, 1, 0);
+    if (nk > 1) { PH_ISSUE(1, 0, 1); PH_ISSUE(1, 1, 1); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PS_BAR();
+    if (wr == 1) PS_BAR();          // the second wave row runs one barrier behind the first
+    for (int t = 0; t < nk; t += 3) {
+        { const int tt = t; PH_PHASE(0, 0); PH_PHASE(1, 0); }
+        if (t + 1 < nk) { const int tt = t + 1; PH_PHASE(0, 1); PH_PHASE(1, 1); }
+        if (t + 2 < nk) { const int tt = t + 2; PH_PHASE(0, 2); PH_PHASE(1, 2); }
+    }
+    if (wr == 0) PS_BAR();          // ... and the first row waits for it at the end
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PS_STAMP
+#define PS_STAMP(i_) do { } while (0)
+    constexpr int WROW = 64, EROW0 = 128;          // tile geometry of a half tile (gemm_f16x2_ps_epilogue.inc)
+    constexpr bool HALF_TILE = true;
+#include "gemm_f16x2_ps_epilogue.inc"
+#undef PS_STAMP
+}
+
+// Whether the per-sample program serves this problem: packed operands, sample-structured rows with 256 < L + 15 <= 288, N
+// in whole 256-column tiles, an even number of k-tiles, 16-byte-aligned row stores.  half: the half-tile program (272-row
+// samples only).  Whether it PAYS is ds_gemm_f16x2_ps_choice below.
+static bool ps_serves(const GemmParams& p, bool half) {
     const int L = p.rows_per_sample;
     if (!p.a_split || L <= 0 || L > PS_BM - 15 || L <= 240 || p.M % L != 0) return false;
+    if (half && L != PS_BM - 16) return false;
     if (p.N % PS_BN != 0 || p.K % 64 != 0 || p.lda != p.K || p.ldw != p.K) return false;
     if (p.store == DS_STORE_ROW && !p.c_split) {
         if (((p.N | p.ldc | p.ldr) & 3) != 0 || (((uintptr_t)p.C | (uintptr_t)p.R) & 15) != 0) return false;
@@ -637,19 +577,34 @@ bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid) {
     } else {
         return false;
     }
-    if (!need_full_grid) return true;
-    return ds_gemm_f16x2_ps_grid_pays((long)(p.M / L) * (p.N / PS_BN));
+    return true;
 }
 
-// THE grid rule of the per-sample program (one copy: ds_launch_gemm_f16x2 dispatches on it, and the denoiser driver's
-// padded-row mode -- api.hip rows_per_sample -- asks ds_gemm_f16x2_ps_taken, which also knows the forced tile): the
-// program pays when its tiles fill the 256 CUs in (nearly) whole rounds.
-bool ds_gemm_f16x2_ps_grid_pays(long tiles) {
-    const long rounds = (tiles + 255) / 256;
-    // measurement hook: DIFFSOUND_PS_MIN_TILES=n takes the program for every grid of >= n tiles
+// THE grid rule of the per-sample programs (one copy: ds_launch_gemm_f16x2 dispatches on it, and the denoiser driver's
+// padded-row mode -- api.hip rows_per_sample -- asks ds_gemm_f16x2_ps_taken, which also knows the forced tile).
+// B samples x N columns -> 0: neither pays, 1: full tiles (B N / 256 of them), 2: half tiles (twice as many; 272-row
+// samples only).  A program pays by the share of the CU-rounds it occupies that do work; half tiles move 1.46x the operand
+// bytes per MFMA, hence the 0.92.  The floor: below ~0.65 the 4-wave programs (0.29-0.30 of the pipe against 0.46) catch up.
+int ds_gemm_f16x2_ps_choice(long B, long N, bool half_ok) {
+    const long tf = B * (N / PS_BN), th = 2 * tf;
+    // measurement hook: DIFFSOUND_PS_MIN_TILES=n takes the full-tile program for every grid of >= n tiles
     static const int env_min = getenv("DIFFSOUND_PS_MIN_TILES") ? atoi(getenv("DIFFSOUND_PS_MIN_TILES")) : 0;
-    if (env_min > 0) return tiles >= env_min;
-    return tiles >= 192 && tiles * 100 >= rounds * 256 * 85;     // >= 85 % of the CU-rounds it occupies do work
+    if (env_min > 0) return tf >= env_min ? 1 : 0;
+    const double ef = (double)tf / (double)(((tf + 255) / 256) * 256);
+    const double eh = half_ok ? 0.92 * (double)th / (double)(((th + 255) / 256) * 256) : 0.0;
+    if (ef < 0.65 && eh < 0.65) return 0;
+    return ef >= eh ? 1 : 2;
+}
+
+bool ds_gemm_f16x2_ps_applies(const GemmParams& p, bool need_full_grid) {
+    if (!ps_serves(p, false)) return false;
+    return !need_full_grid || ds_gemm_f16x2_ps_choice(p.M / p.rows_per_sample, p.N, false) == 1;
+}
+bool ds_gemm_f16x2_ph_applies(const GemmParams& p) { return ps_serves(p, true); }
+// the program ds_launch_gemm_f16x2 should take for p when nothing is forced: 0 none, 1 full tiles, 2 half tiles
+int ds_gemm_f16x2_ps_pick(const GemmParams& p) {
+    if (!ps_serves(p, false)) return 0;
+    return ds_gemm_f16x2_ps_choice(p.M / p.rows_per_sample, p.N, ps_serves(p, true));
 }
 
 template <int EPI, bool NB16>
@@ -676,4 +631,28 @@ int ds_launch_gemm_f16x2_ps(const GemmParams& p, hipStream_t s) {
     if (p.store == DS_STORE_ATTN) return nb16 ? launch_ps<PS_EPI_ATTN, true>(p, s) : launch_ps<PS_EPI_ATTN, false>(p, s);
     if (p.c_split) return nb16 ? launch_ps<PS_EPI_SPLIT, true>(p, s) : launch_ps<PS_EPI_SPLIT, false>(p, s);
     return nb16 ? launch_ps<PS_EPI_ROW, true>(p, s) : launch_ps<PS_EPI_ROW, false>(p, s);
+}
+
+template <int EPI>
+static int launch_ph(const GemmParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_ph_kernel<EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES);
+        if (e != hipSuccess) {
+            ds_set_error("gemm_f16x2_ph: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        attr_set = true;
+    }
+    const int tiles = 2 * (p.M / p.rows_per_sample) * (p.N / PS_BN);
+    hipLaunchKernelGGL((ds_gemm_f16x2_ph_kernel<EPI>), dim3(tiles), dim3(512), PH_LDS_BYTES, s, p);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+int ds_launch_gemm_f16x2_ph(const GemmParams& p, hipStream_t s) {
+    if (p.store == DS_STORE_ATTN) return launch_ph<PS_EPI_ATTN>(p, s);
+    if (p.c_split) return launch_ph<PS_EPI_SPLIT>(p, s);
+    return launch_ph<PS_EPI_ROW>(p, s);
 }
