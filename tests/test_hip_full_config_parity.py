@@ -107,6 +107,8 @@ def test_teacher_forced_100_steps_19_layers(model, g, mode):
     unexplained = [f for f in flips if not (f["tmargin"] < CUT_TIE or f["gap"] < GAP_TIE)]
     assert not unexplained, "token disagreements away from any near-tie: %s" % unexplained[:4]
     assert len(flips) <= MAX_FLIPS, "%d teacher-forced disagreements in %d decisions" % (len(flips), 100 * B * 265)
+    if mode == "fp32":      # an exact FMA chain per element: every run so far (rounds 1-3, several boxes) reproduced all
+        assert len(flips) == 0, flips[:4]   # 212 000 decisions; the near-tie allowance above is for the split arithmetic
 
 
 def test_teacher_forced_batch64_padded_rows(model, g):
