@@ -160,6 +160,29 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
             __builtin_amdgcn_global_load_lds((ds_gptr)((const unsigned char*)(src8 + (unsigned long long)(tile_) * 1024) + lane16), \
                                              (ds_lptr)(smem_raw + (buf_) * (STAGE * 2) + ldsoff8), 16, 0, 0); \
     } while (0)
+    // The same transfers inside the main loop, written out: per transfer the builtin form costs ~7 scalar instructions (a
+    // 64-bit tile address from the k-tile index: 4 adds + v_lshl_add_u64, the LDS address into M0, a wait state) -- 1.6e7
+    // SALU instructions per FC1 launch, and the loop was 9 % longer with the DMA than without (round-3 SQ counters).  Here
+    // every transfer keeps a RUNNING 64-bit base in SGPRs (it moves one k-tile = 1 KB per use), addresses  SGPR base +
+    // lane offset, and gets its LDS address by one s_add into M0: four scalar instructions, no vector one.  (No immediate
+    // offset: the instruction adds it to the LDS address as well.  hipcc does not use M0 in this loop otherwise.)
+    // Same-run A/B against the builtin form (profiles/r03h_*): -2..4 % launch time on every shape.
+#define PS_DMA_ASM(base_, lds_, stage_)                                                              \
+    do {                                                                                             \
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"            \
+                     :: "v"(lane16), "s"(base_), "s"(lds_), "n"(stage_) : "memory", "scc", "m0");    \
+        base_ += 1024;                                                                               \
+    } while (0)
+    // tq_: the k-tile (run time, used by the builtin form)
+#define PS_ISSUE_LOOP(tq_, ty_, buf_)                                                                \
+    do {                                                                                             \
+        if (PS_ABLATE & 128) { PS_ISSUE(tq_, ty_, buf_); }                                           \
+        else {                                                                                       \
+            PS_DMA_ASM(cur[ty_][0], ldsabs[ty_][0], (buf_) * (STAGE * 2));                           \
+            PS_DMA_ASM(cur[ty_][1], ldsabs[ty_][1], (buf_) * (STAGE * 2));                           \
+            if ((ty_) == 3) PS_DMA_ASM(cur8, ldsabs8, (buf_) * (STAGE * 2));                         \
+        }                                                                                            \
+    } while (0)
 #define PS_FENCE()                                                                                   \
     do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PS_BAR()                                                                                     \
@@ -266,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
             constexpr int dq = (P) + LEAD;                     /* quarter 4 t + dq */                \
             const int tq = t + (dq >> 2);                                                            \
             if (tq < nk && !(PS_ABLATE & 1)) {                                                       \
-                PS_ISSUE(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                       \
+                PS_ISSUE_LOOP(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                  \
                 asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   /* the 4 youngest quarters: 2+2+2+3 */ \
             } else {                                                                                 \
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* tail: nothing younger to count */ \
@@ -303,6 +326,18 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
         PS_BAR();
     }
     if (wr == 1) PS_LBAR();         // the second wave row runs one barrier behind the first
+    // running tile bases of the written-out transfers: the first k-tile each quarter type is issued for inside the loop is
+    // 1 (types 2, 3: phases 0, 1 of k-tile 0 issue quarters 6, 7) or 2 (types 0, 1: quarters 8, 9)
+    unsigned long long cur[4][2], cur8 = src8 + 1024;
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+        cur[ty][0] = src[ty][0] + (ty < 2 ? 2048 : 1024);
+        cur[ty][1] = src[ty][1] + (ty < 2 ? 2048 : 1024);
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw);
+    unsigned ldsabs[4][2], ldsabs8 = lds0 + ldsoff8;          // LDS byte address of every transfer in stage 0
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) { ldsabs[ty][0] = lds0 + ldsoff[ty][0]; ldsabs[ty][1] = lds0 + ldsoff[ty][1]; }
     for (int t = 0; t < nk; t += 2) {
         PS_PHASE(0, 0); PS_PHASE(1, 0); PS_PHASE(2, 0); PS_PHASE(3, 0);
         ++t;
@@ -525,7 +560,7 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ph_kernel(const GemmPara
         else { PH_READ_B(ST, 1); if (hasE) { PH_READ_EA16(ST); if (wr == 1) PH_READ_EB16(ST); } }    \
         PS_FENCE();                                                                                  \
         if (tt + 2 < nk) {                                                                           \
-            PH_ISSUE(tt + 2, P, ((ST) + 2) % 3);                                                     \
+            PH_ISSUE_LOOP(P, ((ST) + 2) % 3);                                                        \
             if (P == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   /* halves g + 2 .. g + 4: 4 + 3 + 4 */ \
             else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          /*                        3 + 4 + 3 */ \
         } else {                                                                                     \
@@ -537,6 +572,22 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ph_kernel(const GemmPara
         else { PH_QUAD(1); if (hasE) PH_EXTRA16(); }                                                 \
         __builtin_amdgcn_s_setprio(0);                                                               \
         PS_BAR();                                                                                    \
+    } while (0)
+    // the transfers inside the loop, written out as in the full-tile kernel (PS_DMA_ASM): running bases, first used for k-tile 2
+    unsigned long long curA[2] = {srcA[0] + 2048, srcA[1] + 2048}, curE = srcE + 2048;
+    unsigned long long curB[2][2] = {{srcB[0][0] + 2048, srcB[0][1] + 2048}, {srcB[1][0] + 2048, srcB[1][1] + 2048}};
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw);
+    const unsigned absA[2] = {lds0 + offA[0], lds0 + offA[1]}, absE = lds0 + offE;
+    const unsigned absB[2][2] = {{lds0 + offB[0][0], lds0 + offB[0][1]}, {lds0 + offB[1][0], lds0 + offB[1][1]}};
+#define PH_ISSUE_LOOP(half_, st_)                                                                    \
+    do {                                                                                             \
+        if ((half_) == 0) {                                                                          \
+            PS_DMA_ASM(curA[0], absA[0], (st_) * (STAGE * 2)); PS_DMA_ASM(curA[1], absA[1], (st_) * (STAGE * 2)); \
+            PS_DMA_ASM(curB[0][0], absB[0][0], (st_) * (STAGE * 2)); PS_DMA_ASM(curB[0][1], absB[0][1], (st_) * (STAGE * 2)); \
+        } else {                                                                                     \
+            PS_DMA_ASM(curB[1][0], absB[1][0], (st_) * (STAGE * 2)); PS_DMA_ASM(curB[1][1], absB[1][1], (st_) * (STAGE * 2)); \
+            PS_DMA_ASM(curE, absE, (st_) * (STAGE * 2));                                             \
+        }                                                                                            \
     } while (0)
     // prologue: k-tiles 0 and 1 (halves 0 .. 3 = 14 instructions per wave); half 0 has landed once only halves 1 .. 3
     // (3 + 4 + 3) are outstanding

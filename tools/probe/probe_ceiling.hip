@@ -70,6 +70,16 @@ namespace v14 {
 #include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
 }
 #undef PS_ABLATE
+#define PS_ABLATE 128
+namespace v128 {
+#include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
+}
+#undef PS_ABLATE
+#define PS_ABLATE 136
+namespace v136 {
+#include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
+}
+#undef PS_ABLATE
 #define PS_ABLATE 32
 namespace v32 {
 #include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
@@ -172,7 +182,9 @@ int main(int argc, char** argv) {
                         {"MFMA only", v27::ds_launch_gemm_f16x2_ps},
                         {"DMA + reads + barriers (no MFMA)", v12::ds_launch_gemm_f16x2_ps},
                         {"reads + barriers only", v13::ds_launch_gemm_f16x2_ps},
-                        {"DMA + barriers only", v14::ds_launch_gemm_f16x2_ps}};
+                        {"DMA + barriers only", v14::ds_launch_gemm_f16x2_ps},
+                        {"product, builtin DMA form", v128::ds_launch_gemm_f16x2_ps},
+                        {"no epilogue, builtin DMA form", v136::ds_launch_gemm_f16x2_ps}};
     int K_packed = 0;
     for (const Shape& sh : shapes) {
         const int N = sh.N, K = sh.K;
