@@ -92,6 +92,35 @@ def test_training_step_host_composition(monkeypatch, oracle_grads, precision, at
         assert torch.allclose(params[n].detach(), after_a[n], rtol=0, atol=1e-7), n
 
 
+def test_gradients_are_handed_over_during_the_backward(monkeypatch):
+    """loss_and_grads(on_grads=...): the hook of the overlapped data-parallel reduction (shard.GradientReducer.ready) is
+    called after the logits layer and after every block, last block first, with weight-matrix gradients that are FINAL at
+    that moment (a copy taken inside the hook equals the returned gradient), each name once; what is never handed over is
+    the small rest (biases, norm gains, embedding tables) that the step un-scales at its end."""
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    hip_abi_emulation.install(monkeypatch)
+    dt, _ = _model()
+    step = TrainStep(dt, precision="f16x2")
+    calls, snap = [], {}
+
+    def hook(named, streams):
+        calls.append(sorted(named))
+        for n, t in named.items():
+            assert n not in snap
+            snap[n] = t.clone()
+    loss, grads = step.loss_and_grads(*_batch(), on_grads=hook)
+    assert calls[0] == ["transformer.to_logits.1.weight"] and len(calls) == 1 + 2
+    assert all(n.startswith("transformer.blocks.1.") for n in calls[1]) and all(n.startswith("transformer.blocks.0.") for n in calls[2])
+    assert len(calls[1]) == 16
+    for n, t in snap.items():
+        assert torch.equal(t, grads[n]), n
+    handed = sum(t.numel() for t in snap.values())
+    total = sum(t.numel() for t in grads.values())
+    assert handed / total > 0.97
+    rest = [n for n in grads if n not in snap]
+    assert all(n.endswith((".bias", "ln2.weight", "to_logits.0.weight", "emb.weight")) for n in rest), rest[:5]
+
+
 def test_split_k_plan_and_padding():
     from text_to_sound_synthesis_amd.modeling.train import _SplitGemm, _ceil
     # (N, K) of the denoiser's linears -> K-ranges; the padded contraction length divides into 32-wide k-tiles per range

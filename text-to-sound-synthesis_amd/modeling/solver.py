@@ -197,15 +197,24 @@ class Solver:
     all-reduce, shard.allreduce_gradients) before clipping, which is where DDP's reduction lands too."""
 
     def __init__(self, train_step, lr=3.0e-6, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, scheduler=None,
-                 clip_grad_norm=None, ema=None, allreduce=None):
+                 clip_grad_norm=None, ema=None, allreduce=None, reducer=None):
+        """allreduce: callable(grads) run after the backward (shard.allreduce_gradients); reducer: a shard.GradientReducer --
+        the same reduction overlapped with the backward (buckets are all-reduced while earlier blocks are still being
+        differentiated).  Give one or neither."""
+        assert allreduce is None or reducer is None
         self.train_step, self.lr = train_step, float(lr)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.scheduler, self.clip_grad_norm, self.ema, self.allreduce = scheduler, clip_grad_norm, ema, allreduce
+        self.reducer = reducer
         self.opt_state = {}
         self.last_iter = -1
 
     def step(self, *batch):
-        loss, grads = self.train_step.loss_and_grads(*batch)
+        if self.reducer is not None:
+            loss, grads = self.train_step.loss_and_grads(*batch, on_grads=self.reducer.ready)
+            self.reducer.finish(grads)
+        else:
+            loss, grads = self.train_step.loss_and_grads(*batch)
         if self.allreduce is not None:
             self.allreduce(grads)
         total = self.clip_grad_norm(grads) if self.clip_grad_norm is not None else None

@@ -374,13 +374,17 @@ class TrainStep:
         return out, _Linear("logits", lin.weight.detach(), lin.bias.detach())
 
     @torch.no_grad()
-    def loss_and_grads(self, x0, cond_emb, t, pt, noise):
+    def loss_and_grads(self, x0, cond_emb, t, pt, noise, on_grads=None):
         """x0 i64[B, L] clean tokens, cond_emb f32[B, 77, 512], t i64[B], pt f32[B] (sample_time's output), noise
         f32[B, K+1, L] uniforms for q_sample.  Returns (loss scalar as forward() reports it, {parameter name relative to
-        the DiffusionTransformer: gradient}).  Gradients are those of that loss."""
+        the DiffusionTransformer: gradient}).  Gradients are those of that loss.
+        on_grads(named, streams): called during the backward -- after the logits layer and after every transformer block,
+        last block first -- with the WEIGHT-matrix gradients that are final at that point (98 % of the bytes; biases and
+        norm gains are un-scaled in one multiply at the very end) and the streams that wrote them: the hook of the
+        overlapped data-parallel reduction (shard.GradientReducer.ready)."""
         if self.loss_scale_exp is None:
             self.calibrate(x0, cond_emb, t, pt, noise)
-        return self._run(x0, cond_emb, t, pt, noise, calibrating=False)
+        return self._run(x0, cond_emb, t, pt, noise, calibrating=False, on_grads=on_grads)
 
     @torch.no_grad()
     def calibrate(self, x0, cond_emb, t, pt, noise):
@@ -397,7 +401,7 @@ class TrainStep:
         self.loss_scale_exp = 0 if (m == 0.0 or not math.isfinite(m)) else 12 - math.floor(math.log2(m))
         return self.loss_scale_exp
 
-    def _run(self, x0, cond_emb, t, pt, noise, calibrating, amax=None):
+    def _run(self, x0, cond_emb, t, pt, noise, calibrating, amax=None, on_grads=None):
         dt, tr, G_ = self.dt, self.tr, self.gemm
         dev = x0.device
         B, Lx = x0.shape
@@ -533,7 +537,12 @@ class TrainStep:
                 torch.cuda.current_stream(dev).wait_event(ev)
             reads_dx.clear()
 
+        def hand_over(names):
+            if on_grads is not None and not calibrating:
+                on_grads({n: g[n] for n in names}, (side,) if side is not None else ())
+
         dh, g["transformer.to_logits.1.weight"], g["transformer.to_logits.1.bias"] = lin_bwd(lin_logits, hf, dlog)
+        hand_over(["transformer.to_logits.1.weight"])
         dx, dgam, dbet = _norm_bwd(xf, dh, 1, Lx, gamma=lnf.weight)
         g["transformer.to_logits.0.weight"], g["transformer.to_logits.0.bias"] = dgam[0], dbet[0]
         small += [dgam, dbet]
@@ -601,6 +610,10 @@ class TrainStep:
             dxn, dsc, dsh = _norm_bwd(s["x0"], dh, 0, Lx, table=s["tab1"], t=t)
             adaln_param_grads(blk.ln1, dsc, dsh, p + "ln1")
             axpy(dx, dxn)
+            hand_over([p + n for n in ("mlp.2.weight", "mlp.0.weight", "attn2.proj.weight", "attn2.query.weight",
+                                       "attn2.key.weight", "attn2.value.weight", "attn1.proj.weight", "attn1.query.weight",
+                                       "attn1.key.weight", "attn1.value.weight", "ln1.emb.weight", "ln1.linear.weight",
+                                       "ln1.linear.bias", "ln1_1.emb.weight", "ln1_1.linear.weight", "ln1_1.linear.bias")])
         # ---- embedding
         demb = torch.zeros_like(emb.emb.weight)
         L_.check(L_.lib().ds_embed_bwd(L_.ptr(dx), L_.ptr(xt), L_.ptr(demb), M, D, demb.shape[0], L_.stream()))

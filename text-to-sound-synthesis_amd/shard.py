@@ -154,3 +154,88 @@ def allreduce_gradients(grads, bucket_bytes=256 << 20, group=None, average=True)
     flush()
     return grads
 
+
+
+class GradientReducer:
+    """The same reduction OVERLAPPED with the backward (what DDP's bucketing does for the reference, engine/solver_spec.py:109):
+    the training step hands over gradients as soon as they are final -- `ready(named)`, once per transformer block, in the
+    order the backward produces them -- and every bucket that fills up is flattened and all-reduced ASYNCHRONOUSLY
+    (`async_op=True`; on GPUs on a communication stream that first waits for the streams that produced the tensors), while
+    the backward of the next block runs.  `finish(grads)` reduces what has not been handed over (the small gradients the
+    step un-scales at its very end), waits for everything, averages and writes the results back into the caller's tensors.
+    Buckets of ~one block (50 MB) keep the messages large: the xGMI ring is per-link bound.
+    Every rank must call ready() with the same names in the same order.  Without a process group it does nothing."""
+
+    def __init__(self, bucket_bytes=48 << 20, group=None, average=True):
+        self.bucket_bytes, self.group, self.average = bucket_bytes, group, average
+        self._pending, self._pending_bytes, self._inflight, self._done = [], 0, [], set()
+        self._comm = None
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def ready(self, named, streams=()):
+        """named: {name: tensor} of gradients that will not change any more; streams: the device streams that wrote them
+        (default: the current one)."""
+        if not self._active():
+            return
+        for n, t in named.items():
+            if n in self._done:
+                raise RuntimeError("gradient %r handed over twice" % n)
+            self._done.add(n)
+            self._pending.append((n, t, tuple(streams)))
+            self._pending_bytes += t.numel() * t.element_size()
+        if self._pending_bytes >= self.bucket_bytes:
+            self._flush()
+
+    def _flush(self):
+        if not self._pending:
+            return
+        bucket, self._pending, self._pending_bytes = self._pending, [], 0
+        dev = bucket[0][1].device
+        if dev.type == "cuda":
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(dev)
+            producers = {torch.cuda.current_stream(dev)}
+            for _, _, ss in bucket:
+                producers.update(ss)
+            for st in producers:
+                self._comm.wait_stream(st)
+            with torch.cuda.stream(self._comm):
+                flat = torch.cat([t.reshape(-1) for _, t, _ in bucket])
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            for _, t, _ in bucket:
+                t.record_stream(self._comm)
+        else:
+            flat = torch.cat([t.reshape(-1) for _, t, _ in bucket])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight.append((work, flat, [(n, t) for n, t, _ in bucket]))
+
+    def finish(self, grads):
+        """Reduce the gradients of `grads` that were never handed over, wait for every bucket, average, copy back (in place
+        into the tensors the caller holds).  Returns grads."""
+        if not self._active():
+            self._done.clear()
+            return grads
+        rest = {n: grads[n] for n in sorted(grads) if n not in self._done}
+        unknown = self._done - set(grads)
+        if unknown:
+            raise RuntimeError("gradients handed over but not in the final dict: %s" % sorted(unknown)[:4])
+        for n, t in rest.items():
+            self._pending.append((n, t, ()))
+        self._flush()
+        world = dist.get_world_size(self.group)
+        for work, flat, items in self._inflight:
+            work.wait()                               # (NCCL: makes the current stream wait for the communication)
+            dev = flat.device
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).wait_stream(self._comm)
+            if self.average:
+                flat.div_(world)
+            off = 0
+            for n, t in items:
+                k = t.numel()
+                t.copy_(flat[off:off + k].view_as(t))
+                off += k
+        self._inflight, self._done = [], set()
+        return grads
