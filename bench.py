@@ -344,18 +344,20 @@ def main():
                 "bf16x3": ("ds_gemm_bf16x3_kernel<%d,%d>", 6, PEAK_16BIT_MFMA_TFLOPS, "6-pass bf16 MFMA 32x32x16"),
                 "f16x2": ("ds_gemm_f16x2_kernel<%d,%d>", 3, PEAK_16BIT_MFMA_TFLOPS, "3-pass fp16 MFMA 32x32x16")}
 
-        def leg(precision):
+        def leg(precision, warm=None, steps=None):
+            warm = args.roofline_warm if warm is None else warm
+            steps = args.roofline_steps if steps is None else steps
             dt.transformer.precision = precision
             kv = dt.transformer.condition_kv(cond, dt._schedule_table())
             x = torch.full((B, 265), args.codes, device=dev, dtype=torch.long)
             u = torch.rand((B, args.codes + 1, 265), device=dev)
             t = torch.full((B,), T - 1, device=dev, dtype=torch.long)
             x = dt.p_sample_tokens(x, kv, t, u, initial=True)            # warm-up (also builds the pack)
-            for i in range(args.roofline_warm):                          # bring the board to the timed loop's thermal state
+            for i in range(warm):                                        # bring the board to the timed loop's thermal state
                 x = dt.p_sample_tokens(x, kv, t, u, initial=False)
             torch.cuda.synchronize()
             L.ds_profile_enable(1)
-            for i in range(args.roofline_steps):
+            for i in range(steps):
                 t = torch.full((B,), max(T - 2 - i, 0), device=dev, dtype=torch.long)
                 x = dt.p_sample_tokens(x, kv, t, u, initial=False)
             L.ds_profile_enable(0)
@@ -391,7 +393,7 @@ def main():
                     "all_gemm_tflops": round(sum(fl) / (sum(ms) * 1e-3) / 1e12, 2)}
         roof = leg(args.precision)
         if args.precision != "fp32":                   # the exact-fp32 MFMA kernel on the same shapes, for reference
-            extra["roofline_fp32_mfma_kernel"] = leg("fp32")
+            extra["roofline_fp32_mfma_kernel"] = leg("fp32", warm=0, steps=3)    # (a reference point: three steps suffice)
             dt.transformer.precision = args.precision
     if args.stage_times and world == 1:   # (a lone rank calling the collectives of one_step would hang the others)
         one_step(timed_stages=True)

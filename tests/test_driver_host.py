@@ -74,7 +74,9 @@ def test_dalle_sample_control_flow_with_stub_backends():
 def test_padded_row_mode_selection_and_workspace():
     """Host logic of the native denoiser handle (csrc/api.hip rows_per_sample / carve; no device work, runs without a GPU):
     the sampling step pads every sample to 272 rows exactly where the per-sample GEMM program serves the batch -- f16x2
-    mode, row padding on, grids of whole CU rounds (B = 64, 128; not 8, 32, 48) -- and the workspace query covers it."""
+    mode, row padding on, and the grid rule of csrc/gemm_f16x2_ps.hip (ds_gemm_f16x2_ps_choice, mirrored below) picks full
+    or half tiles for the N = 1024 GEMMs: B = 64 / 128 (full tiles), 32 (half tiles), not 1 / 8 / 16 -- and the workspace
+    query covers it."""
     import ctypes as C
 
     import torch
@@ -94,8 +96,14 @@ def test_padded_row_mode_selection_and_workspace():
         assert [lib.ds_denoiser_rows_per_sample(h, B) for B in (1, 32, 64)] == [265, 265, 265]       # fp32 mode: never
         scales = (C.c_float * n)(*([1.0] * n))
         L.check(lib.ds_denoiser_set_split_weights(h, 2, ptrs, scales, dummy.data_ptr(), 1.0))        # f16x2 mode
-        got = {B: lib.ds_denoiser_rows_per_sample(h, B) for B in (1, 8, 32, 48, 55, 64, 100, 128)}
-        assert got == {1: 265, 8: 265, 32: 265, 48: 265, 55: 272, 64: 272, 100: 265, 128: 272}, got
+        def choice(B, N=1024):                    # share of the occupied CU-rounds that work; x0.92 for half tiles; floor 0.65
+            tf, th = B * (N // 256), 2 * B * (N // 256)
+            ef, eh = tf / (-(-tf // 256) * 256), 0.92 * th / (-(-th // 256) * 256)
+            return 0 if max(ef, eh) < 0.65 else (1 if ef >= eh else 2)
+        got = {B: lib.ds_denoiser_rows_per_sample(h, B) for B in range(1, 131)}
+        assert got == {B: 272 if choice(B) else 265 for B in range(1, 131)}, got
+        assert [got[B] for B in (1, 8, 16, 20, 24, 32, 48, 64, 100, 128)] == [265, 265, 265, 265, 272, 272, 272, 272, 272, 272]
+        assert (choice(32), choice(64), choice(48)) == (2, 1, 1)
         ws = {B: lib.ds_denoiser_workspace_bytes(h, B) for B in (8, 64)}
         assert ws[64] >= 64 * 272 * 1024 * 4 * (1 + 1 + 3 + 1 + 4) and ws[64] > 8 * ws[8] * 0.99
         L.check(lib.ds_denoiser_set_row_padding(h, 0))
