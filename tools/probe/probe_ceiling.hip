@@ -90,6 +90,22 @@ namespace v64 {
 #include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
 }
 
+#undef PS_ABLATE
+#define PS_ABLATE 256
+namespace v256 {
+#include "../../text-to-sound-synthesis_amd/csrc/gemm_f16x2_ps.hip"
+}
+// tools/probe/prev/ (git-ignored): `git show <rev>:<path>` copies of the kernel + its epilogue, for a same-run A/B against
+// an earlier revision
+#if __has_include("prev/gemm_f16x2_ps.hip")
+#undef PS_ABLATE
+#define PS_ABLATE 0
+namespace vprev {
+#include "prev/gemm_f16x2_ps.hip"
+}
+#define PROBE_HAVE_PREV 1
+#endif
+
 // ---- telemetry ------------------------------------------------------------------------------------------------------
 struct Telemetry {
     std::atomic<bool> run{false}, stop{false};
@@ -184,7 +200,12 @@ int main(int argc, char** argv) {
                         {"reads + barriers only", v13::ds_launch_gemm_f16x2_ps},
                         {"DMA + barriers only", v14::ds_launch_gemm_f16x2_ps},
                         {"product, builtin DMA form", v128::ds_launch_gemm_f16x2_ps},
-                        {"no epilogue, builtin DMA form", v136::ds_launch_gemm_f16x2_ps}};
+                        {"no epilogue, builtin DMA form", v136::ds_launch_gemm_f16x2_ps},
+                        {"product, residual requested in its own step", v256::ds_launch_gemm_f16x2_ps},
+#ifdef PROBE_HAVE_PREV
+                        {"previous revision (tools/probe/prev)", vprev::ds_launch_gemm_f16x2_ps},
+#endif
+    };
     int K_packed = 0;
     for (const Shape& sh : shapes) {
         const int N = sh.N, K = sh.K;
