@@ -335,6 +335,20 @@ def main():
 
     roof = None
     extra = {}
+    if rank == 0 and world == 1 and not args.transformer_only:
+        # what handing the result over to the host costs (generate_sample does it before writing .wav files): the batch's
+        # waveforms HBM -> pinned host memory, timed on its own -- reported beside `value`, never part of it
+        host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
+        host.copy_(w, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            host.copy_(w, non_blocking=True)
+        torch.cuda.synchronize()
+        copy_s = (time.perf_counter() - t0) / 5
+        extra["host_copy"] = {"bytes_per_step": w.numel() * w.element_size(), "ms_per_step": round(copy_s * 1e3, 3),
+                              "GB_per_s": round(w.numel() * w.element_size() / copy_s / 1e9, 1),
+                              "clips_per_s_incl_copy": round(n_total * args.steps / (elapsed + copy_s * args.steps), 4)}
+        del host
     if rank == 0 and not args.no_roofline:
         # profiled legs of a few denoiser steps: HIP events around every GEMM launch (ds_profile_*)
         L = _lib.lib()
@@ -403,7 +417,7 @@ def main():
         line = result_line(args, world, elapsed, n_total)
         if roof is not None:
             line["roofline"] = roof
-            line.update(extra)
+        line.update(extra)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.n_layer, args.codes, T)
         print(json.dumps(line))
