@@ -138,18 +138,38 @@ def cpu_baseline(n_layer, codes, T):
         t_step = (time.perf_counter() - t0) / 2
         t_dec, t_voc = tail(B)
         res[B] = (B / (T * t_step + t_dec + t_voc), t_step, t_dec, t_voc)
+    # one clip at FULL length (B = 1: all T steps, decode, vocode), when it fits the bounded sample: what the 2-step
+    # extrapolation above is worth
+    full = None
+    if T * res[1][1] <= 40.0:
+        one = step_fn(1)
+        t0 = time.perf_counter()
+        for t in range(T - 1, -1, -1):
+            one(t)
+        t_loop = time.perf_counter() - t0
+        t_dec, t_voc = tail(1)
+        full = {"seconds": round(t_loop + t_dec + t_voc, 2), "clips_per_s": round(1.0 / (t_loop + t_dec + t_voc), 5),
+                "extrapolated_from_2_steps": round(res[1][0], 5)}
     torch.set_num_threads(default_threads)
     bB = max(res, key=lambda k: res[k][0])
-    return {"value": res[bB][0], "unit": "clips/s", "cores": best_n, "kind": "reference" if use_ref else "port",
+    value = res[bB][0]
+    note = ""
+    if full is not None and full["clips_per_s"] > value:       # the CPU gets its best measured rate
+        value = full["clips_per_s"]
+        note = "; value = the full-length B=1 clip (%.2f s), faster than the extrapolations" % full["seconds"]
+    elif full is not None:
+        note = "; one full-length B=1 clip measured beside it: %.2f s" % full["seconds"]
+    return {"value": value, "unit": "clips/s", "cores": best_n, "kind": "reference" if use_ref else "port",
             "host_hw_threads": hw,
             "thread_sweep_s_per_B8_step": {str(k): round(v, 3) for k, v in sweep.items()},
+            "full_length_B1": full,
             "per_batch": {"B=%d" % B: {"clips_per_s": round(v[0], 5), "s_per_denoiser_step": round(v[1], 3),
                                         "s_decode": round(v[2], 2), "s_vocode": round(v[3], 2)} for B, v in res.items()},
             "sample": "%s, fp32 torch-CPU, %d torch threads (best of the sweep on a B=8 step), B=%d: 2 of %d denoiser "
                       "steps (%.3f s each) + 1 decode (%.2f s) + 1 vocode (%.2f s), extrapolated to %d steps"
                       % ("the unmodified reference under oracle/ref_harness.py" if use_ref else
                          "CPU oracle (restatement of the reference; /root/reference is not on this box)",
-                         best_n, bB, T, res[bB][1], res[bB][2], res[bB][3], T)}
+                         best_n, bB, T, res[bB][1], res[bB][2], res[bB][3], T) + note}
 
 
 def pmc_traffic(kernel, template_tail, algorithmic_mb):
