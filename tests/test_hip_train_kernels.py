@@ -475,6 +475,62 @@ def test_graph_solver_resumes_from_its_state_dict():
     assert d.mean().item() < 1e-7 and (d > 1e-6).float().mean().item() < 1e-4
 
 
+def test_graph_solver_two_segments_with_reduction_hook():
+    """The data-parallel form of the captured iteration (engine/solver_spec.py:109: DDP reduces before the optimizer step):
+    GraphSolver(reduce=...) replays a gradients graph, calls reduce(grads) on the graph's own gradient tensors, replays the
+    clip + AdamW graph.  With an identity reduction it must equal the one-graph solver to rounding over three iterations
+    (one call of the hook per iteration); a reduction that halves the gradients must act on the update: with the clip
+    active at the halved norm as well the step direction is the same and the reported norm is half."""
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.solver import GradClipWindow, GraphSolver
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+
+    def make():
+        m = build_model(default_config(n_layer=2, diffusion_step=100))
+        m.load_state_dict({**dict(synth_sd("dalle", 2)), **synth_sd("encoder")}, strict=False)
+        dt = m.cuda().eval().transformer
+        dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]
+        return dt
+    x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0").cuda()
+    cond = synth.synth_cond_emb(3, key="tl.c").cuda()
+    pt = (torch.ones(3) / 100).cuda()
+    batches = [(torch.tensor([57, 0, 93]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u").cuda()),
+               (torch.tensor([3, 99, 41]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u2").cuda()),
+               (torch.tensor([12, 12, 70]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u3").cuda())]
+    calls = []
+
+    def identity(grads):
+        calls.append(len(grads))
+
+    def halve(grads):
+        torch._foreach_mul_(list(grads.values()), 0.5)
+    dts = [make(), make(), make()]
+    solvers = [GraphSolver(TrainStep(dts[0], precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5)),
+               GraphSolver(TrainStep(dts[1], precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5),
+                           reduce=identity),
+               GraphSolver(TrainStep(dts[2], precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5),
+                           reduce=halve)]
+    outs = [[s.step(x0, cond, t, pt, u) for t, u in batches] for s in solvers]
+    assert solvers[0].iteration_graph.update_graph is None and solvers[1].iteration_graph.update_graph is not None
+    assert calls == [63, 63, 63]
+    for a, b in zip(outs[0], outs[1]):      # (two runs of the same iteration agree to rounding, not bit for bit: the loss
+        la, lb, na, nb = float(a["loss"]), float(b["loss"]), float(a["grad_norm"]), float(b["grad_norm"])   # sums use atomics)
+        assert abs(la - lb) <= 1e-6 * abs(la) and abs(na - nb) <= 1e-5 * abs(na), (la, lb, na, nb)
+    pa, pb = dict(dts[0].named_parameters()), dict(dts[1].named_parameters())
+    for k in pa:
+        if k.endswith("key.bias"):      # softmax is invariant to a key bias: its gradient is rounding noise, which AdamW
+            continue                    # normalises to full-size steps -- not comparable between two runs
+        d = (pa[k].detach() - pb[k].detach()).abs()
+        assert d.mean().item() < 1e-6 and (d > 1e-4).float().mean().item() < 1e-4, (k, d.mean().item(), d.max().item())
+    # halved gradients: same loss at the first iteration, half the norm; the norms (~1e2) are far above the clip (0.5) in
+    # both runs, so the clipped update is the same direction and size up to rounding
+    assert abs(float(outs[2][0]["loss"]) - float(outs[0][0]["loss"])) <= 1e-6 * abs(float(outs[0][0]["loss"]))
+    r = float(outs[2][0]["grad_norm"]) / float(outs[0][0]["grad_norm"])
+    assert abs(r - 0.5) < 1e-5, r
+    assert float(outs[0][0]["grad_norm"]) > 2.0        # (so that both runs clip)
+
+
 def test_overlapped_weight_gradients_identical():
     """TrainStep(overlap_dw=True): the dW / db work of the backward on a second HIP stream (events order it against the
     in-place updates of the residual gradient) must give bit-identical gradients, twice in a row (allocator reuse)."""

@@ -257,15 +257,17 @@ class Solver:
 
 
 class GraphSolver:
-    """`Solver.step` for one GPU with  gradients -> global-norm clip -> AdamW  replayed as ONE hipGraph
-    (`TrainStep.capture`): per iteration the host copies the batch into the graph's static tensors, writes four scalars
+    """`Solver.step` with  gradients -> global-norm clip -> AdamW  replayed as ONE hipGraph (`TrainStep.capture`), or -- data
+    parallel, `reduce` = e.g. `shard.allreduce_gradients` -- as TWO graphs per rank with the bucketed all-reduce enqueued
+    between the replays (engine/solver_spec.py:109: DDP reduces before the optimizer step).  Per iteration the host copies the batch into the graph's static tensors, writes four scalars
     (lr, the two bias corrections, -- the clip coefficient is computed inside the graph) and launches the graph; the LR
     schedule and the EMA stay host-driven, in the reference's order (engine/solver_spec.py:308-331).  The graph is
     captured on the first batch (shapes are fixed from then on)."""
 
     def __init__(self, train_step, lr=3.0e-6, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, scheduler=None,
-                 clip_grad_norm=None, ema=None):
+                 clip_grad_norm=None, ema=None, reduce=None):
         self.train_step, self.lr = train_step, float(lr)
+        self.reduce = reduce
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.scheduler, self.clip_grad_norm, self.ema = scheduler, clip_grad_norm, ema
         # the clip coefficient is computed inside the captured graph on every replay: a window that skips iterations
@@ -282,7 +284,8 @@ class GraphSolver:
         if self.iteration_graph is None:
             max_norm = self.clip_grad_norm.max_norm if self.clip_grad_norm is not None else None
             self.iteration_graph = self.train_step.capture(*batch, betas=self.betas, eps=self.eps,
-                                                           weight_decay=self.weight_decay, max_norm=max_norm)
+                                                           weight_decay=self.weight_decay, max_norm=max_norm,
+                                                           **({"reduce": self.reduce} if self.reduce is not None else {}))
             if self._pending_state is not None:
                 self.iteration_graph.load_state_dict(self._pending_state)
                 self._pending_state = None

@@ -658,23 +658,28 @@ class TrainStep:
         self.tr.invalidate()       # cached weight packs / AdaLN tables are stale now (frees the native handle too)
 
     # ---- the whole iteration as ONE hipGraph -----------------------------------------------------------------------------
-    def capture(self, x0, cond_emb, t, pt, noise, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, max_norm=None):
+    def capture(self, x0, cond_emb, t, pt, noise, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, max_norm=None,
+                reduce=None):
         """Capture  loss_and_grads -> global-norm clip -> AdamW  (engine/solver_spec.py:308-331's order) on static copies of
         the batch tensors into one hipGraph and return a `GraphedIteration`: `it(x0, cond_emb, t, pt, noise, lr)` copies
         the batch in, refreshes the 4 device scalars of the update and replays -- one graph launch per training iteration.
-        Single-GPU form (the data-parallel step all-reduces between gradients and update: use the eager Solver there).
+        Data-parallel form: `reduce(grads)` (e.g. shard.allreduce_gradients: averages the gradient tensors over the
+        ranks, in place, on the current stream) makes it TWO graphs per rank -- gradients | clip + AdamW -- with the
+        reduction enqueued between the two replays (engine/solver_spec.py:109: DDP reduces before the optimizer step).
         The loss scale and the weight pre-scales are the calibrated constants of capture time; `recapture()` refreshes them."""
-        return GraphedIteration(self, (x0, cond_emb, t, pt, noise), betas, eps, weight_decay, max_norm)
+        return GraphedIteration(self, (x0, cond_emb, t, pt, noise), betas, eps, weight_decay, max_norm, reduce=reduce)
 
 
 class GraphedIteration:
-    def __init__(self, step, batch, betas, eps, weight_decay, max_norm):
+    def __init__(self, step, batch, betas, eps, weight_decay, max_norm, reduce=None):
         self.step, self.betas, self.eps, self.weight_decay, self.max_norm = step, betas, eps, weight_decay, max_norm
+        self.reduce = reduce                 # None: one graph; callable(grads): gradients graph | reduce | update graph
         self.static = [b.clone() for b in batch]
         self.hyper = torch.zeros(4, device=batch[0].device)
         self.opt_state = {}
         self.iteration = 0
         self.graph = None
+        self.update_graph = None
         self._capture()
 
     @torch.no_grad()
@@ -698,19 +703,33 @@ class GraphedIteration:
             m.zero_()
             v.zero_()
         self.graph = torch.cuda.CUDAGraph()
+        self.update_graph = None
         st._capturing = True
         try:
-            with torch.cuda.graph(self.graph):
-                self._body()
+            if self.reduce is None:
+                with torch.cuda.graph(self.graph):
+                    self._body()
+            else:       # two segments sharing one memory pool: the gradient tensors of the first are the second's inputs
+                with torch.cuda.graph(self.graph):
+                    self._body_grads()
+                self.update_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.update_graph, pool=self.graph.pool()):
+                    self._body_update()
         finally:
             st._capturing = False
         dt.Lt_history.copy_(keep[0])
         dt.Lt_count.copy_(keep[1])
         st._steps = keep[2]
 
-    def _body(self):
-        st = self.step
-        loss, grads = st._run(*self.static, calibrating=False)
+    def _body(self):                       # (the warm-up runs it un-reduced on every rank alike: lr = 0, state restored)
+        self._body_grads()
+        self._body_update()
+
+    def _body_grads(self):
+        self.loss, self.grads = self.step._run(*self.static, calibrating=False)
+
+    def _body_update(self):
+        st, loss, grads = self.step, self.loss, self.grads
         tensors = list(grads.values())
         total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)))
         if self.max_norm is not None:                  # torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), <= 1
@@ -756,6 +775,9 @@ class GraphedIteration:
         if self.max_norm is None:
             self.hyper[3:4].fill_(1.0)
         self.graph.replay()
+        if self.update_graph is not None:
+            self.reduce(self.grads)        # in place on the graph's own gradient tensors, stream-ordered between the replays
+            self.update_graph.replay()
         self.step._steps += 1
         self._replays = getattr(self, "_replays", 0) + 1
         self.step.tr.invalidate()          # the replay updated the weights: cached inference packs are stale
