@@ -26,6 +26,18 @@ __device__ __forceinline__ _Float16 ds_split_lo(float a, _Float16 hi) {
     return (_Float16)__builtin_amdgcn_fmed3f(a - (float)hi, -65504.f, 65504.f);  // a - hi is exact in fp32
 }
 
+// hi | lo << 16 of the same split in one 32-bit word (the staging format of the per-sample GEMM epilogues): the second
+// conversion and the packing are one v_cvt_pk_f16_f32 (its low half re-derives hi from the same clamped value)
+__device__ __forceinline__ unsigned ds_split_pack(float a) {
+#pragma clang fp contract(off)
+    typedef float ds_f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 ds_h2 __attribute__((ext_vector_type(2)));
+    const float ac = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    const _Float16 hi = (_Float16)ac;
+    const ds_f2 pr = {ac, __builtin_amdgcn_fmed3f(a - (float)hi, -65504.f, 65504.f)};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(pr, ds_h2));
+}
+
 // GELU2 (x * sigmoid(1.702 x), transformer_utils.py:111-115) for the f16x2 GEMM epilogues: v_exp_f32 + v_rcp_f32
 // (~1 ulp each) instead of expf + IEEE division -- a tenth of the instructions, which matters where the epilogue is
 // not hidden behind another workgroup's MFMAs (gemm_f16x2_ps.hip).  ONE definition for every f16x2 program, so their
