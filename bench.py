@@ -47,7 +47,9 @@ def parse():
                          "f16x2 (default): 2 fp16 planes per operand, 3 MFMA passes; bf16x3: 3 bf16 planes, 6 passes")
     ap.add_argument("--rng", default="philox", choices=("philox", "torch"),
                     help="philox (default): Gumbel noise drawn in the sampler kernel, keyed by the global caption index -- "
-                         "the same clips at every world size; torch: torch.rand per step, the reference's own draw")
+                         "the same NOISE for a caption at every world size / batch (identical tokens as long as the same GEMM "
+                         "program serves the local batch: logits differ by ~1e-7 relative between programs, so a near-tie "
+                         "can flip); torch: torch.rand per step, the reference's own draw")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFSOUND_STREAMS", "1")), choices=(1, 2),
                     help="2: the sampling loop runs the batch as two half-batches on two HIP streams")
     ap.add_argument("--transformer-only", action="store_true",

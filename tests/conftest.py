@@ -18,6 +18,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# measured parity figures (N1 flips / identical clips / mel / RMS, text-stage agreement ...): tests append one line each
+# and the terminal summary prints them, so a driver log that only keeps pytest's tail still carries the numbers
+PARITY_SUMMARY = []
+
+
+def parity_line(text):
+    PARITY_SUMMARY.append(text)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if PARITY_SUMMARY:
+        terminalreporter.section("measured parity (vs reference-generated goldens)")
+        for line in PARITY_SUMMARY:
+            terminalreporter.write_line(line)
+
+
 @pytest.fixture(autouse=True)
 def _grad_mode(request):
     """Grad mode is per test, never process-global: modules that set NO_GRAD = True run their tests under

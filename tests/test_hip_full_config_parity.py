@@ -19,7 +19,7 @@ import os
 import pytest
 import torch
 
-from conftest import ROOT, golden, synth_sd
+from conftest import ROOT, golden, parity_line, synth_sd
 from text_to_sound_synthesis_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -29,8 +29,11 @@ MEL_TOL = 1e-3           # BASELINE.json north_star: max-abs on mel
 WAVE_RMS_TOL = 1e-4      # BASELINE.json north_star: RMS on waveform
 CUT_TIE = 2e-5           # |mass ranked before a class - r| below this: the top-r cut is a rounding-level tie
 GAP_TIE = 2e-4           # Gumbel-argmax margin below this: the argmax is a rounding-level tie
-MAX_FLIPS = 8            # teacher-forced disagreements allowed in 212 000 decisions (each must be a near-tie)
-MIN_EXACT_CLIPS = 6      # free-running: clips (of 8) whose final 265 tokens must equal the reference's
+# Gates sit at what has been measured (rounds 1-4, every box: 0 disagreements, 8 of 8 clips) plus the smallest allowance a
+# different box's rounding could need; round 3 had 8 / 6 here, which a real regression would have passed.
+MAX_FLIPS = {"fp32": 0, "f16x2": 2}   # teacher-forced disagreements allowed in 212 000 decisions (each must be a near-tie)
+MIN_EXACT_CLIPS = 7      # free-running: clips (of 8) whose final 265 tokens must equal the reference's; a diverging clip
+                         # must leave the reference's trajectory at a near-tie, which is printed
 
 
 @pytest.fixture(scope="module")
@@ -80,6 +83,8 @@ def report(mode, name, payload):
     with open(path, "w") as f:
         json.dump(data, f, indent=1)
     print("N1 %s %s: %s" % (mode, name, json.dumps(payload)))
+    brief = {k: v for k, v in payload.items() if k not in ("detail",) and not (k == "first_divergence" and not v)}
+    parity_line("N1 %s %s: %s" % (mode, name, json.dumps(brief)))
 
 
 def near_tie(g, step_idx, clip, pos):
@@ -106,16 +111,15 @@ def test_teacher_forced_100_steps_19_layers(model, g, mode):
     report(mode, "teacher_forced", {"decisions": 100 * B * 265, "flips": len(flips), "detail": flips[:16]})
     unexplained = [f for f in flips if not (f["tmargin"] < CUT_TIE or f["gap"] < GAP_TIE)]
     assert not unexplained, "token disagreements away from any near-tie: %s" % unexplained[:4]
-    assert len(flips) <= MAX_FLIPS, "%d teacher-forced disagreements in %d decisions" % (len(flips), 100 * B * 265)
-    if mode == "fp32":      # an exact FMA chain per element: every run so far (rounds 1-3, several boxes) reproduced all
-        assert len(flips) == 0, flips[:4]   # 212 000 decisions; the near-tie allowance above is for the split arithmetic
+    # fp32 = an exact FMA chain per element: 0 allowed; the near-tie allowance is for the split arithmetic only
+    assert len(flips) <= MAX_FLIPS[mode], "%d teacher-forced disagreements in %d decisions: %s" % (len(flips), 100 * B * 265, flips[:4])
 
 
 def test_teacher_forced_batch64_padded_rows(model, g):
     """The same 100 teacher-forced steps AT THE BENCHMARKED BATCH SIZE, where the step runs in padded-row mode (272 rows
     per sample, per-sample GEMM program with a 16-row ninth block: csrc/api.hip rows_per_sample): the 8 reference captions
     replicated 8 times = 64 clips.  Every replica must reproduce the reference's tokens (disagreements only at the
-    reference's own near-ties, at most MAX_FLIPS per replica set), and the 8 replicas of a caption must agree."""
+    reference's own near-ties, at most MAX_FLIPS["f16x2"] per replica set), and the 8 replicas of a caption must agree."""
     set_precision(model, "f16x2")
     dt = model.transformer
     assert dt.transformer.row_padding
@@ -139,7 +143,7 @@ def test_teacher_forced_batch64_padded_rows(model, g):
                                                            "replica_mismatches": replica_mismatch, "detail": flips[:16]})
     unexplained = [f for f in flips if not (f["tmargin"] < CUT_TIE or f["gap"] < GAP_TIE)]
     assert not unexplained, "token disagreements away from any near-tie: %s" % unexplained[:4]
-    assert len(flips) <= MAX_FLIPS * R and replica_mismatch == 0
+    assert len(flips) <= MAX_FLIPS["f16x2"] * R and replica_mismatch == 0
 
 
 @pytest.mark.parametrize("mode", ["fp32", "f16x2"])
@@ -198,3 +202,67 @@ def test_free_running_tokens_mel_wave(model, voc, g, mode):
         else:
             assert first[b]["near_tie"], "clip %d left the reference trajectory away from a near-tie: %s" % (b, first[b])
     assert sum(same) >= MIN_EXACT_CLIPS, "only %d of %d clips reproduce the reference's tokens" % (sum(same), B)
+
+
+# ---- "same TEXT + seed": the chain entered at the caption STRINGS (BASELINE.json north_star) ------------------------------
+# traj_T100_L19 is a reference run from caption strings: oracle/make_golden.py traj_full() tokenises 8 captions with the
+# reference's Tokenize, embeds them with its fp16 CLIPTextEmbedding (the golden stores tokens and embedding) and runs the
+# 100-step loop on that embedding.  The tests above enter at `cond_emb`; this one enters at the strings: this package's
+# tokenizer -> the HIP CLIP tower (fp16 semantics) -> the same loop.  The tower is pinned to the reference to TEXT_COND_TOL on
+# unit-norm rows (an fp16 pipeline is reproducible to about that across devices / library builds, the reference's own
+# included); what that embedding difference does to the 212 000 decisions is MEASURED here and reported, with floors that
+# only catch a broken text stage.
+TEXT_COND_TOL = 5e-4
+TEXT_MIN_AGREEMENT = 0.998      # teacher-forced token agreement from the strings
+
+
+def test_same_text_and_seed_from_caption_strings(model, voc, g):
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    with open(os.path.join(ROOT, "tests", "golden", "traj_T100_L19_captions.json")) as f:
+        captions = json.load(f)
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys_clip.json")) as f:
+        clip_sd = synth.synth_state_dict(json.load(f))      # the weights oracle/ref_harness.py build_clip_text() gave the reference
+    text = build_model(default_config(n_layer=1, with_clip=True))
+    _, unexpected = text.load_state_dict(clip_sd, strict=False)
+    assert not unexpected
+    text = text.cuda().eval()
+    ids = text.condition_codec.get_tokens(captions)["token"]
+    assert torch.equal(ids.long().cpu(), g["caption_tokens"].long()), "BPE ids differ from the reference's"
+    cond = text.transformer.condition_emb(ids.cuda()).float()
+    ref_cond = g["cond_emb"].float()
+    cond_err = (cond.cpu() - ref_cond).abs().max().item()
+    set_precision(model, "f16x2")
+    dt = model.transformer
+    trace = g["step_tokens"].long()
+    B = trace.shape[1]
+    kv = dt.transformer.condition_kv(cond, dt._schedule_table())
+    flips, gaps, cuts = 0, [], []
+    for i in range(100):
+        t = 99 - i
+        x_t = torch.full((B, 265), 256, dtype=torch.long) if i == 0 else trace[i - 1]
+        tok = dt.p_sample_tokens(x_t.cuda(), kv, torch.full((B,), t, dtype=torch.long).cuda(),
+                                 noise(t, (B, 257, 265)).cuda(), initial=(i == 0)).cpu()
+        for b, p in (tok != trace[i]).nonzero().tolist():
+            flips += 1
+            gaps.append(float(g["gap"][i, b, p]))
+            cuts.append(float(g["tmargin"][i, b, p]))
+    agree = 1.0 - flips / (100.0 * B * 265)
+    out = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, noise_fn=noise)
+    tokens = out["content_token"].cpu()
+    same = [bool(torch.equal(tokens[b], g["tokens"][b].long())) for b in range(B)]
+    mel = model.decode_to_img(tokens.cuda(), (B, 256, 5, 53))
+    wave = voc(mel[:, 0], scale=0.5, shift=0.5)
+    n = g["wave_head"].shape[1]
+    e2e_mel = [(mel[b, 0].cpu() - g["mel"][b]).abs().max().item() for b in range(B) if same[b]]
+    e2e_rms = [(wave[b, 0, :n].cpu() - g["wave_head"][b]).pow(2).mean().sqrt().item() for b in range(B) if same[b]]
+    report("f16x2", "from_caption_strings", {
+        "bpe_ids_identical": True, "clip_cond_max_abs_vs_reference": cond_err,
+        "teacher_forced_decisions": 100 * B * 265, "teacher_forced_flips": flips, "teacher_forced_agreement": agree,
+        "largest_argmax_margin_of_a_flip": max(gaps, default=None), "largest_cut_margin_of_a_flip": max(cuts, default=None),
+        "free_running_clips_with_identical_tokens": sum(same),
+        "free_running_token_agreement": float((tokens == g["tokens"].long()).float().mean()),
+        "e2e_mel_max_abs_identical_clips": max(e2e_mel, default=None), "e2e_wave_rms_identical_clips": max(e2e_rms, default=None)})
+    assert cond_err < TEXT_COND_TOL
+    assert agree >= TEXT_MIN_AGREEMENT, "%d flips in %d teacher-forced decisions from the caption strings" % (flips, 100 * B * 265)
+    for m_, r_ in zip(e2e_mel, e2e_rms):
+        assert m_ < MEL_TOL and r_ < WAVE_RMS_TOL

@@ -137,7 +137,9 @@ def _grad_worker(rank, world, port, q):
         grads = {"b.weight": torch.randn(300, 7, generator=g), "a.bias": torch.randn(11, generator=g),
                  "c.emb": torch.randn(64, 33, generator=g)}
         shard.allreduce_gradients(grads, bucket_bytes=4096)        # small buckets: several flushes
-        q.put((rank, {k: v.clone() for k, v in grads.items()}))
+        # plain numpy through the queue: a torch tensor travels as a shared file descriptor, which the parent can only
+        # rebuild while this process is still alive (the test used to race the worker's exit)
+        q.put((rank, {k: v.numpy().copy() for k, v in grads.items()}))
     finally:
         dist.destroy_process_group()
 
@@ -160,6 +162,7 @@ def test_gradient_allreduce_world2():
         g = torch.Generator().manual_seed(100 + rank)
         per_rank.append({"b.weight": torch.randn(300, 7, generator=g), "a.bias": torch.randn(11, generator=g),
                          "c.emb": torch.randn(64, 33, generator=g)})
+    got = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in got.items()}
     for k in per_rank[0]:
         mean = (per_rank[0][k] + per_rank[1][k]) / 2
         assert torch.allclose(got[0][k], mean, atol=1e-6) and torch.equal(got[0][k], got[1][k])
@@ -205,7 +208,7 @@ def _ddp_worker(rank, world, port, q):
         g = torch.Generator().manual_seed(9)
         batches = [torch.randn(8, 4, generator=g) for _ in range(4)]
         lo, hi = shard.shard_bounds(8, world, rank)
-        q.put((rank, _solver_run([b[lo:hi] for b in batches], shard.allreduce_gradients)))
+        q.put((rank, _solver_run([b[lo:hi] for b in batches], shard.allreduce_gradients).numpy().copy()))   # numpy: no fd sharing
     finally:
         dist.destroy_process_group()
 
@@ -226,6 +229,7 @@ def test_data_parallel_solver_equals_single_process():
     g = torch.Generator().manual_seed(9)
     batches = [torch.randn(8, 4, generator=g) for _ in range(4)]
     single = _solver_run(batches, None)
+    got = {r: torch.from_numpy(v) for r, v in got.items()}
     assert torch.equal(got[0], got[1])
     assert torch.allclose(got[0], single, rtol=1e-5, atol=1e-7)
 
@@ -287,7 +291,7 @@ def _overlap_worker(rank, world, port, q):
                        allreduce=None if red is not None else shard.allreduce_gradients, reducer=red)
             for b in batches:
                 s.step(b[lo:hi])
-            out[mode] = ([w.clone() for w in ws], [b.clone() for b in bs])
+            out[mode] = ([w.numpy().copy() for w in ws], [b.numpy().copy() for b in bs])   # numpy: no fd sharing (see _grad_worker)
             if red is not None:
                 assert step.handed[:3] == ["w2", "w1", "w0"] and not red._inflight and not red._done
         # a name handed over twice, or one that never reaches the final dict, is an error -- not a silent wrong reduction
@@ -322,6 +326,7 @@ def test_overlapped_gradient_reduction_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    got = {r: {m: tuple([torch.from_numpy(x) for x in part] for part in pair) for m, pair in d.items()} for r, d in got.items()}
     for kind in (0, 1):
         for a, b, c, d in zip(got[0]["overlapped"][kind], got[1]["overlapped"][kind], got[0]["after"][kind],
                               got[1]["after"][kind]):

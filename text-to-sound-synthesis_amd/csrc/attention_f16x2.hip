@@ -3,332 +3,557 @@
 // 16x slower rate.  Same contract as ds_attention (attention.hip); replaces FullAttention /
 // CrossAttention cores (transformer_utils.py:43-58, :91-109) when the denoiser runs in f16x2 mode.
 //
-//   pass 1  S^T[key][q] = sum_d K[key][d] Q[q][d]:  k = k0 + k1, q = q0 + q1 (fp16), MFMAs k1q0 + k0q1 + k0q0.
+// Round 4: STREAMED form.  Rounds 1-3 kept all 288 key slots of a head resident (72 KB of LDS per workgroup, K then V^T in
+// the same buffer) and the whole 32 x 288 score tile of a wave in registers (196 VGPRs): 1.5 waves per SIMD, phases of
+// ~100 MFMAs / ~600 VALU instructions that nothing on the SIMD could overlap with (profiles/r02g_attn_kernel_timeline.txt).
+// Now a workgroup (3 waves = 3 query tiles of 32) walks the keys in CHUNKS of 96 (three 32-key tiles) with a running row
+// maximum / row sum (the online-softmax recurrence): 48 score registers instead of 144, 24 KB of K + 24 KB of V^T per
+// workgroup instead of 72 KB -- three workgroups per CU at <= 168 registers, whose short MFMA and VALU phases interleave.
+//
+//   scores  S^T[key][q] = sum_d K[key][d] Q[q][d]:  k = k0 + k1, q = q0 + q1 (fp16), MFMAs k1q0 + k0q1 + k0q0.
 //           A operand = K rows from LDS (two fp16 planes, 128-byte rows, 16-byte chunks XOR-swizzled by
 //           (key>>1)&7 -> conflict-free ds_read_b128), B operand = the wave's own Q rows in registers.
 //           Transposed scores: lane&31 is the query, the keys of a tile are spread over the 16 accumulator
-//           registers, so the softmax is in-lane + one cross-half shuffle (as in attention.hip).
+//           registers, so the softmax statistics are in-lane + one cross-half shuffle.
 //           MFMA row i of a 32-key tile is fed with key pi(i) (bits 2 and 3 of i swapped, ds_attn_pi), so that
 //           accumulator register r of lane half h holds key (r&3) + 4((r>>2)&1) + 8h + 16(r>>3): the 8 registers
 //           of a k-step are 8 CONSECUTIVE keys.
-//   pass 2  O[q][d] = sum_key P[q][key] V[key][d]:  the P registers are split (p0 + p1) and packed straight
-//           into the MFMA A operand: k-step s of a 32-key tile takes registers 8s..8s+7 = keys 16s + 8*half + e.
-//           V is staged TRANSPOSED in natural key order, VT[plane][d][key], so the B operand is one ds_read_b128
-//           per plane (16-byte chunks swizzled by (d>>2)&3).  MFMAs p1v0 + p0v1 + p0v0.
-// K and V^T share one 72 KB LDS buffer (K first), so two workgroups fit per CU.
+//   output  O^T[d][q] = sum_key V^T[d][key] P[q][key]  (TRANSPOSED as well since round 4: A operand = V^T rows from LDS,
+//           one ds_read_b128 per plane; B operand = the P registers, split p0 + p1 and packed: k-step s of a 32-key
+//           tile takes registers 8s..8s+7 = keys 16s + 8*half + e).  MFMAs v0p1 + v1p0 + v0p0.  lane&31 is the query in
+//           the scores AND in the output, so the rescale by exp(m_old - m_new) when the running maximum moves and the
+//           final division by the row sum are in-lane multiplies (the round-3 form needed 16 cross-lane reads for the
+//           normalisation alone), and a lane owns 4 consecutive d per register quad: 8-byte staging writes.
+// LDS per workgroup: K chunk [2 planes][96 keys][64 d] + V^T chunk [2 planes][4 d-blocks][3 key tiles][16 d][32 keys]
+// (1 KB tiles = what ONE LDS-DMA instruction moves: lane -> (d = lane>>2, 16-byte piece = lane&3)), 48 KB.
 //
-// READY variant (the denoiser's path): Q arrives as two fp16 planes and K / V^T as ready-made LDS images
+// READY variant (the denoiser's path): Q arrives as two fp16 planes and K / V^T as ready-made images
 // (common.h "attention-ready operands", written by the QKV / cross-Q GEMM epilogues and ds_attn_pack_kv), so
-// staging is 1 KB LDS-DMA transfers with no conversion work, and the V^T transfer runs under the softmax.
-// The generic variant below converts fp32 Q / K / V itself and was latency-bound on that staging (per workgroup
-// ~12 us of load -> convert -> ds_write chains against ~4 us of MFMA work).
+// staging is 1 KB LDS-DMA transfers with no conversion work: chunk c + 1 of K lands under the softmax and the P V of
+// chunk c, chunk c + 1 of V^T under the scores of chunk c + 1; two barriers per chunk.
+// The generic variant converts fp32 Q / K / V itself (same arithmetic, same bits).
 #include "common.h"
+#include <type_traits>
+// (the LDS-DMA is written out with M0 as its LDS address register; hipcc warns about M0 on a clobber list)
+#pragma clang diagnostic ignored "-Winline-asm"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define AH_WAVES 3
+#ifndef AH_TPC
+#define AH_TPC 3                       // 32-key tiles per chunk (probe switch: 2 -> 32 KB of operands, four workgroups per CU)
+#endif
+#define AH_CK (32 * AH_TPC)            // keys per chunk
+#define AH_PL (AH_CK * 64)             // halves per plane of a K or V^T chunk
+#define AH_PP (4 * AH_TPC)             // 1 KB LDS-DMA pieces per plane of a chunk
+#define AH_TS 72                       // halves per staged output row (64 + 8: 16-byte aligned, 2-way banks at most)
+#ifndef AH_KAHEAD
+#define AH_KAHEAD 2
+#endif
+#ifndef AH_WPE1                        // waves per SIMD the one-chunk READY kernel (cross-attention) is compiled for
+#define AH_WPE1 3
+#endif
+#ifndef AH_PRIO                        // probe switch: 1 = s_setprio 1 around the MFMA phases, 2 = static priority by query group
+#define AH_PRIO 0
+#endif
+#ifndef AH_VAHEAD
+#define AH_VAHEAD 1
+#endif
+#ifndef AH_XSHARE                      // READY: K and V^T chunks share ONE buffer (V^T lands under the softmax, the next K chunk
+#define AH_XSHARE 1                    // next K chunk is waited for) -> four (self) / five (cross) workgroups per CU.  0 = separate buffers (probe switch)
+#endif
 
 __device__ __forceinline__ _Float16 ah_hi(float a) { return ds_split_hi(a); }
 __device__ __forceinline__ _Float16 ah_lo(float a, _Float16 h) { return ds_split_lo(a, h); }
 
 typedef __attribute__((address_space(1))) const void* ah_gptr;
 typedef __attribute__((address_space(3))) void* ah_lptr;
+typedef float ah_f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ah_h2 __attribute__((ext_vector_type(2)));
+typedef unsigned ah_u4 __attribute__((ext_vector_type(4)));
+
+// halves offset of V^T element (d, local key kl) inside one plane of the V^T chunk buffer
+__device__ __forceinline__ int ah_vt_off(int d, int kl) {
+    return (((d >> 4) * AH_TPC + (kl >> 5)) << 9) + ((d & 15) << 5) + ((((kl >> 3) & 3) ^ ((d >> 2) & 3)) << 3) + (kl & 7);
+}
+
+// fp16 split of two probabilities e0, e1 in [0, 1] as packed pairs: p0 = RNE(e) by v_cvt_pk_f16_f32, p1 = RNE(e - p0) by
+// v_fma_mix{lo,hi}_f16 (an fp32 fma p0 * -1 + e, exact, rounded once to fp16) -- the same bits as
+// (_Float16)(e - (float)(_Float16)e) in 1.5 instead of 2.5 instructions per value (hipcc: cvt_pk + 2 cvt_f32 + pk_add + cvt_pk)
+__device__ __forceinline__ void ah_split2(float e0, float e1, unsigned& p0, unsigned& p1) {
+    const ah_f2 pr = {e0, e1};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, ah_h2));
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p0), "v"(e0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(p0), "v"(e1));
+    p1 = r;
+}
 
 template <int NKT, bool READY>
-__global__ __launch_bounds__(AH_WAVES * 64, 2) void ds_attn_f16x2_kernel(const float* __restrict__ Q, int ldq,
+__global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC == 1 ? AH_WPE1 : 3) : 2) void ds_attn_f16x2_kernel(const float* __restrict__ Q, int ldq,
                                                                         const float* __restrict__ Kp, int ldk,
                                                                         const float* __restrict__ Vp, int ldv,
                                                                         float* __restrict__ O, int ldo, int Lq, int Lk,
                                                                         int heads, float scale, long long o_plane,
                                                                         long long q_plane) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int TPC = AH_TPC;
+    constexpr int NCH = (NKT + TPC - 1) / TPC;   // chunks the images hold (self: 288 key slots, cross: 96)
     constexpr int NKEY = NKT * 32;
-    constexpr int KPL = NKEY * 64;   // halves per K plane   ([key][64 d])
-    constexpr int VPL = 64 * NKEY;   // halves per V^T plane ([d][NKEY keys, permuted])
-    _Float16* buf = (_Float16*)smem_raw;   // K: [2][NKEY][64]   then   V^T: [2][64][NKEY]   (same size)
+    constexpr int KPL = NKEY * 64;   // halves per K plane of the image ([key][64 d]) = per V^T plane ([d][NKEY])
+    constexpr bool XS = READY && AH_XSHARE;
+    _Float16* Kb = (_Float16*)smem_raw;            // [2][AH_CK][64]
+    _Float16* Vb = Kb + (XS ? 0 : 2 * AH_PL);      // [2][4 d-blocks][TPC][16][32]
+    constexpr int VB_BYTES = XS ? 0 : 4 * AH_PL;   // byte offset of the V^T chunk buffer
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int head = blockIdx.x % heads;
     const int grp = blockIdx.x / heads;
     const int b = blockIdx.y;
     const int q0 = (grp * AH_WAVES + wave) * 32;
     const bool active = q0 < Lq;   // wave-uniform
+    const int nch = (Lk + AH_CK - 1) / AH_CK;   // chunks that hold keys (<= NCH by the launch rule)
 
     const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
     const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
-#ifdef AH_TIMING   // probe build only (tools/attn_timing.py): per-workgroup s_memrealtime stamps through the unused V pointer
-    unsigned long long ah_ts[6];
-#define AH_STAMP(i_) do { ah_ts[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    AH_STAMP(0);
+#ifdef AH_TIMING   // probe build only (tools/attn_timing.py): per-wave s_memrealtime accounting through the unused V pointer
+    unsigned long long ah_t0 = __builtin_amdgcn_s_memrealtime(), ah_tl = ah_t0, ah_acc[6] = {0, 0, 0, 0, 0, 0};
+#define AH_STAMP(i_) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ah_acc[i_] += n_ - ah_tl; ah_tl = n_; } while (0)
 #else
 #define AH_STAMP(i_) do { } while (0)
 #endif
 
     // READY: this (sample, head)'s image  K hi | K lo | V^T hi | V^T lo  (bytes), NKEY/4 KB per operand
     const unsigned char* img = (const unsigned char*)Kp + ((size_t)b * heads + head) * (size_t)(8 * KPL);
-    constexpr int NDMA = NKEY / 4 / AH_WAVES;   // 1 KB transfers per wave per operand: 24 (self) / 8 (cross)
-    static_assert(NKEY / 4 % AH_WAVES == 0, "whole transfers per wave");
-    if constexpr (READY) {
-#pragma unroll
-        for (int j = 0; j < NDMA; ++j) {
-            const int piece = j * AH_WAVES + wave;
-            __builtin_amdgcn_global_load_lds((ah_gptr)(img + piece * 1024 + lane * 16),
-                                             (ah_lptr)(smem_raw + piece * 1024), 16, 0, 0);
-        }
-    } else {
-        // ---- stage K: fp32 -> two fp16 planes, 8-byte half-chunks, chunk swizzle (key>>1)&7 ----
-        // (loads are issued 8 deep before the first dependent conversion: a load -> convert -> ds_write chain
-        //  per iteration would serialise 24 L2/HBM round trips per thread)
-        constexpr int NIT = NKEY * 16 / (AH_WAVES * 64);   // 24 (self) / 8 (cross), exact
-        static_assert(NIT % 8 == 0, "staging loop is unrolled 8 deep");
-        for (int it0 = 0; it0 < NIT; it0 += 8) {
-            f32x4 v[8];
-    #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int f = tid + (it0 + u) * (AH_WAVES * 64);
-                const int row = f >> 4, c4 = f & 15;          // 4 consecutive d at c4*4
-                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (row < Lk) v[u] = *(const f32x4*)(kb + (size_t)row * ldk + c4 * 4);
-            }
-    #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int f = tid + (it0 + u) * (AH_WAVES * 64);
-                const int row = f >> 4, c4 = f & 15;
-                h4 s0, s1;
-    #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s0[e] = ah_hi(v[u][e]);
-                    s1[e] = ah_lo(v[u][e], s0[e]);
-                }
-                const int chunk = (c4 >> 1) ^ ((row >> 1) & 7);
-                _Float16* dst = buf + row * 64 + chunk * 8 + (c4 & 1) * 4;
-                *(h4*)dst = s0;
-                *(h4*)(dst + KPL) = s1;
-            }
-        }
+    const unsigned vlane = (lane >> 2) * (NKEY * 2) + (lane & 3) * 16;   // V^T gather: lane -> (d row, 16-byte piece) of a tile
+
+    // 2 * AH_PP one-KB transfers per operand and chunk, dealt round-robin to the waves: transfer p = plane (p / AH_PP),
+    // piece (p % AH_PP); the pieces of key tiles the image does not have (last chunk, NKT % TPC != 0) are skipped.
+    // Written out as  SGPR base + ONE per-lane byte offset  (the form of gemm_f16x2_ps.hip): through the builtin hipcc
+    // keeps a 64-bit per-lane pointer per transfer alive across the chunk loop -- 32 VGPRs this kernel does not have.
+    constexpr int NXF = (2 * AH_PP + AH_WAVES - 1) / AH_WAVES;
+    unsigned long long img_s;      // wave-uniform image base in SGPRs
+    {
+        const unsigned long long a_ = (unsigned long long)img;
+        img_s = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
+                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);
     }
-    // ---- Q operand: lane (q = l31, half hh) keeps Q[q][16 ks + 8 hh + 0..7], ks = 0..3, both planes ----
-    h8 q_hi[4], q_lo[4];
-    if constexpr (READY) {
-        int qr = q0 + l31;
-        if (qr >= Lq) qr = Lq - 1;
-        const _Float16* qp = (const _Float16*)Q + (((size_t)b * heads + head) * Lq + qr) * 64 + 8 * hh;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw);
+    const unsigned klane = lane * 16;
+#define AH_DMA(vofs_, base_, lds_)                                                                   \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vofs_), "s"(base_), "s"(lds_) : "memory", "m0")
+    auto issue_k = [&](int c) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            q_hi[ks] = *(const h8*)(qp + 16 * ks);
-            q_lo[ks] = *(const h8*)(qp + q_plane + 16 * ks);
+        for (int j = 0; j < NXF; ++j) {
+            const int p = j * AH_WAVES + wave, pl = p >= AH_PP ? 1 : 0, pp = p - AH_PP * pl;   // pp / 4 = key tile
+            if (p < 2 * AH_PP && c * TPC + (pp >> 2) < NKT) {
+                const unsigned long long src = img_s + (unsigned long long)(pl * (2 * KPL) + c * (AH_CK * 128) + pp * 1024);
+                const unsigned dst = lds0 + pl * (2 * AH_PL) + pp * 1024;
+                AH_DMA(klane, src, dst);
+            }
         }
-    } else {
-        int qr = q0 + l31;
-        if (qr >= Lq) qr = Lq - 1;
-        const float* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 64 + 8 * hh;
+    };
+    auto issue_v = [&](int c) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const f32x4 a = *(const f32x4*)(qp + 16 * ks), c = *(const f32x4*)(qp + 16 * ks + 4);
+        for (int j = 0; j < NXF; ++j) {
+            const int p = j * AH_WAVES + wave, pl = p >= AH_PP ? 1 : 0, pp = p - AH_PP * pl;   // pp = d-block * TPC + key tile
+            const int db = pp / TPC, kt = pp - TPC * db;
+            if (p < 2 * AH_PP && c * TPC + kt < NKT) {
+                const unsigned long long src = img_s + (unsigned long long)((2 + pl) * (2 * KPL) + db * (16 * NKEY * 2) + (c * AH_PP + kt * 4) * 16);
+                const unsigned dst = lds0 + VB_BYTES + pl * (2 * AH_PL) + pp * 1024;
+                AH_DMA(vlane, src, dst);
+            }
+        }
+    };
+    // generic variant: fp32 rows -> fp16 planes in the same LDS layouts (keys >= Lk are zero rows)
+    auto stage_k = [&](int c) {
+        constexpr int NIT = (AH_CK * 16 + AH_WAVES * 64 - 1) / (AH_WAVES * 64);   // AH_CK keys x 16 float4 over 192 threads
+        f32x4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {      // loads first (NIT round trips in flight)
+            const int f = tid + u * (AH_WAVES * 64), row = f >> 4, c4 = f & 15;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < AH_CK && c * AH_CK + row < Lk) v[u] = *(const f32x4*)(kb + (size_t)(c * AH_CK + row) * ldk + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int f = tid + u * (AH_WAVES * 64), row = f >> 4, c4 = f & 15;
+            if (row >= AH_CK) break;
+            h4 s0, s1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                q_hi[ks][e] = ah_hi(a[e]);
-                q_lo[ks][e] = ah_lo(a[e], q_hi[ks][e]);
-                q_hi[ks][4 + e] = ah_hi(c[e]);
-                q_lo[ks][4 + e] = ah_lo(c[e], q_hi[ks][4 + e]);
+                s0[e] = ah_hi(v[u][e]);
+                s1[e] = ah_lo(v[u][e], s0[e]);
             }
+            _Float16* dst = Kb + row * 64 + ((c4 >> 1) ^ ((row >> 1) & 7)) * 8 + (c4 & 1) * 4;
+            *(h4*)dst = s0;
+            *(h4*)(dst + AH_PL) = s1;
         }
-    }
-    // (explicit: hipcc does not reliably add the vmcnt(0) an in-flight LDS-DMA needs before a barrier, see gemm_f16x2.hip)
-    if constexpr (READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // K is in LDS
-    AH_STAMP(1);
-
-    f32x16 s[NKT];
-    if (active) {
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-            const int key = kt * 32 + ds_attn_pi(l31);
-            const _Float16* kr = buf + key * 64;
-            const int sw = (key >> 1) & 7;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = ((2 * ks + hh) ^ sw) * 8;
-                const h8 k0 = *(const h8*)(kr + off), k1 = *(const h8*)(kr + KPL + off);
-                f32x16 c = s[kt];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q_hi[ks], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q_lo[ks], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q_hi[ks], c, 0, 0, 0);
-                s[kt] = c;
-            }
-        }
-    }
-    AH_STAMP(2);
-    __syncthreads();  // everyone is done reading K
-
-    if constexpr (READY) {   // the V^T image replaces K in the same buffer; the transfer runs under the softmax
-#pragma unroll 4   // (the score registers are live here: a fully unrolled loop's 24 address pairs would spill)
-        for (int j = 0; j < NDMA; ++j) {
-            const int piece = j * AH_WAVES + wave;
-            __builtin_amdgcn_global_load_lds((ah_gptr)(img + 4 * KPL + piece * 1024 + lane * 16),
-                                             (ah_lptr)(smem_raw + piece * 1024), 16, 0, 0);
-        }
-    } else {
-        // ---- stage V transposed + key-permuted: VT[plane][d][kt*32 + s*16 + half*8 + e], chunk swizzle (d>>2)&3 ----
-        // Work item = (group of 4 consecutive keys, 4 consecutive d): the 4 keys are e&3 = 0..3 of one (tile, s, half,
-        // e>>2) slot, i.e. 4 contiguous halves of a V^T row -> one ds_write_b64 per (d, plane) instead of four b16 writes.
-        constexpr int NITV = NKEY / 4 * 16 / (AH_WAVES * 64);   // 6 (self) / 2 (cross)
-    #pragma unroll
-        for (int it = 0; it < NITV; ++it) {
-            const int f = tid + it * (AH_WAVES * 64);
-            const int kg = f >> 4, c4 = f & 15;                 // keys 4kg .. 4kg+3, d = 4 c4 .. 4 c4 + 3
+    };
+    auto stage_v = [&](int c) {
+        // work item = (4 consecutive keys, 4 consecutive d): AH_CK / 4 x 16 items
+        for (int f = tid; f < AH_CK * 4; f += AH_WAVES * 64) {
+            const int kg = f >> 4, c4 = f & 15;
             f32x4 v[4];
-    #pragma unroll
+#pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
-                const int key = 4 * kg + kx;
+                const int key = c * AH_CK + 4 * kg + kx;
                 v[kx] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (key < Lk) v[kx] = *(const f32x4*)(vb + (size_t)key * ldv + c4 * 4);
             }
-            const int e0 = (4 * kg) & 7;                        // e = e0 + kx inside the 8-key chunk
-            const int chunk = (4 * kg) >> 3;
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int d = c4 * 4 + j;
                 h4 s0, s1;
-    #pragma unroll
+#pragma unroll
                 for (int kx = 0; kx < 4; ++kx) {
                     s0[kx] = ah_hi(v[kx][j]);
                     s1[kx] = ah_lo(v[kx][j], s0[kx]);
                 }
-                _Float16* dst = buf + d * NKEY + ((chunk ^ ((d >> 2) & 3)) * 8) + e0;
+                _Float16* dst = Vb + ah_vt_off(c4 * 4 + j, 4 * kg);
                 *(h4*)dst = s0;
-                *(h4*)(dst + VPL) = s1;
+                *(h4*)(dst + AH_PL) = s1;
+            }
+        }
+    };
+
+    if constexpr (READY) {
+        issue_k(0);
+        if constexpr (!XS) issue_v(0);
+    }
+    // ---- Q operand: lane (q = l31, half hh) keeps Q[q][16 ks + 8 hh + 0..7], ks = 0..3, both planes ----
+    h8 q_hi[4], q_lo[4];
+    {
+        int qr = q0 + l31;
+        if (qr >= Lq) qr = Lq - 1;
+        if constexpr (READY) {
+            const _Float16* qp = (const _Float16*)Q + (((size_t)b * heads + head) * Lq + qr) * 64 + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                q_hi[ks] = *(const h8*)(qp + 16 * ks);
+                q_lo[ks] = *(const h8*)(qp + q_plane + 16 * ks);
+            }
+        } else {
+            const float* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 64 + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 a = *(const f32x4*)(qp + 16 * ks), c = *(const f32x4*)(qp + 16 * ks + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q_hi[ks][e] = ah_hi(a[e]);
+                    q_lo[ks][e] = ah_lo(a[e], q_hi[ks][e]);
+                    q_hi[ks][4 + e] = ah_hi(c[e]);
+                    q_lo[ks][4 + e] = ah_lo(c[e], q_hi[ks][4 + e]);
+                }
             }
         }
     }
+    if constexpr (READY) {
+        // (explicit: hipcc does not reliably add the vmcnt(0) an in-flight LDS-DMA needs before a barrier, see gemm_f16x2.hip)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        stage_k(0);
+        stage_v(0);
+    }
+    __syncthreads();   // chunk 0 of K (and V^T) is in LDS
+    AH_STAMP(0);
 
-    // ---- softmax over keys (fp32, in registers) ----
-    // The longest VALU stretch of a wave (measured in-kernel: 5.9 of 23 us), so it is kept to 4 operations per score:
-    // the row maximum is taken on the RAW scores (scale > 0), keys past Lk are masked only in the tiles that contain
-    // them, each exponential is one v_fma (scale into the log2 domain and subtract the maximum) + one v_exp, and the
-    // division by the row sum is applied to the 32 output values after P V instead of to the 144 probabilities (the
-    // unnormalised e <= 1 splits into fp16 planes exactly as well).
-    float inv = 1.f;
-    if (active) {
-        const float sl = scale * 1.4426950408889634f;   // exp(x) = 2^(x log2 e)
-        float mx = -INFINITY;
+    const float sl = scale * 1.4426950408889634f;   // exp(x) = 2^(x log2 e)
+    float m_run = -INFINITY, l_run = 0.f;           // running row maximum (raw scores) / row sum of this lane's keys
+    f32x16 o[2];                                    // O^T: register r = d (r&3) + 8 (r>>2) + 4 hh (+ 32 for o[1]), lane&31 = query
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            if (kt * 32 + 32 > Lk) {                    // wave-uniform: this tile holds keys >= Lk
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    f32x16 s[TPC];                                  // S^T of the current chunk, then its exponentials
+
+    // scores of chunk c.  FULL: all AH_CK keys of the chunk are < Lk -- straight-line code, no masks, no tests; the K
+    // fragments are read two k-steps ahead of their MFMAs and every k-step is its own scheduling region (left to itself
+    // hipcc hoists every fragment read of the chunk to the top: 40+ registers of spills at the 168 this kernel may use)
+    auto kfrag = [&](int it, h8& k0, h8& k1) {       // it = key tile * 4 + k-step
+        const int kl = (it >> 2) * 32 + ds_attn_pi(l31);
+        const _Float16* kr = Kb + kl * 64 + ((((2 * (it & 3) + hh) ^ ((kl >> 1) & 7))) << 3);
+        k0 = *(const h8*)kr;
+        k1 = *(const h8*)(kr + AH_PL);
+    };
+    auto scores = [&](auto full_tag, int c) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        if constexpr (FULL) {
+            constexpr int NIT = 4 * TPC;
+            constexpr int KA = AH_KAHEAD;           // k-steps a fragment is read ahead of its MFMAs
+            h8 kf[KA + 1][2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hh + 16 * (r >> 3);   // pi(MFMA row)
-                    s[kt][r] = key < Lk ? s[kt][r] : -INFINITY;
+            for (int it = 0; it < KA; ++it) kfrag(it, kf[it][0], kf[it][1]);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (it + KA < NIT) kfrag(it + KA, kf[(it + KA) % (KA + 1)][0], kf[(it + KA) % (KA + 1)][1]);
+                const int kt = it >> 2, ks = it & 3;
+                f32x16 a;
+                if (ks == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+                } else {
+                    a = s[kt];
                 }
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[it % (KA + 1)][1], q_hi[ks], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[it % (KA + 1)][0], q_lo[ks], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[it % (KA + 1)][0], q_hi[ks], a, 0, 0, 0);
+                s[kt] = a;
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < TPC; ++kt) {
+                const int kbase = c * AH_CK + kt * 32;
+                if (kbase < Lk) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        h8 k0, k1;
+                        kfrag(kt * 4 + ks, k0, k1);
+                        f32x16 a = s[kt];
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q_hi[ks], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q_lo[ks], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q_hi[ks], a, 0, 0, 0);
+                        s[kt] = a;
+                    }
+                    if (kbase + 32 > Lk) {   // wave-uniform: this tile holds keys >= Lk
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = kbase + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hh + 16 * (r >> 3);   // pi(MFMA row)
+                            s[kt][r] = key < Lk ? s[kt][r] : -INFINITY;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kt][r] = -INFINITY;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // online softmax: new running maximum, rescale what is accumulated, exponentials of this chunk (first chunk: m_run =
+    // -inf makes the rescale factor 2^-inf = 0 on accumulators that are still 0)
+    auto softmax = [&]() {
+        float mx = m_run;
+#pragma unroll
+        for (int kt = 0; kt < TPC; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float msl = mx * sl;
+        const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, sl, -msl));
+        l_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        m_run = mx;
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < TPC; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sl, -msl));   // masked: 2^-inf = 0
                 s[kt][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 32);
-        inv = 1.f / sum;
-    }
-    AH_STAMP(3);
-    if constexpr (READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // V^T is in LDS
-    AH_STAMP(4);
-
-    f32x16 o0, o1;
+        l_run += sum;
+    };
+    // O^T += V^T P^T over the chunk's 16-key k-steps (FULL: all of them, the V^T fragments read one k-step ahead; else
+    // those that hold keys < Lk).  One scheduling region per k-step, as in the scores.
+    const _Float16* vr = Vb + ((l31 >> 4) * TPC << 9) + ((l31 & 15) << 5);   // d = l31; d = 32 + l31 is 2 d-blocks on
+    auto vfrag = [&](int step, h8 (&v)[4]) {           // step = key tile * 2 + half tile
+        const int off = ((step >> 1) << 9) + (((((step & 1) * 2 + hh) ^ ((l31 >> 2) & 3))) << 3);
+        v[0] = *(const h8*)(vr + off);
+        v[1] = *(const h8*)(vr + AH_PL + off);
+        v[2] = *(const h8*)(vr + 2 * TPC * 512 + off);
+        v[3] = *(const h8*)(vr + 2 * TPC * 512 + AH_PL + off);
+    };
+    auto pv_step = [&](int step, const h8 (&v)[4]) {
+        const int kt = step >> 1, st = step & 1;
+        ah_u4 p0, p1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    if (active) {
-        const _Float16* v0r = buf + l31 * NKEY;          // d = l31
-        const _Float16* v1r = buf + (32 + l31) * NKEY;   // d = 32 + l31   ((d>>2)&3 is the same for both)
-        const int sw = (l31 >> 2) & 3;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                h8 p0, p1;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pv = s[kt][8 * st + e];
-                    p0[e] = (_Float16)pv;                 // p in [0, 1]
-                    p1[e] = (_Float16)(pv - (float)p0[e]);
-                }
-                const int off = ((kt * 4 + st * 2 + hh) ^ sw) * 8;
-                const h8 va0 = *(const h8*)(v0r + off), va1 = *(const h8*)(v0r + VPL + off);
-                const h8 vb0 = *(const h8*)(v1r + off), vb1 = *(const h8*)(v1r + VPL + off);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, va0, o0, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, va1, o0, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, va0, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, vb0, o1, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, vb1, o1, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, vb0, o1, 0, 0, 0);
-            }
-    }
-    if (active) {   // normalise: output register r holds query (r & 3) + 8 (r >> 2) + 4 hh, whose 1 / sum sits in that lane
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float iq = __shfl(inv, (r & 3) + 8 * (r >> 2) + 4 * hh);
-            o0[r] *= iq;
-            o1[r] *= iq;
+        for (int e = 0; e < 4; ++e) {
+            unsigned a0, a1;
+            ah_split2(s[kt][8 * st + 2 * e], s[kt][8 * st + 2 * e + 1], a0, a1);
+            p0[e] = a0;
+            p1[e] = a1;
         }
+        const h8 ph = __builtin_bit_cast(h8, p0), pl = __builtin_bit_cast(h8, p1);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[0], pl, o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[2], pl, o[1], 0, 0, 0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[1], ph, o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[3], ph, o[1], 0, 0, 0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[0], ph, o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[2], ph, o[1], 0, 0, 0);
+    };
+    auto pv = [&](auto full_tag, int c) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int NS = 2 * TPC;
+        if constexpr (FULL) {
+#if AH_VAHEAD
+            h8 vf[2][4];
+            vfrag(0, vf[0]);
+#pragma unroll
+            for (int step = 0; step < NS; ++step) {
+                if (step + 1 < NS) vfrag(step + 1, vf[(step + 1) & 1]);
+                pv_step(step, vf[step & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
+#pragma unroll
+            for (int step = 0; step < NS; ++step) {
+                h8 v[4];
+                vfrag(step, v);
+                pv_step(step, v);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        } else {
+#pragma unroll
+            for (int step = 0; step < NS; ++step) {
+                if (c * AH_CK + step * 16 < Lk) {   // wave-uniform: k-steps past the last key are skipped
+                    h8 v[4];
+                    vfrag(step, v);
+                    pv_step(step, v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    const std::true_type yes{};
+    const std::false_type no{};
+
+    // chunks 0 .. nch-2 hold AH_CK keys < Lk each (FULL); ONE copy of that code in a rolled loop, then the last chunk
+    int c = 0;
+    if constexpr (AH_PRIO == 2) {
+        if (grp % 3 == 1) __builtin_amdgcn_s_setprio(1);
+        else if (grp % 3 == 2) __builtin_amdgcn_s_setprio(2);
     }
-    AH_STAMP(5);
+    if constexpr (NCH > 1)
+#pragma nounroll
+    for (; c + 1 < nch; ++c) {
+        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (active) scores(yes, c);
+        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        AH_STAMP(1);
+        if constexpr (XS) {
+            __syncthreads();            // every wave is done with the K chunk: V^T replaces it, landing under the softmax
+            issue_v(c);
+        } else if constexpr (READY) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's V^T (issued one barrier ago; chunk 0: in the prologue)
+            __syncthreads();            // every wave is done with the K chunk; the V^T chunk is visible
+            issue_k(c + 1);
+        }
+        AH_STAMP(2);
+        if (active) softmax();
+        AH_STAMP(3);
+        if constexpr (XS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();            // V^T is in LDS
+        }
+        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (active) pv(yes, c);
+        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        AH_STAMP(4);
+        if constexpr (XS) {
+            __syncthreads();            // every wave is done with the V^T chunk: the next K chunk replaces it
+            issue_k(c + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else if constexpr (READY) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K chunk (issued under the softmax)
+            __syncthreads();            // every wave is done with the V^T chunk; the next K chunk is visible
+            issue_v(c + 1);
+        } else {
+            __syncthreads();
+            stage_k(c + 1);
+            stage_v(c + 1);
+            __syncthreads();
+        }
+        AH_STAMP(0);
+    }
+    {   // last chunk: keys c * AH_CK .. Lk - 1
+        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (active) scores(no, c);
+        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        AH_STAMP(1);
+        if constexpr (XS) {
+            __syncthreads();
+            issue_v(c);
+        } else if constexpr (READY) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();            // (orders the V^T chunk's arrival; nothing is issued behind it)
+        }
+        AH_STAMP(2);
+        if (active) softmax();
+        AH_STAMP(3);
+        if constexpr (XS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (active) pv(no, c);
+        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        AH_STAMP(4);
+    }
+    // ---- normalise (in-lane: the row sum of query l31 is this lane's + the other half's) ----
+    if (active) {
+        const float inv = 1.f / (l_run + __shfl_xor(l_run, 32));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= inv; o[1][r] *= inv; }
+    }
     if (o_plane > 0) {
         // packed split planes for the f16x2 projection GEMM (K = ldo): each wave stages its 32 x 64 tile (hi, lo) in
-        // the now free LDS and stores 16-byte chunks (8 d of one row) instead of 2-byte pieces
-        __syncthreads();                                   // every wave is done reading V^T
+        // the now free LDS (8-byte writes: 4 consecutive d of a query) and stores 16-byte chunks (8 d of one row)
+        __syncthreads();                                   // every wave is done reading K / V^T
         if (active) {
-            _Float16* T = buf + wave * (2 * 32 * 64);      // [plane][32 rows][64 d]
+            _Float16* T = (_Float16*)smem_raw + wave * (2 * 32 * AH_TS);      // [plane][32 rows][AH_TS]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const _Float16 a0 = ds_split_hi(o0[r]), a1 = ds_split_hi(o1[r]);
-                T[rl * 64 + l31] = a0;
-                T[rl * 64 + 32 + l31] = a1;
-                T[2048 + rl * 64 + l31] = ds_split_lo(o0[r], a0);
-                T[2048 + rl * 64 + 32 + l31] = ds_split_lo(o1[r], a1);
-            }
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h4 a, c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = ds_split_hi(o[dh][4 * g + e]);
+                        c[e] = ds_split_lo(o[dh][4 * g + e], a[e]);
+                    }
+                    _Float16* dst = T + l31 * AH_TS + dh * 32 + 8 * g + 4 * hh;
+                    *(h4*)dst = a;
+                    *(h4*)(dst + 32 * AH_TS) = c;
+                }
             // (LDS operations of one wave complete in order: no barrier between its own writes and reads)
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int c = lane + 64 * it, pl = c >> 8, rl = (c >> 3) & 31, ch = c & 7;
+                const int cc = lane + 64 * it, pl = cc >> 8, rl = (cc >> 3) & 31, ch = cc & 7;
                 const int qr = q0 + rl;
                 if (qr < Lq) {
-                    const h8 val = *(const h8*)(T + pl * 2048 + rl * 64 + ch * 8);
+                    const h8 val = *(const h8*)(T + pl * (32 * AH_TS) + rl * AH_TS + ch * 8);
                     *(h8*)((_Float16*)O + (size_t)pl * o_plane + ds_packed_off(b * Lq + qr, head * 64 + ch * 8, ldo >> 5)) = val;
                 }
             }
         }
     } else if (active) {
+        const int qr = q0 + l31;
+        if (qr < Lq) {
+            float* orow = O + ((size_t)b * Lq + qr) * ldo + head * 64 + 4 * hh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (qr < Lq) {
-                const size_t off = ((size_t)b * Lq + qr) * ldo + head * 64 + l31;
-                O[off] = o0[r];
-                O[off + 32] = o1[r];
-            }
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(f32x4*)(orow + dh * 32 + 8 * g) = f32x4{o[dh][4 * g], o[dh][4 * g + 1], o[dh][4 * g + 2], o[dh][4 * g + 3]};
         }
     }
 #ifdef AH_TIMING
     if (READY && Vp && lane == 0) {
+        AH_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* o = (unsigned long long*)Vp + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * AH_WAVES + wave) * 8;
-        for (int i = 0; i < 6; ++i) o[i] = ah_ts[i];
-        o[6] = __builtin_amdgcn_s_memrealtime();
-        o[7] = active;
+        unsigned long long* ot = (unsigned long long*)Vp + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * AH_WAVES + wave) * 8;
+        ot[0] = ah_t0;                                   // entry
+        for (int i = 0; i < 5; ++i) ot[1 + i] = ah_acc[i];   // operands landed | scores | barrier + DMA issue | softmax | P V
+        ot[6] = __builtin_amdgcn_s_memrealtime();        // end (output staged and stored)
+        ot[7] = active;
     }
 #endif
 }
@@ -342,22 +567,29 @@ static int attn_f16x2_launch(const float* q, int ldq, const float* k, int ldk, c
     // the softmax takes the row maximum on the RAW scores and folds `scale` into the exp2 FMA: correct for scale > 0 only
     DS_CHECK_ARG(scale > 0.f, "scale must be positive");
     DS_CHECK_ARG(READY || (ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0), "leading dims must be multiples of 4");
+    DS_CHECK_ARG(o_plane > 0 || ldo % 4 == 0, "ldo must be a multiple of 4");
     const int qtiles = (Lq + 31) / 32;
     const int groups = (qtiles + AH_WAVES - 1) / AH_WAVES;
     dim3 grid(groups * heads, B), block(AH_WAVES * 64);
+    // K chunk + V^T chunk (one shared buffer in the READY && AH_XSHARE build), at least the staged output tiles (27 KB)
+    constexpr size_t stage_bytes = (size_t)AH_WAVES * 2 * 32 * AH_TS * sizeof(unsigned short);
+    constexpr size_t op_bytes = (size_t)(READY && AH_XSHARE ? 2 : 4) * AH_PL * sizeof(unsigned short);
+    const size_t lds = op_bytes > stage_bytes ? op_bytes : stage_bytes;
     static bool attr9 = false, attr3 = false;
     if (Lk <= 96) {
-        const size_t lds = (size_t)2 * 96 * 64 * sizeof(unsigned short);
         if (!attr3) {
-            (void)hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<3, READY>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<3, READY>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                ds_set_error("attention_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return -2;
+            }
             attr3 = true;
         }
         hipLaunchKernelGGL((ds_attn_f16x2_kernel<3, READY>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq,
                            Lk, heads, scale, o_plane, q_plane);
     } else {
         DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
-        const size_t lds = (size_t)2 * 288 * 64 * sizeof(unsigned short);
         if (!attr9) {
             hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<9, READY>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

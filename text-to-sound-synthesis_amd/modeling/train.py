@@ -316,6 +316,9 @@ class TrainStep:
         self._calib_norm = None
         if self._amax_live is not None:
             self._amax_live.zero_()
+        # a captured iteration (GraphedIteration) has the OLD pre-scales and loss scale baked into its graph: it must be
+        # re-captured BEFORE its next replay (swapped-in weights a few times larger would saturate the fp16 planes silently)
+        self._scales_epoch = getattr(self, "_scales_epoch", 0) + 1
 
     def check_loss_scale(self, force=False):
         """Host side of the saturation monitor: every `monitor_interval` calls (or when forced) read max |scaled dY| since
@@ -330,7 +333,9 @@ class TrainStep:
         self._since_check = 0
         m = float(self._amax_live.item())
         self._amax_live.zero_()
-        if math.isfinite(m) and m > 0.0 and 2.0 ** 6 <= m < 2.0 ** 15:
+        if m == 0.0:                 # genuinely zero gradients (nothing was scaled): not a reason to re-calibrate / re-capture
+            return False
+        if math.isfinite(m) and 2.0 ** 6 <= m < 2.0 ** 15:
             return False
         self.loss_scale_exp, self._calib_norm = None, None
         return True
@@ -704,6 +709,7 @@ class GraphedIteration:
             v.zero_()
         self.graph = torch.cuda.CUDAGraph()
         self.update_graph = None
+        self._scales_epoch = getattr(st, "_scales_epoch", 0)     # the scales this graph bakes in (TrainStep.reset_scales bumps it)
         st._capturing = True
         try:
             if self.reduce is None:
@@ -738,8 +744,12 @@ class GraphedIteration:
                       hyper=self.hyper)
         self.loss, self.grad_norm, self.grads = loss, total, grads
 
-    def recapture(self):
-        """New calibration of the loss scale / weight pre-scales on the current static batch, then a new graph."""
+    def recapture(self, static=None):
+        """New calibration of the loss scale / weight pre-scales on the current static batch (or `static`, the batch about
+        to run), then a new graph."""
+        if static is not None:
+            for dst, src in zip(self.static, static):
+                dst.copy_(src)
         self.step.reset_scales()
         keep_state = {k: (m.clone(), v.clone()) for k, (m, v) in self.opt_state.items()}
         self._capture()
@@ -767,6 +777,10 @@ class GraphedIteration:
 
     @torch.no_grad()
     def __call__(self, x0, cond_emb, t, pt, noise, lr):
+        if getattr(self.step, "_scales_epoch", 0) != self._scales_epoch:
+            # the weights were replaced behind the graph (checkpoint / EMA load -> TrainStep.reset_scales): its frozen
+            # pre-scales belong to the old weights.  Re-capture on THIS batch before anything is replayed.
+            self.recapture(static=(x0, cond_emb, t, pt, noise))
         for dst, src in zip(self.static, (x0, cond_emb, t, pt, noise)):
             dst.copy_(src)
         self.iteration += 1

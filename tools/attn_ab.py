@@ -44,4 +44,6 @@ for name, Lk in (("self-attention", 265), ("cross-attention", 77)):
     for i, (nm, _) in enumerate(libs):
         t = sorted(times[i])
         print("%-16s %-28s median %7.1f us  min %7.1f us" % (name, nm, t[len(t) // 2], t[0]))
-    print("%-16s outputs bit-identical: %s" % (name, torch.equal(outs[0], outs[1])))
+    val = [o[0].float() + o[1].float() for o in outs]          # hi + lo, same packed positions in both
+    print("%-16s outputs bit-identical: %s, max |a - b| %.3e (max |a| %.3e)"
+          % (name, torch.equal(outs[0], outs[1]), float((val[0] - val[1]).abs().max()), float(val[0].abs().max())))

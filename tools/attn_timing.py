@@ -1,6 +1,7 @@
 """Where a wave of the attention kernel spends its time, measured INSIDE the kernel: a probe build of
 attention_f16x2.hip (-DAH_TIMING: tools/build_variant.sh attn_timing attention_f16x2.hip -DAH_TIMING) stamps
-s_memrealtime per wave at entry / K image landed / scores done / softmax done / V^T image landed / PV done / output stored,
+s_memrealtime per wave and accumulates, over the key chunks, the time spent waiting for operands / in the scores / at the
+barrier + DMA issue / in the online softmax / in P V (round 4: streamed kernel; rounds 2-3 stamped the whole-head phases),
 on the denoiser's attention-ready path (B = 64, 16 heads; self: 265 keys, cross: 77 keys).
 
     DIFFSOUND_LIB=$PWD/gpurun_ab_attn_timing.so python tools/attn_timing.py [rows_per_sample]
@@ -52,14 +53,18 @@ for name, Lk in (("self-attention", 265), ("cross-attention", 77)):
     t = tbuf.cpu().view(nwave, 8).double()
     act = t[:, 7] > 0
     ts = t[act][:, :7] * 0.01
-    names = ["K image landed (+ Q loads)", "scores S^T = K Q^T", "softmax (+ V^T DMA issue)", "wait for V^T", "O = P V", "output staging + stores"]
+    # round-4 (streamed) kernel: slot 0 = entry, slots 1..5 = time ACCUMULATED over the chunks in
+    # operands landed | scores | barrier + DMA issue | softmax | P V, slot 6 = end
+    names = ["wait for K / V^T chunks (+ Q)", "scores S^T = K Q^T", "barrier + next DMA issue", "online softmax", "O^T = V^T P^T"]
     print("%s: Lq %d, Lk %d, %d active waves, HIP events %.1f us, first entry -> last store %.1f us"
           % (name, Lq, Lk, int(act.sum()), t_ev, float(ts[:, 6].max() - ts[:, 0].min())))
     for i, nm in enumerate(names):
-        d = ts[:, i + 1] - ts[:, i]
-        print("    %-28s mean %6.2f  min %6.2f  max %6.2f us" % (nm, float(d.mean()), float(d.min()), float(d.max())))
+        d = ts[:, i + 1]
+        print("    %-30s mean %6.2f  min %6.2f  max %6.2f us" % (nm, float(d.mean()), float(d.min()), float(d.max())))
     d = ts[:, 6] - ts[:, 0]
-    print("    %-28s mean %6.2f  min %6.2f  max %6.2f us" % ("whole wave", float(d.mean()), float(d.min()), float(d.max())))
+    rest = d - ts[:, 1:6].sum(1)
+    print("    %-30s mean %6.2f  min %6.2f  max %6.2f us" % ("normalise, stage, store", float(rest.mean()), float(rest.min()), float(rest.max())))
+    print("    %-30s mean %6.2f  min %6.2f  max %6.2f us" % ("whole wave", float(d.mean()), float(d.min()), float(d.max())))
     # residency: waves alive per CU-slot ~ sum of lifetimes / span / 256 CUs
     span = float(ts[:, 6].max() - ts[:, 0].min())
     print("    mean waves in flight per CU: %.2f" % (float(d.sum()) / span / 256.0))
