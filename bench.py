@@ -54,6 +54,10 @@ def parse():
                     help="2: the sampling loop runs the batch as two half-batches on two HIP streams")
     ap.add_argument("--transformer-only", action="store_true",
                     help="BASELINE configs[1]: CLIP + sampling loop only (no decode / vocoder); not the default metric")
+    ap.add_argument("--train-leg", action="store_true",
+                    help="also time BASELINE configs[4] (the discrete-diffusion training step, B = 20 per GPU, 19 layers: loss + "
+                         "hand-written backward + all-reduce + clip + AdamW + EMA) after the sampling measurement and add a "
+                         "\"train\" object to the JSON line; off by default (the default line is the sampling metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
@@ -435,8 +439,22 @@ def main():
         one_step(timed_stages=True)
         print("stage seconds (1 step, B=%d): %s" % (B, {k: round(v, 3) for k, v in stage.items()}), file=sys.stderr)
 
+    train = None
+    if args.train_leg:       # every rank takes part (data-parallel step; one GPU: the iteration replayed as one hipGraph)
+        del model, voc, dt
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_train
+        r = bench_train.run(batch=20, steps=10, warmup=3, n_layer=args.n_layer, codes=args.codes, precision="f16x2",
+                            graph=True, world=world, rank=rank, dev=dev, profile_gemm=(world == 1))
+        train = {"it_per_s": round(r["value"], 3), "samples_per_s": round(r["samples_per_s"], 2), "ms_per_it": round(r["ms_per_step"], 2),
+                 "gemm_tflops": r["gemm_tflops"], "allreduce_ms": round(r["ms"]["allreduce"], 3) if world > 1 else None,
+                 "batch_per_gpu": 20, "graph": r["graph"], "dtype": r["dtype"], "loss": r["loss"],
+                 "workload": r["config"]["workload"], "parallelism": r["config"]["parallelism"]}
     if rank == 0:
         line = result_line(args, world, elapsed, n_total)
+        if train is not None:
+            line["train"] = train
         if roof is not None:
             line["roofline"] = roof
         line.update(extra)

@@ -62,7 +62,7 @@ def text_stage():
     caps = synth.synth_captions(6) + ["It's 3 o'clock: RAIN &amp; thunder!!  (loud)   <café>", " ".join(["buzzing"] * 90)]
     tk = rh.reference_tokenize(caps)
     clip = rh.build_clip_text()
-    emb = clip(tk["token"][:2].clone())
+    emb = clip(tk["token"].clone())          # all 8 captions (round 4; rounds 1-3 stored the first two)
     with open(os.path.join(OUT, "captions.json"), "w") as f:
         json.dump(caps, f)
     save("text_stage", tokens=tk["token"], mask=tk["mask"], cond_emb=emb.float())

@@ -210,10 +210,12 @@ def test_free_running_tokens_mel_wave(model, voc, g, mode):
 # 100-step loop on that embedding.  The tests above enter at `cond_emb`; this one enters at the strings: this package's
 # tokenizer -> the HIP CLIP tower (fp16 semantics) -> the same loop.  The tower is pinned to the reference to TEXT_COND_TOL on
 # unit-norm rows (an fp16 pipeline is reproducible to about that across devices / library builds, the reference's own
-# included); what that embedding difference does to the 212 000 decisions is MEASURED here and reported, with floors that
-# only catch a broken text stage.
+# included); what that embedding difference does to the 212 000 decisions is MEASURED here and reported.  Measured on MI355X
+# (round 4, profiles/r04f_new_tests.log): embedding max-abs 4.3e-4, 0 of 212 000 teacher-forced decisions differ, 8 of 8
+# free-running clips end on the reference's tokens, mel 2.5e-5, waveform RMS 3.6e-7 -- the gates sit just above that.
 TEXT_COND_TOL = 5e-4
-TEXT_MIN_AGREEMENT = 0.998      # teacher-forced token agreement from the strings
+TEXT_MAX_FLIPS = 4              # teacher-forced disagreements from the strings (measured: 0)
+TEXT_MIN_EXACT_CLIPS = 7        # free-running clips (of 8) that must end on the reference's tokens (measured: 8)
 
 
 def test_same_text_and_seed_from_caption_strings(model, voc, g):
@@ -226,7 +228,11 @@ def test_same_text_and_seed_from_caption_strings(model, voc, g):
     _, unexpected = text.load_state_dict(clip_sd, strict=False)
     assert not unexpected
     text = text.cuda().eval()
-    ids = text.condition_codec.get_tokens(captions)["token"]
+    # (clip.tokenize semantics on the closed-vocabulary merge table shipped with the package -- the part of CLIP's table the
+    #  synthetic captions use; the 1.3 MB full table is not on the GPU box.  bench.py tokenises the same way.)
+    from text_to_sound_synthesis_amd import tokenizer as tz
+    ids = tz.tokenize(captions, context_length=77, add_start_and_end=True,
+                      tokenizer=tz.SimpleTokenizer(bpe_path=tz.CLOSED_VOCAB_PATH))["token"]
     assert torch.equal(ids.long().cpu(), g["caption_tokens"].long()), "BPE ids differ from the reference's"
     cond = text.transformer.condition_emb(ids.cuda()).float()
     ref_cond = g["cond_emb"].float()
@@ -263,6 +269,7 @@ def test_same_text_and_seed_from_caption_strings(model, voc, g):
         "free_running_token_agreement": float((tokens == g["tokens"].long()).float().mean()),
         "e2e_mel_max_abs_identical_clips": max(e2e_mel, default=None), "e2e_wave_rms_identical_clips": max(e2e_rms, default=None)})
     assert cond_err < TEXT_COND_TOL
-    assert agree >= TEXT_MIN_AGREEMENT, "%d flips in %d teacher-forced decisions from the caption strings" % (flips, 100 * B * 265)
+    assert flips <= TEXT_MAX_FLIPS, "%d flips in %d teacher-forced decisions from the caption strings" % (flips, 100 * B * 265)
+    assert sum(same) >= TEXT_MIN_EXACT_CLIPS, "only %d of %d clips reproduce the reference's tokens from the strings" % (sum(same), B)
     for m_, r_ in zip(e2e_mel, e2e_rms):
         assert m_ < MEL_TOL and r_ < WAVE_RMS_TOL

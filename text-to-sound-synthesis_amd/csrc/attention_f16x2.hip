@@ -41,28 +41,30 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define AH_WAVES 3
+// Probe switches (tools/build_variant.sh; the defaults are the adopted configuration, DESIGN.md section 3 "Attention"):
 #ifndef AH_TPC
-#define AH_TPC 3                       // 32-key tiles per chunk (probe switch: 2 -> 32 KB of operands, four workgroups per CU)
+#define AH_TPC 3                       // 32-key tiles per chunk, many-chunk kernel (self-attention: 288 key slots = 3 chunks of 96)
 #endif
-#define AH_CK (32 * AH_TPC)            // keys per chunk
-#define AH_PL (AH_CK * 64)             // halves per plane of a K or V^T chunk
-#define AH_PP (4 * AH_TPC)             // 1 KB LDS-DMA pieces per plane of a chunk
-#define AH_TS 72                       // halves per staged output row (64 + 8: 16-byte aligned, 2-way banks at most)
+#ifndef AH_TPC1
+#define AH_TPC1 3                      // ... of the kernel for <= 96 keys (cross-attention): 3 = one chunk
+#endif
 #ifndef AH_KAHEAD
-#define AH_KAHEAD 2
-#endif
-#ifndef AH_WPE1                        // waves per SIMD the one-chunk READY kernel (cross-attention) is compiled for
-#define AH_WPE1 3
-#endif
-#ifndef AH_PRIO                        // probe switch: 1 = s_setprio 1 around the MFMA phases, 2 = static priority by query group
-#define AH_PRIO 0
+#define AH_KAHEAD 2                    // k-steps a K fragment is read ahead of its MFMAs
 #endif
 #ifndef AH_VAHEAD
-#define AH_VAHEAD 1
+#define AH_VAHEAD 1                    // V^T fragments read one k-step ahead
 #endif
-#ifndef AH_XSHARE                      // READY: K and V^T chunks share ONE buffer (V^T lands under the softmax, the next K chunk
-#define AH_XSHARE 1                    // next K chunk is waited for) -> four (self) / five (cross) workgroups per CU.  0 = separate buffers (probe switch)
+#ifndef AH_XSHARE
+#define AH_XSHARE 1                    // READY: K and V^T chunks share ONE LDS buffer (4 / 5 workgroups per CU; every next K chunk is waited for)
 #endif
+#ifndef AH_PERSIST
+#define AH_PERSIST 0                   // READY, separate buffers (AH_XSHARE 0): a workgroup walks several (sample, head, query group) items
+#endif                                 // and fetches the next item's first K chunk + Q rows under the last chunk of the current one.
+                                       // Measured SLOWER than one item per workgroup (profiles/r04g_*): kept as a probe switch.
+#ifndef AH_WGS_PER_CU
+#define AH_WGS_PER_CU 0                // persistent grid = CUs x this (0: what the occupancy query says)
+#endif
+#define AH_TS 72                       // halves per staged output row (64 + 8: 16-byte aligned, 2-way banks at most)
 
 __device__ __forceinline__ _Float16 ah_hi(float a) { return ds_split_hi(a); }
 __device__ __forceinline__ _Float16 ah_lo(float a, _Float16 h) { return ds_split_lo(a, h); }
@@ -73,9 +75,12 @@ typedef float ah_f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 ah_h2 __attribute__((ext_vector_type(2)));
 typedef unsigned ah_u4 __attribute__((ext_vector_type(4)));
 
-// halves offset of V^T element (d, local key kl) inside one plane of the V^T chunk buffer
+__host__ __device__ constexpr int ah_tpc(int nkt) { return nkt <= 3 ? AH_TPC1 : AH_TPC; }
+
+// halves offset of V^T element (d, local key kl) inside one plane of the V^T chunk buffer (TPC key tiles per chunk)
+template <int TPC>
 __device__ __forceinline__ int ah_vt_off(int d, int kl) {
-    return (((d >> 4) * AH_TPC + (kl >> 5)) << 9) + ((d & 15) << 5) + ((((kl >> 3) & 3) ^ ((d >> 2) & 3)) << 3) + (kl & 7);
+    return (((d >> 4) * TPC + (kl >> 5)) << 9) + ((d & 15) << 5) + ((((kl >> 3) & 3) ^ ((d >> 2) & 3)) << 3) + (kl & 7);
 }
 
 // fp16 split of two probabilities e0, e1 in [0, 1] as packed pairs: p0 = RNE(e) by v_cvt_pk_f16_f32, p1 = RNE(e - p0) by
@@ -90,35 +95,35 @@ __device__ __forceinline__ void ah_split2(float e0, float e1, unsigned& p0, unsi
     p1 = r;
 }
 
+// One ITEM = (sample b, head, query group grp): three query tiles of 32 rows (one per wave) against all keys of the head.
+// Items are numbered b * (groups * heads) + grp * heads + head; workgroup w works items w, w + gridDim.x, ... (one item per
+// workgroup unless the READY kernel is launched persistent).
 template <int NKT, bool READY>
-__global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC == 1 ? AH_WPE1 : 3) : 2) void ds_attn_f16x2_kernel(const float* __restrict__ Q, int ldq,
+__global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_kernel(const float* __restrict__ Q, int ldq,
                                                                         const float* __restrict__ Kp, int ldk,
                                                                         const float* __restrict__ Vp, int ldv,
                                                                         float* __restrict__ O, int ldo, int Lq, int Lk,
                                                                         int heads, float scale, long long o_plane,
-                                                                        long long q_plane) {
+                                                                        long long q_plane, int groups, int n_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int TPC = AH_TPC;
+    constexpr int TPC = ah_tpc(NKT);
+    constexpr int CK = 32 * TPC;                 // keys per chunk
+    constexpr int PL = CK * 64;                  // halves per plane of a K or V^T chunk
+    constexpr int PP = 4 * TPC;                  // 1 KB LDS-DMA pieces per plane of a chunk
     constexpr int NCH = (NKT + TPC - 1) / TPC;   // chunks the images hold (self: 288 key slots, cross: 96)
     constexpr int NKEY = NKT * 32;
     constexpr int KPL = NKEY * 64;   // halves per K plane of the image ([key][64 d]) = per V^T plane ([d][NKEY])
     constexpr bool XS = READY && AH_XSHARE;
-    _Float16* Kb = (_Float16*)smem_raw;            // [2][AH_CK][64]
-    _Float16* Vb = Kb + (XS ? 0 : 2 * AH_PL);      // [2][4 d-blocks][TPC][16][32]
-    constexpr int VB_BYTES = XS ? 0 : 4 * AH_PL;   // byte offset of the V^T chunk buffer
+    constexpr bool PERSIST = READY && !XS && AH_PERSIST;
+    _Float16* Kb = (_Float16*)smem_raw;            // [2][CK][64]
+    _Float16* Vb = Kb + (XS ? 0 : 2 * PL);         // [2][4 d-blocks][TPC][16][32]
+    constexpr int VB_BYTES = XS ? 0 : 4 * PL;      // byte offset of the V^T chunk buffer
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int head = blockIdx.x % heads;
-    const int grp = blockIdx.x / heads;
-    const int b = blockIdx.y;
-    const int q0 = (grp * AH_WAVES + wave) * 32;
-    const bool active = q0 < Lq;   // wave-uniform
-    const int nch = (Lk + AH_CK - 1) / AH_CK;   // chunks that hold keys (<= NCH by the launch rule)
-
-    const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
-    const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
+    const int nch = (Lk + CK - 1) / CK;          // chunks that hold keys (<= NCH by the launch rule)
+    const int per_b = groups * heads;
 #ifdef AH_TIMING   // probe build only (tools/attn_timing.py): per-wave s_memrealtime accounting through the unused V pointer
     unsigned long long ah_t0 = __builtin_amdgcn_s_memrealtime(), ah_tl = ah_t0, ah_acc[6] = {0, 0, 0, 0, 0, 0};
 #define AH_STAMP(i_) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ah_acc[i_] += n_ - ah_tl; ah_tl = n_; } while (0)
@@ -126,62 +131,60 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC
 #define AH_STAMP(i_) do { } while (0)
 #endif
 
-    // READY: this (sample, head)'s image  K hi | K lo | V^T hi | V^T lo  (bytes), NKEY/4 KB per operand
-    const unsigned char* img = (const unsigned char*)Kp + ((size_t)b * heads + head) * (size_t)(8 * KPL);
+    // READY: a (sample, head)'s image  K hi | K lo | V^T hi | V^T lo  (bytes), NKEY/4 KB per operand
     const unsigned vlane = (lane >> 2) * (NKEY * 2) + (lane & 3) * 16;   // V^T gather: lane -> (d row, 16-byte piece) of a tile
-
-    // 2 * AH_PP one-KB transfers per operand and chunk, dealt round-robin to the waves: transfer p = plane (p / AH_PP),
-    // piece (p % AH_PP); the pieces of key tiles the image does not have (last chunk, NKT % TPC != 0) are skipped.
+    const unsigned klane = lane * 16;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw);
+    // wave-uniform image base (SGPRs) of (b, head)
+    auto image_of = [&](int b_, int head_) {
+        const unsigned long long a_ = (unsigned long long)((const unsigned char*)Kp + ((size_t)b_ * heads + head_) * (size_t)(8 * KPL));
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);
+    };
+    // 2 * PP one-KB transfers per operand and chunk, dealt round-robin to the waves: transfer p = plane (p / PP), piece
+    // (p % PP); the pieces of key tiles the image does not have (last chunk, NKT % TPC != 0) are skipped.
     // Written out as  SGPR base + ONE per-lane byte offset  (the form of gemm_f16x2_ps.hip): through the builtin hipcc
     // keeps a 64-bit per-lane pointer per transfer alive across the chunk loop -- 32 VGPRs this kernel does not have.
-    constexpr int NXF = (2 * AH_PP + AH_WAVES - 1) / AH_WAVES;
-    unsigned long long img_s;      // wave-uniform image base in SGPRs
-    {
-        const unsigned long long a_ = (unsigned long long)img;
-        img_s = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32)) << 32) |
-                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a_);
-    }
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw);
-    const unsigned klane = lane * 16;
+    constexpr int NXF = (2 * PP + AH_WAVES - 1) / AH_WAVES;
 #define AH_DMA(vofs_, base_, lds_)                                                                   \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vofs_), "s"(base_), "s"(lds_) : "memory", "m0")
-    auto issue_k = [&](int c) {
+    auto issue_k = [&](unsigned long long img_s, int c) {
 #pragma unroll
         for (int j = 0; j < NXF; ++j) {
-            const int p = j * AH_WAVES + wave, pl = p >= AH_PP ? 1 : 0, pp = p - AH_PP * pl;   // pp / 4 = key tile
-            if (p < 2 * AH_PP && c * TPC + (pp >> 2) < NKT) {
-                const unsigned long long src = img_s + (unsigned long long)(pl * (2 * KPL) + c * (AH_CK * 128) + pp * 1024);
-                const unsigned dst = lds0 + pl * (2 * AH_PL) + pp * 1024;
+            const int p = j * AH_WAVES + wave, pl = p >= PP ? 1 : 0, pp = p - PP * pl;   // pp / 4 = key tile
+            if (p < 2 * PP && c * TPC + (pp >> 2) < NKT) {
+                const unsigned long long src = img_s + (unsigned long long)(pl * (2 * KPL) + c * (CK * 128) + pp * 1024);
+                const unsigned dst = lds0 + pl * (2 * PL) + pp * 1024;
                 AH_DMA(klane, src, dst);
             }
         }
     };
-    auto issue_v = [&](int c) {
+    auto issue_v = [&](unsigned long long img_s, int c) {
 #pragma unroll
         for (int j = 0; j < NXF; ++j) {
-            const int p = j * AH_WAVES + wave, pl = p >= AH_PP ? 1 : 0, pp = p - AH_PP * pl;   // pp = d-block * TPC + key tile
+            const int p = j * AH_WAVES + wave, pl = p >= PP ? 1 : 0, pp = p - PP * pl;   // pp = d-block * TPC + key tile
             const int db = pp / TPC, kt = pp - TPC * db;
-            if (p < 2 * AH_PP && c * TPC + kt < NKT) {
-                const unsigned long long src = img_s + (unsigned long long)((2 + pl) * (2 * KPL) + db * (16 * NKEY * 2) + (c * AH_PP + kt * 4) * 16);
-                const unsigned dst = lds0 + VB_BYTES + pl * (2 * AH_PL) + pp * 1024;
+            if (p < 2 * PP && c * TPC + kt < NKT) {
+                const unsigned long long src = img_s + (unsigned long long)((2 + pl) * (2 * KPL) + db * (16 * NKEY * 2) + (c * PP + kt * 4) * 16);
+                const unsigned dst = lds0 + VB_BYTES + pl * (2 * PL) + pp * 1024;
                 AH_DMA(vlane, src, dst);
             }
         }
     };
     // generic variant: fp32 rows -> fp16 planes in the same LDS layouts (keys >= Lk are zero rows)
-    auto stage_k = [&](int c) {
-        constexpr int NIT = (AH_CK * 16 + AH_WAVES * 64 - 1) / (AH_WAVES * 64);   // AH_CK keys x 16 float4 over 192 threads
+    auto stage_k = [&](const float* kb, int c) {
+        constexpr int NIT = (CK * 16 + AH_WAVES * 64 - 1) / (AH_WAVES * 64);   // CK keys x 16 float4 over 192 threads
         f32x4 v[NIT];
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {      // loads first (NIT round trips in flight)
             const int f = tid + u * (AH_WAVES * 64), row = f >> 4, c4 = f & 15;
             v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < AH_CK && c * AH_CK + row < Lk) v[u] = *(const f32x4*)(kb + (size_t)(c * AH_CK + row) * ldk + c4 * 4);
+            if (row < CK && c * CK + row < Lk) v[u] = *(const f32x4*)(kb + (size_t)(c * CK + row) * ldk + c4 * 4);
         }
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
             const int f = tid + u * (AH_WAVES * 64), row = f >> 4, c4 = f & 15;
-            if (row >= AH_CK) break;
+            if (row >= CK) break;
             h4 s0, s1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -190,17 +193,17 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC
             }
             _Float16* dst = Kb + row * 64 + ((c4 >> 1) ^ ((row >> 1) & 7)) * 8 + (c4 & 1) * 4;
             *(h4*)dst = s0;
-            *(h4*)(dst + AH_PL) = s1;
+            *(h4*)(dst + PL) = s1;
         }
     };
-    auto stage_v = [&](int c) {
-        // work item = (4 consecutive keys, 4 consecutive d): AH_CK / 4 x 16 items
-        for (int f = tid; f < AH_CK * 4; f += AH_WAVES * 64) {
+    auto stage_v = [&](const float* vb, int c) {
+        // work item = (4 consecutive keys, 4 consecutive d): CK / 4 x 16 items
+        for (int f = tid; f < CK * 4; f += AH_WAVES * 64) {
             const int kg = f >> 4, c4 = f & 15;
             f32x4 v[4];
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
-                const int key = c * AH_CK + 4 * kg + kx;
+                const int key = c * CK + 4 * kg + kx;
                 v[kx] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (key < Lk) v[kx] = *(const f32x4*)(vb + (size_t)key * ldv + c4 * 4);
             }
@@ -212,31 +215,26 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC
                     s0[kx] = ah_hi(v[kx][j]);
                     s1[kx] = ah_lo(v[kx][j], s0[kx]);
                 }
-                _Float16* dst = Vb + ah_vt_off(c4 * 4 + j, 4 * kg);
+                _Float16* dst = Vb + ah_vt_off<TPC>(c4 * 4 + j, 4 * kg);
                 *(h4*)dst = s0;
-                *(h4*)(dst + AH_PL) = s1;
+                *(h4*)(dst + PL) = s1;
             }
         }
     };
-
-    if constexpr (READY) {
-        issue_k(0);
-        if constexpr (!XS) issue_v(0);
-    }
     // ---- Q operand: lane (q = l31, half hh) keeps Q[q][16 ks + 8 hh + 0..7], ks = 0..3, both planes ----
     h8 q_hi[4], q_lo[4];
-    {
-        int qr = q0 + l31;
+    auto load_q = [&](int b_, int head_, int q0_) {
+        int qr = q0_ + l31;
         if (qr >= Lq) qr = Lq - 1;
         if constexpr (READY) {
-            const _Float16* qp = (const _Float16*)Q + (((size_t)b * heads + head) * Lq + qr) * 64 + 8 * hh;
+            const _Float16* qp = (const _Float16*)Q + (((size_t)b_ * heads + head_) * Lq + qr) * 64 + 8 * hh;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 q_hi[ks] = *(const h8*)(qp + 16 * ks);
                 q_lo[ks] = *(const h8*)(qp + q_plane + 16 * ks);
             }
         } else {
-            const float* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 64 + 8 * hh;
+            const float* qp = Q + ((size_t)b_ * Lq + qr) * ldq + head_ * 64 + 8 * hh;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const f32x4 a = *(const f32x4*)(qp + 16 * ks), c = *(const f32x4*)(qp + 16 * ks + 4);
@@ -249,38 +247,27 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC
                 }
             }
         }
-    }
-    if constexpr (READY) {
-        // (explicit: hipcc does not reliably add the vmcnt(0) an in-flight LDS-DMA needs before a barrier, see gemm_f16x2.hip)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        stage_k(0);
-        stage_v(0);
-    }
-    __syncthreads();   // chunk 0 of K (and V^T) is in LDS
-    AH_STAMP(0);
+    };
 
     const float sl = scale * 1.4426950408889634f;   // exp(x) = 2^(x log2 e)
-    float m_run = -INFINITY, l_run = 0.f;           // running row maximum (raw scores) / row sum of this lane's keys
+    float m_run, l_run;                             // running row maximum (raw scores) / row sum of this lane's keys
     f32x16 o[2];                                    // O^T: register r = d (r&3) + 8 (r>>2) + 4 hh (+ 32 for o[1]), lane&31 = query
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     f32x16 s[TPC];                                  // S^T of the current chunk, then its exponentials
 
-    // scores of chunk c.  FULL: all AH_CK keys of the chunk are < Lk -- straight-line code, no masks, no tests; the K
+    // scores of chunk c.  FULL: all CK keys of the chunk are < Lk -- straight-line code, no masks, no tests; the K
     // fragments are read two k-steps ahead of their MFMAs and every k-step is its own scheduling region (left to itself
     // hipcc hoists every fragment read of the chunk to the top: 40+ registers of spills at the 168 this kernel may use)
     auto kfrag = [&](int it, h8& k0, h8& k1) {       // it = key tile * 4 + k-step
         const int kl = (it >> 2) * 32 + ds_attn_pi(l31);
         const _Float16* kr = Kb + kl * 64 + ((((2 * (it & 3) + hh) ^ ((kl >> 1) & 7))) << 3);
         k0 = *(const h8*)kr;
-        k1 = *(const h8*)(kr + AH_PL);
+        k1 = *(const h8*)(kr + PL);
     };
     auto scores = [&](auto full_tag, int c) {
         constexpr bool FULL = decltype(full_tag)::value;
         if constexpr (FULL) {
             constexpr int NIT = 4 * TPC;
-            constexpr int KA = AH_KAHEAD;           // k-steps a fragment is read ahead of its MFMAs
+            constexpr int KA = AH_KAHEAD;
             h8 kf[KA + 1][2];
 #pragma unroll
             for (int it = 0; it < KA; ++it) kfrag(it, kf[it][0], kf[it][1]);
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC
         } else {
 #pragma unroll
             for (int kt = 0; kt < TPC; ++kt) {
-                const int kbase = c * AH_CK + kt * 32;
+                const int kbase = c * CK + kt * 32;
                 if (kbase < Lk) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
@@ -365,9 +352,9 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC
     auto vfrag = [&](int step, h8 (&v)[4]) {           // step = key tile * 2 + half tile
         const int off = ((step >> 1) << 9) + (((((step & 1) * 2 + hh) ^ ((l31 >> 2) & 3))) << 3);
         v[0] = *(const h8*)(vr + off);
-        v[1] = *(const h8*)(vr + AH_PL + off);
+        v[1] = *(const h8*)(vr + PL + off);
         v[2] = *(const h8*)(vr + 2 * TPC * 512 + off);
-        v[3] = *(const h8*)(vr + 2 * TPC * 512 + AH_PL + off);
+        v[3] = *(const h8*)(vr + 2 * TPC * 512 + PL + off);
     };
     auto pv_step = [&](int step, const h8 (&v)[4]) {
         const int kt = step >> 1, st = step & 1;
@@ -412,7 +399,7 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC
         } else {
 #pragma unroll
             for (int step = 0; step < NS; ++step) {
-                if (c * AH_CK + step * 16 < Lk) {   // wave-uniform: k-steps past the last key are skipped
+                if (c * CK + step * 16 < Lk) {   // wave-uniform: k-steps past the last key are skipped
                     h8 v[4];
                     vfrag(step, v);
                     pv_step(step, v);
@@ -424,138 +411,232 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? ((NKT + AH_TPC - 1) / AH_TPC
     const std::true_type yes{};
     const std::false_type no{};
 
-    // chunks 0 .. nch-2 hold AH_CK keys < Lk each (FULL); ONE copy of that code in a rolled loop, then the last chunk
-    int c = 0;
-    if constexpr (AH_PRIO == 2) {
-        if (grp % 3 == 1) __builtin_amdgcn_s_setprio(1);
-        else if (grp % 3 == 2) __builtin_amdgcn_s_setprio(2);
-    }
-    if constexpr (NCH > 1)
-#pragma nounroll
-    for (; c + 1 < nch; ++c) {
-        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        if (active) scores(yes, c);
-        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        AH_STAMP(1);
-        if constexpr (XS) {
-            __syncthreads();            // every wave is done with the K chunk: V^T replaces it, landing under the softmax
-            issue_v(c);
-        } else if constexpr (READY) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's V^T (issued one barrier ago; chunk 0: in the prologue)
-            __syncthreads();            // every wave is done with the K chunk; the V^T chunk is visible
-            issue_k(c + 1);
-        }
-        AH_STAMP(2);
-        if (active) softmax();
-        AH_STAMP(3);
-        if constexpr (XS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();            // V^T is in LDS
-        }
-        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        if (active) pv(yes, c);
-        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        AH_STAMP(4);
-        if constexpr (XS) {
-            __syncthreads();            // every wave is done with the V^T chunk: the next K chunk replaces it
-            issue_k(c + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        } else if constexpr (READY) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K chunk (issued under the softmax)
-            __syncthreads();            // every wave is done with the V^T chunk; the next K chunk is visible
-            issue_v(c + 1);
-        } else {
-            __syncthreads();
-            stage_k(c + 1);
-            stage_v(c + 1);
-            __syncthreads();
+    // (one pass unless the launch is persistent: the launcher gives every item its own workgroup otherwise)
+    int item = blockIdx.x;
+    if (item < n_items) while (true) {
+        const int b = item / per_b, rem = item - b * per_b;
+        const int grp = rem / heads, head = rem - grp * heads;
+        const int q0 = (grp * AH_WAVES + wave) * 32;
+        const bool active = q0 < Lq;   // wave-uniform
+        const unsigned long long img_s = image_of(b, head);
+        const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
+        const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
+        const int next = item + (int)gridDim.x;
+        const bool has_next = PERSIST && next < n_items;   // workgroup-uniform
+
+        if (!PERSIST || item == (int)blockIdx.x) {
+            // ---- first chunk of K (and V^T), the wave's Q rows ----
+            if constexpr (READY) {
+                issue_k(img_s, 0);
+                if constexpr (!XS) issue_v(img_s, 0);
+            }
+            load_q(b, head, q0);
+            if constexpr (READY) {
+                // (explicit: hipcc does not reliably add the vmcnt(0) an in-flight LDS-DMA needs before a barrier, see gemm_f16x2.hip)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                stage_k(kb, 0);
+                stage_v(vb, 0);
+            }
+            __syncthreads();   // chunk 0 of K (and V^T) is in LDS
         }
         AH_STAMP(0);
-    }
-    {   // last chunk: keys c * AH_CK .. Lk - 1
-        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        if (active) scores(no, c);
-        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        AH_STAMP(1);
-        if constexpr (XS) {
-            __syncthreads();
-            issue_v(c);
-        } else if constexpr (READY) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();            // (orders the V^T chunk's arrival; nothing is issued behind it)
+        m_run = -INFINITY;
+        l_run = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+        if constexpr (PERSIST) {
+            // the score registers are written under `if (active)`: without a definition here they would count as live
+            // across the item loop's back edge (through the whole output staging) -- 30 registers of pressure, spills
+#pragma unroll
+            for (int kt = 0; kt < TPC; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
         }
-        AH_STAMP(2);
-        if (active) softmax();
-        AH_STAMP(3);
-        if constexpr (XS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+
+        // chunks 0 .. nch-2 hold CK keys < Lk each (FULL); ONE copy of that code in a rolled loop, then the last chunk
+        int c = 0;
+        if constexpr (NCH > 1)
+#pragma nounroll
+        for (; c + 1 < nch; ++c) {
+            if (active) scores(yes, c);
+            AH_STAMP(1);
+            if constexpr (XS) {
+                __syncthreads();            // every wave is done with the K chunk: V^T replaces it, landing under the softmax
+                issue_v(img_s, c);
+            } else if constexpr (READY) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's V^T (issued one barrier ago)
+                __syncthreads();            // every wave is done with the K chunk; the V^T chunk is visible
+                issue_k(img_s, c + 1);
+            }
+            AH_STAMP(2);
+            if (active) softmax();
+            AH_STAMP(3);
+            if constexpr (XS) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();            // V^T is in LDS
+            }
+            if (active) pv(yes, c);
+            AH_STAMP(4);
+            if constexpr (XS) {
+                __syncthreads();            // every wave is done with the V^T chunk: the next K chunk replaces it
+                issue_k(img_s, c + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            } else if constexpr (READY) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K chunk (issued under the softmax)
+                __syncthreads();            // every wave is done with the V^T chunk; the next K chunk is visible
+                issue_v(img_s, c + 1);
+            } else {
+                __syncthreads();
+                stage_k(kb, c + 1);
+                stage_v(vb, c + 1);
+                __syncthreads();
+            }
+            AH_STAMP(0);
         }
-        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        if (active) pv(no, c);
-        if constexpr (AH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        AH_STAMP(4);
-    }
-    // ---- normalise (in-lane: the row sum of query l31 is this lane's + the other half's) ----
-    if (active) {
-        const float inv = 1.f / (l_run + __shfl_xor(l_run, 32));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= inv; o[1][r] *= inv; }
-    }
-    if (o_plane > 0) {
-        // packed split planes for the f16x2 projection GEMM (K = ldo): each wave stages its 32 x 64 tile (hi, lo) in
-        // the now free LDS (8-byte writes: 4 consecutive d of a query) and stores 16-byte chunks (8 d of one row)
-        __syncthreads();                                   // every wave is done reading K / V^T
-        if (active) {
-            _Float16* T = (_Float16*)smem_raw + wave * (2 * 32 * AH_TS);      // [plane][32 rows][AH_TS]
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    h4 a, c;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a[e] = ds_split_hi(o[dh][4 * g + e]);
-                        c[e] = ds_split_lo(o[dh][4 * g + e], a[e]);
-                    }
-                    _Float16* dst = T + l31 * AH_TS + dh * 32 + 8 * g + 4 * hh;
-                    *(h4*)dst = a;
-                    *(h4*)(dst + 32 * AH_TS) = c;
-                }
-            // (LDS operations of one wave complete in order: no barrier between its own writes and reads)
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int cc = lane + 64 * it, pl = cc >> 8, rl = (cc >> 3) & 31, ch = cc & 7;
-                const int qr = q0 + rl;
-                if (qr < Lq) {
-                    const h8 val = *(const h8*)(T + pl * (32 * AH_TS) + rl * AH_TS + ch * 8);
-                    *(h8*)((_Float16*)O + (size_t)pl * o_plane + ds_packed_off(b * Lq + qr, head * 64 + ch * 8, ldo >> 5)) = val;
+        {   // last chunk: keys c * CK .. Lk - 1
+            if (active) scores(no, c);
+            AH_STAMP(1);
+            if constexpr (XS) {
+                __syncthreads();
+                issue_v(img_s, c);
+            } else if constexpr (READY) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();            // every wave is done with the K chunk (and with its Q rows); V^T is visible
+                if (has_next) {
+                    // PERSIST: the next item's first K chunk and Q rows, under this item's last softmax + P V
+                    const int nb = next / per_b, nrem = next - nb * per_b, ngrp = nrem / heads, nhead = nrem - ngrp * heads;
+                    issue_k(image_of(nb, nhead), 0);
+                    load_q(nb, nhead, (ngrp * AH_WAVES + wave) * 32);
                 }
             }
+            AH_STAMP(2);
+            if (active) softmax();
+            AH_STAMP(3);
+            if constexpr (XS) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if (active) pv(no, c);
+            AH_STAMP(4);
         }
-    } else if (active) {
-        const int qr = q0 + l31;
-        if (qr < Lq) {
-            float* orow = O + ((size_t)b * Lq + qr) * ldo + head * 64 + 4 * hh;
+        // ---- normalise (in-lane: the row sum of query l31 is this lane's + the other half's) ----
+        if (active) {
+            const float inv = 1.f / (l_run + __shfl_xor(l_run, 32));
 #pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *(f32x4*)(orow + dh * 32 + 8 * g) = f32x4{o[dh][4 * g], o[dh][4 * g + 1], o[dh][4 * g + 2], o[dh][4 * g + 3]};
+            for (int r = 0; r < 16; ++r) { o[0][r] *= inv; o[1][r] *= inv; }
         }
+        if (o_plane > 0) {
+            // packed split planes for the f16x2 projection GEMM (K = ldo): each wave stages its 32 x 64 tile, one plane after
+            // the other, in the now free V^T buffer (8-byte writes: 4 consecutive d of a query) and stores 16-byte chunks (8 d
+            // of one row).  PERSIST: the next item's K chunk may be landing in the K buffer meanwhile.
+            if (has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (before this item's stores join the queue)
+            __syncthreads();                                   // every wave is done reading K / V^T; the next K chunk is visible
+            if (active) {
+                _Float16* T = (_Float16*)(smem_raw + VB_BYTES) + wave * (32 * AH_TS);      // [32 rows][AH_TS]
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            h4 a;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const _Float16 hi_ = ds_split_hi(o[dh][4 * g + e]);
+                                a[e] = pl == 0 ? hi_ : ds_split_lo(o[dh][4 * g + e], hi_);
+                            }
+                            *(h4*)(T + l31 * AH_TS + dh * 32 + 8 * g + 4 * hh) = a;
+                        }
+                    // (LDS operations of one wave complete in order: no barrier between its own writes and reads)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int cc = lane + 64 * it, rl = cc >> 3, ch = cc & 7;
+                        const int qr = q0 + rl;
+                        if (qr < Lq) {
+                            const h8 val = *(const h8*)(T + rl * AH_TS + ch * 8);
+                            *(h8*)((_Float16*)O + (size_t)pl * o_plane + ds_packed_off(b * Lq + qr, head * 64 + ch * 8, ldo >> 5)) = val;
+                        }
+                    }
+                }
+            }
+            if (has_next) {
+                __syncthreads();                               // the staged tiles are read: the buffers belong to the next item
+                issue_v(image_of(next / per_b, (next % per_b) % heads), 0);
+            }
+        } else {
+            if (active) {
+                const int qr = q0 + l31;
+                if (qr < Lq) {
+                    float* orow = O + ((size_t)b * Lq + qr) * ldo + head * 64 + 4 * hh;
+#pragma unroll
+                    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *(f32x4*)(orow + dh * 32 + 8 * g) = f32x4{o[dh][4 * g], o[dh][4 * g + 1], o[dh][4 * g + 2], o[dh][4 * g + 3]};
+                }
+            }
+            if (has_next) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                issue_v(image_of(next / per_b, (next % per_b) % heads), 0);
+            }
+        }
+        AH_STAMP(5);
+        if constexpr (!PERSIST) break;      // compile-time single pass: nothing is live around a back edge
+        item += (int)gridDim.x;
+        if (item >= n_items) break;
     }
 #ifdef AH_TIMING
     if (READY && Vp && lane == 0) {
-        AH_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* ot = (unsigned long long*)Vp + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * AH_WAVES + wave) * 8;
+        unsigned long long* ot = (unsigned long long*)Vp + ((size_t)blockIdx.x * AH_WAVES + wave) * 8;
         ot[0] = ah_t0;                                   // entry
         for (int i = 0; i < 5; ++i) ot[1 + i] = ah_acc[i];   // operands landed | scores | barrier + DMA issue | softmax | P V
         ot[6] = __builtin_amdgcn_s_memrealtime();        // end (output staged and stored)
-        ot[7] = active;
+        ot[7] = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // items this workgroup worked
     }
 #endif
+}
+
+template <int NKT, bool READY>
+static int attn_f16x2_launch_n(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                               int B, int heads, int Lq, int Lk, float scale, long long o_plane, long long q_plane,
+                               hipStream_t stream) {
+    constexpr int TPC = ah_tpc(NKT);
+    constexpr bool XS = READY && AH_XSHARE;
+    constexpr bool PERSIST = READY && !XS && AH_PERSIST;
+    const int qtiles = (Lq + 31) / 32;
+    const int groups = (qtiles + AH_WAVES - 1) / AH_WAVES;
+    const long long items = (long long)groups * heads * B;
+    DS_CHECK_ARG(items < (1ll << 30), "too many (sample, head, query group) items");
+    // K chunk + V^T chunk (one shared buffer in the XS build); the staged output plane (14 KB) lives in the V^T buffer
+    constexpr size_t stage_bytes = (size_t)AH_WAVES * 32 * AH_TS * sizeof(unsigned short);
+    constexpr size_t pl_bytes = (size_t)2 * TPC * 32 * 64 * sizeof(unsigned short);       // one operand chunk, both planes
+    constexpr size_t lds = XS ? (pl_bytes > stage_bytes ? pl_bytes : stage_bytes) : 2 * pl_bytes;
+    static_assert(pl_bytes >= stage_bytes, "the staged output plane fits in the V^T chunk buffer");
+    static int grid_cap = -1;      // persistent launches: workgroups that are resident at once
+    if (grid_cap < 0) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<NKT, READY>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            ds_set_error("attention_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        int per_cu = AH_WGS_PER_CU, dev = 0, cus = 0;
+        if (per_cu <= 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ds_attn_f16x2_kernel<NKT, READY>,
+                                                                        AH_WAVES * 64, lds) != hipSuccess)
+            per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        grid_cap = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+    }
+    const int grid = PERSIST && items > grid_cap ? grid_cap : (int)items;
+    hipLaunchKernelGGL((ds_attn_f16x2_kernel<NKT, READY>), dim3(grid), dim3(AH_WAVES * 64), lds, stream, q, ldq, k, ldk, v, ldv,
+                       o, ldo, Lq, Lk, heads, scale, o_plane, q_plane, groups, (int)items);
+    DS_CHECK_LAUNCH();
+    return 0;
 }
 
 template <bool READY>
@@ -568,42 +649,9 @@ static int attn_f16x2_launch(const float* q, int ldq, const float* k, int ldk, c
     DS_CHECK_ARG(scale > 0.f, "scale must be positive");
     DS_CHECK_ARG(READY || (ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0), "leading dims must be multiples of 4");
     DS_CHECK_ARG(o_plane > 0 || ldo % 4 == 0, "ldo must be a multiple of 4");
-    const int qtiles = (Lq + 31) / 32;
-    const int groups = (qtiles + AH_WAVES - 1) / AH_WAVES;
-    dim3 grid(groups * heads, B), block(AH_WAVES * 64);
-    // K chunk + V^T chunk (one shared buffer in the READY && AH_XSHARE build), at least the staged output tiles (27 KB)
-    constexpr size_t stage_bytes = (size_t)AH_WAVES * 2 * 32 * AH_TS * sizeof(unsigned short);
-    constexpr size_t op_bytes = (size_t)(READY && AH_XSHARE ? 2 : 4) * AH_PL * sizeof(unsigned short);
-    const size_t lds = op_bytes > stage_bytes ? op_bytes : stage_bytes;
-    static bool attr9 = false, attr3 = false;
-    if (Lk <= 96) {
-        if (!attr3) {
-            hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<3, READY>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) {
-                ds_set_error("attention_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
-                return -2;
-            }
-            attr3 = true;
-        }
-        hipLaunchKernelGGL((ds_attn_f16x2_kernel<3, READY>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq,
-                           Lk, heads, scale, o_plane, q_plane);
-    } else {
-        DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
-        if (!attr9) {
-            hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<9, READY>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) {
-                ds_set_error("attention_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
-                return -2;
-            }
-            attr9 = true;
-        }
-        hipLaunchKernelGGL((ds_attn_f16x2_kernel<9, READY>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq,
-                           Lk, heads, scale, o_plane, q_plane);
-    }
-    DS_CHECK_LAUNCH();
-    return 0;
+    if (Lk <= 96) return attn_f16x2_launch_n<3, READY>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Lq, Lk, scale, o_plane, q_plane, stream);
+    DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
+    return attn_f16x2_launch_n<9, READY>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Lq, Lk, scale, o_plane, q_plane, stream);
 }
 
 extern "C" int ds_attention_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,

@@ -52,7 +52,10 @@ for name, Lk in (("self-attention", 265), ("cross-attention", 77)):
     torch.cuda.synchronize()
     t = tbuf.cpu().view(nwave, 8).double()
     act = t[:, 7] > 0
+    items = t[act][:, 7:8]               # (sample, head, query group) items the wave worked (persistent launch: several)
     ts = t[act][:, :7] * 0.01
+    print("%s: %.0f waves resident, %.2f items per wave" % (name, float(act.sum()), float(items.mean())))
+    ts[:, 1:6] = ts[:, 1:6] / items      # per item
     # round-4 (streamed) kernel: slot 0 = entry, slots 1..5 = time ACCUMULATED over the chunks in
     # operands landed | scores | barrier + DMA issue | softmax | P V, slot 6 = end
     names = ["wait for K / V^T chunks (+ Q)", "scores S^T = K Q^T", "barrier + next DMA issue", "online softmax", "O^T = V^T P^T"]
@@ -61,10 +64,10 @@ for name, Lk in (("self-attention", 265), ("cross-attention", 77)):
     for i, nm in enumerate(names):
         d = ts[:, i + 1]
         print("    %-30s mean %6.2f  min %6.2f  max %6.2f us" % (nm, float(d.mean()), float(d.min()), float(d.max())))
-    d = ts[:, 6] - ts[:, 0]
+    d = (ts[:, 6] - ts[:, 0]) / items[:, 0]
     rest = d - ts[:, 1:6].sum(1)
     print("    %-30s mean %6.2f  min %6.2f  max %6.2f us" % ("normalise, stage, store", float(rest.mean()), float(rest.min()), float(rest.max())))
-    print("    %-30s mean %6.2f  min %6.2f  max %6.2f us" % ("whole wave", float(d.mean()), float(d.min()), float(d.max())))
+    print("    %-30s mean %6.2f  min %6.2f  max %6.2f us" % ("whole item (per wave)", float(d.mean()), float(d.min()), float(d.max())))
     # residency: waves alive per CU-slot ~ sum of lifetimes / span / 256 CUs
     span = float(ts[:, 6].max() - ts[:, 0].min())
-    print("    mean waves in flight per CU: %.2f" % (float(d.sum()) / span / 256.0))
+    print("    mean waves in flight per CU: %.2f" % (float((ts[:, 6] - ts[:, 0]).sum()) / span / 256.0))

@@ -24,41 +24,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=20, help="samples per GPU (configs/caps.yaml:136)")
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n-layer", type=int, default=19)
-    ap.add_argument("--codes", type=int, default=256)
-    ap.add_argument("--precision", default="fp32", choices=("f16x2", "fp32"),
-                    help="linear-layer GEMMs (forward, dX, dW): 3-pass fp16 split or exact-fp32 MFMA")
-    ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
-    ap.add_argument("--attention", default="fused", choices=("fused", "composed"),
-                    help="fused: ds_attention + ds_attention_bwd (recompute); composed: grouped GEMMs with stored probabilities")
-    ap.add_argument("--overlap-dw", action="store_true", help="weight-gradient GEMMs on a second HIP stream")
-    ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
-    args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
+def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", ema_device="cuda", attention="fused",
+        overlap_dw=False, graph=True, world=1, rank=0, dev=None, profile_gemm=False):
+    """Time `steps` training iterations (after `warmup`) and return the result dict (see the module docstring).
+    profile_gemm: one extra EAGER iteration with the library's per-launch HIP-event profile on (ds_profile_*), giving the
+    split / fp32 GEMMs' summed algorithmic flops over their summed durations (`gemm_tflops`)."""
     from text_to_sound_synthesis_amd import shard, synth
     from text_to_sound_synthesis_amd.config import build_model, default_config
     from text_to_sound_synthesis_amd.modeling.solver import EMA, GradClipWindow, PlateauWarmupLR, Solver
     from text_to_sound_synthesis_amd.modeling.train import TrainStep
 
-    m = build_model(default_config(n_layer=args.n_layer, diffusion_step=100, n_embed=args.codes))
+    m = build_model(default_config(n_layer=n_layer, diffusion_step=100, n_embed=codes))
     synth.synth_init_(m, seed=0)
     m = m.to(dev).eval()
     dt = m.transformer
     dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]   # configs/caps.yaml
-    B, K1, L = args.batch, args.codes + 1, 265
-    x0 = synth.synth_tokens(B, L, args.codes, mask_frac=0.0, key="bt.x0.%d" % rank).to(dev)
+    B, K1, L = batch, codes + 1, 265
+    x0 = synth.synth_tokens(B, L, codes, mask_frac=0.0, key="bt.x0.%d" % rank).to(dev)
     cond = synth.synth_cond_emb(B, key="bt.c.%d" % rank).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
@@ -86,13 +68,14 @@ def main():
             return out
 
     sched = PlateauWarmupLR(3.0e-6, factor=0.5, patience=25000, min_lr=1.0e-6, threshold=1.0e-1, warmup_lr=4.5e-4, warmup=1000)
-    ema = EMA(dt, decay=0.99, update_interval=25, device=args.ema_device)
-    if args.graph and world == 1:
+    ema = EMA(dt, decay=0.99, update_interval=25, device=ema_device)
+    use_graph = bool(graph and world == 1)
+    if use_graph:
         from text_to_sound_synthesis_amd.modeling.solver import GraphSolver
-        solver = GraphSolver(TrainStep(dt, precision=args.precision, attention=args.attention, overlap_dw=args.overlap_dw), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = GraphSolver(TrainStep(dt, precision=precision, attention=attention, overlap_dw=overlap_dw), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                              scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema)
     else:
-        solver = Solver(Timed(dt, precision=args.precision, attention=args.attention, overlap_dw=args.overlap_dw), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = Solver(Timed(dt, precision=precision, attention=attention, overlap_dw=overlap_dw), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                         scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
                         allreduce=timed_allreduce if world > 1 else None)
 
@@ -101,14 +84,14 @@ def main():
         u = torch.rand((B, K1, L), device=dev, generator=gen)
         return solver.step(x0, cond, t, pt, u)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         out = one()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     timing[0] = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = one()
     torch.cuda.synchronize()
     if world > 1:
@@ -117,19 +100,67 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = el.item()
+    timing[0] = False
     times["update"] = el - times["grads"] - times["allreduce"]
+    gemm_tflops = None
+    if profile_gemm:
+        import ctypes
+        from text_to_sound_synthesis_amd import _lib
+        Lb = _lib.lib()
+        ts = TrainStep(dt, precision=precision, attention=attention)
+        t, pt = dt.sample_time(B, dev, "importance")
+        u = torch.rand((B, K1, L), device=dev, generator=gen)
+        ts.loss_and_grads(x0, cond, t, pt, u)           # calibration / packs
+        torch.cuda.synchronize()
+        Lb.ds_profile_enable(1)
+        ts.loss_and_grads(x0, cond, t, pt, u)
+        Lb.ds_profile_enable(0)
+        ms, fl, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+        _lib.check(Lb.ds_profile_collect_n(ms, fl, n, 5))
+        if sum(ms) > 0:
+            gemm_tflops = round(sum(fl) / (sum(ms) * 1e-3) / 1e12, 2)
+    return {
+        "metric": "training iterations/s (denoiser step: loss + backward + clip + AdamW + EMA)", "value": steps / el,
+        "unit": "it/s", "samples_per_s": steps * B * world / el, "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": 1e3 * el / steps,
+        "dtype": "f32 via 2-way fp16 split (linear layers fwd + dX + dW), fp32 elsewhere" if precision == "f16x2" else "f32",
+        "data": "synthetic", "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
+        "ms": {k: 1e3 * v / steps for k, v in times.items()},
+        "gemm_tflops": gemm_tflops,
+        "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+        "graph": use_graph, "attention": attention, "overlap_dw": overlap_dw,
+        "loss_scale_exp": solver.train_step.loss_scale_exp,
+        "config": {"workload": "BASELINE configs[4]: training step, B=%d per GPU, %d layers, K=%d" % (B, n_layer, codes),
+                   "parallelism": "dp%d" % world}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=20, help="samples per GPU (configs/caps.yaml:136)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-layer", type=int, default=19)
+    ap.add_argument("--codes", type=int, default=256)
+    ap.add_argument("--precision", default="fp32", choices=("f16x2", "fp32"),
+                    help="linear-layer GEMMs (forward, dX, dW): 3-pass fp16 split or exact-fp32 MFMA")
+    ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
+    ap.add_argument("--attention", default="fused", choices=("fused", "composed"),
+                    help="fused: ds_attention + ds_attention_bwd (recompute); composed: grouped GEMMs with stored probabilities")
+    ap.add_argument("--overlap-dw", action="store_true", help="weight-gradient GEMMs on a second HIP stream")
+    ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
+    ap.add_argument("--profile-gemm", action="store_true", help="add gemm_tflops (one extra eager iteration under ds_profile_*)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    out = run(args.batch, args.steps, args.warmup, args.n_layer, args.codes, args.precision, args.ema_device, args.attention,
+              args.overlap_dw, args.graph, world, rank, dev, args.profile_gemm)
     if rank == 0:
-        print(json.dumps({
-            "metric": "training iterations/s (denoiser step: loss + backward + clip + AdamW + EMA)", "value": args.steps / el,
-            "unit": "it/s", "samples_per_s": args.steps * B * world / el, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "dtype": "f32 via 2-way fp16 split (linear layers fwd + dX + dW), fp32 elsewhere" if args.precision == "f16x2" else "f32", "data": "synthetic",
-            "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
-            "ms": {k: 1e3 * v / args.steps for k, v in times.items()},
-            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-            "graph": bool(args.graph and world == 1), "attention": args.attention, "overlap_dw": args.overlap_dw,
-            "loss_scale_exp": solver.train_step.loss_scale_exp,
-            "config": {"workload": "BASELINE configs[4]: training step, B=%d per GPU, %d layers, K=%d" % (B, args.n_layer, args.codes),
-                       "parallelism": "dp%d" % world}}))
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

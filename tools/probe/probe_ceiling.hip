@@ -167,6 +167,19 @@ int main(int argc, char** argv) {
     const int L = 272, M = B * L, H = 16;
     const int Nmax = 4096, Kmax = 4096;
     const int zero_lo = getenv("PROBE_ZERO_LO") ? atoi(getenv("PROBE_ZERO_LO")) : 0;   // 1: lo planes zero, 2: everything zero
+    // round 4: the lowest n mantissa bits of every lo-plane value cleared (the power experiment of DESIGN.md section 3:
+    // how much of the clock the chip loses to full-mantissa lo operands comes back when a few of their bits stop toggling)
+    const int mask_lo = getenv("PROBE_MASK_LO") ? atoi(getenv("PROBE_MASK_LO")) : 0;
+    auto lo_of = [&](float a, _Float16 hi) {
+        _Float16 lo = (_Float16)(a - (float)hi);
+        if (mask_lo > 0) {
+            unsigned short u;
+            memcpy(&u, &lo, 2);
+            u &= (unsigned short)(0xffffu << mask_lo);
+            memcpy(&lo, &u, 2);
+        }
+        return lo;
+    };
     // operands with the statistics of the denoiser: activations ~ N(0, 1), weights ~ N(0, 0.02) pre-scaled by 2^s so that
     // max |w| ~ 2^13 (what _lib.split_f16x2 does), both split hi + lo and stored as packed planes
     std::vector<_Float16> ha((size_t)2 * M * Kmax), hw((size_t)2 * Nmax * Kmax);
@@ -216,7 +229,7 @@ int main(int argc, char** argv) {
                     const _Float16 hi = (_Float16)a;
                     const size_t o = packed_off(r, k, K / 32);
                     ha[o] = hi;
-                    ha[(size_t)M * K + o] = zero_lo ? (_Float16)0.f : (_Float16)(a - (float)hi);
+                    ha[(size_t)M * K + o] = zero_lo ? (_Float16)0.f : lo_of(a, hi);
                 }
             for (int r = 0; r < Nmax; ++r)
                 for (int k = 0; k < K; ++k) {
@@ -224,7 +237,7 @@ int main(int argc, char** argv) {
                     const _Float16 hi = (_Float16)a;
                     const size_t o = packed_off(r, k, K / 32);
                     hw[o] = hi;
-                    hw[(size_t)Nmax * K + o] = zero_lo ? (_Float16)0.f : (_Float16)(a - (float)hi);
+                    hw[(size_t)Nmax * K + o] = zero_lo ? (_Float16)0.f : lo_of(a, hi);
                 }
             hipMemcpy(A, ha.data(), (size_t)2 * M * K * 2, hipMemcpyHostToDevice);
             hipMemcpy(W, hw.data(), (size_t)2 * Nmax * K * 2, hipMemcpyHostToDevice);
@@ -240,7 +253,7 @@ int main(int argc, char** argv) {
         if (sh.epi == 1) { p.store = DS_STORE_ROW; p.c_split = 1; p.c_plane = (long long)M * N; p.act = DS_ACT_GELU2; }
         if (sh.epi == 2) { p.store = DS_STORE_ATTN; p.attn_kv = img; p.attn_heads = H; p.attn_nkey = 288; p.attn_qplane = (long long)B * H * L * 64; }
         printf("B = %d: %s   %d tiles = %.2f per CU%s\n", B, sh.name, B * N / 256, B * N / 256 / 256.0,
-               zero_lo == 2 ? "   [all operands zero]" : zero_lo ? "   [lo planes zero]" : "");
+               zero_lo == 2 ? "   [all operands zero]" : zero_lo ? "   [lo planes zero]" : mask_lo ? "   [lo planes: low mantissa bits cleared, PROBE_MASK_LO]" : "");
         int vi = -1;
         for (const Var& v : vars) {
             ++vi;
