@@ -435,9 +435,13 @@ def main():
         if args.precision != "fp32":                   # the exact-fp32 MFMA kernel on the same shapes, for reference
             extra["roofline_fp32_mfma_kernel"] = leg("fp32", warm=0, steps=3)    # (a reference point: three steps suffice)
             dt.transformer.precision = args.precision
-    if args.stage_times and world == 1:   # (a lone rank calling the collectives of one_step would hang the others)
+    if world == 1 and not args.transformer_only:   # (a lone rank calling the collectives of one_step would hang the others)
+        # one more step with a synchronisation between the stages (outside the timed region): where a batch's time goes
         one_step(timed_stages=True)
-        print("stage seconds (1 step, B=%d): %s" % (B, {k: round(v, 3) for k, v in stage.items()}), file=sys.stderr)
+        extra["stage_ms"] = {k: round(v * 1e3, 2) for k, v in stage.items() if k != "kv"}
+        extra["stage_ms"]["note"] = "one extra step, device-synchronised between stages: tokenise+scatter | CLIP + 100-step sampling | SpecVQGAN decode | MelGAN vocode | gather"
+        if args.stage_times:
+            print("stage seconds (1 step, B=%d): %s" % (B, {k: round(v, 3) for k, v in stage.items()}), file=sys.stderr)
 
     train = None
     if args.train_leg:       # every rank takes part (data-parallel step; one GPU: the iteration replayed as one hipGraph)

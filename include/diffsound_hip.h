@@ -363,6 +363,24 @@ int ds_vq_argmin(const float* z, const float* ze, const float* ee, int64_t* idx,
  * (model.py:34-35); work >= B*ceil(P/256)*2*C doubles */
 int ds_groupnorm_stats(const float* x, int B, int P, int C, int groups, const float* gamma, const float* beta,
                        float eps, double* work, float* scale, float* shift, ds_stream_t stream);
+/* its second half alone: part = [B][nchunk][2][C] double partial sums (sum | sum of squares per channel over a chunk of
+ * the P pixels) produced elsewhere -- ds_conv3x3_f16x2 writes them per output tile (nchunk = ds_conv3x3_tiles(H, W)) */
+int ds_groupnorm_finish(const double* part, int B, int nchunk, int P, int C, int groups, const float* gamma,
+                        const float* beta, float eps, float* scale, float* shift, ds_stream_t stream);
+/* The decoder's hot 3x3 convolutions as ONE halo-tiled kernel (csrc/conv3x3_f16x2.hip): ResnetBlock conv1 / conv2 with
+ * the preceding GroupNorm + swish as a prologue (specvqgan/modules/diffusionmodules/model.py:92-151) and the Upsample
+ * conv (:37-52: nearest-2x, then conv).  x [B][H][W][Cin] channels-last fp32 ([B][H/2][W/2][Cin] when up = 1); w2 = the
+ * two fp16 planes of W * 2^s (split_f16x2 of W[Cout][9 Cin], K ordered [tap][channel]) in the fragment-packed layout
+ * [Cout/128][Cin/32][9][2 planes][2][2][2][64 lanes][8]: lane (hh = lane >> 5, l = lane & 31) of fragment (wn, j, ks) holds
+ * W[128 nt + 64 wn + 32 j + l][tap][32 slab + 16 ks + 8 hh + 0..7] (_lib.pack_conv3x3_weights), w_halves = 2 Cout 9 Cin halves
+ * in all; out_scale = 2^-s; y = conv(act(x)) + bias (+ residual) [B][H][W][Cout]; stride 1, zero padding 1 (in the activated domain, as
+ * the reference pads after the activation).  pro_scale / pro_shift [B][Cin]: GroupNorm folded to a * s + o, followed by
+ * swish; NULL = no prologue.  gn_part != NULL: also writes the GroupNorm partial sums of y, [B][ds_conv3x3_tiles(H, W)]
+ * [2][Cout] doubles, for ds_groupnorm_finish.  Cin % 32 == 0, Cout % 128 == 0; 3-pass fp16 split, fp32 accumulate. */
+int ds_conv3x3_f16x2(const float* x, const void* w2, long long w_halves, float out_scale, const float* bias,
+                     const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int up,
+                     const float* pro_scale, const float* pro_shift, double* gn_part, ds_stream_t stream);
+int ds_conv3x3_tiles(int H, int W);   /* 4 x 32 pixel tiles per image */
 /* AttnBlock softmax (model.py:214-216): x[row][0..n) <- softmax(scale*x), x[row][n..ld) <- 0 */
 int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t stream);
 /* tap-sum for single-output-channel convs fed by a GEMM with N = taps */

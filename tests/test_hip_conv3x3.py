@@ -1,0 +1,112 @@
+"""The halo-tiled 3x3 convolution (csrc/conv3x3_f16x2.hip: ds_conv3x3_f16x2, the SpecVQGAN decoder's hot convs --
+specvqgan/modules/diffusionmodules/model.py:92-151 ResnetBlock, :37-52 Upsample) against float64 and against the
+tap-by-tap kernel it replaces, and the GroupNorm partial sums of its epilogue (ds_groupnorm_finish) against the
+statistics pass (ds_groupnorm_stats).  GPU only; everything through libdiffsound_hip.so."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from text_to_sound_synthesis_amd import synth
+
+pytestmark = pytest.mark.gpu
+NO_GRAD = True
+
+
+@pytest.fixture(scope="module")
+def L():
+    from text_to_sound_synthesis_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def rnd(shape, key, scale=1.0):
+    return (synth.synth_uniform(shape, key=key) * 2 - 1) * scale
+
+
+def relerr(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30)).item()
+
+
+# (B, H, W, Cin, Cout): whole tiles, ragged tiles in both directions (H % 4, W % 32 != 0), several slabs / n-tiles
+SHAPES = [(2, 20, 212, 64, 128), (1, 6, 40, 32, 128), (2, 8, 64, 128, 256), (1, 40, 424, 256, 128)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mode", ["plain", "gn", "up"])
+def test_conv3x3_halo_vs_float64_and_gather_kernel(L, shape, mode):
+    B, H, W, Cin, Cout = shape
+    up = 1 if mode == "up" else 0
+    gn = mode == "gn"
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    x = rnd((B, hs, ws, Cin), "c3.x", 2.0)
+    x[0, 0, 0, :4] = torch.tensor([40.0, -35.0, 1e-4, 0.0])           # a corner with large values: padding / halo edges
+    w, bias = rnd((Cout, Cin, 3, 3), "c3.w", 0.1), rnd((Cout,), "c3.b")
+    R = rnd((B, H, W, Cout), "c3.r")
+    xin = x.permute(0, 3, 1, 2).double()
+    sc = sh = None
+    if gn:
+        sc, sh = rnd((B, Cin), "c3.s") + 1.5, rnd((B, Cin), "c3.o")
+        xin = xin * sc.double()[:, :, None, None] + sh.double()[:, :, None, None]
+        xin = xin * torch.sigmoid(xin)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = (F.conv2d(xin, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1) + R.double())
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().cuda()
+    w2, scale = L.split_f16x2(wp)
+    xc, Rc, bc = x.cuda(), R.cuda(), bias.cuda()
+    scc, shc = (sc.cuda(), sh.cuda()) if gn else (None, None)
+    lib = L.lib()
+    tiles = lib.ds_conv3x3_tiles(H, W)
+    assert tiles == ((H + 3) // 4) * ((W + 31) // 32)
+    part = torch.full((B, tiles, 2, Cout), float("nan"), device="cuda", dtype=torch.float64)
+    y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    wq = L.pack_conv3x3_weights(w2, Cout, Cin)
+    L.check(lib.ds_conv3x3_f16x2(L.ptr(xc), L.ptr(wq), wq.numel(), scale, L.ptr(bc), L.ptr(Rc), L.ptr(y), B, H, W, Cin, Cout,
+                                 up, L.ptr(scc), L.ptr(shc), L.ptr(part), L.stream()))
+    old = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    L.gemm(xc, w2, old, B * H * W, Cout, 9 * Cin, split2=scale, conv_split=True, bias=bc, R=Rc, loader=L.LOAD_CONV2D,
+           pro=L.PRO_AFFINE_SWISH if gn else L.PRO_NONE, pro_scale=scc, pro_shift=shc, Cin=Cin, H=H, Wd=W, up=up)
+    e_new, e_old = relerr(y.cpu(), ref), relerr(old.cpu(), ref)
+    print("conv3x3 %s %s: halo %.2e, gather kernel %.2e (relative max error vs float64)" % (shape, mode, e_new, e_old))
+    assert torch.isfinite(y).all()
+    assert e_new < max(3e-6, 1.2 * e_old)
+    # the epilogue's partial sums are the sums of the STORED values (double accumulation)
+    yd = y.double().cpu()
+    s_ref, q_ref = yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))
+    pc = part.cpu()
+    assert torch.isfinite(pc).all()
+    assert (pc[:, :, 0].sum(1) - s_ref).abs().max() <= 1e-9 * max(1.0, float(q_ref.max()))
+    assert (pc[:, :, 1].sum(1) - q_ref).abs().max() <= 1e-9 * float(q_ref.max())
+    # ... and ds_groupnorm_finish on them gives the affine of the statistics pass over y
+    if Cout % 32 == 0:
+        gam, bet = rnd((Cout,), "c3.g") + 1.0, rnd((Cout,), "c3.be")
+        a0, b0 = torch.empty(B, Cout, device="cuda"), torch.empty(B, Cout, device="cuda")
+        a1, b1 = torch.empty(B, Cout, device="cuda"), torch.empty(B, Cout, device="cuda")
+        P = H * W
+        work = torch.empty(B * ((P + 255) // 256) * 2 * Cout, device="cuda", dtype=torch.float64)
+        L.check(lib.ds_groupnorm_stats(L.ptr(y), B, P, Cout, 32, L.ptr(gam.cuda()), L.ptr(bet.cuda()), 1e-6, L.ptr(work), L.ptr(a0),
+                                       L.ptr(b0), L.stream()))
+        L.check(lib.ds_groupnorm_finish(L.ptr(part), B, tiles, P, Cout, 32, L.ptr(gam.cuda()), L.ptr(bet.cuda()), 1e-6, L.ptr(a1),
+                                        L.ptr(b1), L.stream()))
+        assert (a0 - a1).abs().max().item() <= 2e-6 * a0.abs().max().item()
+        assert (b0 - b1).abs().max().item() <= 2e-6 * max(1.0, b0.abs().max().item())
+
+
+def test_decoder_same_mel_on_both_conv_kernels():
+    """VQModel.decode with the halo-tiled convs + folded GroupNorm statistics against the tap-by-tap kernels: the mel agrees
+    far inside the north-star tolerance (both are fp32-class; only summation orders differ)."""
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    m = build_model(default_config(n_layer=1))
+    m.load_state_dict(dict(synth_sd("dalle", 1)), strict=False)
+    m = m.cuda().eval()
+    tok = synth.synth_tokens(2, mask_frac=0.0, key="c3.codes").cuda()
+    codec = m.content_codec
+    codec.conv_halo = True
+    a = m.decode_to_img(tok, (2, 256, 5, 53)).cpu()
+    codec.conv_halo = False
+    b = m.decode_to_img(tok, (2, 256, 5, 53)).cpu()
+    codec.conv_halo = True
+    d = (a - b).abs().max().item()
+    print("decode: halo-tiled vs gather convs, mel max-abs difference %.2e (mel range %.2f)" % (d, float(b.abs().max())))
+    assert torch.isfinite(a).all() and d < 1e-4

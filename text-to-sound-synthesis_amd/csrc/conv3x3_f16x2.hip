@@ -1,0 +1,345 @@
+// 3x3 convolution (stride 1, zero padding 1) over a channels-last fp32 image on the fp16 matrix cores, 2-way fp16 split
+// (3 MFMA passes, fp32-class): the hot convs of the SpecVQGAN decoder -- ResnetBlock conv1 / conv2 with their
+// GroupNorm + swish in front (specvqgan/modules/diffusionmodules/model.py:92-151) and the Upsample conv (:37-52) -- at the
+// resolutions that carry 94 % of the decoder's flops (20x212 and up).  Round 4: HALO-TILED form of conv_f16x2.hip's conv2d
+// loader.  That kernel gathers the A operand tap by tap: every input element is loaded, normalised, swish-ed (v_exp + v_rcp)
+// and split into fp16 planes NINE times per output-channel tile, and the kernel was bound by that vector work (~1500 VALU
+// cycles against 768 MFMA cycles per k-tile: 214 TF-eq, 0.26 of the 3-pass ceiling).  Here a workgroup owns a 4 x 32 pixel
+// output tile (M = 128) x 128 output channels and walks the input channels in slabs of 32: the slab's 6 x 34 pixel HALO is
+// loaded, activated and split ONCE into LDS and all nine taps read their A fragments from it at shifted pixel offsets.
+// The weights do not pass through LDS at all: they are packed once (host, _lib.pack_conv3x3_weights) so that every MFMA
+// B fragment of a (n-tile, slab, tap) is one contiguous KB, and each wave loads its own eight fragments per tap straight
+// from L2 into registers, one tap ahead -- so the ONLY barrier is the halo swap, once per slab = per 216 MFMAs of a wave
+// (the first form of this kernel staged a [128][32] weight tile per tap through LDS behind a barrier per tap: 308 TF-eq).
+// Vector work per output element drops ~6x against the gather kernel, activation traffic out of L2 ~5x.
+//   LDS: two halo slabs [2 planes][204 px][32 ch] (2 x 26 KB; 64-byte pixel rows, 16-byte chunks XOR-swizzled by
+//        (px>>2)&3: the 32 consecutive pixels of an MFMA block row are conflict-free for ds_read_b128 at every tap
+//        offset); slab s + 1 is loaded into registers and written into the other buffer in two halves under taps 0 - 5.
+//   Epilogue: bias, optional residual, row-major fp32 store through LDS (16-byte accesses), and optionally the GroupNorm
+//        partial sums of the OUTPUT per (tile, channel) in double -- the statistics pass of the next GroupNorm
+//        (ds_gn_partial_kernel: one more read of the tensor) disappears; ds_groupnorm_finish turns them into the affine.
+#include "common.h"
+#include <type_traits>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define C3_TH 4                       // tile: 4 rows x 32 pixels
+#define C3_TW 32
+#define C3_HW (C3_TW + 2)             // halo pitch (pixels)
+#define C3_HPX ((C3_TH + 2) * C3_HW)  // 204 halo pixels
+#define C3_HPL (C3_HPX * 32)          // halves per halo plane
+#define C3_BN 128
+#define C3_WSTEP 8192                 // halves of packed weights per (n-tile, slab, tap): [plane 2][wn 2][j 2][ks 2][lane 64][8]
+#define C3_NF4 ((C3_HPX * 8 + 255) / 256)   // float4 work items of a halo slab per thread (7)
+#ifndef C3_PIN
+#define C3_PIN 0
+#endif
+#ifndef C3_APRE                       // probe: A fragments of k-step ks + 1 read before the MFMAs of k-step ks
+#define C3_APRE 0
+#endif
+
+struct Conv3Params {
+    const float* x;        // [B][Hs][Ws][Cin]
+    const _Float16* w;     // W * 2^s as fp16 planes in the fragment-packed layout [Cout/128][Cin/32][9][C3_WSTEP]
+    const float* bias;     // [Cout] or null
+    const float* R;        // residual [B][H][W][Cout] or null
+    float* y;              // [B][H][W][Cout]
+    const float* pro_scale;  // [B][Cin] GroupNorm folded to a * s + o (PRO) or null
+    const float* pro_shift;
+    double* gn_part;       // [B][tiles][2][Cout] partial sums of the output (STATS) or null
+    float out_scale;
+    int B, H, W, Cin, Cout, tiles_x, tiles_y;
+};
+
+template <int PRO, int UP, bool STATS>
+__global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* halo = (_Float16*)smem_raw;                  // [2 buffers][2 planes][204][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;               // wave tile: tile rows 2 wm, 2 wm + 1 x columns wn * 64 .. + 63
+    const int tiles_n = p.Cout / C3_BN, tiles_s = p.tiles_x * p.tiles_y, nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {   // each XCD works a contiguous run of tiles (the n-tiles of a pixel tile share its halo through that XCD's L2)
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = bid % tiles_n, pt = bid / tiles_n;
+    const int b = pt / tiles_s, ts = pt - b * tiles_s;
+    const int ty0 = (ts / p.tiles_x) * C3_TH, tx0 = (ts % p.tiles_x) * C3_TW;
+    const int n0 = nt * C3_BN;
+    const int Hs = UP ? p.H >> 1 : p.H, Ws = UP ? p.W >> 1 : p.W;
+    const float* xb = p.x + (size_t)b * Hs * Ws * p.Cin;
+
+    // ---- halo staging: work item f = tid + 256 u -> halo pixel f >> 3, float4 (4 channels) f & 7 of the 32-channel slab ----
+    // (source / destination offsets are re-derived per use: kept in registers they cost 14 VGPRs the main loop does not have)
+    auto h_item = [&](int u, int& src, int& dst) {
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));     // opaque: hipcc must not hoist these (slab-invariant) offsets out of the slab loop
+        const int f = tid_o + 256 * u, px = f >> 3, c4 = f & 7;
+        const int hy = px / C3_HW, hx = px - hy * C3_HW;
+        int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+        const bool ok = px < C3_HPX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        if (UP) { yy >>= 1; xx >>= 1; }
+        src = ok ? (yy * Ws + xx) * p.Cin + c4 * 4 : -1;      // element offset of the source pixel's channel quad (-1: zeros)
+        dst = px < C3_HPX ? px * 32 + (((c4 >> 1) ^ ((px >> 2) & 3)) << 3) + ((c4 & 1) << 2) : -1;   // halves, inside a plane
+    };
+    // (in two halves, work items [0, 4) and [4, 7): 16 instead of 28 registers of halo data in flight next to the 64
+    //  accumulators and the two sets of weight fragments)
+    f32x4 hv[C3_NF4];
+    auto halo_load = [&](int slab, auto u0_, auto u1_) {
+        constexpr int U0 = decltype(u0_)::value, U1 = decltype(u1_)::value;
+#pragma unroll
+        for (int u = U0; u < U1; ++u) {
+            int src, dst;
+            h_item(u, src, dst);
+            hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (src >= 0) hv[u] = *(const f32x4*)(xb + src + slab * 32);
+        }
+    };
+    auto halo_write = [&](int slab, auto u0_, auto u1_) {
+        constexpr int U0 = decltype(u0_)::value, U1 = decltype(u1_)::value;
+        _Float16* hb = halo + (slab & 1) * (2 * C3_HPL);
+#pragma unroll
+        for (int u = U0; u < U1; ++u) {
+            int src, dst;
+            h_item(u, src, dst);
+            if (dst < 0) continue;
+            f32x4 v = hv[u];
+            if (PRO) {
+                const int ch = slab * 32 + ((tid + 256 * u) & 7) * 4;
+                const f32x4 sc = *(const f32x4*)(p.pro_scale + (size_t)b * p.Cin + ch);
+                const f32x4 sh = *(const f32x4*)(p.pro_shift + (size_t)b * p.Cin + ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = v[e] * sc[e] + sh[e];
+                    v[e] = t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * t));   // swish (as conv_f16x2.hip)
+                }
+            }
+            const bool ok = src >= 0;               // zero padding lives in the activated domain
+            h4 s0, s1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = ok ? v[e] : 0.f;
+                s0[e] = ds_split_hi(a);
+                s1[e] = ds_split_lo(a, s0[e]);
+            }
+            *(h4*)(hb + dst) = s0;
+            *(h4*)(hb + C3_HPL + dst) = s1;
+        }
+    };
+    // ---- this wave's eight B fragments of step t = slab * 9 + tap: [plane][j][ks], each one 16-byte load per lane ----
+    const int nslab = p.Cin >> 5;
+    const _Float16* wq = p.w + (size_t)nt * nslab * 9 * C3_WSTEP + wn * 2048 + lane * 8;
+    auto w_load = [&](int t, h8 (&f)[8]) {
+        const _Float16* q = wq + (size_t)t * C3_WSTEP;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) f[pl * 4 + jj * 2 + ks] = *(const h8*)(q + pl * 4096 + jj * 1024 + ks * 512);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int px_base = (wm * 2) * C3_HW + l31;      // halo pixel of (tile row 2 wm, column l31) at tap (0, 0)
+
+    h8 bc[8], bn[8];
+    const std::integral_constant<int, 0> U_A{};
+    const std::integral_constant<int, 4> U_B{};
+    const std::integral_constant<int, C3_NF4> U_C{};
+    halo_load(0, U_A, U_C);
+    w_load(0, bc);
+    halo_write(0, U_A, U_C);
+    __syncthreads();
+    for (int slab = 0; slab < nslab; ++slab) {
+        const bool more_slabs = slab + 1 < nslab;
+        const _Float16* hb = halo + (slab & 1) * (2 * C3_HPL);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool more = tap < 8 || more_slabs;
+            if (more) w_load(slab * 9 + tap + 1, bn);
+            if (tap == 0 && more_slabs) halo_load(slab + 1, U_A, U_B);      // first half of the next slab: lands under taps 0, 1
+            if (tap == 3 && more_slabs) halo_load(slab + 1, U_B, U_C);      // second half: under taps 3, 4
+#if C3_PIN     // probe: pin the prefetch loads where they are written (hipcc sinks them towards their first use); measured slower
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                auto afrag = [&](int ks, h8 (&f0)[2], h8 (&f1)[2]) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int px = px_base + (i + ky) * C3_HW + kx;
+                        const _Float16* ar = hb + px * 32 + ((((2 * ks + hh) ^ ((px >> 2) & 3))) << 3);
+                        f0[i] = *(const h8*)ar;
+                        f1[i] = *(const h8*)(ar + C3_HPL);
+                    }
+                };
+                auto mm = [&](int ks, const h8 (&f0)[2], const h8 (&f1)[2]) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f32x16 c = acc[i][j];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[i], bc[j * 2 + ks], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[i], bc[4 + j * 2 + ks], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[i], bc[j * 2 + ks], c, 0, 0, 0);
+                            acc[i][j] = c;
+                        }
+                };
+                h8 fa0[2], fa1[2], fb0[2], fb1[2];
+                afrag(0, fa0, fa1);
+#if C3_APRE
+                afrag(1, fb0, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(0, fa0, fa1);
+                mm(1, fb0, fb1);
+#else
+                mm(0, fa0, fa1);
+                afrag(1, fb0, fb1);
+                mm(1, fb0, fb1);
+#endif
+            }
+            // the other halo buffer is free: every wave passed the barrier that ended the slab before this one
+            if (tap == 2 && more_slabs) halo_write(slab + 1, U_A, U_B);
+            if (tap == 5 && more_slabs) halo_write(slab + 1, U_B, U_C);
+#if C3_PIN
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (more) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bc[e] = bn[e];
+            }
+        }
+        __syncthreads();            // slab s is read, slab s + 1 is written
+    }
+
+    // ---- epilogue: two passes of 64 tile rows (the rows of wave row wm = pass) staged as fp32 [64][128] in LDS ----
+    const float osc = p.out_scale;
+    float* Tf = (float*)smem_raw;
+    const int cc = tid & 31, col = n0 + cc * 4;
+    double s_acc[4] = {0.0, 0.0, 0.0, 0.0}, q_acc[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *(const f32x4*)(p.bias + col);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cl = (wn * 2 + j) * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        Tf[rl * C3_BN + cl] = acc[i][j][r] * osc;
+                    }
+                }
+        }
+        __syncthreads();
+        // staged row rl (0..63) = tile row 2 pass + (rl >> 5), pixel rl & 31
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = (tid >> 5) + 8 * it;
+            const int yy = ty0 + 2 * pass + (rl >> 5), xx = tx0 + (rl & 31);
+            if (yy < p.H && xx < p.W) {
+                f32x4 val = *(const f32x4*)(Tf + rl * C3_BN + cc * 4) + bias4;
+                const size_t o = (((size_t)b * p.H + yy) * p.W + xx) * p.Cout + col;
+                if (p.R) val += *(const f32x4*)(p.R + o);
+                *(f32x4*)(p.y + o) = val;
+                if (STATS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double d = (double)val[e];
+                        s_acc[e] += d;
+                        q_acc[e] += d * d;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (STATS) {
+        // the 8 threads that share a column group (tid & 31) add up through LDS; thread (tid < 32) writes 4 channels
+        double* Td = (double*)smem_raw;           // [8][32][8]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Td[((tid >> 5) * 32 + cc) * 8 + e] = s_acc[e];
+            Td[((tid >> 5) * 32 + cc) * 8 + 4 + e] = q_acc[e];
+        }
+        __syncthreads();
+        if (tid < 32) {
+            double* o = p.gn_part + (((size_t)b * tiles_s + ts) * 2) * p.Cout;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double s = 0.0, q = 0.0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    s += Td[(g * 32 + cc) * 8 + e];
+                    q += Td[(g * 32 + cc) * 8 + 4 + e];
+                }
+                o[col + e] = s;
+                o[p.Cout + col + e] = q;
+            }
+        }
+    }
+}
+
+template <int PRO, int UP, bool STATS>
+static int conv3_launch(const Conv3Params& p, hipStream_t s) {
+    const size_t lds = (size_t)(2 * 2 * C3_HPL) * sizeof(unsigned short);     // two halo slabs: 52 224 bytes
+    static_assert((2 * 2 * C3_HPL) * 2 >= 64 * C3_BN * 4, "the staged output half tile fits");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_conv3x3_f16x2_kernel<PRO, UP, STATS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            ds_set_error("conv3x3_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        attr_set = true;
+    }
+    const long long blocks = (long long)p.B * p.tiles_x * p.tiles_y * (p.Cout / C3_BN);
+    hipLaunchKernelGGL((ds_conv3x3_f16x2_kernel<PRO, UP, STATS>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ds_conv3x3_tiles(int H, int W) {
+    return H > 0 && W > 0 ? ((H + C3_TH - 1) / C3_TH) * ((W + C3_TW - 1) / C3_TW) : -1;
+}
+
+extern "C" int ds_conv3x3_f16x2(const float* x, const void* w2, long long w_halves, float out_scale, const float* bias,
+                                const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int up,
+                                const float* pro_scale, const float* pro_shift, double* gn_part, ds_stream_t stream) {
+    DS_CHECK_ARG(x && w2 && y, "null pointer");
+    DS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % C3_BN == 0,
+                 "Cin % 32 == 0 and Cout % 128 == 0");
+    DS_CHECK_ARG(up == 0 || (up == 1 && H % 2 == 0 && W % 2 == 0), "up: 0, or 1 (source is H/2 x W/2, nearest-upsampled)");
+    DS_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "prologue: both of scale / shift or neither");
+    DS_CHECK_ARG(!(up == 1 && pro_scale), "no prologue on the upsampling conv");
+    DS_CHECK_ARG(w_halves == (long long)2 * Cout * 9 * Cin && out_scale > 0.f, "packed weights: 2 * Cout * 9 * Cin halves");
+    DS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)residual & 15) == 0 &&
+                     ((uintptr_t)bias & 15) == 0 && ((uintptr_t)pro_scale & 15) == 0 && ((uintptr_t)pro_shift & 15) == 0,
+                 "operands must be 16-byte aligned");
+    DS_CHECK_ARG((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31), "32-bit element offsets");
+    Conv3Params p;
+    p.x = x; p.w = (const _Float16*)w2; p.bias = bias; p.R = residual; p.y = y;
+    p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.gn_part = gn_part; p.out_scale = out_scale;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.tiles_x = (W + C3_TW - 1) / C3_TW; p.tiles_y = (H + C3_TH - 1) / C3_TH;
+    hipStream_t s = (hipStream_t)stream;
+    const bool st = gn_part != nullptr;
+    if (up == 1) return st ? conv3_launch<0, 1, true>(p, s) : conv3_launch<0, 1, false>(p, s);
+    if (pro_scale) return st ? conv3_launch<1, 0, true>(p, s) : conv3_launch<1, 0, false>(p, s);
+    return st ? conv3_launch<0, 0, true>(p, s) : conv3_launch<0, 0, false>(p, s);
+}

@@ -124,58 +124,85 @@ __global__ __launch_bounds__(256) void ds_layernorm_kernel(const float* __restri
 // pass 1: grid (chunks, B): each block reduces PCHUNK pixels into per-channel double partials
 // pass 2: grid (B): combine chunks -> per-group mean/rstd -> scale/shift per channel.
 #define GN_PCHUNK 256
+// A block reduces GN_PCHUNK pixels x C channels: thread = (pixel lane, 4 consecutive channels as one float4); the pixel lanes
+// of a channel quad are added up through LDS.  (The first version gave a thread ONE channel and walked the 256 pixels in a
+// dependent load -> double-add chain: 126-260 us per call on tensors that take 1-2 us to read.)  C % 4 == 0, C <= 1024.
 __global__ __launch_bounds__(256) void ds_gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
                                                             int P, int C) {
     // part[b][chunk][2][C]
+    __shared__ double red[256][8];
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int p0 = chunk * GN_PCHUNK;
     const int p1 = min(P, p0 + GN_PCHUNK);
     const float* xb = x + ((size_t)b * P) * C;
-    // thread owns channel set {c = tid + 256*j}; loop pixels (coalesced across threads)
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double s = 0.0, q = 0.0;
-        for (int p = p0; p < p1; ++p) {
-            const double v = (double)xb[(size_t)p * C + c];
-            s += v;
-            q += v * v;
+    const int quads = C >> 2;                       // float4 columns
+    const int lanes = 256 / quads > 0 ? 256 / quads : 1;   // pixel lanes per pass over the channel quads
+    double* o = part + (((size_t)b * nchunk + chunk) * 2) * C;
+    for (int q0 = 0; q0 < quads; q0 += 256) {       // (C > 1024 would take more than one pass; not used)
+        const int qd = q0 + (int)threadIdx.x % (quads < 256 ? quads : 256);
+        const int pl = (int)threadIdx.x / (quads < 256 ? quads : 256);
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+        if (qd < quads && pl < lanes) {
+            for (int p = p0 + pl; p < p1; p += lanes) {
+                const f32x4 v = *(const f32x4*)(xb + (size_t)p * C + qd * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double d = (double)v[e];
+                    s[e] += d;
+                    q[e] += d * d;
+                }
+            }
         }
-        double* o = part + (((size_t)b * nchunk + chunk) * 2) * C;
-        o[c] = s;
-        o[C + c] = q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = q[e]; }
+        __syncthreads();
+        if (pl == 0 && qd < quads) {
+            for (int l = 1; l < lanes; ++l)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + l * quads][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[qd * 4 + e] = red[threadIdx.x][e];
+                o[C + qd * 4 + e] = red[threadIdx.x][4 + e];
+            }
+        }
+        __syncthreads();
     }
 }
 
+// grid (groups, B): one block per (sample, group) adds that group's partial sums over the chunks (fixed order: thread t
+// takes items t, t + 256, ..., then a tree over the block) and writes the group's channels.  (Rounds 1-3 ran ONE block per
+// sample over all groups -- 48 us per call once ds_conv3x3_f16x2 hands over 540 tile partials per sample.)
 __global__ __launch_bounds__(256) void ds_gn_finish_kernel(const double* __restrict__ part, int nchunk, int P, int C,
                                                            int groups, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
                                                            float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double gs[64], gq[64];  // groups <= 64
-    const int b = blockIdx.x;
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, b = blockIdx.y;
     const int cpg = C / groups;
-    if (threadIdx.x < 64) { gs[threadIdx.x] = 0.0; gq[threadIdx.x] = 0.0; }
-    __syncthreads();
-    // one wave per group (strided), lanes over (chunk, channel-in-group)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int g = wave; g < groups; g += 4) {
-        double s = 0.0, q = 0.0;
-        for (int i = lane; i < nchunk * cpg; i += 64) {
-            const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
-            const double* o = part + (((size_t)b * nchunk + ch) * 2) * C;
-            s += o[c];
-            q += o[C + c];
-        }
-        s = wave_sum_d(s);
-        q = wave_sum_d(q);
-        if (lane == 0) { gs[g] = s; gq[g] = q; }
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nchunk * cpg; i += 256) {
+        const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
+        const double* o = part + (((size_t)b * nchunk + ch) * 2) * C;
+        s += o[c];
+        q += o[C + c];
     }
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
     __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            rs[threadIdx.x] += rs[threadIdx.x + w];
+            rq[threadIdx.x] += rq[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
     const double n = (double)P * cpg;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const int g = c / cpg;
-        const double mean = gs[g] / n;
-        double var = gq[g] / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double mean = rs[0] / n;
+    double var = rq[0] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int c = g * cpg + threadIdx.x; c < (g + 1) * cpg; c += 256) {
         const double ga = gamma[c], be = beta[c];
         scale[(size_t)b * C + c] = (float)(rstd * ga);
         shift[(size_t)b * C + c] = (float)(be - mean * rstd * ga);
@@ -234,11 +261,25 @@ extern "C" int ds_groupnorm_stats(const float* x, int B, int P, int C, int group
     hipStream_t stream = (hipStream_t)stream_;
     DS_CHECK_ARG(x && gamma && beta && work && scale && shift, "null pointer");
     DS_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0, "bad group count");
+    DS_CHECK_ARG(C % 4 == 0 && C <= 1024 && ((uintptr_t)x & 15) == 0, "C % 4 == 0, C <= 1024, 16-byte aligned x");
     const int nchunk = (P + GN_PCHUNK - 1) / GN_PCHUNK;
     hipLaunchKernelGGL(ds_gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, stream, x, work, P, C);
     DS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ds_gn_finish_kernel, dim3(B), dim3(256), 0, stream, work, nchunk, P, C, groups, gamma, beta,
+    hipLaunchKernelGGL(ds_gn_finish_kernel, dim3(groups, B), dim3(256), 0, stream, work, nchunk, P, C, groups, gamma, beta,
                        eps, scale, shift);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// The second half alone: `part` = [B][nchunk][2][C] double partial sums (sum, sum of squares per channel) that another
+// kernel produced -- ds_conv3x3_f16x2 writes them per output tile, so the statistics read of the tensor disappears.
+extern "C" int ds_groupnorm_finish(const double* part, int B, int nchunk, int P, int C, int groups, const float* gamma,
+                                   const float* beta, float eps, float* scale, float* shift, ds_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DS_CHECK_ARG(part && gamma && beta && scale && shift, "null pointer");
+    DS_CHECK_ARG(B > 0 && nchunk > 0 && P > 0 && groups > 0 && groups <= 64 && C % groups == 0, "bad shape / group count");
+    hipLaunchKernelGGL(ds_gn_finish_kernel, dim3(groups, B), dim3(256), 0, stream, part, nchunk, P, C, groups, gamma, beta, eps,
+                       scale, shift);
     DS_CHECK_LAUNCH();
     return 0;
 }

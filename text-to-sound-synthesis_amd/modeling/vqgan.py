@@ -192,9 +192,12 @@ class ColumnMajor(nn.Module):
 
 
 def _with_split(w, b):
-    """(w [N][K] fp32, bias) + the two fp16 planes of w * 2^s and 2^-s for the 3x3 convs' f16x2 kernel"""
+    """(w [N][K] fp32, bias) + the two fp16 planes of w * 2^s and 2^-s for the 3x3 convs' f16x2 kernel (+ the same planes
+    in the fragment-packed layout of the halo-tiled kernel, where its shape constraints hold)"""
     w2, sc = _lib.split_f16x2(w)
-    return w, b, w2, sc
+    N, K = w.shape
+    wq = _lib.pack_conv3x3_weights(w2, N, K // 9) if (K % 9 == 0 and N % 128 == 0 and (K // 9) % 32 == 0) else None
+    return w, b, w2, sc, wq
 
 
 def _pack_conv3(conv):
@@ -222,6 +225,11 @@ class VQModel(nn.Module):
         # arithmetic of the 3x3 convolutions: "f16x2" (default; fp32-class 3-pass fp16 split on the 16-bit matrix
         # cores, csrc/conv_f16x2.hip) or "fp32" (exact fp32 MFMA, csrc/gemm_f32.hip)
         self.conv_precision = os.environ.get("DIFFSOUND_CONV", "f16x2")
+        # 3x3 convs at >= conv_halo_min_rows image rows on the halo-tiled kernel (csrc/conv3x3_f16x2.hip: the input tile is
+        # activated and split once for all nine taps, the GroupNorm statistics of the output come out of its epilogue);
+        # False / DIFFSOUND_CONV_HALO=0: every conv on the tap-by-tap gather kernel (csrc/conv_f16x2.hip)
+        self.conv_halo = os.environ.get("DIFFSOUND_CONV_HALO", "1") != "0"
+        self.conv_halo_min_rows = 20
         self._pk = None
         # samples decoded / encoded at once: bounds the full-resolution workspace (34.7 MB per sample and tensor,
         # ~15 GB live at 64) and the 32-bit element indices inside the kernels ([B][80][848][128] < 2^31 up to B=247);
@@ -313,9 +321,14 @@ class VQModel(nn.Module):
     @staticmethod
     def _gn(x, B, P, Cc, gamma_beta):
         dev = x.device
-        work = torch.empty(B * ((P + 255) // 256) * 2 * Cc, device=dev, dtype=torch.float64)
         sc = torch.empty(B, Cc, device=dev)
         sh = torch.empty(B, Cc, device=dev)
+        part = getattr(x, "_gn_part", None)
+        if part is not None:      # the conv that produced x left the partial sums of its output tiles: no statistics pass
+            _lib.check(_lib.lib().ds_groupnorm_finish(_lib.ptr(part), B, part.shape[1], P, Cc, 32, _lib.ptr(gamma_beta[0]),
+                                                      _lib.ptr(gamma_beta[1]), 1e-6, _lib.ptr(sc), _lib.ptr(sh), _lib.stream()))
+            return sc, sh
+        work = torch.empty(B * ((P + 255) // 256) * 2 * Cc, device=dev, dtype=torch.float64)
         _lib.check(_lib.lib().ds_groupnorm_stats(_lib.ptr(x), B, P, Cc, 32, _lib.ptr(gamma_beta[0]),
                                                  _lib.ptr(gamma_beta[1]), 1e-6, _lib.ptr(work), _lib.ptr(sc),
                                                  _lib.ptr(sh), _lib.stream()))
@@ -324,9 +337,18 @@ class VQModel(nn.Module):
     def _conv3(self, x, B, H, W, Cin, wb, gn=None, R=None, up=0):
         """3x3 conv, output H x W (input H/2 x W/2 if up == 1, 2H x 2W if up == 2).  gn = (scale, shift) ->
         GroupNorm + swish prologue."""
-        w, b, w2, sc = wb
+        w, b, w2, sc, wq = wb
         Cout = w.shape[0]
         out = torch.empty(B, H, W, Cout, device=x.device)
+        if (self.conv_precision == "f16x2" and self.conv_halo and H >= self.conv_halo_min_rows and up in (0, 1)
+                and wq is not None):
+            L = _lib.lib()
+            part = torch.empty(B, L.ds_conv3x3_tiles(H, W), 2, Cout, device=x.device, dtype=torch.float64)
+            _lib.check(L.ds_conv3x3_f16x2(_lib.ptr(x), _lib.ptr(wq), wq.numel(), sc, _lib.ptr(b), _lib.ptr(R), _lib.ptr(out),
+                                          B, H, W, Cin, Cout, up, _lib.ptr(gn[0]) if gn is not None else None,
+                                          _lib.ptr(gn[1]) if gn is not None else None, _lib.ptr(part), _lib.stream()))
+            out._gn_part = part       # picked up by _gn() if a GroupNorm reads this tensor next
+            return out
         kw = dict(bias=b, R=R, loader=_lib.LOAD_CONV2D,
                   pro=_lib.PRO_AFFINE_SWISH if gn is not None else _lib.PRO_NONE,
                   pro_scale=gn[0] if gn is not None else None, pro_shift=gn[1] if gn is not None else None,
