@@ -381,6 +381,12 @@ int ds_conv3x3_f16x2(const float* x, const void* w2, long long w_halves, float o
                      const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int up,
                      const float* pro_scale, const float* pro_shift, double* gn_part, ds_stream_t stream);
 int ds_conv3x3_tiles(int H, int W);   /* 4 x 32 pixel tiles per image */
+/* MelGAN ResnetBlock tail (vocoder/modules.py:72-85) in one contraction over K = 2 C: y = W2 LReLU(h) + Ws x + bias, h = the
+ * block's dilated k3 conv output [M][C], x = the block input [M][C] (channels-last rows), w = the two fp16 planes of
+ * [W2 | Ws] * 2^s ([C][2 C] row-major, w_plane halves apart, split_f16x2), out_scale = 2^-s, bias = b2 + bs.  Replaces the
+ * shortcut GEMM + the 1x1 GEMM with residual: the shortcut tensor never goes through HBM.  C % 32 == 0. */
+int ds_melgan_resblock_tail(const float* h, const float* x, const void* w, long long w_plane, float out_scale,
+                            const float* bias, float* y, int M, int C, ds_stream_t stream);
 /* AttnBlock softmax (model.py:214-216): x[row][0..n) <- softmax(scale*x), x[row][n..ld) <- 0 */
 int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t stream);
 /* tap-sum for single-output-channel convs fed by a GEMM with N = taps */

@@ -84,9 +84,10 @@ def test_conv3x3_halo_vs_float64_and_gather_kernel(L, shape, mode):
         a1, b1 = torch.empty(B, Cout, device="cuda"), torch.empty(B, Cout, device="cuda")
         P = H * W
         work = torch.empty(B * ((P + 255) // 256) * 2 * Cout, device="cuda", dtype=torch.float64)
-        L.check(lib.ds_groupnorm_stats(L.ptr(y), B, P, Cout, 32, L.ptr(gam.cuda()), L.ptr(bet.cuda()), 1e-6, L.ptr(work), L.ptr(a0),
+        gc, bec = gam.cuda(), bet.cuda()
+        L.check(lib.ds_groupnorm_stats(L.ptr(y), B, P, Cout, 32, L.ptr(gc), L.ptr(bec), 1e-6, L.ptr(work), L.ptr(a0),
                                        L.ptr(b0), L.stream()))
-        L.check(lib.ds_groupnorm_finish(L.ptr(part), B, tiles, P, Cout, 32, L.ptr(gam.cuda()), L.ptr(bet.cuda()), 1e-6, L.ptr(a1),
+        L.check(lib.ds_groupnorm_finish(L.ptr(part), B, tiles, P, Cout, 32, L.ptr(gc), L.ptr(bec), 1e-6, L.ptr(a1),
                                         L.ptr(b1), L.stream()))
         assert (a0 - a1).abs().max().item() <= 2e-6 * a0.abs().max().item()
         assert (b0 - b1).abs().max().item() <= 2e-6 * max(1.0, b0.abs().max().item())
@@ -110,3 +111,33 @@ def test_decoder_same_mel_on_both_conv_kernels():
     d = (a - b).abs().max().item()
     print("decode: halo-tiled vs gather convs, mel max-abs difference %.2e (mel range %.2f)" % (d, float(b.abs().max())))
     assert torch.isfinite(a).all() and d < 1e-4
+
+
+def test_melgan_resblock_tail_one_gemm():
+    """ds_melgan_resblock_tail (vocoder/modules.py:72-85: 1x1 conv on the activated k3 output + 1x1 shortcut as ONE contraction
+    over [LReLU(h) | x]) against float64, and the whole Generator with and without it."""
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd import _lib as L
+    from text_to_sound_synthesis_amd.modeling.vocoder import Generator
+    M, C = 1000, 64
+    h, x = rnd((M, C), "rt.h", 3.0), rnd((M, C), "rt.x", 3.0)
+    w2, ws = rnd((C, C), "rt.w2", 0.2), rnd((C, C), "rt.ws", 0.2)
+    b = rnd((C,), "rt.b")
+    ref = (F.leaky_relu(h.double(), 0.2) @ w2.double().t() + x.double() @ ws.double().t() + b.double())
+    planes, osc = L.split_f16x2(torch.cat((w2, ws), 1).contiguous().cuda())
+    y = torch.full((M, C), float("nan"), device="cuda")
+    hc, xc, bc = h.cuda(), x.cuda(), b.cuda()          # (kept alive: a temporary's memory is reused by the next allocation)
+    L.check(L.lib().ds_melgan_resblock_tail(L.ptr(hc), L.ptr(xc), L.ptr(planes), C * 2 * C, osc, L.ptr(bc), L.ptr(y), M, C,
+                                            L.stream()))
+    assert relerr(y.cpu(), ref) < 3e-6
+    g = Generator(80, 32, 3)
+    g.load_state_dict(synth_sd("generator"))
+    g = g.cuda().eval()
+    mel = synth.synth_uniform((2, 80, 53), key="rt.mel").cuda()
+    g.fuse_tail = True
+    a = g(mel).cpu()
+    g.fuse_tail = False
+    bb = g(mel).cpu()
+    rms = float((a - bb).pow(2).mean().sqrt())
+    print("MelGAN: one-GEMM block tails vs three launches per block, waveform RMS difference %.2e" % rms)
+    assert torch.isfinite(a).all() and rms < 1e-6

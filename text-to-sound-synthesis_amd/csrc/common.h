@@ -128,6 +128,10 @@ struct GemmParams {
     int up;                     // conv2d: 1 => input is (H/2, W/2), nearest-upsampled on the fly
     int taps, dil;              // conv1d: taps, dilation (reflect padding)
     int ct_r, ct_p, ct_tin;     // convT1d: stride r, padding p, input length
+    // f16x2 conv kernel, dense loader: a SECOND row source for the k-tiles k >= k_split (A2 [M][lda2], column k - k_split);
+    // the prologue applies to the first source only.  (ds_melgan_resblock_tail: [LReLU(h) | x] x [W2 | Ws]^T in one GEMM)
+    const float* A2;
+    int k_split, lda2;
 };
 
 // padded-row forms used by the native denoiser driver (api.hip): Lp / logits_rows >= L rows per sample

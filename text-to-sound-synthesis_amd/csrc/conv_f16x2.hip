@@ -14,6 +14,7 @@
 // reads of gemm_f16x2.hip (64-byte rows, 16-byte chunks XOR-swizzled by (row>>2)&3), register-staged double
 // buffering: the raw loads of tile t+1 are issued before the MFMAs of tile t, prologue + split + LDS write after.
 #include "common.h"
+#include <string.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
                 src = Ag + ((size_t)a_b[i] * p.ct_tin + s_) * p.Cin + c0;                           \
             } else {                                                                                \
                 okmask |= 1u << i;                                                                  \
-                src = Ag + (size_t)a_x[i] * p.lda + c0;                                             \
+                src = (p.A2 && (k0_) >= p.k_split) ? p.A2 + (size_t)a_x[i] * p.lda2 + (c0 - p.k_split) /* second row source */ \
+                                                   : Ag + (size_t)a_x[i] * p.lda + c0;              \
             }                                                                                       \
             ra[2 * i] = *(const f32x4*)src;                                                         \
             ra[2 * i + 1] = *(const f32x4*)(src + 4);                                               \
@@ -155,7 +157,9 @@ __global__ __launch_bounds__(256, 2) void ds_conv2d_f16x2_kernel(const GemmParam
                     }                                                                               \
                 }                                                                                   \
                 if constexpr (PRO == DS_PRO_LRELU) {                                                \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e]; \
+                    if (!(LOADER == DS_LOAD_DENSE && p.A2 && (k0_) >= p.k_split)) {   /* (the second row source is taken as it is) */ \
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e]; \
+                    }                                                                               \
                 }                                                                                   \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
                     const float a = ok ? v[e] : 0.f;   /* zero padding lives in the activated domain */ \
@@ -325,12 +329,33 @@ int ds_launch_conv2d_f16x2(const GemmParams& p, hipStream_t stream, int loader) 
             return p.pro == DS_PRO_NONE ? conv_tile<DS_LOAD_CONVT1D, DS_PRO_NONE>(p, stream)
                                         : conv_tile<DS_LOAD_CONVT1D, DS_PRO_LRELU>(p, stream);
         case DS_LOAD_DENSE:
-            DS_CHECK_ARG(p.lda >= p.K && p.lda % 4 == 0 && p.store == DS_STORE_ROW && p.groups <= 1,
-                         "dense: lda >= K, row store, no groups");
+            DS_CHECK_ARG((p.A2 ? p.lda >= p.k_split && p.lda2 >= p.K - p.k_split && p.lda2 % 4 == 0 && p.k_split % 32 == 0 &&
+                                     p.k_split > 0 && p.k_split < p.K && ((uintptr_t)p.A2 & 15) == 0
+                               : p.lda >= p.K) && p.lda % 4 == 0 && p.store == DS_STORE_ROW && p.groups <= 1,
+                         "dense: lda >= K (two sources: lda >= k_split, lda2 >= K - k_split, k_split % 32 == 0), row store, no groups");
             DS_CHECK_ARG(p.pro == DS_PRO_NONE || p.pro == DS_PRO_LRELU, "dense prologue: none or LeakyReLU(0.2)");
             return p.pro == DS_PRO_NONE ? conv_tile<DS_LOAD_DENSE, DS_PRO_NONE>(p, stream)
                                         : conv_tile<DS_LOAD_DENSE, DS_PRO_LRELU>(p, stream);
         default:
             DS_CHECK_ARG(false, "unknown loader");
     }
+}
+
+// MelGAN ResnetBlock tail in ONE contraction (vocoder/modules.py:72-85):  y = W2 LReLU(h) + Ws x + (b2 + bs)  -- the block's 1x1
+// conv on the activated k3 output and its 1x1 shortcut, K = 2 C over the two row sources [LReLU(h) | x].  Against three
+// launches (k3 conv | shortcut | 1x1 + residual) the shortcut tensor is never written and read back: two of the block's
+// five tensor passes disappear on layers that are HBM-bound.  w = the fp16 planes of [W2 | Ws] * 2^s ([C][2 C], w_plane
+// halves apart), bias = b2 + bs.
+extern "C" int ds_melgan_resblock_tail(const float* h, const float* x, const void* w, long long w_plane, float out_scale,
+                                       const float* bias, float* y, int M, int C, ds_stream_t stream) {
+    DS_CHECK_ARG(h && x && w && y, "null pointer");
+    DS_CHECK_ARG(M > 0 && C > 0 && C % 32 == 0, "C % 32 == 0");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = h; p.A2 = x; p.W = (const float*)w; p.bias = bias; p.C = y;
+    p.M = M; p.N = C; p.K = 2 * C; p.k_split = C;
+    p.lda = C; p.lda2 = C; p.ldw = 2 * C; p.ldc = C; p.ldr = C; p.groups = 1;
+    p.pro = DS_PRO_LRELU; p.act = DS_ACT_NONE; p.store = DS_STORE_ROW;
+    p.w3_plane = w_plane; p.out_scale = out_scale;
+    return ds_launch_conv2d_f16x2(p, (hipStream_t)stream, DS_LOAD_DENSE);
 }

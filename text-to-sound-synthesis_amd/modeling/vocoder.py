@@ -74,6 +74,9 @@ class Generator(nn.Module):
         self.model = nn.Sequential(*model)
         self.n_residual_layers = n_residual_layers
         self.conv_precision = os.environ.get("DIFFSOUND_VOCODER_CONV", "f16x2")   # "f16x2" | "fp32"
+        # ResnetBlock tail (1x1 conv + 1x1 shortcut) as ONE contraction over [LReLU(h) | x] (ds_melgan_resblock_tail): the
+        # shortcut tensor never goes through HBM.  False / DIFFSOUND_VOCODER_FUSE_TAIL=0: three launches per block.
+        self.fuse_tail = os.environ.get("DIFFSOUND_VOCODER_FUSE_TAIL", "1") != "0"
         self._pk = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
 
@@ -122,6 +125,9 @@ class Generator(nn.Module):
             for rb in st["res"]:
                 for k in ("c3", "c1", "sc"):
                     rb[k + "_s"] = sp(rb[k][0])
+                # [W2 | Ws] (one power-of-two scale for both) and b2 + bs for the one-GEMM block tail
+                rb["tail_s"] = sp(torch.cat((rb["c1"][0], rb["sc"][0]), dim=1).contiguous())
+                rb["tail_b"] = (rb["c1"][1] + rb["sc"][1]).contiguous()
         self._pk = pk
         return pk
 
@@ -164,8 +170,13 @@ class Generator(nn.Module):
                 self._mm(h, rb["c3"][0], rb["c3_s"], h1, M, cout, 3 * cout, bias=rb["c3"][1], loader=_lib.LOAD_CONV1D,
                          pro=_lib.PRO_LRELU, Cin=cout, Wd=T, taps=3, dil=rb["dil"])
                 sc = torch.empty(B, T, cout, device=dev)
-                self._mm(h, rb["sc"][0], rb["sc_s"], sc, M, cout, cout, bias=rb["sc"][1])
-                self._mm(h1, rb["c1"][0], rb["c1_s"], sc, M, cout, cout, bias=rb["c1"][1], R=sc, pro=_lib.PRO_LRELU)
+                if self.fuse_tail and self.conv_precision == "f16x2":
+                    w2, osc = rb["tail_s"]
+                    _lib.check(_lib.lib().ds_melgan_resblock_tail(_lib.ptr(h1), _lib.ptr(h), _lib.ptr(w2), cout * 2 * cout, osc,
+                                                                  _lib.ptr(rb["tail_b"]), _lib.ptr(sc), M, cout, _lib.stream()))
+                else:
+                    self._mm(h, rb["sc"][0], rb["sc_s"], sc, M, cout, cout, bias=rb["sc"][1])
+                    self._mm(h1, rb["c1"][0], rb["c1_s"], sc, M, cout, cout, bias=rb["c1"][1], R=sc, pro=_lib.PRO_LRELU)
                 h = sc
         wl, bl = pk["last"]
         taps = torch.empty(B * T, 8, device=dev)
