@@ -217,3 +217,27 @@ def test_full_batch_padded_rows_with_in_kernel_noise():
     differing = int((big[0] != small).any(1).sum())
     print("B=64 (272-row tiles) vs B=8: %d of 8 clips differ" % differing)
     assert differing <= 1
+
+
+def test_cross_program_agreement_at_the_benchmarked_configuration():
+    """what "sharding-invariant" means once the GEMM PROGRAM changes with the local batch size.  64 distinct captions,
+    19 layers, 100 steps, in-kernel noise keyed by the caption ids: one batch of 64 (per-sample 272-row program) against eight
+    shards of 8 (4-wave programs).  The NOISE is identical by construction; the logits of a sample's rows 256..264 differ by
+    ~1e-7 relative between the programs, so a Gumbel near-tie may fall differently and the chain is chaotic from there on.
+    The measured agreement is reported (pytest terminal summary); the floor only catches a broken key / id plumbing."""
+    from conftest import parity_line
+    m = build(19, T=100)
+    dt = m.transformer
+    cond = synth.synth_cond_emb(64, key="rng.xprog.cond").cuda()
+    ids = torch.arange(5000, 5064)
+    whole = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0, caption_ids=ids,
+                      seed=SEED)["content_token"].cpu()
+    parts = [dt.sample(condition_token=None, condition_mask=None, condition_embed=cond[8 * r:8 * r + 8].contiguous(), filter_ratio=0,
+                       caption_ids=ids[8 * r:8 * r + 8], seed=SEED)["content_token"].cpu() for r in range(8)]
+    sharded = torch.cat(parts)
+    same = int((whole == sharded).all(1).sum())
+    agree = float((whole == sharded).float().mean())
+    parity_line("Philox path, one batch of 64 vs eight shards of 8 (19 layers, 100 steps, different GEMM programs): %d of 64 clips "
+                "identical, token agreement %.4f" % (same, agree))
+    print("one batch of 64 vs 8 x 8: %d of 64 clips identical, token agreement %.4f" % (same, agree))
+    assert same >= 32, "most clips must not depend on the sharding (got %d of 64)" % same
