@@ -25,10 +25,9 @@ sys.path.insert(0, ROOT)
 
 
 def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", ema_device="cuda", attention="fused",
-        overlap_dw=False, graph=True, world=1, rank=0, dev=None, profile_gemm=False):
-    """Time `steps` training iterations (after `warmup`) and return the result dict (see the module docstring).
-    profile_gemm: one extra EAGER iteration with the library's per-launch HIP-event profile on (ds_profile_*), giving the
-    split / fp32 GEMMs' summed algorithmic flops over their summed durations (`gemm_tflops`)."""
+        overlap_dw=False, graph=True, world=1, rank=0, dev=None):
+    """Time `steps` training iterations (after `warmup`) and return the result dict (see the module docstring).  (Per-kernel
+    rates: tools/train_profile.sh -- rocprofv3 --stats over this script.)"""
     from text_to_sound_synthesis_amd import shard, synth
     from text_to_sound_synthesis_amd.config import build_model, default_config
     from text_to_sound_synthesis_amd.modeling.solver import EMA, GradClipWindow, PlateauWarmupLR, Solver
@@ -102,23 +101,6 @@ def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", e
     el = el.item()
     timing[0] = False
     times["update"] = el - times["grads"] - times["allreduce"]
-    gemm_tflops = None
-    if profile_gemm:
-        import ctypes
-        from text_to_sound_synthesis_amd import _lib
-        Lb = _lib.lib()
-        ts = TrainStep(dt, precision=precision, attention=attention)
-        t, pt = dt.sample_time(B, dev, "importance")
-        u = torch.rand((B, K1, L), device=dev, generator=gen)
-        ts.loss_and_grads(x0, cond, t, pt, u)           # calibration / packs
-        torch.cuda.synchronize()
-        Lb.ds_profile_enable(1)
-        ts.loss_and_grads(x0, cond, t, pt, u)
-        Lb.ds_profile_enable(0)
-        ms, fl, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
-        _lib.check(Lb.ds_profile_collect_n(ms, fl, n, 5))
-        if sum(ms) > 0:
-            gemm_tflops = round(sum(fl) / (sum(ms) * 1e-3) / 1e12, 2)
     return {
         "metric": "training iterations/s (denoiser step: loss + backward + clip + AdamW + EMA)", "value": steps / el,
         "unit": "it/s", "samples_per_s": steps * B * world / el, "n_gpus": world, "steps": steps,
@@ -126,7 +108,6 @@ def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", e
         "dtype": "f32 via 2-way fp16 split (linear layers fwd + dX + dW), fp32 elsewhere" if precision == "f16x2" else "f32",
         "data": "synthetic", "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
         "ms": {k: 1e3 * v / steps for k, v in times.items()},
-        "gemm_tflops": gemm_tflops,
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         "graph": use_graph, "attention": attention, "overlap_dw": overlap_dw,
         "loss_scale_exp": solver.train_step.loss_scale_exp,
@@ -148,7 +129,6 @@ def main():
                     help="fused: ds_attention + ds_attention_bwd (recompute); composed: grouped GEMMs with stored probabilities")
     ap.add_argument("--overlap-dw", action="store_true", help="weight-gradient GEMMs on a second HIP stream")
     ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
-    ap.add_argument("--profile-gemm", action="store_true", help="add gemm_tflops (one extra eager iteration under ds_profile_*)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,7 +138,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     out = run(args.batch, args.steps, args.warmup, args.n_layer, args.codes, args.precision, args.ema_device, args.attention,
-              args.overlap_dw, args.graph, world, rank, dev, args.profile_gemm)
+              args.overlap_dw, args.graph, world, rank, dev)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
