@@ -442,3 +442,35 @@ def test_packed_gemm_argument_checks():
         L.gemm(A2, W2, out, 8, 32, 32, R=out, split2=sc, a_plane=16 * 32, c_plane=16 * 32)
     L.gemm(A2, W2, out, 8, 32, 32, split2=sc, a_plane=16 * 32)
     assert torch.equal(out, torch.zeros_like(out))
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 1, 1), (2, 3, 31, 16), (1, 2, 33, 17), (2, 16, 64, 96), (1, 4, 100, 97), (2, 2, 265, 128),
+                                       (1, 3, 272, 191), (1, 16, 265, 192), (2, 5, 40, 193), (1, 2, 272, 288), (3, 1, 7, 250)])
+def test_streamed_attention_shape_sweep(B, H, Lq, Lk):
+    """The streamed (chunked, online-softmax) attention kernel on ragged shapes: query counts that leave waves of the last
+    workgroup idle, key counts on and around the 96-key chunk boundaries (one / two / three chunks, last chunk full, one key
+    into a chunk, one short of it), head counts that are not 16 -- the generic entry (fp32 operands, converted in the kernel),
+    its packed-plane output form and the attention-ready entry (Q planes, K / V^T images by LDS-DMA), all against float64 and
+    against one another (bit-identical: same arithmetic, different staging)."""
+    import diffsound_oracle as O
+    from text_to_sound_synthesis_amd import _lib as L
+    D = H * 64
+    q, k, v = rnd((B, Lq, D), "sw.q"), rnd((B, Lk, D), "sw.k"), rnd((B, Lk, D), "sw.v", 2.0)
+    k[:, Lk // 2] *= 5.0                                     # one dominant key: far-from-uniform rows
+    ref = O._mha(q.double(), k.double(), v.double(), H).float()
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    out = torch.full((B * Lq, D), float("nan"), device="cuda")
+    L.check(L.lib().ds_attention_f16x2(L.ptr(qc), D, L.ptr(kc), D, L.ptr(vc), D, L.ptr(out), D, B, H, Lq, Lk, 0.125, L.stream()))
+    err = (out.cpu().view_as(ref) - ref).abs().max().item()
+    assert torch.isfinite(out).all() and err < 2e-5, err
+    if D % 32 == 0:
+        M16 = (B * Lq + 15) // 16 * 16
+        sp = torch.zeros(2, M16 * D, device="cuda", dtype=torch.float16)
+        L.check(L.lib().ds_attention_f16x2_split(L.ptr(qc), D, L.ptr(kc), D, L.ptr(vc), D, L.ptr(sp), D, B, H, Lq, Lk, 0.125, L.stream()))
+        assert torch.equal(L.unpack_planes(sp, B * Lq, D), torch_split(out))
+        heads = lambda x, n: torch_split(x).view(2, B, n, H, 64).permute(0, 1, 3, 2, 4).contiguous()
+        qh = heads(qc, Lq)
+        img = L.attn_images(heads(kc, Lk), heads(vc, Lk), L.lib().ds_attn_nkey(Lk))
+        rd = torch.zeros_like(sp)
+        L.check(L.lib().ds_attention_f16x2_ready(L.ptr(qh), B * H * Lq * 64, L.ptr(img), L.ptr(rd), D, B, H, Lq, Lk, 0.125, L.stream()))
+        assert torch.equal(rd, sp)
