@@ -387,6 +387,14 @@ int ds_conv3x3_tiles(int H, int W);   /* 4 x 32 pixel tiles per image */
  * shortcut GEMM + the 1x1 GEMM with residual: the shortcut tensor never goes through HBM.  C % 32 == 0. */
 int ds_melgan_resblock_tail(const float* h, const float* x, const void* w, long long w_plane, float out_scale,
                             const float* bias, float* y, int M, int C, ds_stream_t stream);
+/* The whole ResnetBlock behind one entry (SURVEY.md section 8b's `ds_melgan_resblock`): y = shortcut(x) +
+ * conv1x1(LReLU(conv_k3_dil(reflect_pad_dil(LReLU(x))))) as two launches -- the dilated k3 conv into the scratch tensor h
+ * ([B][T][C], caller-owned), then ds_melgan_resblock_tail.  x, y [B][T][C] channels-last fp32; w3 = the fp16 planes of the
+ * weight-norm-folded k3 weights * 2^s ([C][3 C], K ordered [tap][channel]; w3_plane halves apart; w3_scale = 2^-s), b3 [C];
+ * wt / wt_plane / wt_scale / bt = ds_melgan_resblock_tail's operands.  C % 32 == 0, 0 < dil < T. */
+int ds_melgan_resblock(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
+                       long long wt_plane, float wt_scale, const float* bt, float* h, float* y, int B, int T, int C,
+                       int dil, ds_stream_t stream);
 /* AttnBlock softmax (model.py:214-216): x[row][0..n) <- softmax(scale*x), x[row][n..ld) <- 0 */
 int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t stream);
 /* tap-sum for single-output-channel convs fed by a GEMM with N = taps */

@@ -359,3 +359,26 @@ extern "C" int ds_melgan_resblock_tail(const float* h, const float* x, const voi
     p.w3_plane = w_plane; p.out_scale = out_scale;
     return ds_launch_conv2d_f16x2(p, (hipStream_t)stream, DS_LOAD_DENSE);
 }
+
+// The whole MelGAN ResnetBlock (vocoder/modules.py:72-85) behind one entry:
+//   y = shortcut(x) + conv1x1(LReLU(conv_k3_dil(reflect_pad_dil(LReLU(x)))))
+// as two launches -- the dilated k3 conv into the scratch tensor h, then the one-GEMM tail above.  x, h, y: [B][T][C]
+// channels-last fp32; w3 = fp16 planes of W1 * 2^s1 ([C][3 C], K ordered [tap][channel], w3_plane halves apart), b3 [C];
+// wt / bt = the tail's [W2 | Ws] planes and b2 + bs.  C % 32 == 0, dil < T.
+extern "C" int ds_melgan_resblock(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3,
+                                  const void* wt, long long wt_plane, float wt_scale, const float* bt, float* h, float* y,
+                                  int B, int T, int C, int dil, ds_stream_t stream) {
+    DS_CHECK_ARG(x && w3 && wt && h && y, "null pointer");
+    DS_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 32 == 0 && dil > 0 && dil < T, "C % 32 == 0, 0 < dil < T");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.W = (const float*)w3; p.bias = b3; p.C = h;
+    p.M = B * T; p.N = C; p.K = 3 * C;
+    p.lda = C; p.ldw = 3 * C; p.ldc = C; p.ldr = C; p.groups = 1;
+    p.pro = DS_PRO_LRELU; p.act = DS_ACT_NONE; p.store = DS_STORE_ROW;
+    p.Cin = C; p.W_ = T; p.taps = 3; p.dil = dil;
+    p.w3_plane = w3_plane; p.out_scale = w3_scale;
+    const int rc = ds_launch_conv2d_f16x2(p, (hipStream_t)stream, DS_LOAD_CONV1D);
+    if (rc) return rc;
+    return ds_melgan_resblock_tail(h, x, wt, wt_plane, wt_scale, bt, y, B * T, C, stream);
+}

@@ -167,14 +167,17 @@ class Generator(nn.Module):
             for rb in st["res"]:
                 M = B * T
                 h1 = torch.empty(B, T, cout, device=dev)
-                self._mm(h, rb["c3"][0], rb["c3_s"], h1, M, cout, 3 * cout, bias=rb["c3"][1], loader=_lib.LOAD_CONV1D,
-                         pro=_lib.PRO_LRELU, Cin=cout, Wd=T, taps=3, dil=rb["dil"])
                 sc = torch.empty(B, T, cout, device=dev)
                 if self.fuse_tail and self.conv_precision == "f16x2":
+                    # the whole block behind one entry: dilated k3 conv into h1, then [LReLU(h1) | h] x [W2 | Ws]^T
+                    w3, s3 = rb["c3_s"]
                     w2, osc = rb["tail_s"]
-                    _lib.check(_lib.lib().ds_melgan_resblock_tail(_lib.ptr(h1), _lib.ptr(h), _lib.ptr(w2), cout * 2 * cout, osc,
-                                                                  _lib.ptr(rb["tail_b"]), _lib.ptr(sc), M, cout, _lib.stream()))
+                    _lib.check(_lib.lib().ds_melgan_resblock(_lib.ptr(h), _lib.ptr(w3), cout * 3 * cout, s3, _lib.ptr(rb["c3"][1]),
+                                                             _lib.ptr(w2), cout * 2 * cout, osc, _lib.ptr(rb["tail_b"]), _lib.ptr(h1),
+                                                             _lib.ptr(sc), B, T, cout, rb["dil"], _lib.stream()))
                 else:
+                    self._mm(h, rb["c3"][0], rb["c3_s"], h1, M, cout, 3 * cout, bias=rb["c3"][1], loader=_lib.LOAD_CONV1D,
+                             pro=_lib.PRO_LRELU, Cin=cout, Wd=T, taps=3, dil=rb["dil"])
                     self._mm(h, rb["sc"][0], rb["sc_s"], sc, M, cout, cout, bias=rb["sc"][1])
                     self._mm(h1, rb["c1"][0], rb["c1_s"], sc, M, cout, cout, bias=rb["c1"][1], R=sc, pro=_lib.PRO_LRELU)
                 h = sc
