@@ -462,3 +462,39 @@ def test_generic_tile_data_path_emulation():
         assert (done == 1).all(), (BM, BN)
         A0, A1, W0, W1 = (x.astype(np.float64) for x in (Ah[0], Ah[1], Wh[0], Wh[1]))
         assert np.array_equal(C, A1 @ W0.T + A0 @ W1.T + A0 @ W0.T), (BM, BN, WGM, WGN)
+
+
+def test_conv3x3_fragment_packed_weights():
+    """_lib.pack_conv3x3_weights: the host-side layout ds_conv3x3_f16x2 loads straight into MFMA B operands
+    (csrc/conv3x3_f16x2.hip): [Cout/128][Cin/32][9 taps][2 planes][2 wave columns][2 blocks][2 k-steps][64 lanes][8 halves],
+    lane (hh = lane >> 5, l = lane & 31) of fragment (wn, j, ks) holding W[128 nt + 64 wn + 32 j + l][tap][32 slab + 16 ks + 8 hh + e]."""
+    import random
+    import torch
+    from text_to_sound_synthesis_amd import _lib
+    Cout, Cin = 256, 96
+    w = torch.randn(Cout, 9 * Cin)
+    planes, sc = _lib.split_f16x2(w)
+    q = _lib.pack_conv3x3_weights(planes, Cout, Cin)
+    assert q.numel() == 2 * Cout * 9 * Cin
+    q = q.view(Cout // 128, Cin // 32, 9, 2, 2, 2, 2, 64, 8)
+    pl = planes.view(torch.int16).view(2, Cout, 9, Cin)
+    rng = random.Random(3)
+    for _ in range(4000):
+        nt, ns, tap, p_, wn, j, ks, lane, e = [rng.randrange(n) for n in (Cout // 128, Cin // 32, 9, 2, 2, 2, 2, 64, 8)]
+        hh, l = lane >> 5, lane & 31
+        assert q[nt, ns, tap, p_, wn, j, ks, lane, e] == pl[p_, nt * 128 + wn * 64 + j * 32 + l, tap, ns * 32 + ks * 16 + hh * 8 + e]
+    # the planes reconstruct the scaled weights (hi + lo = w * 2^s to fp32 rounding of the split)
+    back = (planes.view(torch.float16)[0].float() + planes.view(torch.float16)[1].float()) * sc
+    assert (back - w).abs().max() <= 2e-7 * w.abs().max()
+
+
+def test_vocoder_args_yml_reader(tmp_path):
+    """pipeline.read_vocoder_args: the three integers of a MelGAN args.yml (an argparse.Namespace dump,
+    evaluation/generate_samples_batch.py:34-36) read as plain text -- nothing is unpickled."""
+    from text_to_sound_synthesis_amd.pipeline import read_vocoder_args
+    f = tmp_path / "args.yml"
+    f.write_text("!!python/object:argparse.Namespace\nbatch_size: 16\ndata_path: /x/y\nn_mel_channels: 80\nngf: 48  # wider\n"
+                 "n_residual_layers: 4\nsave_path: logs/vggsound\n")
+    assert read_vocoder_args(str(f)) == (80, 48, 4)
+    f.write_text("ngf: 32\n")
+    assert read_vocoder_args(str(f)) == (80, 32, 3)          # missing fields keep the reference configuration's values
