@@ -388,13 +388,21 @@ int ds_conv3x3_tiles(int H, int W);   /* 4 x 32 pixel tiles per image */
 int ds_melgan_resblock_tail(const float* h, const float* x, const void* w, long long w_plane, float out_scale,
                             const float* bias, float* y, int M, int C, ds_stream_t stream);
 /* The whole ResnetBlock behind one entry (SURVEY.md section 8b's `ds_melgan_resblock`): y = shortcut(x) +
- * conv1x1(LReLU(conv_k3_dil(reflect_pad_dil(LReLU(x))))) as two launches -- the dilated k3 conv into the scratch tensor h
- * ([B][T][C], caller-owned), then ds_melgan_resblock_tail.  x, y [B][T][C] channels-last fp32; w3 = the fp16 planes of the
+ * conv1x1(LReLU(conv_k3_dil(reflect_pad_dil(LReLU(x))))).  x, y [B][T][C] channels-last fp32; w3 = the fp16 planes of the
  * weight-norm-folded k3 weights * 2^s ([C][3 C], K ordered [tap][channel]; w3_plane halves apart; w3_scale = 2^-s), b3 [C];
- * wt / wt_plane / wt_scale / bt = ds_melgan_resblock_tail's operands.  C % 32 == 0, 0 < dil < T. */
+ * wt / wt_plane / wt_scale / bt = ds_melgan_resblock_tail's operands.  C % 32 == 0, 0 < dil < T.
+ *   h != NULL: two launches -- the dilated k3 conv into the scratch tensor h ([B][T][C], caller-owned), then
+ *              ds_melgan_resblock_tail;
+ *   h == NULL: ONE single-pass kernel (x read once, y written once; the intermediate stays in registers) -- built for the
+ *              shapes ds_melgan_resblock_fused_ok() accepts (C = 32, T % 128 == 0, dil <= 16), an error elsewhere. */
 int ds_melgan_resblock(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
                        long long wt_plane, float wt_scale, const float* bt, float* h, float* y, int B, int T, int C,
                        int dil, ds_stream_t stream);
+int ds_melgan_resblock_fused_ok(int T, int C, int dil);   /* 1: ds_melgan_resblock(h = NULL) is available for this block */
+/* Generator tail (vocoder/modules.py:119-124) in one pass: out[b][t] = tanh(bias + sum_j sum_c w[j][c] *
+ * LReLU_0.2(x[b][reflect(t + j - 3)][c])), x [B][T][C] channels-last fp32, w [7][C] fp32 (tap-major), out [B][T].
+ * C = 32 (ngf = 32) is built; other widths use the 7-column GEMM + ds_stencil7_tanh. */
+int ds_melgan_final(const float* x, const float* w, float bias, float* out, int B, int T, int C, ds_stream_t stream);
 /* AttnBlock softmax (model.py:214-216): x[row][0..n) <- softmax(scale*x), x[row][n..ld) <- 0 */
 int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t stream);
 /* tap-sum for single-output-channel convs fed by a GEMM with N = taps */

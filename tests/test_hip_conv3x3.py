@@ -141,3 +141,73 @@ def test_melgan_resblock_tail_one_gemm():
     rms = float((a - bb).pow(2).mean().sqrt())
     print("MelGAN: one-GEMM block tails vs three launches per block, waveform RMS difference %.2e" % rms)
     assert torch.isfinite(a).all() and rms < 1e-6
+
+
+def _resblock_ref64(x, w3, b3, w2, b2, ws, bs, dil):
+    """vocoder/modules.py:72-85 in float64: x [B][T][C] channels-last; w3 [C][C][3], w2 / ws [C][C]."""
+    xc = x.double().permute(0, 2, 1)                                           # [B][C][T]
+    h = F.conv1d(F.pad(F.leaky_relu(xc, 0.2), (dil, dil), mode="reflect"), w3.double(), b3.double(), dilation=dil)
+    y = F.conv1d(F.leaky_relu(h, 0.2), w2.double()[:, :, None], b2.double()) + F.conv1d(xc, ws.double()[:, :, None], bs.double())
+    return y.permute(0, 2, 1).contiguous()
+
+
+@pytest.mark.parametrize("dil", [1, 3, 9])
+def test_melgan_resblock_single_pass(dil):
+    """ds_melgan_resblock(h = NULL): the 32-channel ResnetBlock as ONE kernel (melgan_fused.hip) against float64 and against the
+    two-launch form, clip ends (reflection) and tile borders included; three clips so that a persistent workgroup crosses clips."""
+    from text_to_sound_synthesis_amd import _lib as L
+    B, T, C = 3, 640, 32
+    assert L.lib().ds_melgan_resblock_fused_ok(T, C, dil) == 1
+    assert L.lib().ds_melgan_resblock_fused_ok(T + 64, C, dil) == 0 and L.lib().ds_melgan_resblock_fused_ok(T, 64, dil) == 0
+    x = rnd((B, T, C), "rb1.x%d" % dil, 2.0)
+    w3, w2, ws = rnd((C, C, 3), "rb1.w3", 0.15), rnd((C, C), "rb1.w2", 0.2), rnd((C, C), "rb1.ws", 0.2)
+    b3, b2, bs = rnd((C,), "rb1.b3"), rnd((C,), "rb1.b2"), rnd((C,), "rb1.bs")
+    ref = _resblock_ref64(x, w3, b3, w2, b2, ws, bs, dil)
+    p3, s3 = L.split_f16x2(w3.permute(0, 2, 1).reshape(C, 3 * C).contiguous().cuda())       # K ordered [tap][channel]
+    pt, st = L.split_f16x2(torch.cat((w2, ws), 1).contiguous().cuda())
+    xc, b3c, btc = x.cuda(), b3.cuda(), (b2 + bs).cuda()
+    out = {}
+    for name, hbuf in (("one", None), ("two", torch.empty(B, T, C, device="cuda"))):
+        y = torch.full((B, T, C), float("nan"), device="cuda")
+        L.check(L.lib().ds_melgan_resblock(L.ptr(xc), L.ptr(p3), C * 3 * C, s3, L.ptr(b3c), L.ptr(pt), C * 2 * C, st, L.ptr(btc),
+                                           L.ptr(hbuf), L.ptr(y), B, T, C, dil, L.stream()))
+        out[name] = y.cpu()
+    e1, e2 = relerr(out["one"], ref), relerr(out["two"], ref)
+    d = float((out["one"] - out["two"]).abs().max())
+    print("MelGAN ResnetBlock dil %d: single pass %.2e, two launches %.2e vs float64; max |one - two| %.2e" % (dil, e1, e2, d))
+    assert torch.isfinite(out["one"]).all() and e1 < 3e-6 and e2 < 3e-6
+    # a request the single-pass kernel is not built for fails loudly instead of falling back
+    y = torch.empty(B, T + 64, C, device="cuda")
+    xx = torch.zeros(B, T + 64, C, device="cuda")
+    assert L.lib().ds_melgan_resblock(L.ptr(xx), L.ptr(p3), C * 3 * C, s3, L.ptr(b3c), L.ptr(pt), C * 2 * C, st, L.ptr(btc), None,
+                                      L.ptr(y), B, T + 64, C, dil, L.stream()) != 0
+
+
+def test_melgan_final_single_pass_and_generator_ab():
+    """ds_melgan_final (LReLU + reflect k7 conv 32 -> 1 + tanh in one pass) against float64, ragged last tile and clip ends
+    included; then the whole Generator with the single-pass kernels on and off."""
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd import _lib as L
+    from text_to_sound_synthesis_amd.modeling.vocoder import Generator
+    B, T, C = 3, 1000, 32
+    x = rnd((B, T, C), "fin.x", 2.0)
+    w, bias = rnd((7, C), "fin.w", 0.1), 0.05
+    xr = F.pad(F.leaky_relu(x.double().permute(0, 2, 1), 0.2), (3, 3), mode="reflect")
+    ref = torch.tanh(F.conv1d(xr, w.double().t()[None], torch.tensor([bias], dtype=torch.float64)))[:, 0]
+    xc, wc = x.cuda(), w.cuda()
+    out = torch.full((B, T), float("nan"), device="cuda")
+    L.check(L.lib().ds_melgan_final(L.ptr(xc), L.ptr(wc), bias, L.ptr(out), B, T, C, L.stream()))
+    e = float((out.cpu().double() - ref).abs().max())
+    print("MelGAN final layer, single pass: max abs error vs float64 %.2e" % e)
+    assert torch.isfinite(out).all() and e < 2e-6
+    assert L.lib().ds_melgan_final(L.ptr(xc), L.ptr(wc), bias, L.ptr(out), B, T, 64, L.stream()) != 0      # not built: loud
+    g = Generator(80, 32, 3)
+    g.load_state_dict(synth_sd("generator"))
+    g = g.cuda().eval()
+    mel = synth.synth_uniform((2, 80, 53), key="rt.mel").cuda()
+    a = g(mel).cpu()
+    g.fuse_block, g.fuse_final = False, False
+    bb = g(mel).cpu()
+    rms = float((a - bb).pow(2).mean().sqrt())
+    print("MelGAN: single-pass 32-channel blocks + final layer vs the GEMM forms, waveform RMS difference %.2e" % rms)
+    assert torch.isfinite(a).all() and rms < 1e-6

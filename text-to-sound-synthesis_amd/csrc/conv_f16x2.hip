@@ -362,14 +362,24 @@ extern "C" int ds_melgan_resblock_tail(const float* h, const float* x, const voi
 
 // The whole MelGAN ResnetBlock (vocoder/modules.py:72-85) behind one entry:
 //   y = shortcut(x) + conv1x1(LReLU(conv_k3_dil(reflect_pad_dil(LReLU(x)))))
-// as two launches -- the dilated k3 conv into the scratch tensor h, then the one-GEMM tail above.  x, h, y: [B][T][C]
-// channels-last fp32; w3 = fp16 planes of W1 * 2^s1 ([C][3 C], K ordered [tap][channel], w3_plane halves apart), b3 [C];
-// wt / bt = the tail's [W2 | Ws] planes and b2 + bs.  C % 32 == 0, dil < T.
+// x, y: [B][T][C] channels-last fp32; w3 = fp16 planes of W1 * 2^s1 ([C][3 C], K ordered [tap][channel], w3_plane halves
+// apart), b3 [C]; wt / bt = the tail's [W2 | Ws] planes and b2 + bs.  C % 32 == 0, dil < T.
+//   h != NULL: two launches -- the dilated k3 conv into the scratch tensor h [B][T][C], then the one-GEMM tail above;
+//   h == NULL: the single-pass kernel (melgan_fused.hip: x read once, y written once, LReLU(h) never leaves registers) --
+//              only where ds_melgan_resblock_fused_ok(T, C, dil) says so, an error otherwise.
+int ds_launch_melgan_rb32(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
+                          long long wt_plane, float wt_scale, const float* bt, float* y, int B, int T, int dil, hipStream_t s);
+
 extern "C" int ds_melgan_resblock(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3,
                                   const void* wt, long long wt_plane, float wt_scale, const float* bt, float* h, float* y,
                                   int B, int T, int C, int dil, ds_stream_t stream) {
-    DS_CHECK_ARG(x && w3 && wt && h && y, "null pointer");
+    DS_CHECK_ARG(x && w3 && wt && y && b3 && bt, "null pointer");
     DS_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 32 == 0 && dil > 0 && dil < T, "C % 32 == 0, 0 < dil < T");
+    if (!h) {
+        DS_CHECK_ARG(ds_melgan_resblock_fused_ok(T, C, dil), "h == NULL asks for the single-pass kernel: not built for this (T, C, dil)");
+        DS_CHECK_ARG(w3_scale > 0.f && wt_scale > 0.f, "out scales must be set");
+        return ds_launch_melgan_rb32(x, w3, w3_plane, w3_scale, b3, wt, wt_plane, wt_scale, bt, y, B, T, dil, (hipStream_t)stream);
+    }
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.W = (const float*)w3; p.bias = b3; p.C = h;

@@ -1,0 +1,270 @@
+// MelGAN tail stages as single-pass kernels (vocoder/modules.py:72-85 ResnetBlock, :119-124 final conv + tanh).
+//
+// At 32 channels and 217 088 samples per clip a ResnetBlock is HBM-bound: its tensor is 1.78 GB per 64 clips, and the
+// two-launch form (dilated k3 conv -> h, then [LReLU(h) | x] x [W2 | Ws]^T) moves it five times (x, h out, h in, x, y).
+// ds_melgan_rb32_kernel moves it twice: a workgroup takes 128 consecutive time positions of one clip (+ dil halo rows each
+// side, reflected at the clip's ends like ReflectionPad1d), stages LReLU(x) and x once as fp16 hi | lo planes in LDS, and
+// runs both contractions TRANSPOSED -- H^T = W1 XL^T, Y^T = [W2 | Ws] [LReLU(H)^T ; X^T] -- so that a lane owns one time
+// position throughout: the accumulator layout of the first product (lane = time, registers = channels 8 jj + 4 g + i) IS a
+// B operand of the second once the k index of W2 is read in the same order, and LReLU(H) never leaves registers.  All
+// weights (W1: 12, [W2 | Ws]: 8 fragments of 4 VGPRs) stay in registers of a persistent workgroup; the next tile's global
+// loads are in flight while the current one is computed.  Same arithmetic as the two-launch form: 3-pass fp16 split
+// (lo x hi, hi x lo, hi x hi per 16-k step, fp32 accumulate), h = acc * 2^-s1 + b1 in fp32, split again after LReLU.
+//
+// ds_melgan_final32_kernel: LReLU -> ReflectionPad1d(3) -> Conv1d(32 -> 1, k7) -> tanh in one pass over the 32-channel
+// tensor (exact fp32 FMA chains per tap, taps added in order), instead of a 7-column fp32 GEMM + a stencil.
+#include "common.h"
+
+typedef _Float16 mg_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mg_h4 __attribute__((ext_vector_type(4)));
+
+#define MG_TT 128          // time positions per tile
+#define MG_PITCH 80        // bytes per LDS row of 32 halves (+ 16: the 16 rows a ds_read_b128 group touches hit 16 different slots)
+#define MG_MAXDIL 16       // 5 float4 per thread cover (128 + 2 * 16) rows
+#define MG_NLD 5
+#define MG_YPITCH 144      // bytes per staged output row (32 floats + 4)
+
+__device__ __forceinline__ float mg_lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
+
+__device__ __forceinline__ void mg_split4(const f32x4& v, mg_h4& hi, mg_h4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = ds_split_hi(v[e]);
+        lo[e] = ds_split_lo(v[e], hi[e]);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void ds_melgan_rb32_kernel(const float* __restrict__ x, const _Float16* __restrict__ w3,
+                                                                long long w3_plane, float s3, const float* __restrict__ b3,
+                                                                const _Float16* __restrict__ wt, long long wt_plane, float st,
+                                                                const float* __restrict__ bt, float* __restrict__ y, int T,
+                                                                int dil, int tiles_per_clip, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tc = lane & 31, g = lane >> 5;
+    const int R = MG_TT + 2 * dil;                       // staged rows of LReLU(x)
+    unsigned char* XL = mg_smem;                         // [2 planes][R][80 B]
+    const int PLXL = R * MG_PITCH;
+    unsigned char* XS = mg_smem + 2 * PLXL;              // [4 waves][2 planes][32 rows][80 B]; a wave's block doubles as its output stage
+    constexpr int XSW = 2 * 32 * MG_PITCH;               // 5120 B per wave (>= 32 * 144)
+
+    // ---- weights and biases into registers, once ------------------------------------------------------------------
+    mg_h8 a1h[3][2], a1l[3][2];                          // W1 fragments: rows = output channel tc', k = tap * 32 + 16 ks + 8 g ..
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const _Float16* p = w3 + (size_t)tc * 96 + tap * 32 + ks * 16 + g * 8;
+            a1h[tap][ks] = *(const mg_h8*)p;
+            a1l[tap][ks] = *(const mg_h8*)(p + w3_plane);
+        }
+    mg_h8 a2h[4], a2l[4];                                // [W2 | Ws] fragments; the h part in the accumulator's channel order
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const _Float16* p = wt + (size_t)tc * 64 + ks * 16 + g * 4;          // channels 16 ks + 4 g + {0..3} and + 8
+        const mg_h4 h0 = *(const mg_h4*)p, h1 = *(const mg_h4*)(p + 8);
+        const mg_h4 l0 = *(const mg_h4*)(p + wt_plane), l1 = *(const mg_h4*)(p + wt_plane + 8);
+        a2h[ks] = mg_h8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        a2l[ks] = mg_h8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        const _Float16* q = wt + (size_t)tc * 64 + 32 + ks * 16 + g * 8;     // the shortcut's x channels, natural order
+        a2h[2 + ks] = *(const mg_h8*)q;
+        a2l[2 + ks] = *(const mg_h8*)(q + wt_plane);
+    }
+    float b3v[16], btv[16];                              // bias of the channel accumulator register j holds: 8 (j >> 2) + 4 g + (j & 3)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int n = 8 * (j >> 2) + 4 * g + (j & 3);
+        b3v[j] = b3[n];
+        btv[j] = bt[n];
+    }
+
+    f32x4 pre[MG_NLD];
+    auto load_tile = [&](int tile) {
+        const int b = tile / tiles_per_clip, t0 = (tile - b * tiles_per_clip) * MG_TT;
+        const float* xb = x + (size_t)b * T * 32;
+#pragma unroll
+        for (int k = 0; k < MG_NLD; ++k) {
+            const int i = tid + 256 * k, r = i >> 3, c4 = i & 7;
+            if (r < R) {
+                int t = t0 - dil + r;
+                if (t < 0) t = -t;
+                if (t >= T) t = 2 * (T - 1) - t;
+                pre[k] = *(const f32x4*)(xb + (size_t)t * 32 + c4 * 4);
+            }
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < MG_NLD; ++k) {
+            const int i = tid + 256 * k, r = i >> 3, c4 = i & 7;
+            if (r < R) {
+                const f32x4 v = pre[k];
+                f32x4 l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) l[e] = mg_lrelu(v[e]);
+                mg_h4 hi, lo;
+                mg_split4(l, hi, lo);
+                *(mg_h4*)(XL + r * MG_PITCH + c4 * 8) = hi;
+                *(mg_h4*)(XL + PLXL + r * MG_PITCH + c4 * 8) = lo;
+                const int rr = r - dil;
+                if (rr >= 0 && rr < MG_TT) {
+                    mg_split4(v, hi, lo);
+                    unsigned char* d = XS + (rr >> 5) * XSW + (rr & 31) * MG_PITCH + c4 * 8;
+                    *(mg_h4*)d = hi;
+                    *(mg_h4*)(d + 32 * MG_PITCH) = lo;
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        write_tile();
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) load_tile(next);
+
+        // ---- H^T = W1 x LReLU(X)^T over the three taps ------------------------------------------------------------
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned char* xl = XL + (wave * 32 + tc) * MG_PITCH + g * 16;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char* p = xl + tap * dil * MG_PITCH + ks * 32;
+                const mg_h8 bh = *(const mg_h8*)p, bl = *(const mg_h8*)(p + PLXL);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[tap][ks], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[tap][ks], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[tap][ks], bh, acc, 0, 0, 0);
+            }
+        // ---- h = acc 2^-s1 + b1, LReLU, split: registers 8 ks .. 8 ks + 7 are the B fragment of k-step ks ------------
+        mg_h8 hh[2], hl[2];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float hv = mg_lrelu(acc[j] * s3 + b3v[j]);
+            const _Float16 hi = ds_split_hi(hv);
+            hh[j >> 3][j & 7] = hi;
+            hl[j >> 3][j & 7] = ds_split_lo(hv, hi);
+        }
+        // ---- Y^T = [W2 | Ws] x [LReLU(H)^T ; X^T] ----------------------------------------------------------------
+        f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2h[ks], hl[ks], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2l[ks], hh[ks], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2h[ks], hh[ks], acc2, 0, 0, 0);
+        }
+        unsigned char* xs = XS + wave * XSW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned char* p = xs + tc * MG_PITCH + ks * 32 + g * 16;
+            const mg_h8 bh = *(const mg_h8*)p, bl = *(const mg_h8*)(p + 32 * MG_PITCH);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2h[2 + ks], bl, acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2l[2 + ks], bh, acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2h[2 + ks], bh, acc2, 0, 0, 0);
+        }
+        // ---- y = acc2 2^-s2 + (b2 + bs): through the wave's own LDS block (its X^T rows are consumed), 128-byte rows out ----
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc2[4 * jj + e] * st + btv[4 * jj + e];
+            *(f32x4*)(xs + tc * MG_YPITCH + (8 * jj + 4 * g) * 4) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const int b = tile / tiles_per_clip, t0 = (tile - b * tiles_per_clip) * MG_TT;
+            float* yb = y + ((size_t)b * T + t0 + wave * 32) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q, r = i >> 3, c4 = i & 7;
+                *(f32x4*)(yb + r * 32 + c4 * 4) = *(const f32x4*)(xs + r * MG_YPITCH + c4 * 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Whether the single-pass kernel takes this block: 32 channels, whole 128-position tiles, the halo within the staging loop.
+extern "C" int ds_melgan_resblock_fused_ok(int T, int C, int dil) {
+    return C == 32 && T > 0 && T % MG_TT == 0 && dil > 0 && dil <= MG_MAXDIL && dil < T;
+}
+
+int ds_launch_melgan_rb32(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
+                          long long wt_plane, float wt_scale, const float* bt, float* y, int B, int T, int dil, hipStream_t s) {
+    static int wgs_per_cu = 0, n_cu = 0;
+    const int R = MG_TT + 2 * dil;
+    const size_t lds = (size_t)2 * R * MG_PITCH + 4 * 2 * 32 * MG_PITCH;
+    if (!n_cu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceProp_t prop;
+        hipGetDeviceProperties(&prop, dev);
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ds_melgan_rb32_kernel, 256,
+                                                         (size_t)2 * (MG_TT + 2 * MG_MAXDIL) * MG_PITCH + 8 * 32 * MG_PITCH) != hipSuccess || occ < 1)
+            occ = 2;
+        wgs_per_cu = occ;
+    }
+    const int tiles_per_clip = T / MG_TT;
+    const long long n_tiles = (long long)B * tiles_per_clip;
+    DS_CHECK_ARG(n_tiles < (1ll << 31), "too many tiles");
+    long long grid = (long long)n_cu * wgs_per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(ds_melgan_rb32_kernel, dim3((unsigned)grid), dim3(256), lds, s, x, (const _Float16*)w3, w3_plane, w3_scale,
+                       b3, (const _Float16*)wt, wt_plane, wt_scale, bt, y, T, dil, tiles_per_clip, (int)n_tiles);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- final layer: out[b][t] = tanh(bias + sum_j sum_c w[j][c] LReLU(x[b][reflect(t + j - 3)][c])) ----------------------------
+#define MG_FT 256          // outputs per workgroup
+#define MG_FPITCH 36       // floats per staged row (32 + 4: conflict-free 16-byte reads down a column of rows)
+
+__global__ __launch_bounds__(256) void ds_melgan_final32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float bias, float* __restrict__ out, int T, int tiles_per_clip) {
+    __shared__ __attribute__((aligned(16))) float xs[(MG_FT + 6) * MG_FPITCH];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / tiles_per_clip, t0 = (blockIdx.x - b * tiles_per_clip) * MG_FT;
+    const float* xb = x + (size_t)b * T * 32;
+    for (int i = tid; i < (MG_FT + 6) * 8; i += 256) {
+        const int r = i >> 3, c4 = i & 7;
+        int t = t0 - 3 + r;
+        if (t < 0) t = -t;
+        if (t >= T) t = 2 * (T - 1) - t;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) v = *(const f32x4*)(xb + (size_t)t * 32 + c4 * 4);      // (rows past a ragged last tile: unused)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = mg_lrelu(v[e]);
+        *(f32x4*)(xs + r * MG_FPITCH + c4 * 4) = v;
+    }
+    __syncthreads();
+    if (t0 + tid >= T) return;
+    float acc = bias;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const float* row = xs + (tid + j) * MG_FPITCH;
+        float s = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const f32x4 v = *(const f32x4*)(row + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(v[e], w[j * 32 + c4 * 4 + e], s);      // uniform address: scalar loads
+        }
+        acc += s;
+    }
+    out[(size_t)b * T + t0 + tid] = tanhf(acc);
+}
+
+// x [B][T][32] channels-last fp32, w [7 taps][32] fp32 (the folded weight of Conv1d(32, 1, 7), tap-major), out [B][T].
+extern "C" int ds_melgan_final(const float* x, const float* w, float bias, float* out, int B, int T, int C, ds_stream_t stream) {
+    DS_CHECK_ARG(x && w && out && B > 0 && T > 3, "bad arguments");
+    DS_CHECK_ARG(C == 32, "C = 32 is built (ngf = 32, the reference configuration)");
+    const int tiles_per_clip = (T + MG_FT - 1) / MG_FT;
+    hipLaunchKernelGGL(ds_melgan_final32_kernel, dim3((unsigned)(B * tiles_per_clip)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                       out, T, tiles_per_clip);
+    DS_CHECK_LAUNCH();
+    return 0;
+}

@@ -77,6 +77,10 @@ class Generator(nn.Module):
         # ResnetBlock tail (1x1 conv + 1x1 shortcut) as ONE contraction over [LReLU(h) | x] (ds_melgan_resblock_tail): the
         # shortcut tensor never goes through HBM.  False / DIFFSOUND_VOCODER_FUSE_TAIL=0: three launches per block.
         self.fuse_tail = os.environ.get("DIFFSOUND_VOCODER_FUSE_TAIL", "1") != "0"
+        # Single-pass kernels where they are built (melgan_fused.hip): the whole ResnetBlock of the 32-channel stage (its
+        # tensor crosses HBM twice instead of five times) and LReLU + k7 conv + tanh of the last layer.  "0": the GEMM forms.
+        self.fuse_block = os.environ.get("DIFFSOUND_VOCODER_FUSE_BLOCK", "1") != "0"
+        self.fuse_final = os.environ.get("DIFFSOUND_VOCODER_FUSE_FINAL", "1") != "0"
         self._pk = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
 
@@ -166,24 +170,30 @@ class Generator(nn.Module):
             h, T = y, T * r
             for rb in st["res"]:
                 M = B * T
-                h1 = torch.empty(B, T, cout, device=dev)
                 sc = torch.empty(B, T, cout, device=dev)
                 if self.fuse_tail and self.conv_precision == "f16x2":
-                    # the whole block behind one entry: dilated k3 conv into h1, then [LReLU(h1) | h] x [W2 | Ws]^T
+                    # the whole block behind one entry: ONE kernel where it is built (h1 = None), else the dilated k3 conv
+                    # into h1, then [LReLU(h1) | h] x [W2 | Ws]^T
+                    one_pass = self.fuse_block and _lib.lib().ds_melgan_resblock_fused_ok(T, cout, rb["dil"])
+                    h1 = None if one_pass else torch.empty(B, T, cout, device=dev)
                     w3, s3 = rb["c3_s"]
                     w2, osc = rb["tail_s"]
                     _lib.check(_lib.lib().ds_melgan_resblock(_lib.ptr(h), _lib.ptr(w3), cout * 3 * cout, s3, _lib.ptr(rb["c3"][1]),
                                                              _lib.ptr(w2), cout * 2 * cout, osc, _lib.ptr(rb["tail_b"]), _lib.ptr(h1),
                                                              _lib.ptr(sc), B, T, cout, rb["dil"], _lib.stream()))
                 else:
+                    h1 = torch.empty(B, T, cout, device=dev)
                     self._mm(h, rb["c3"][0], rb["c3_s"], h1, M, cout, 3 * cout, bias=rb["c3"][1], loader=_lib.LOAD_CONV1D,
                              pro=_lib.PRO_LRELU, Cin=cout, Wd=T, taps=3, dil=rb["dil"])
                     self._mm(h, rb["sc"][0], rb["sc_s"], sc, M, cout, cout, bias=rb["sc"][1])
                     self._mm(h1, rb["c1"][0], rb["c1_s"], sc, M, cout, cout, bias=rb["c1"][1], R=sc, pro=_lib.PRO_LRELU)
                 h = sc
         wl, bl = pk["last"]
+        out = torch.empty(B, 1, T, device=dev)
+        if self.fuse_final and wl.shape[1] == 32:
+            _lib.check(_lib.lib().ds_melgan_final(_lib.ptr(h), _lib.ptr(wl), bl, _lib.ptr(out), B, T, 32, _lib.stream()))
+            return out
         taps = torch.empty(B * T, 8, device=dev)
         _lib.gemm(h, wl, taps, B * T, 7, wl.shape[1], ldc=8, pro=_lib.PRO_LRELU)
-        out = torch.empty(B, 1, T, device=dev)
         _lib.check(_lib.lib().ds_stencil7_tanh(_lib.ptr(taps), 8, bl, _lib.ptr(out), B, T, _lib.stream()))
         return out
