@@ -394,7 +394,8 @@ int ds_melgan_resblock_tail(const float* h, const float* x, const void* w, long 
  *   h != NULL: two launches -- the dilated k3 conv into the scratch tensor h ([B][T][C], caller-owned), then
  *              ds_melgan_resblock_tail;
  *   h == NULL: ONE single-pass kernel (x read once, y written once; the intermediate stays in registers) -- built for the
- *              shapes ds_melgan_resblock_fused_ok() accepts (C = 32, T % 128 == 0, dil <= 16), an error elsewhere. */
+ *              shapes ds_melgan_resblock_fused_ok() accepts (C = 32: T % 128 == 0, dil <= 16; C = 64: T % 256 == 0, dil <= 9), an
+ *              error elsewhere. */
 int ds_melgan_resblock(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
                        long long wt_plane, float wt_scale, const float* bt, float* h, float* y, int B, int T, int C,
                        int dil, ds_stream_t stream);

@@ -152,16 +152,17 @@ def _resblock_ref64(x, w3, b3, w2, b2, ws, bs, dil):
 
 
 @pytest.mark.parametrize("dil", [1, 3, 9])
-def test_melgan_resblock_single_pass(dil):
-    """ds_melgan_resblock(h = NULL): the 32-channel ResnetBlock as ONE kernel (melgan_fused.hip) against float64 and against the
-    two-launch form, clip ends (reflection) and tile borders included; three clips so that a persistent workgroup crosses clips."""
+@pytest.mark.parametrize("C,T", [(32, 640), (64, 768)])
+def test_melgan_resblock_single_pass(C, T, dil):
+    """ds_melgan_resblock(h = NULL): the 32- / 64-channel ResnetBlock as ONE kernel (melgan_fused.hip) against float64 and against
+    the two-launch form, clip ends (reflection) and tile borders included; three clips so that a persistent workgroup crosses clips."""
     from text_to_sound_synthesis_amd import _lib as L
-    B, T, C = 3, 640, 32
+    B = 3
     assert L.lib().ds_melgan_resblock_fused_ok(T, C, dil) == 1
-    assert L.lib().ds_melgan_resblock_fused_ok(T + 64, C, dil) == 0 and L.lib().ds_melgan_resblock_fused_ok(T, 64, dil) == 0
-    x = rnd((B, T, C), "rb1.x%d" % dil, 2.0)
-    w3, w2, ws = rnd((C, C, 3), "rb1.w3", 0.15), rnd((C, C), "rb1.w2", 0.2), rnd((C, C), "rb1.ws", 0.2)
-    b3, b2, bs = rnd((C,), "rb1.b3"), rnd((C,), "rb1.b2"), rnd((C,), "rb1.bs")
+    assert L.lib().ds_melgan_resblock_fused_ok(T + 64, C, dil) == 0 and L.lib().ds_melgan_resblock_fused_ok(T, 128, dil) == 0
+    x = rnd((B, T, C), "rb1.x%d.%d" % (dil, C), 2.0)
+    w3, w2, ws = rnd((C, C, 3), "rb1.w3.%d" % C, 0.15), rnd((C, C), "rb1.w2.%d" % C, 0.2), rnd((C, C), "rb1.ws.%d" % C, 0.2)
+    b3, b2, bs = rnd((C,), "rb1.b3.%d" % C), rnd((C,), "rb1.b2.%d" % C), rnd((C,), "rb1.bs.%d" % C)
     ref = _resblock_ref64(x, w3, b3, w2, b2, ws, bs, dil)
     p3, s3 = L.split_f16x2(w3.permute(0, 2, 1).reshape(C, 3 * C).contiguous().cuda())       # K ordered [tap][channel]
     pt, st = L.split_f16x2(torch.cat((w2, ws), 1).contiguous().cuda())
@@ -174,7 +175,7 @@ def test_melgan_resblock_single_pass(dil):
         out[name] = y.cpu()
     e1, e2 = relerr(out["one"], ref), relerr(out["two"], ref)
     d = float((out["one"] - out["two"]).abs().max())
-    print("MelGAN ResnetBlock dil %d: single pass %.2e, two launches %.2e vs float64; max |one - two| %.2e" % (dil, e1, e2, d))
+    print("MelGAN ResnetBlock C %d dil %d: single pass %.2e, two launches %.2e vs float64; max |one - two| %.2e" % (C, dil, e1, e2, d))
     assert torch.isfinite(out["one"]).all() and e1 < 3e-6 and e2 < 3e-6
     # a request the single-pass kernel is not built for fails loudly instead of falling back
     y = torch.empty(B, T + 64, C, device="cuda")

@@ -367,8 +367,8 @@ extern "C" int ds_melgan_resblock_tail(const float* h, const float* x, const voi
 //   h != NULL: two launches -- the dilated k3 conv into the scratch tensor h [B][T][C], then the one-GEMM tail above;
 //   h == NULL: the single-pass kernel (melgan_fused.hip: x read once, y written once, LReLU(h) never leaves registers) --
 //              only where ds_melgan_resblock_fused_ok(T, C, dil) says so, an error otherwise.
-int ds_launch_melgan_rb32(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
-                          long long wt_plane, float wt_scale, const float* bt, float* y, int B, int T, int dil, hipStream_t s);
+int ds_launch_melgan_rb(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
+                        long long wt_plane, float wt_scale, const float* bt, float* y, int B, int T, int C, int dil, hipStream_t s);
 
 extern "C" int ds_melgan_resblock(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3,
                                   const void* wt, long long wt_plane, float wt_scale, const float* bt, float* h, float* y,
@@ -378,7 +378,7 @@ extern "C" int ds_melgan_resblock(const float* x, const void* w3, long long w3_p
     if (!h) {
         DS_CHECK_ARG(ds_melgan_resblock_fused_ok(T, C, dil), "h == NULL asks for the single-pass kernel: not built for this (T, C, dil)");
         DS_CHECK_ARG(w3_scale > 0.f && wt_scale > 0.f, "out scales must be set");
-        return ds_launch_melgan_rb32(x, w3, w3_plane, w3_scale, b3, wt, wt_plane, wt_scale, bt, y, B, T, dil, (hipStream_t)stream);
+        return ds_launch_melgan_rb(x, w3, w3_plane, w3_scale, b3, wt, wt_plane, wt_scale, bt, y, B, T, C, dil, (hipStream_t)stream);
     }
     GemmParams p;
     memset(&p, 0, sizeof(p));

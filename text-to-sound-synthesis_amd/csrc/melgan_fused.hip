@@ -186,14 +186,244 @@ __global__ __launch_bounds__(256, 2) void ds_melgan_rb32_kernel(const float* __r
     }
 }
 
-// Whether the single-pass kernel takes this block: 32 channels, whole 128-position tiles, the halo within the staging loop.
-extern "C" int ds_melgan_resblock_fused_ok(int T, int C, int dil) {
-    return C == 32 && T > 0 && T % MG_TT == 0 && dil > 0 && dil <= MG_MAXDIL && dil < T;
+// ---- 64 channels (the stage before: 108 544 samples per clip, the same 1.78 GB per tensor) ----------------------------------
+// The same transposed two-product scheme with 256 time positions per tile and eight waves of 32 positions.  80 weight
+// fragments no longer fit a wave's registers: both matrices sit in LDS for the lifetime of the persistent workgroup, stored
+// FRAGMENT-MAJOR (one KB per (row block, k-step, plane): lane l's 16 bytes at l * 16, conflict-free and address-free), 80 KB;
+// the LReLU(x) image takes the other 79 KB, so the shortcut's operand never enters LDS: every lane loads exactly the 8-channel
+// chunks of ITS row that are its B fragments of x (and, after LReLU, its 16-byte pieces of the image), splits them in
+// registers and keeps them there.  The output is staged through the image's space once all waves are past the first product.
+#define MG64_TT 256
+#define MG64_PITCH 144     // bytes per image row of 64 halves (+ 16)
+#define MG64_MAXDIL 9
+#define MG64_W1 0          // 48 fragments of W1:  ((nb * 3 + tap) * 4 + ks) * 2 + plane
+#define MG64_W2 49152      // 32 fragments of [W2 | Ws]:  (mb * 8 + k2) * 2 + plane; k2 < 4: LReLU(h) channels in accumulator order
+#define MG64_BIAS 81920    // b1 [64] | b2 + bs [64]
+#define MG64_XL 82432
+#define MG64_YPITCH 272    // bytes per staged output row (64 floats + 4)
+
+__device__ __forceinline__ void mg_split8(const f32x4& a, const f32x4& b, mg_h8& hi, mg_h8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = ds_split_hi(a[e]);
+        lo[e] = ds_split_lo(a[e], hi[e]);
+        hi[4 + e] = ds_split_hi(b[e]);
+        lo[4 + e] = ds_split_lo(b[e], hi[4 + e]);
+    }
 }
 
-int ds_launch_melgan_rb32(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
-                          long long wt_plane, float wt_scale, const float* bt, float* y, int B, int T, int dil, hipStream_t s) {
+__global__ __launch_bounds__(512, 2) void ds_melgan_rb64_kernel(const float* __restrict__ x, const _Float16* __restrict__ w3,
+                                                                long long w3_plane, float s3, const float* __restrict__ b3,
+                                                                const _Float16* __restrict__ wt, long long wt_plane, float st,
+                                                                const float* __restrict__ bt, float* __restrict__ y, int T,
+                                                                int dil, int tiles_per_clip, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tc = lane & 31, g = lane >> 5;
+    const int R = MG64_TT + 2 * dil;
+    const int PLXL = R * MG64_PITCH;
+    unsigned char* XL = mg_smem + MG64_XL;               // [2 planes][R][144 B]
+    const float* bias_s = (const float*)(mg_smem + MG64_BIAS);
+
+    // ---- weights into LDS, fragment-major, once ----------------------------------------------------------------------
+    for (int f = wave; f < 48; f += 8) {
+        const int plane = f & 1, ks = (f >> 1) & 3, tn = f >> 3, tap = tn % 3, nb = tn / 3;
+        *(mg_h8*)(mg_smem + MG64_W1 + f * 1024 + lane * 16) =
+            *(const mg_h8*)(w3 + plane * w3_plane + (size_t)(nb * 32 + tc) * 192 + tap * 64 + ks * 16 + g * 8);
+    }
+    for (int f = wave; f < 32; f += 8) {
+        const int plane = f & 1, k2 = (f >> 1) & 7, mb = f >> 4;
+        const _Float16* row = wt + plane * wt_plane + (size_t)(mb * 32 + tc) * 128;
+        mg_h8 v;
+        if (k2 < 4) {                                    // channels 16 k2 + 4 g + {0..3} and the same + 8
+            const mg_h4 h0 = *(const mg_h4*)(row + k2 * 16 + g * 4), h1 = *(const mg_h4*)(row + k2 * 16 + g * 4 + 8);
+            v = mg_h8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        } else {
+            v = *(const mg_h8*)(row + 64 + (k2 - 4) * 16 + g * 8);
+        }
+        *(mg_h8*)(mg_smem + MG64_W2 + f * 1024 + lane * 16) = v;
+    }
+    if (tid < 64) ((float*)(mg_smem + MG64_BIAS))[tid] = b3[tid];
+    else if (tid < 128) ((float*)(mg_smem + MG64_BIAS))[tid] = bt[tid - 64];
+
+    f32x4 pre[8], preh;
+    auto load_tile = [&](int tile) {
+        const int b = tile / tiles_per_clip, t0 = (tile - b * tiles_per_clip) * MG64_TT;
+        const float* xb = x + (size_t)b * T * 64;
+        const float* own = xb + (size_t)(t0 + wave * 32 + tc) * 64 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            pre[2 * ks] = *(const f32x4*)(own + ks * 16);
+            pre[2 * ks + 1] = *(const f32x4*)(own + ks * 16 + 4);
+        }
+        if (tid < 32 * dil) {                            // 2 dil halo rows of 16 float4
+            const int hr = tid >> 4, c4 = tid & 15, r = hr < dil ? hr : MG64_TT + hr;
+            int t = t0 - dil + r;
+            if (t < 0) t = -t;
+            if (t >= T) t = 2 * (T - 1) - t;
+            preh = *(const f32x4*)(xb + (size_t)t * 64 + c4 * 4);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        // ---- this tile's rows: x fragments stay in registers, LReLU(x) goes to the image -----------------------------------
+        mg_h8 xsh[4], xsl[4];
+        {
+            unsigned char* d = XL + (dil + wave * 32 + tc) * MG64_PITCH + g * 16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                mg_split8(pre[2 * ks], pre[2 * ks + 1], xsh[ks], xsl[ks]);
+                f32x4 l0, l1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    l0[e] = mg_lrelu(pre[2 * ks][e]);
+                    l1[e] = mg_lrelu(pre[2 * ks + 1][e]);
+                }
+                mg_h8 hi, lo;
+                mg_split8(l0, l1, hi, lo);
+                *(mg_h8*)(d + ks * 32) = hi;
+                *(mg_h8*)(d + ks * 32 + PLXL) = lo;
+            }
+            if (tid < 32 * dil) {
+                const int hr = tid >> 4, c4 = tid & 15, r = hr < dil ? hr : MG64_TT + hr;
+                f32x4 l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) l[e] = mg_lrelu(preh[e]);
+                mg_h4 hi, lo;
+                mg_split4(l, hi, lo);
+                *(mg_h4*)(XL + r * MG64_PITCH + c4 * 8) = hi;
+                *(mg_h4*)(XL + PLXL + r * MG64_PITCH + c4 * 8) = lo;
+            }
+        }
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) load_tile(next);
+
+        // ---- H^T = W1 x LReLU(X)^T --------------------------------------------------------------------------------------
+        f32x16 acc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[nb][j] = 0.f;
+        {
+            const unsigned char* xl = XL + (wave * 32 + tc) * MG64_PITCH + g * 16;
+            const unsigned char* wl = mg_smem + MG64_W1 + lane * 16;
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const unsigned char* p = xl + tap * dil * MG64_PITCH + ks * 32;
+                    const mg_h8 bh = *(const mg_h8*)p, bl = *(const mg_h8*)(p + PLXL);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const unsigned char* a = wl + (((nb * 3 + tap) * 4 + ks) * 2) * 1024;
+                        const mg_h8 ah = *(const mg_h8*)a, al = *(const mg_h8*)(a + 1024);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[nb], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();                                 // every wave is past its image reads: the image's space takes the output
+
+        // ---- h = acc 2^-s1 + b1, LReLU, split: accumulator registers 8 k' .. 8 k' + 7 of block nb = k-step 2 nb + k' ----------
+        mg_h8 hh[4], hl[4];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 bv = *(const f32x4*)(bias_s + nb * 32 + jj * 8 + g * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = jj * 4 + e;
+                    const float hv = mg_lrelu(acc[nb][j] * s3 + bv[e]);
+                    const _Float16 hi = ds_split_hi(hv);
+                    hh[nb * 2 + (j >> 3)][j & 7] = hi;
+                    hl[nb * 2 + (j >> 3)][j & 7] = ds_split_lo(hv, hi);
+                }
+            }
+        // ---- Y^T = [W2 | Ws] x [LReLU(H)^T ; X^T] ------------------------------------------------------------------------
+        f32x16 acc2[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[mb][j] = 0.f;
+        {
+            const unsigned char* wl = mg_smem + MG64_W2 + lane * 16;
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const mg_h8 bh = k2 < 4 ? hh[k2 & 3] : xsh[k2 & 3], bl = k2 < 4 ? hl[k2 & 3] : xsl[k2 & 3];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const unsigned char* a = wl + ((mb * 8 + k2) * 2) * 1024;
+                    const mg_h8 ah = *(const mg_h8*)a, al = *(const mg_h8*)(a + 1024);
+                    acc2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[mb], 0, 0, 0);
+                    acc2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[mb], 0, 0, 0);
+                    acc2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2[mb], 0, 0, 0);
+                }
+            }
+        }
+        // ---- y = acc2 2^-s2 + (b2 + bs): the wave's 32 rows through LDS, 256-byte rows out ---------------------------------
+        unsigned char* ys = XL + wave * (32 * MG64_YPITCH);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 bv = *(const f32x4*)(bias_s + 64 + mb * 32 + jj * 8 + g * 4);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc2[mb][4 * jj + e] * st + bv[e];
+                *(f32x4*)(ys + tc * MG64_YPITCH + (mb * 32 + 8 * jj + 4 * g) * 4) = o;
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const int b = tile / tiles_per_clip, t0 = (tile - b * tiles_per_clip) * MG64_TT;
+            float* yb = y + ((size_t)b * T + t0 + wave * 32) * 64;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = lane + 64 * q, r = i >> 4, c4 = i & 15;
+                *(f32x4*)(yb + r * 64 + c4 * 4) = *(const f32x4*)(ys + r * MG64_YPITCH + c4 * 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Whether the single-pass kernel takes this block: 32 channels, whole 128-position tiles, the halo within the staging loop.
+extern "C" int ds_melgan_resblock_fused_ok(int T, int C, int dil) {
+    if (C == 32) return T > 0 && T % MG_TT == 0 && dil > 0 && dil <= MG_MAXDIL && dil < T;
+    if (C == 64) return T > 0 && T % MG64_TT == 0 && dil > 0 && dil <= MG64_MAXDIL && dil < T;
+    return 0;
+}
+
+int ds_launch_melgan_rb(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
+                        long long wt_plane, float wt_scale, const float* bt, float* y, int B, int T, int C, int dil, hipStream_t s) {
     static int wgs_per_cu = 0, n_cu = 0;
+    if (C == 64) {                                       // one 8-wave workgroup per CU (161 KB of LDS)
+        static int attr_set = 0;
+        const size_t lds64 = (size_t)MG64_XL + 2 * (size_t)(MG64_TT + 2 * dil) * MG64_PITCH;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)ds_melgan_rb64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    MG64_XL + 2 * (MG64_TT + 2 * MG64_MAXDIL) * MG64_PITCH) != hipSuccess) {
+                ds_set_error("ds_melgan_resblock: cannot reserve %d bytes of LDS", MG64_XL + 2 * (MG64_TT + 2 * MG64_MAXDIL) * MG64_PITCH);
+                return -1;
+            }
+            attr_set = 1;
+        }
+        int dev = 0, cus = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int tpc = T / MG64_TT;
+        const long long nt = (long long)B * tpc;
+        DS_CHECK_ARG(nt < (1ll << 31), "too many tiles");
+        const long long grid64 = nt < cus ? nt : cus;
+        hipLaunchKernelGGL(ds_melgan_rb64_kernel, dim3((unsigned)grid64), dim3(512), lds64, s, x, (const _Float16*)w3, w3_plane,
+                           w3_scale, b3, (const _Float16*)wt, wt_plane, wt_scale, bt, y, T, dil, tpc, (int)nt);
+        DS_CHECK_LAUNCH();
+        return 0;
+    }
     const int R = MG_TT + 2 * dil;
     const size_t lds = (size_t)2 * R * MG_PITCH + 4 * 2 * 32 * MG_PITCH;
     if (!n_cu) {
