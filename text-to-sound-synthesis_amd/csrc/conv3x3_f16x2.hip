@@ -8,13 +8,21 @@
 // output tile (M = 128) x 128 output channels and walks the input channels in slabs of 32: the slab's 6 x 34 pixel HALO is
 // loaded, activated and split ONCE into LDS and all nine taps read their A fragments from it at shifted pixel offsets.
 // The weights do not pass through LDS at all: they are packed once (host, _lib.pack_conv3x3_weights) so that every MFMA
-// B fragment of a (n-tile, slab, tap) is one contiguous KB, and each wave loads its own eight fragments per tap straight
-// from L2 into registers, one tap ahead -- so the ONLY barrier is the halo swap, once per slab = per 216 MFMAs of a wave
-// (the first form of this kernel staged a [128][32] weight tile per tap through LDS behind a barrier per tap: 308 TF-eq).
+// B fragment of a (n-tile, slab, tap) is one contiguous KB, and each wave loads the fragments of ITS 32 output channels
+// straight from L2 into a register ring, C3_RING - 1 = 5 k-steps (60 MFMAs) ahead -- so the ONLY barrier is the halo swap, once
+// per slab = per 216 MFMAs of a wave.  A wave's tile is all four tile rows x 32 output channels (no two waves load the same
+// weight bytes; the A fragments, four block rows per k-step, come from LDS with immediate offsets off ONE base register).
+// Round 5 (this form): the wave tile was 2 x 2 blocks with the weights one tap ahead and the GroupNorm affine loaded from
+// global memory inside every halo work item -- the ISA showed s_waitcnt vmcnt(0) there, seven exposed L2 round trips per
+// slab that also drained the weight prefetch (45 % of the wave time in s_waitcnt, profiles/r04m_*): 305-344 -> 335-372 TF-eq.
+// Measured null on top of this form (profiles/r05e_*): a ring of 9 k-steps, A fragments read one k-step ahead into a second
+// register set -- the kernel now sits at 0.40-0.45 of the nominal ceiling where the dominant GEMM, whose matrix pipe is 98 %
+// busy, reaches 0.485 under the same board power cap.
 // Vector work per output element drops ~6x against the gather kernel, activation traffic out of L2 ~5x.
-//   LDS: two halo slabs [2 planes][204 px][32 ch] (2 x 26 KB; 64-byte pixel rows, 16-byte chunks XOR-swizzled by
-//        (px>>2)&3: the 32 consecutive pixels of an MFMA block row are conflict-free for ds_read_b128 at every tap
-//        offset); slab s + 1 is loaded into registers and written into the other buffer in two halves under taps 0 - 5.
+//   LDS: two halo slabs [2 planes][204 px][32 ch + 8] (2 x 32 KB; 80-byte pixel rows: the 16 consecutive pixels a
+//        ds_read_b128 service group touches land in 16 different 16-byte slots of the 256-byte bank row at every tap offset,
+//        with no swizzle in the address), then the sample's GroupNorm [scale | shift]; slab s + 1 is loaded into registers
+//        and written into the other buffer in two halves under taps 0 - 5.
 //   Epilogue: bias, optional residual, row-major fp32 store through LDS (16-byte accesses), and optionally the GroupNorm
 //        partial sums of the OUTPUT per (tile, channel) in double -- the statistics pass of the next GroupNorm
 //        (ds_gn_partial_kernel: one more read of the tensor) disappears; ds_groupnorm_finish turns them into the affine.
@@ -29,16 +37,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define C3_TW 32
 #define C3_HW (C3_TW + 2)             // halo pitch (pixels)
 #define C3_HPX ((C3_TH + 2) * C3_HW)  // 204 halo pixels
-#define C3_HPL (C3_HPX * 32)          // halves per halo plane
+#define C3_PXP 40                     // halves per halo pixel in LDS: 32 channels + 8 (80-byte rows: see "LDS" above)
+#define C3_HPL (C3_HPX * C3_PXP)      // halves per halo plane
 #define C3_BN 128
-#define C3_WSTEP 8192                 // halves of packed weights per (n-tile, slab, tap): [plane 2][wn 2][j 2][ks 2][lane 64][8]
+#define C3_WSTEP 8192                 // halves of packed weights per (n-tile, slab, tap): [plane 2][column block 4 = wave][ks 2][lane 64][8]
 #define C3_NF4 ((C3_HPX * 8 + 255) / 256)   // float4 work items of a halo slab per thread (7)
-#ifndef C3_PIN
-#define C3_PIN 0
+#ifndef C3_RING                       // k-steps of weight fragments in flight per wave (divides 18)
+#define C3_RING 6
 #endif
-#ifndef C3_APRE                       // probe: A fragments of k-step ks + 1 read before the MFMAs of k-step ks
-#define C3_APRE 0
-#endif
+#define C3_HALO_BYTES (2 * 2 * C3_HPL * 2)
+#define C3_MAXCIN 1024               // (the LDS reservation of the prologue affine)
 
 struct Conv3Params {
     const float* x;        // [B][Hs][Ws][Cin]
@@ -60,7 +68,6 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;               // wave tile: tile rows 2 wm, 2 wm + 1 x columns wn * 64 .. + 63
     const int tiles_n = p.Cout / C3_BN, tiles_s = p.tiles_x * p.tiles_y, nblk = gridDim.x;
     int bid = blockIdx.x;
     {   // each XCD works a contiguous run of tiles (the n-tiles of a pixel tile share its halo through that XCD's L2)
@@ -73,6 +80,17 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
     const int n0 = nt * C3_BN;
     const int Hs = UP ? p.H >> 1 : p.H, Ws = UP ? p.W >> 1 : p.W;
     const float* xb = p.x + (size_t)b * Hs * Ws * p.Cin;
+    // GroupNorm's folded affine of this sample, [scale Cin | shift Cin], behind the halo buffers: read per slab from LDS.
+    // (Loaded from global memory at its use it sat behind an s_waitcnt vmcnt(0) in every halo work item -- seven exposed L2
+    // round trips per slab that also drained the weight prefetch.)
+    const float* scs = (const float*)(smem_raw + C3_HALO_BYTES);
+    if (PRO) {
+        float* w_ = (float*)(smem_raw + C3_HALO_BYTES);
+        for (int i = tid * 4; i < 2 * p.Cin; i += 1024)
+            *(f32x4*)(w_ + i) = i < p.Cin ? *(const f32x4*)(p.pro_scale + (size_t)b * p.Cin + i)
+                                          : *(const f32x4*)(p.pro_shift + (size_t)b * p.Cin + (i - p.Cin));
+        __syncthreads();
+    }
 
     // ---- halo staging: work item f = tid + 256 u -> halo pixel f >> 3, float4 (4 channels) f & 7 of the 32-channel slab ----
     // (source / destination offsets are re-derived per use: kept in registers they cost 14 VGPRs the main loop does not have)
@@ -85,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
         const bool ok = px < C3_HPX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
         if (UP) { yy >>= 1; xx >>= 1; }
         src = ok ? (yy * Ws + xx) * p.Cin + c4 * 4 : -1;      // element offset of the source pixel's channel quad (-1: zeros)
-        dst = px < C3_HPX ? px * 32 + (((c4 >> 1) ^ ((px >> 2) & 3)) << 3) + ((c4 & 1) << 2) : -1;   // halves, inside a plane
+        dst = px < C3_HPX ? px * C3_PXP + c4 * 4 : -1;       // halves, inside a plane
     };
     // (in two halves, work items [0, 4) and [4, 7): 16 instead of 28 registers of halo data in flight next to the 64
     //  accumulators and the two sets of weight fragments)
@@ -96,13 +114,29 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
         for (int u = U0; u < U1; ++u) {
             int src, dst;
             h_item(u, src, dst);
-            hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (src >= 0) hv[u] = *(const f32x4*)(xb + src + slab * 32);
+            // asm like the weight loads below (the compiler's own s_waitcnt for a load it knows would be vmcnt(0): it cannot see the
+            // asm loads around it, and would drain the weight ring); a pixel outside the image loads pixel 0 and is zeroed below
+            const unsigned off = (unsigned)((src < 0 ? 0 : src) + slab * 32) * 4u;
+            f32x4 t;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t) : "v"(off), "s"(xb) : "memory");
+            hv[u] = t;
         }
     };
-    auto halo_write = [&](int slab, auto u0_, auto u1_) {
-        constexpr int U0 = decltype(u0_)::value, U1 = decltype(u1_)::value;
+    // wait_: the loads issued since the matching halo_load (they may stay in flight)
+    auto halo_write = [&](int slab, auto u0_, auto u1_, auto wait_) {
+        constexpr int U0 = decltype(u0_)::value, U1 = decltype(u1_)::value, WAIT = decltype(wait_)::value;
         _Float16* hb = halo + (slab & 1) * (2 * C3_HPL);
+#pragma unroll
+        for (int u = U0; u < U1; ++u) {
+            f32x4 t = hv[u];
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(t) : "n"(WAIT));
+            hv[u] = t;
+        }
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};     // the thread's channel quad is the same for every work item
+        if (PRO) {
+            sc = *(const f32x4*)(scs + slab * 32 + (tid & 7) * 4);
+            sh = *(const f32x4*)(scs + p.Cin + slab * 32 + (tid & 7) * 4);
+        }
 #pragma unroll
         for (int u = U0; u < U1; ++u) {
             int src, dst;
@@ -110,9 +144,6 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
             if (dst < 0) continue;
             f32x4 v = hv[u];
             if (PRO) {
-                const int ch = slab * 32 + ((tid + 256 * u) & 7) * 4;
-                const f32x4 sc = *(const f32x4*)(p.pro_scale + (size_t)b * p.Cin + ch);
-                const f32x4 sh = *(const f32x4*)(p.pro_shift + (size_t)b * p.Cin + ch);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = v[e] * sc[e] + sh[e];
@@ -131,99 +162,79 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
             *(h4*)(hb + C3_HPL + dst) = s1;
         }
     };
-    // ---- this wave's eight B fragments of step t = slab * 9 + tap: [plane][j][ks], each one 16-byte load per lane ----
+    // ---- wave tile: all four tile rows (4 MFMA block rows) x output channels wave * 32 .. + 31 --------------------------------
+    // Its B fragments of k-step q = (slab * 9 + tap) * 2 + ks are [plane][64 lanes][8]: two 16-byte loads per lane straight from
+    // L2, no two waves loading the same bytes.  C3_RING k-steps are held in a register ring: the fragments of k-step q + RING - 1
+    // are requested at the start of k-step q into the slot k-step q - 1 has just consumed, i.e. (RING - 1) * 12 MFMAs ahead.
     const int nslab = p.Cin >> 5;
-    const _Float16* wq = p.w + (size_t)nt * nslab * 9 * C3_WSTEP + wn * 2048 + lane * 8;
-    auto w_load = [&](int t, h8 (&f)[8]) {
-        const _Float16* q = wq + (size_t)t * C3_WSTEP;
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) f[pl * 4 + jj * 2 + ks] = *(const h8*)(q + pl * 4096 + jj * 1024 + ks * 512);
+    // The loads are written as asm: hipcc sinks compiler-visible prefetch loads towards their first use (the whole ring then
+    // refills in one burst right before it is needed); asm volatile keeps them where they are written, in order, and the
+    // matching wait is explicit -- s_waitcnt vmcnt(2 (RING - 1)) leaves exactly the younger k-steps in flight (loads the compiler
+    // issues in between, the halo's, only make that wait conservative).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* wbase = (const char*)(p.w + (size_t)nt * nslab * 9 * C3_WSTEP + wave_u * 1024);
+    const unsigned voff0 = lane * 16, voff1 = lane * 16 + 8192;          // plane 1 sits 4096 halves behind plane 0
+    const int nq = nslab * 18;
+    h8 bq[C3_RING][2];
+    auto w_load = [&](int q, h8 (&f)[2]) {
+        const char* r = wbase + (size_t)(q >> 1) * (C3_WSTEP * 2) + (q & 1) * 1024;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f[0]) : "v"(voff0), "s"(r) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f[1]) : "v"(voff1), "s"(r) : "memory");
     };
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int px_base = (wm * 2) * C3_HW + l31;      // halo pixel of (tile row 2 wm, column l31) at tap (0, 0)
-
-    h8 bc[8], bn[8];
     const std::integral_constant<int, 0> U_A{};
     const std::integral_constant<int, 4> U_B{};
     const std::integral_constant<int, C3_NF4> U_C{};
+    const std::integral_constant<int, 12> W12{};
     halo_load(0, U_A, U_C);
-    w_load(0, bc);
-    halo_write(0, U_A, U_C);
+#pragma unroll
+    for (int q = 0; q < C3_RING - 1; ++q) w_load(q, bq[q]);         // (nq >= 18 > RING - 1)
+    halo_write(0, U_A, U_C, std::integral_constant<int, 2 * (C3_RING - 1)>{});
     __syncthreads();
     for (int slab = 0; slab < nslab; ++slab) {
         const bool more_slabs = slab + 1 < nslab;
-        const _Float16* hb = halo + (slab & 1) * (2 * C3_HPL);
+        const _Float16* ab = halo + (slab & 1) * (2 * C3_HPL) + l31 * C3_PXP + hh * 8;    // lane's pixel column and k half
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const bool more = tap < 8 || more_slabs;
-            if (more) w_load(slab * 9 + tap + 1, bn);
             if (tap == 0 && more_slabs) halo_load(slab + 1, U_A, U_B);      // first half of the next slab: lands under taps 0, 1
             if (tap == 3 && more_slabs) halo_load(slab + 1, U_B, U_C);      // second half: under taps 3, 4
-#if C3_PIN     // probe: pin the prefetch loads where they are written (hipcc sinks them towards their first use); measured slower
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            {
-                const int ky = tap / 3, kx = tap - ky * 3;
-                auto afrag = [&](int ks, h8 (&f0)[2], h8 (&f1)[2]) {
+            const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int px = px_base + (i + ky) * C3_HW + kx;
-                        const _Float16* ar = hb + px * 32 + ((((2 * ks + hh) ^ ((px >> 2) & 3))) << 3);
-                        f0[i] = *(const h8*)ar;
-                        f1[i] = *(const h8*)(ar + C3_HPL);
-                    }
-                };
-                auto mm = [&](int ks, const h8 (&f0)[2], const h8 (&f1)[2]) {
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ql = tap * 2 + ks;                                 // k-step inside the slab; 18 % C3_RING == 0
+                const int qn = slab * 18 + ql + C3_RING - 1;
+                w_load(qn < nq ? qn : nq - 1, bq[(ql + C3_RING - 1) % C3_RING]);     // (past the end: a harmless reload, no branch)
+                h8 fa0[4], fa1[4];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const _Float16* ar = ab + ((i + ky) * C3_HW + kx) * C3_PXP + ks * 16;     // an immediate offset
+                    fa0[i] = *(const h8*)ar;
+                    fa1[i] = *(const h8*)(ar + C3_HPL);
+                }
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bq[ql % C3_RING][0]), "+v"(bq[ql % C3_RING][1]) : "n"(2 * (C3_RING - 1)));
+                const h8 b0 = bq[ql % C3_RING][0], b1 = bq[ql % C3_RING][1];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            f32x16 c = acc[i][j];
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[i], bc[j * 2 + ks], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[i], bc[4 + j * 2 + ks], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[i], bc[j * 2 + ks], c, 0, 0, 0);
-                            acc[i][j] = c;
-                        }
-                };
-                h8 fa0[2], fa1[2], fb0[2], fb1[2];
-                afrag(0, fa0, fa1);
-#if C3_APRE
-                afrag(1, fb0, fb1);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(0, fa0, fa1);
-                mm(1, fb0, fb1);
-#else
-                mm(0, fa0, fa1);
-                afrag(1, fb0, fb1);
-                mm(1, fb0, fb1);
-#endif
+                for (int i = 0; i < 4; ++i) {
+                    f32x16 c = acc[i];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[i], b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[i], b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[i], b0, c, 0, 0, 0);
+                    acc[i] = c;
+                }
             }
             // the other halo buffer is free: every wave passed the barrier that ended the slab before this one
-            if (tap == 2 && more_slabs) halo_write(slab + 1, U_A, U_B);
-            if (tap == 5 && more_slabs) halo_write(slab + 1, U_B, U_C);
-#if C3_PIN
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            if (more) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bc[e] = bn[e];
-            }
+            if (tap == 2 && more_slabs) halo_write(slab + 1, U_A, U_B, W12);      // 3 taps x 2 k-steps x 2 loads since its halo_load
+            if (tap == 5 && more_slabs) halo_write(slab + 1, U_B, U_C, W12);
         }
         __syncthreads();            // slab s is read, slab s + 1 is written
     }
 
-    // ---- epilogue: two passes of 64 tile rows (the rows of wave row wm = pass) staged as fp32 [64][128] in LDS ----
+    // ---- epilogue: two passes of 64 tile rows (block rows 2 pass, 2 pass + 1 of every wave) staged as fp32 [64][128] in LDS ----
     const float osc = p.out_scale;
     float* Tf = (float*)smem_raw;
     const int cc = tid & 31, col = n0 + cc * 4;
@@ -232,18 +243,14 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
     if (p.bias) bias4 = *(const f32x4*)(p.bias + col);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        if (wm == pass) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {                     // every wave: its block rows 2 pass, 2 pass + 1, columns wave * 32 ..
+            const int cl = wave * 32 + l31;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int cl = (wn * 2 + j) * 32 + l31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        Tf[rl * C3_BN + cl] = acc[i][j][r] * osc;
-                    }
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                Tf[rl * C3_BN + cl] = acc[2 * pass + i][r] * osc;
+            }
         }
         __syncthreads();
         // staged row rl (0..63) = tile row 2 pass + (rl >> 5), pixel rl & 31
@@ -296,12 +303,13 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
 
 template <int PRO, int UP, bool STATS>
 static int conv3_launch(const Conv3Params& p, hipStream_t s) {
-    const size_t lds = (size_t)(2 * 2 * C3_HPL) * sizeof(unsigned short);     // two halo slabs: 52 224 bytes
+    // two halo slabs (52 224 bytes) + the sample's [scale | shift] of the prologue
+    const size_t lds = (size_t)C3_HALO_BYTES + (PRO ? (size_t)2 * p.Cin * sizeof(float) : 0);
     static_assert((2 * 2 * C3_HPL) * 2 >= 64 * C3_BN * 4, "the staged output half tile fits");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_conv3x3_f16x2_kernel<PRO, UP, STATS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C3_HALO_BYTES + 2 * C3_MAXCIN * 4);
         if (e != hipSuccess) {
             ds_set_error("conv3x3_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
@@ -322,8 +330,8 @@ extern "C" int ds_conv3x3_f16x2(const float* x, const void* w2, long long w_halv
                                 const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int up,
                                 const float* pro_scale, const float* pro_shift, double* gn_part, ds_stream_t stream) {
     DS_CHECK_ARG(x && w2 && y, "null pointer");
-    DS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % C3_BN == 0,
-                 "Cin % 32 == 0 and Cout % 128 == 0");
+    DS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 32 == 0 && Cin <= C3_MAXCIN && Cout > 0 && Cout % C3_BN == 0,
+                 "Cin % 32 == 0, Cin <= 1024 and Cout % 128 == 0");
     DS_CHECK_ARG(up == 0 || (up == 1 && H % 2 == 0 && W % 2 == 0), "up: 0, or 1 (source is H/2 x W/2, nearest-upsampled)");
     DS_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "prologue: both of scale / shift or neither");
     DS_CHECK_ARG(!(up == 1 && pro_scale), "no prologue on the upsampling conv");
