@@ -229,7 +229,7 @@ class VQModel(nn.Module):
         # activated and split once for all nine taps, the GroupNorm statistics of the output come out of its epilogue);
         # False / DIFFSOUND_CONV_HALO=0: every conv on the tap-by-tap gather kernel (csrc/conv_f16x2.hip)
         self.conv_halo = os.environ.get("DIFFSOUND_CONV_HALO", "1") != "0"
-        self.conv_halo_min_rows = 20
+        self.conv_halo_min_rows = int(os.environ.get("DIFFSOUND_CONV_HALO_MIN_ROWS", "5"))
         self._pk = None
         # samples decoded / encoded at once: bounds the full-resolution workspace (34.7 MB per sample and tensor,
         # ~15 GB live at 64) and the 32-bit element indices inside the kernels ([B][80][848][128] < 2^31 up to B=247);
