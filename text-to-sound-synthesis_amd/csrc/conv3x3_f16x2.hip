@@ -12,10 +12,10 @@
 // straight from L2 into a register ring, C3_RING - 1 = 5 k-steps (60 MFMAs) ahead -- so the ONLY barrier is the halo swap, once
 // per slab = per 216 MFMAs of a wave.  A wave's tile is all four tile rows x 32 output channels (no two waves load the same
 // weight bytes; the A fragments, four block rows per k-step, come from LDS with immediate offsets off ONE base register).
-// Round 5 (this form): the wave tile was 2 x 2 blocks with the weights one tap ahead and the GroupNorm affine loaded from
+// Round 4, second form: the wave tile had been 2 x 2 blocks with the weights one tap ahead and the GroupNorm affine loaded from
 // global memory inside every halo work item -- the ISA showed s_waitcnt vmcnt(0) there, seven exposed L2 round trips per
 // slab that also drained the weight prefetch (45 % of the wave time in s_waitcnt, profiles/r04m_*): 305-344 -> 335-372 TF-eq.
-// Measured null on top of this form (profiles/r05e_*): a ring of 9 k-steps, A fragments read one k-step ahead into a second
+// Measured null on top of this form (profiles/r04ze_*): a ring of 9 k-steps, A fragments read one k-step ahead into a second
 // register set -- the kernel now sits at 0.40-0.45 of the nominal ceiling where the dominant GEMM, whose matrix pipe is 98 %
 // busy, reaches 0.485 under the same board power cap.
 // Vector work per output element drops ~6x against the gather kernel, activation traffic out of L2 ~5x.
