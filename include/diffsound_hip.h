@@ -381,6 +381,13 @@ int ds_conv3x3_f16x2(const float* x, const void* w2, long long w_halves, float o
                      const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int up,
                      const float* pro_scale, const float* pro_shift, double* gn_part, ds_stream_t stream);
 int ds_conv3x3_tiles(int H, int W);   /* 4 x 32 pixel tiles per image */
+/* Dilated k = 3 Conv1d with ReflectionPad1d(dil) (MelGAN ResnetBlock's first conv, vocoder/modules.py:75-78), halo-tiled like
+ * ds_conv3x3_f16x2:  y[b][t][n] = bias[n] + 2^-s sum_{j<3} sum_c W[n][j][c] act(x[b][reflect(t + (j - 1) dil)][c]),  act =
+ * LeakyReLU(0.2) if lrelu.  x [B][T][Cin], y [B][T][Cout] channels-last fp32; w2 = the fp16 planes of W * 2^s fragment-packed
+ * (_lib.pack_conv_weights(.., taps = 3); w_halves = 2 * Cout * 3 * Cin); out_scale = 2^-s.  Cin % 32 == 0, Cout % 128 == 0,
+ * 0 < dil <= 27. */
+int ds_conv1d_k3_f16x2(const float* x, const void* w2, long long w_halves, float out_scale, const float* bias, float* y, int B,
+                       int T, int Cin, int Cout, int dil, int lrelu, ds_stream_t stream);
 /* MelGAN ResnetBlock tail (vocoder/modules.py:72-85) in one contraction over K = 2 C: y = W2 LReLU(h) + Ws x + bias, h = the
  * block's dilated k3 conv output [M][C], x = the block input [M][C] (channels-last rows), w = the two fp16 planes of
  * [W2 | Ws] * 2^s ([C][2 C] row-major, w_plane halves apart, split_f16x2), out_scale = 2^-s, bias = b2 + bs.  Replaces the

@@ -212,3 +212,43 @@ def test_melgan_final_single_pass_and_generator_ab():
     rms = float((a - bb).pow(2).mean().sqrt())
     print("MelGAN: single-pass 32-channel blocks + final layer vs the GEMM forms, waveform RMS difference %.2e" % rms)
     assert torch.isfinite(a).all() and rms < 1e-6
+
+
+@pytest.mark.parametrize("C,T,dil", [(128, 700, 1), (128, 512, 9), (256, 300, 3), (128, 1000, 27)])
+def test_conv1d_k3_halo_vs_float64_and_gather_kernel(C, T, dil):
+    """ds_conv1d_k3_f16x2 (conv1d_f16x2.hip: MelGAN's dilated k3 conv with ReflectionPad1d, LeakyReLU in front) against float64
+    and against the tap-by-tap kernel; ragged last tile, clip ends, one / two output-channel tiles, several slabs."""
+    from text_to_sound_synthesis_amd import _lib as L
+    B = 3
+    x = rnd((B, T, C), "c1.x%d.%d" % (C, dil), 2.0)
+    w, bias = rnd((C, C, 3), "c1.w%d" % C, 0.1), rnd((C,), "c1.b%d" % C)
+    xr = F.pad(F.leaky_relu(x.double().permute(0, 2, 1), 0.2), (dil, dil), mode="reflect")
+    ref = F.conv1d(xr, w.double(), bias.double(), dilation=dil).permute(0, 2, 1).contiguous()
+    w2d = w.permute(0, 2, 1).reshape(C, 3 * C).contiguous().cuda()                      # K ordered [tap][channel]
+    planes, sc = L.split_f16x2(w2d)
+    wq = L.pack_conv_weights(planes, C, C, 3)
+    xc, bc = x.cuda(), bias.cuda()
+    y = torch.full((B, T, C), float("nan"), device="cuda")
+    L.check(L.lib().ds_conv1d_k3_f16x2(L.ptr(xc), L.ptr(wq), wq.numel(), sc, L.ptr(bc), L.ptr(y), B, T, C, C, dil, 1, L.stream()))
+    y2 = torch.empty(B, T, C, device="cuda")
+    L.gemm(xc, planes, y2, B * T, C, 3 * C, split2=sc, conv_split=True, bias=bc, loader=L.LOAD_CONV1D, pro=L.PRO_LRELU, Cin=C, Wd=T,
+           taps=3, dil=dil)
+    e1, e2 = relerr(y.cpu(), ref), relerr(y2.cpu(), ref)
+    print("conv1d k3 C %d T %d dil %d: halo kernel %.2e, gather kernel %.2e vs float64; max |a - b| %.2e"
+          % (C, T, dil, e1, e2, float((y - y2).abs().max())))
+    assert torch.isfinite(y).all() and e1 < 3e-6 and e1 <= 1.5 * e2 + 1e-7
+
+
+def test_generator_conv1d_halo_ab():
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd.modeling.vocoder import Generator
+    g = Generator(80, 32, 3)
+    g.load_state_dict(synth_sd("generator"))
+    g = g.cuda().eval()
+    mel = synth.synth_uniform((2, 80, 53), key="rt.mel").cuda()
+    a = g(mel).cpu()
+    g.conv1d_halo = False
+    bb = g(mel).cpu()
+    rms = float((a - bb).pow(2).mean().sqrt())
+    print("MelGAN: halo-tiled k3 convs of the 128 / 256-channel blocks vs the gather kernel, waveform RMS difference %.2e" % rms)
+    assert torch.isfinite(a).all() and rms < 1e-6

@@ -124,6 +124,7 @@ _PROTOS = {
     "ds_conv3x3_f16x2": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _vp, _vp, _vp, _vp]),
     "ds_conv3x3_tiles": (C.c_int, [C.c_int, C.c_int]),
+    "ds_conv1d_k3_f16x2": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_melgan_resblock_tail": (C.c_int, [_vp, _vp, _vp, _i64, _f, _vp, _vp, C.c_int, C.c_int, _vp]),
     "ds_melgan_resblock": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _i64, _f, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_softmax_rows": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f, _vp]),
@@ -248,14 +249,18 @@ def split_bf16x3(w):
     return torch.stack((p0, p1, p2)).contiguous().view(torch.int16)
 
 
-def pack_conv3x3_weights(planes, Cout, Cin):
-    """[2][Cout][9 * Cin] fp16 planes of a 3x3 conv's weights (K ordered [tap][channel], split_f16x2) -> the fragment-packed
-    layout ds_conv3x3_f16x2 loads straight into MFMA B operands (csrc/conv3x3_f16x2.hip):
-    [Cout/128][Cin/32][9 taps][2 planes][2 wave columns][2 blocks of 32 channels][2 k-steps][64 lanes][8 halves], where lane
-    (hh = lane >> 5, l = lane & 31) of fragment (wn, j, ks) holds W[n = 128 nt + 64 wn + 32 j + l][tap][32 slab + 16 ks + 8 hh + 0..7]."""
+def pack_conv_weights(planes, Cout, Cin, taps):
+    """[2][Cout][taps * Cin] fp16 planes of a conv's weights (K ordered [tap][channel], split_f16x2) -> the fragment-packed
+    layout ds_conv3x3_f16x2 (taps = 9) / ds_conv1d_k3_f16x2 (taps = 3) load straight into MFMA B operands:
+    [Cout/128][Cin/32][taps][2 planes][4 blocks of 32 output channels = the wave][2 k-steps][64 lanes][8 halves], where lane
+    (hh = lane >> 5, l = lane & 31) of fragment (wave, ks) holds W[n = 128 nt + 32 wave + l][tap][32 slab + 16 ks + 8 hh + 0..7]."""
     assert Cout % 128 == 0 and Cin % 32 == 0
-    w = planes.view(torch.int16).view(2, Cout // 128, 2, 2, 32, 9, Cin // 32, 2, 2, 8)     # pl nt wn j l tap ns ks hh e
+    w = planes.view(torch.int16).view(2, Cout // 128, 2, 2, 32, taps, Cin // 32, 2, 2, 8)     # pl nt wn j l tap ns ks hh e
     return w.permute(1, 6, 5, 0, 2, 3, 7, 8, 4, 9).contiguous().view(-1)
+
+
+def pack_conv3x3_weights(planes, Cout, Cin):
+    return pack_conv_weights(planes, Cout, Cin, 9)
 
 
 def pack_planes(x2):

@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
         __syncthreads();            // slab s is read, slab s + 1 is written
     }
 
+    // The asm loads still in flight (the ring's clamped refills of the last k-steps, the redundant last halo request) must land
+    // BEFORE the epilogue reuses their registers: hipcc does not know they are outstanding.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
     // ---- epilogue: two passes of 64 tile rows (block rows 2 pass, 2 pass + 1 of every wave) staged as fp32 [64][128] in LDS ----
     const float osc = p.out_scale;
     float* Tf = (float*)smem_raw;

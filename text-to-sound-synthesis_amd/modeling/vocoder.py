@@ -81,6 +81,9 @@ class Generator(nn.Module):
         # tensor crosses HBM twice instead of five times) and LReLU + k7 conv + tanh of the last layer.  "0": the GEMM forms.
         self.fuse_block = os.environ.get("DIFFSOUND_VOCODER_FUSE_BLOCK", "1") != "0"
         self.fuse_final = os.environ.get("DIFFSOUND_VOCODER_FUSE_FINAL", "1") != "0"
+        # the dilated k3 conv of the 128- / 256-channel blocks on the halo-tiled kernel (conv1d_f16x2.hip: the input tile is
+        # activated and split once for the three taps); "0": the tap-by-tap gather kernel
+        self.conv1d_halo = os.environ.get("DIFFSOUND_VOCODER_CONV1D_HALO", "1") != "0"
         self._pk = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
 
@@ -131,6 +134,8 @@ class Generator(nn.Module):
                     rb[k + "_s"] = sp(rb[k][0])
                 # [W2 | Ws] (one power-of-two scale for both) and b2 + bs for the one-GEMM block tail
                 rb["tail_s"] = sp(torch.cat((rb["c1"][0], rb["sc"][0]), dim=1).contiguous())
+                c = rb["c3"][0].shape[0]
+                rb["c3_q"] = _lib.pack_conv_weights(rb["c3_s"][0], c, c, 3) if c % 128 == 0 else None
                 rb["tail_b"] = (rb["c1"][1] + rb["sc"][1]).contiguous()
         self._pk = pk
         return pk
@@ -178,6 +183,15 @@ class Generator(nn.Module):
                     h1 = None if one_pass else torch.empty(B, T, cout, device=dev)
                     w3, s3 = rb["c3_s"]
                     w2, osc = rb["tail_s"]
+                    if not one_pass and self.conv1d_halo and rb["c3_q"] is not None and rb["dil"] <= 27:
+                        # 128 / 256 channels: the k3 conv on the halo-tiled kernel, then the one-GEMM tail
+                        L = _lib.lib()
+                        _lib.check(L.ds_conv1d_k3_f16x2(_lib.ptr(h), _lib.ptr(rb["c3_q"]), rb["c3_q"].numel(), s3, _lib.ptr(rb["c3"][1]),
+                                                        _lib.ptr(h1), B, T, cout, cout, rb["dil"], 1, _lib.stream()))
+                        _lib.check(L.ds_melgan_resblock_tail(_lib.ptr(h1), _lib.ptr(h), _lib.ptr(w2), cout * 2 * cout, osc,
+                                                             _lib.ptr(rb["tail_b"]), _lib.ptr(sc), M, cout, _lib.stream()))
+                        h = sc
+                        continue
                     _lib.check(_lib.lib().ds_melgan_resblock(_lib.ptr(h), _lib.ptr(w3), cout * 3 * cout, s3, _lib.ptr(rb["c3"][1]),
                                                              _lib.ptr(w2), cout * 2 * cout, osc, _lib.ptr(rb["tail_b"]), _lib.ptr(h1),
                                                              _lib.ptr(sc), B, T, cout, rb["dil"], _lib.stream()))
