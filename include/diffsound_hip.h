@@ -407,6 +407,13 @@ int ds_melgan_resblock(const float* x, const void* w3, long long w3_plane, float
                        long long wt_plane, float wt_scale, const float* bt, float* h, float* y, int B, int T, int C,
                        int dil, ds_stream_t stream);
 int ds_melgan_resblock_fused_ok(int T, int C, int dil);   /* 1: ds_melgan_resblock(h = NULL) is available for this block */
+/* MelGAN's two last upsampling layers in one pass each (vocoder/modules.py:104-113): y [B][2 Tin][Cout] =
+ * ConvTranspose1d(k = 4, stride 2, padding 1)(LeakyReLU_0.2(x [B][Tin][Cin])), channels-last fp32.  w = the fp16 planes of the
+ * polyphase weights * 2^s, [2 phases][Cout][2 taps][Cin] (phase p: W[:, :, p] on x[s0], W[:, :, p + 2] on x[s0 - 1]), w_plane
+ * halves apart; out_scale = 2^-s.  (Cin, Cout) = (128, 64) and (64, 32) are built (ds_melgan_convt2_ok), an error elsewhere. */
+int ds_melgan_convt2(const float* x, const void* w, long long w_plane, float out_scale, const float* bias, float* y, int B, int Tin,
+                     int Cin, int Cout, ds_stream_t stream);
+int ds_melgan_convt2_ok(int Cin, int Cout);
 /* Generator tail (vocoder/modules.py:119-124) in one pass: out[b][t] = tanh(bias + sum_j sum_c w[j][c] *
  * LReLU_0.2(x[b][reflect(t + j - 3)][c])), x [B][T][C] channels-last fp32, w [7][C] fp32 (tap-major), out [B][T].
  * C = 32 (ngf = 32) is built; other widths use the 7-column GEMM + ds_stencil7_tanh. */

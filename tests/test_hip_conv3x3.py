@@ -252,3 +252,45 @@ def test_generator_conv1d_halo_ab():
     rms = float((a - bb).pow(2).mean().sqrt())
     print("MelGAN: halo-tiled k3 convs of the 128 / 256-channel blocks vs the gather kernel, waveform RMS difference %.2e" % rms)
     assert torch.isfinite(a).all() and rms < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,T", [(128, 64, 300), (64, 32, 1000)])
+def test_melgan_convt2_single_pass(cin, cout, T):
+    """ds_melgan_convt2: LeakyReLU + ConvTranspose1d(k = 4, s = 2, p = 1) in one pass against float64 (torch's conv_transpose1d)
+    and against the polyphase GEMMs; ragged last tile, both clip ends."""
+    from text_to_sound_synthesis_amd import _lib as L
+    B = 3
+    x = rnd((B, T, cin), "ct.x%d" % cin, 2.0)
+    w, bias = rnd((cin, cout, 4), "ct.w%d" % cin, 0.1), rnd((cout,), "ct.b%d" % cin)
+    ref = F.conv_transpose1d(F.leaky_relu(x.double().permute(0, 2, 1), 0.2), w.double(), bias.double(), stride=2, padding=1)
+    ref = ref.permute(0, 2, 1).contiguous()                                      # [B][2 T][cout]
+    # polyphase packing of modeling/vocoder.py: [r][Cout][2][Cin], phase p: taps p (on x[s0]) and p + r (on x[s0 - 1])
+    wph = w.permute(2, 1, 0).reshape(2, 2, cout, cin).permute(1, 2, 0, 3).reshape(2, cout, 2 * cin).contiguous()
+    planes, sc = L.split_f16x2(wph.reshape(-1, 2 * cin).cuda())
+    xc, bc = x.cuda(), bias.cuda()
+    y = torch.full((B, 2 * T, cout), float("nan"), device="cuda")
+    assert L.lib().ds_melgan_convt2_ok(cin, cout) == 1 and L.lib().ds_melgan_convt2_ok(cin, 128) == 0
+    L.check(L.lib().ds_melgan_convt2(L.ptr(xc), L.ptr(planes), 2 * cout * 2 * cin, sc, L.ptr(bc), L.ptr(y), B, T, cin, cout, L.stream()))
+    y2 = torch.empty(B, 2 * T, cout, device="cuda")
+    L.gemm(xc, planes, y2, B * T, cout, 2 * cin, split2=sc, conv_split=True, bias=bc, ldc=cout, loader=L.LOAD_CONVT1D, pro=L.PRO_LRELU,
+           store=L.STORE_CONVT, groups=2, w_gstride=cout * 2 * cin, Cin=cin, Wd=T, ct_r=2, ct_p=1, ct_tin=T)
+    e1, e2 = relerr(y.cpu(), ref), relerr(y2.cpu(), ref)
+    print("ConvTranspose1d %d -> %d, T %d: single pass %.2e, polyphase GEMMs %.2e vs float64; max |a - b| %.2e"
+          % (cin, cout, T, e1, e2, float((y - y2).abs().max())))
+    assert torch.isfinite(y).all() and e1 < 3e-6
+    assert L.lib().ds_melgan_convt2(L.ptr(xc), L.ptr(planes), 2 * cout * 2 * cin, sc, L.ptr(bc), L.ptr(y), B, T, cin, 128, L.stream()) != 0
+
+
+def test_generator_fused_convt_ab():
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd.modeling.vocoder import Generator
+    g = Generator(80, 32, 3)
+    g.load_state_dict(synth_sd("generator"))
+    g = g.cuda().eval()
+    mel = synth.synth_uniform((2, 80, 53), key="rt.mel").cuda()
+    a = g(mel).cpu()
+    g.fuse_convt = False
+    bb = g(mel).cpu()
+    rms = float((a - bb).pow(2).mean().sqrt())
+    print("MelGAN: single-pass stride-2 ConvTranspose1d layers vs the polyphase GEMMs, waveform RMS difference %.2e" % rms)
+    assert torch.isfinite(a).all() and rms < 1e-6

@@ -449,6 +449,161 @@ int ds_launch_melgan_rb(const float* x, const void* w3, long long w3_plane, floa
     return 0;
 }
 
+// ---- ConvTranspose1d(k = 4, stride 2, padding 1) of the two last upsampling stages (128 -> 64, 64 -> 32 channels) ---------------
+// LeakyReLU in front (vocoder/modules.py:104-113).  out[2 q + 1] = W[:, :, 0] a[q + 1] + W[:, :, 2] a[q],  out[2 q] = W[:, :, 1] a[q]
+// + W[:, :, 3] a[q - 1]  (a = LReLU(x), rows outside [0, Tin) are zero): two phases over the same input rows.  As r polyphase
+// GEMMs on the gather kernel each phase re-read and re-split the input (2.2 x the layer's byte floor).  Here a workgroup stages the
+// LReLU(x) rows of 128 input positions (+ 1 each side) once as fp16 hi | lo planes, eight waves = (phase, 32-channel block,
+// position range) each keep THEIR weight fragments in registers for the lifetime of the persistent workgroup (transposed product:
+// lane = position), and the 256 output rows of the tile -- one contiguous block of y -- leave through LDS as full rows.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512, 2) void ds_melgan_convt2_kernel(const float* __restrict__ x, const _Float16* __restrict__ w,
+                                                                  long long w_plane, float osc, const float* __restrict__ bias,
+                                                                  float* __restrict__ y, int Tin, int tiles_per_clip, int n_tiles) {
+    constexpr int NMB = COUT / 32, NCOMBO = 2 * NMB, NSPLIT = 8 / NCOMBO, NPOS = 128 / NSPLIT, NCB = NPOS / 32;
+    constexpr int KS = CIN / 16;                         // k-steps per tap
+    constexpr int PITCH = CIN * 2 + 16;                  // image row bytes
+    constexpr int ROWS = 130;
+    constexpr int PL = ROWS * PITCH;
+    constexpr int YP = COUT * 4 + 16;                    // staged output row bytes
+    constexpr int NLD = (ROWS * CIN / 4 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mg_smem[];
+    unsigned char* IM = mg_smem;                         // [2 planes][130][PITCH]
+    unsigned char* YS = mg_smem + 2 * PL;                // [256][YP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tc = lane & 31, g = lane >> 5;
+    const int combo = wave / NSPLIT, part = wave % NSPLIT, ph = combo / NMB, mb = combo % NMB;
+    const int e_p = ph == 0 ? 1 : 0;                     // source index s0 = q + e_p; taps read s0 and s0 - 1
+
+    mg_h8 ah[2][KS], al[2][KS];                          // this wave's weights: rows ph * COUT + mb * 32 + tc, k = tap * CIN + 16 ks + 8 g ..
+#pragma unroll
+    for (int tap = 0; tap < 2; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const _Float16* p = w + (size_t)(ph * COUT + mb * 32 + tc) * (2 * CIN) + tap * CIN + ks * 16 + g * 8;
+            ah[tap][ks] = *(const mg_h8*)p;
+            al[tap][ks] = *(const mg_h8*)(p + w_plane);
+        }
+    float* BS = (float*)(mg_smem + 2 * PL + 256 * YP);   // the bias [COUT]
+    if (tid < COUT) BS[tid] = bias[tid];
+
+    f32x4 pre[NLD];
+    auto load_tile = [&](int tile) {
+        const int b = tile / tiles_per_clip, q0 = (tile - b * tiles_per_clip) * 128;
+        const float* xb = x + (size_t)b * Tin * CIN;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));                  // opaque: hipcc must not keep the nine (tile-invariant) row / column pairs in registers
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid_o + 512 * k, r = i / (CIN / 4), c4 = i - r * (CIN / 4);
+            const int sidx = q0 - 1 + r;
+            pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < ROWS && sidx >= 0 && sidx < Tin) pre[k] = *(const f32x4*)(xb + (size_t)sidx * CIN + c4 * 4);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        int tid_w = tid;
+        asm volatile("" : "+v"(tid_w));
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid_w + 512 * k, r = i / (CIN / 4), c4 = i - r * (CIN / 4);
+            if (r < ROWS) {
+                f32x4 l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) l[e] = mg_lrelu(pre[k][e]);
+                mg_h4 hi, lo;
+                mg_split4(l, hi, lo);
+                *(mg_h4*)(IM + r * PITCH + c4 * 8) = hi;
+                *(mg_h4*)(IM + PL + r * PITCH + c4 * 8) = lo;
+            }
+        }
+        __syncthreads();                                 // image written (and every wave is past the previous tile's output rows)
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) load_tile(next);
+
+        // one 32-position block at a time (16 accumulator registers next to the 4 CIN resident weight registers)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int j = part * NPOS + cb * 32 + tc;                         // position inside the tile; image row j + 1 + e_p - tap
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 2; ++tap)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned char* p = IM + (j + 1 + e_p - tap) * PITCH + ks * 32 + g * 16;
+                    const mg_h8 bh = *(const mg_h8*)p, bl = *(const mg_h8*)(p + PL);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap][ks], bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap][ks], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap][ks], bh, acc, 0, 0, 0);
+                    if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // (hipcc would hoist all 4 KS fragment reads: spills)
+                }
+            // output row of position j, phase ph: 2 j + (ph == 0); the wave's 32 channels as four 16-byte pieces per lane
+            unsigned char* d = YS + (2 * j + e_p) * YP + (mb * 32 + 4 * g) * 4;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 b4 = *(const f32x4*)(BS + mb * 32 + 8 * jj + 4 * g);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[4 * jj + e] * osc + b4[e];
+                *(f32x4*)(d + jj * 32) = o;
+            }
+        }
+        __syncthreads();                                 // rows complete; the image is free for the next tile
+        {
+            const int b = tile / tiles_per_clip, q0 = (tile - b * tiles_per_clip) * 128;
+            float* yb = y + ((size_t)b * Tin * 2 + 2 * q0) * COUT;
+            constexpr int PER_ROW = COUT / 4;
+#pragma unroll
+            for (int k = 0; k < 256 * PER_ROW / 512; ++k) {
+                const int i = tid + 512 * k, r = i / PER_ROW, c4 = i - r * PER_ROW;
+                if (2 * q0 + r < 2 * Tin) *(f32x4*)(yb + (size_t)r * COUT + c4 * 4) = *(const f32x4*)(YS + r * YP + c4 * 16);
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT>
+static int mg_launch_convt2(const float* x, const void* w, long long w_plane, float osc, const float* bias, float* y, int B, int Tin,
+                            hipStream_t s) {
+    constexpr int lds = 2 * 130 * (CIN * 2 + 16) + 256 * (COUT * 4 + 16) + COUT * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)ds_melgan_convt2_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            ds_set_error("ds_melgan_convt2: cannot reserve %d bytes of LDS", lds);
+            return -1;
+        }
+        attr_set = true;
+    }
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int tpc = (Tin + 127) / 128;
+    const long long nt = (long long)B * tpc;
+    DS_CHECK_ARG(nt < (1ll << 31), "too many tiles");
+    const long long grid = nt < cus ? nt : cus;
+    hipLaunchKernelGGL((ds_melgan_convt2_kernel<CIN, COUT>), dim3((unsigned)grid), dim3(512), lds, s, x, (const _Float16*)w, w_plane, osc,
+                       bias, y, Tin, tpc, (int)nt);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// y [B][2 Tin][Cout] = ConvTranspose1d(k = 4, s = 2, p = 1)(LeakyReLU_0.2(x [B][Tin][Cin])), channels-last fp32.  w = the fp16
+// planes of the polyphase weights * 2^s, [2 phases][Cout][2 taps][Cin] (phase p: taps W[:, :, p] on x[s0], W[:, :, p + 2] on
+// x[s0 - 1]; what modeling/vocoder.py packs for the polyphase GEMMs), w_plane halves apart; out_scale = 2^-s.
+// (Cin, Cout) = (128, 64) or (64, 32) are built.
+extern "C" int ds_melgan_convt2(const float* x, const void* w, long long w_plane, float out_scale, const float* bias, float* y, int B,
+                                int Tin, int Cin, int Cout, ds_stream_t stream) {
+    DS_CHECK_ARG(x && w && bias && y && B > 0 && Tin > 1 && out_scale > 0.f, "bad arguments");
+    DS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0, "operands must be 16-byte aligned");
+    if (Cin == 128 && Cout == 64) return mg_launch_convt2<128, 64>(x, w, w_plane, out_scale, bias, y, B, Tin, (hipStream_t)stream);
+    if (Cin == 64 && Cout == 32) return mg_launch_convt2<64, 32>(x, w, w_plane, out_scale, bias, y, B, Tin, (hipStream_t)stream);
+    ds_set_error("ds_melgan_convt2: (Cin, Cout) = (%d, %d) is not built (128 -> 64 and 64 -> 32 are)", Cin, Cout);
+    return -1;
+}
+extern "C" int ds_melgan_convt2_ok(int Cin, int Cout) { return (Cin == 128 && Cout == 64) || (Cin == 64 && Cout == 32); }
+
 // ---- final layer: out[b][t] = tanh(bias + sum_j sum_c w[j][c] LReLU(x[b][reflect(t + j - 3)][c])) ----------------------------
 #define MG_FT 256          // outputs per workgroup
 #define MG_FPITCH 36       // floats per staged row (32 + 4: conflict-free 16-byte reads down a column of rows)

@@ -84,6 +84,8 @@ class Generator(nn.Module):
         # the dilated k3 conv of the 128- / 256-channel blocks on the halo-tiled kernel (conv1d_f16x2.hip: the input tile is
         # activated and split once for the three taps); "0": the tap-by-tap gather kernel
         self.conv1d_halo = os.environ.get("DIFFSOUND_VOCODER_CONV1D_HALO", "1") != "0"
+        # the two stride-2 ConvTranspose1d layers as one pass each (ds_melgan_convt2); "0": polyphase GEMMs on the gather kernel
+        self.fuse_convt = os.environ.get("DIFFSOUND_VOCODER_FUSE_CONVT", "1") != "0"
         self._pk = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
 
@@ -169,9 +171,13 @@ class Generator(nn.Module):
             r, cin, cout = st["r"], st["cin"], st["cout"]
             w, b = st["ct"]
             y = torch.empty(B, T * r, cout, device=dev)
-            self._mm(h, w, st["ct_s"], y, B * T, cout, 2 * cin, bias=b, ldc=cout, loader=_lib.LOAD_CONVT1D,
-                     pro=_lib.PRO_LRELU, store=_lib.STORE_CONVT, groups=r, w_gstride=cout * 2 * cin, Cin=cin, Wd=T,
-                     ct_r=r, ct_p=r // 2 + r % 2, ct_tin=T)
+            if r == 2 and self.fuse_convt and self.conv_precision == "f16x2" and _lib.lib().ds_melgan_convt2_ok(cin, cout):
+                _lib.check(_lib.lib().ds_melgan_convt2(_lib.ptr(h), _lib.ptr(st["ct_s"][0]), r * cout * 2 * cin, st["ct_s"][1], _lib.ptr(b),
+                                                       _lib.ptr(y), B, T, cin, cout, _lib.stream()))
+            else:
+                self._mm(h, w, st["ct_s"], y, B * T, cout, 2 * cin, bias=b, ldc=cout, loader=_lib.LOAD_CONVT1D,
+                         pro=_lib.PRO_LRELU, store=_lib.STORE_CONVT, groups=r, w_gstride=cout * 2 * cin, Cin=cin, Wd=T,
+                         ct_r=r, ct_p=r // 2 + r % 2, ct_tin=T)
             h, T = y, T * r
             for rb in st["res"]:
                 M = B * T
