@@ -407,6 +407,14 @@ int ds_melgan_resblock(const float* x, const void* w3, long long w3_plane, float
                        long long wt_plane, float wt_scale, const float* bt, float* h, float* y, int B, int T, int C,
                        int dil, ds_stream_t stream);
 int ds_melgan_resblock_fused_ok(int T, int C, int dil);   /* 1: ds_melgan_resblock(h = NULL) is available for this block */
+/* ConvTranspose1d(k = 2 r, stride r, padding pad) in polyphase form on the halo-tiled kernel (MelGAN's stride-8 upsampling layers,
+ * vocoder/modules.py:104-113):  y[b][(q + e_p) r + p - pad][n] = bias[n] + 2^-s sum_c (W[p][n][0][c] act(x[b][q + e_p][c]) +
+ * W[p][n][1][c] act(x[b][q + e_p - 1][c])),  e_p = p < pad, source rows outside [0, T) zero, act = LeakyReLU(0.2) if lrelu.
+ * x [B][T][Cin], y [B][T r][Cout] channels-last fp32; w2 = the r phases' weights [Cout][2 Cin] (tap 0 = W[:, :, p], tap 1 =
+ * W[:, :, p + r]), each split (one scale) and fragment-packed (_lib.pack_conv_weights(.., taps = 2)), concatenated;
+ * w_halves = r * 2 * Cout * 2 * Cin.  Cin % 32 == 0, Cout % 128 == 0. */
+int ds_convt1d_f16x2(const float* x, const void* w2, long long w_halves, float out_scale, const float* bias, float* y, int B, int T,
+                     int Cin, int Cout, int r, int pad, int lrelu, ds_stream_t stream);
 /* MelGAN's two last upsampling layers in one pass each (vocoder/modules.py:104-113): y [B][2 Tin][Cout] =
  * ConvTranspose1d(k = 4, stride 2, padding 1)(LeakyReLU_0.2(x [B][Tin][Cin])), channels-last fp32.  w = the fp16 planes of the
  * polyphase weights * 2^s, [2 phases][Cout][2 taps][Cin] (phase p: W[:, :, p] on x[s0], W[:, :, p + 2] on x[s0 - 1]), w_plane

@@ -294,3 +294,29 @@ def test_generator_fused_convt_ab():
     rms = float((a - bb).pow(2).mean().sqrt())
     print("MelGAN: single-pass stride-2 ConvTranspose1d layers vs the polyphase GEMMs, waveform RMS difference %.2e" % rms)
     assert torch.isfinite(a).all() and rms < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,T,r", [(256, 128, 300, 8), (512, 256, 130, 8), (128, 128, 257, 2)])
+def test_convt1d_halo_polyphase(cin, cout, T, r):
+    """ds_convt1d_f16x2: LeakyReLU + ConvTranspose1d(k = 2 r, stride r, padding r / 2) as r two-tap convs over one staged input
+    tile, against float64 (torch's conv_transpose1d) and against the polyphase GEMMs of the gather kernel."""
+    from text_to_sound_synthesis_amd import _lib as L
+    B, pad = 2, r // 2 + r % 2
+    x = rnd((B, T, cin), "cth.x%d" % cin, 2.0)
+    w, bias = rnd((cin, cout, 2 * r), "cth.w%d.%d" % (cin, r), 0.05), rnd((cout,), "cth.b%d" % cin)
+    ref = F.conv_transpose1d(F.leaky_relu(x.double().permute(0, 2, 1), 0.2), w.double(), bias.double(), stride=r, padding=pad,
+                             output_padding=r % 2).permute(0, 2, 1).contiguous()
+    wph = w.permute(2, 1, 0).reshape(2, r, cout, cin).permute(1, 2, 0, 3).reshape(r, cout, 2 * cin).contiguous()
+    planes, sc = L.split_f16x2(wph.reshape(-1, 2 * cin).cuda())
+    pl = planes.view(2, r, cout, 2 * cin)
+    wq = torch.cat([L.pack_conv_weights(pl[:, g].contiguous(), cout, cin, 2) for g in range(r)])
+    xc, bc = x.cuda(), bias.cuda()
+    y = torch.full((B, T * r, cout), float("nan"), device="cuda")
+    L.check(L.lib().ds_convt1d_f16x2(L.ptr(xc), L.ptr(wq), wq.numel(), sc, L.ptr(bc), L.ptr(y), B, T, cin, cout, r, pad, 1, L.stream()))
+    y2 = torch.empty(B, T * r, cout, device="cuda")
+    L.gemm(xc, planes, y2, B * T, cout, 2 * cin, split2=sc, conv_split=True, bias=bc, ldc=cout, loader=L.LOAD_CONVT1D, pro=L.PRO_LRELU,
+           store=L.STORE_CONVT, groups=r, w_gstride=cout * 2 * cin, Cin=cin, Wd=T, ct_r=r, ct_p=pad, ct_tin=T)
+    e1, e2 = relerr(y.cpu(), ref), relerr(y2.cpu(), ref)
+    print("ConvTranspose1d %d -> %d, r %d, T %d: halo kernel %.2e, gather kernel %.2e vs float64; max |a - b| %.2e"
+          % (cin, cout, r, T, e1, e2, float((y - y2).abs().max())))
+    assert torch.isfinite(y).all() and e1 < 3e-6

@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.jo
 # kernels that must not touch scratch memory: a register demotion in one of them is a silent 3x slowdown
 # (it happened once: accumulators of the f16x2 GEMM went to scratch when its epilogue grew a second store family)
 NO_SCRATCH = ("ds_gemm_f16x2", "ds_gemm_bf16x3", "ds_attn_f16x2", "ds_gemm_kernel", "ds_sample_tail", "ds_conv2d_f16x2", "ds_conv3x3_f16x2",
-              "ds_attn_bwd", "ds_melgan_rb", "ds_melgan_convt2", "ds_conv1d_k3")
+              "ds_attn_bwd", "ds_melgan_rb", "ds_melgan_convt2", "ds_conv1d_f16x2")
 
 
 def _code_only(text):

@@ -9,6 +9,10 @@
 // fragment-major on the host, _lib.pack_conv_weights(taps = 3)) come straight from L2 into a register ring of 6 k-steps = one
 // slab, loaded by asm 5 k-steps ahead with explicit vmcnt waits (hipcc sinks visible prefetch loads to their use and waits for
 // them with vmcnt(0)); the next slab's halo is held in registers for a whole slab before it is written.  One barrier per slab.
+// The same kernel with two taps is MelGAN's stride-8 ConvTranspose1d (vocoder/modules.py:104-113) in polyphase form: phase p of
+// out[(q + e_p) r + p - pad] = W[:, :, p] a[q + e_p] + W[:, :, p + r] a[q + e_p - 1]  (e_p = p < pad; rows outside the clip are
+// zero) is a 2-tap conv over the staged rows q0 - 1 .. q0 + 128 with its own weights and an interleaving store; a workgroup
+// computes ONE phase of a 128-position tile, the r phases of a tile are neighbours in the grid (the tile comes out of L2).
 #include "common.h"
 #include <type_traits>
 
@@ -24,18 +28,22 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 struct Conv1Params {
     const float* x;        // [B][T][Cin]
-    const _Float16* w;     // fragment-packed planes of W * 2^s: [Cout/128][Cin/32][3][C1_WSTEP]
+    const _Float16* w;     // fragment-packed planes of W * 2^s: [phases][Cout/128][Cin/32][taps][C1_WSTEP]
     const float* bias;     // [Cout] or null
-    float* y;              // [B][T][Cout]
+    float* y;              // [B][T][Cout]  (transposed conv: [B][T r][Cout])
     float out_scale;
     int B, T, Cin, Cout, dil, tiles_t, lrelu;
+    int ct_r, ct_pad;      // transposed conv: stride = number of phases, padding
 };
 
-__global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1Params p) {
+// TAPS = 3, CT = false: the dilated conv;  TAPS = 2, CT = true: one phase of the transposed conv
+template <int TAPS, bool CT>
+__global__ __launch_bounds__(256, 2) void ds_conv1d_f16x2_kernel(const Conv1Params p) {
+    constexpr int NK = TAPS * 2;                           // k-steps per 32-channel slab = slots of the weight ring
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int R = C1_TT + 2 * p.dil;                       // staged rows
+    const int R = CT ? C1_TT + 2 : C1_TT + 2 * p.dil;      // staged rows
     const int HPL = R * C1_PXP;                            // halves per plane
     _Float16* halo = (_Float16*)smem_raw;                  // [2 buffers][2 planes][R][40]
     const int tiles_n = p.Cout / C1_BN, nblk = gridDim.x;
@@ -44,7 +52,9 @@ __global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1P
         const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int nt = bid % tiles_n, pt = bid / tiles_n;
+    const int nt = bid % tiles_n;
+    const int ph = CT ? (bid / tiles_n) % p.ct_r : 0, pt = CT ? bid / (tiles_n * p.ct_r) : bid / tiles_n;
+    const int e_p = CT && ph < p.ct_pad ? 1 : 0;           // transposed conv: source index s0 = q + e_p, taps read s0 and s0 - 1
     const int b = pt / p.tiles_t, t0 = (pt - b * p.tiles_t) * C1_TT;
     const int n0 = nt * C1_BN;
     const float* xb = p.x + (size_t)b * p.T * p.Cin;
@@ -57,10 +67,12 @@ __global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1P
 #pragma unroll
         for (int u = 0; u < C1_NF4; ++u) {
             const int f = tid + 256 * u, r = f >> 3, c4 = f & 7;
-            int t = t0 - p.dil + (r < R ? r : 0);
-            if (t < 0) t = -t;
-            if (t >= p.T) t = 2 * (p.T - 1) - t;
-            if (t < 0) t = 0;                               // (rows of a ragged last tile far past the end: unused)
+            int t = t0 - (CT ? 1 : p.dil) + (r < R ? r : 0);
+            if (!CT) {
+                if (t < 0) t = -t;
+                if (t >= p.T) t = 2 * (p.T - 1) - t;
+            }
+            if (t < 0 || t >= p.T) t = 0;                   // (transposed conv: zeroed below; conv: rows of a ragged last tile, unused)
             const unsigned off = (unsigned)(t * p.Cin + slab * 32 + c4 * 4) * 4u;
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hvr[u]) : "v"(off), "s"(xb) : "memory");
         }
@@ -74,10 +86,13 @@ __global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1P
             const f32x4 v = hvr[u];
             const int f = tid + 256 * u, r = f >> 3, c4 = f & 7;
             if (u >= C1_TT / 32 && r >= R) continue;        // (items 0 .. 3 are rows 0 .. 127 < R)
+            const int ts = t0 - 1 + r;
+            const bool zero = CT && (ts < 0 || ts >= p.T);   // outside the clip: no contribution
             h4 s0, s1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float a = p.lrelu ? (v[e] > 0.f ? v[e] : 0.2f * v[e]) : v[e];
+                float a = p.lrelu ? (v[e] > 0.f ? v[e] : 0.2f * v[e]) : v[e];
+                if (zero) a = 0.f;
                 s0[e] = ds_split_hi(a);
                 s1[e] = ds_split_lo(a, s0[e]);
             }
@@ -86,12 +101,12 @@ __global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1P
         }
     };
 
-    // ---- weight ring: k-step q = (slab * 3 + tap) * 2 + ks, slot q % 6 ----
-    const int nslab = p.Cin >> 5, nq = nslab * 6;
+    // ---- weight ring: k-step q = (slab * TAPS + tap) * 2 + ks, slot q % NK ----
+    const int nslab = p.Cin >> 5, nq = nslab * NK;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const char* wbase = (const char*)(p.w + (size_t)nt * nslab * 3 * C1_WSTEP + wave_u * 1024);
+    const char* wbase = (const char*)(p.w + (size_t)(ph * tiles_n + nt) * nslab * TAPS * C1_WSTEP + wave_u * 1024);
     const unsigned voff0 = lane * 16, voff1 = lane * 16 + 8192;
-    h8 bq[6][2];
+    h8 bq[NK][2];
     auto w_load = [&](int q, h8 (&f)[2]) {
         const char* r = wbase + (size_t)(q >> 1) * (C1_WSTEP * 2) + (q & 1) * 1024;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f[0]) : "v"(voff0), "s"(r) : "memory");
@@ -105,20 +120,20 @@ __global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1P
 
     halo_load(hv, 0);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) w_load(q, bq[q]);
-    halo_write(hv, 0, std::integral_constant<int, 10>{});
+    for (int q = 0; q < NK - 1; ++q) w_load(q, bq[q]);
+    halo_write(hv, 0, std::integral_constant<int, 2 * (NK - 1)>{});
     halo_load(hv, nslab > 1 ? 1 : 0);
     __syncthreads();
     for (int slab = 0; slab < nslab; ++slab) {
         const _Float16* ab = halo + (slab & 1) * (2 * HPL) + l31 * C1_PXP + hh * 8;      // lane's row inside a block and k half
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            const _Float16* at = ab + tap * p.dil * C1_PXP;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const _Float16* at = ab + (CT ? 1 + e_p - tap : tap * p.dil) * C1_PXP;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int ql = tap * 2 + ks;
-                const int qn = slab * 6 + ql + 5;
-                w_load(qn < nq ? qn : nq - 1, bq[(ql + 5) % 6]);
+                const int qn = slab * NK + ql + NK - 1;
+                w_load(qn < nq ? qn : nq - 1, bq[(ql + NK - 1) % NK]);
                 h8 fa0[4], fa1[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1P
                     fa0[i] = *(const h8*)ar;
                     fa1[i] = *(const h8*)(ar + HPL);
                 }
-                asm volatile("s_waitcnt vmcnt(10)" : "+v"(bq[ql][0]), "+v"(bq[ql][1]));
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bq[ql][0]), "+v"(bq[ql][1]) : "n"(2 * (NK - 1)));
                 const h8 b0 = bq[ql][0], b1 = bq[ql][1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -151,8 +166,13 @@ __global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1P
     }
 
     // The asm loads still in flight (the ring's clamped refills of the last k-steps, the redundant last halo request) must land
-    // BEFORE the epilogue reuses their registers: hipcc does not know they are outstanding.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // BEFORE anything reuses their registers: hipcc does not know they are outstanding.  Ring and halo registers go INTO the
+    // drain as operands: a load whose result is never read is dead to the compiler, which gave all of them ONE throw-away
+    // register and reused it for an A fragment while they were in flight (seen in the ISA of the first version).
+#pragma unroll
+    for (int q = 0; q < NK; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[q][0]), "+v"(bq[q][1])::"memory");
+#pragma unroll
+    for (int u = 0; u < C1_NF4; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[u])::"memory");
 
     // ---- epilogue: two passes of 64 rows (block rows 2 pass, 2 pass + 1 of every wave) staged as fp32 [64][128] in LDS ----
     const float osc = p.out_scale;
@@ -177,11 +197,37 @@ __global__ __launch_bounds__(256, 2) void ds_conv1d_k3_f16x2_kernel(const Conv1P
             const int rl = (tid >> 5) + 8 * it, t = t0 + 64 * pass + rl;
             if (t < p.T) {
                 const f32x4 val = *(const f32x4*)(Tf + rl * C1_BN + cc * 4) + bias4;
-                *(f32x4*)(p.y + ((size_t)b * p.T + t) * p.Cout + col) = val;
+                // transposed conv: position q = t of phase ph is output row (q + e_p) r + ph - pad (always inside [0, T r))
+                const long long row = CT ? (long long)(t + e_p) * p.ct_r + ph - p.ct_pad : t;
+                const long long rows = CT ? (long long)p.T * p.ct_r : p.T;
+                if (row < rows) *(f32x4*)(p.y + ((size_t)b * rows + row) * p.Cout + col) = val;
             }
         }
         __syncthreads();
     }
+}
+
+template <int TAPS, bool CT>
+static int c1_launch(Conv1Params& p, hipStream_t s) {
+    p.tiles_t = (p.T + C1_TT - 1) / C1_TT;
+    const int R = CT ? C1_TT + 2 : C1_TT + 2 * p.dil;
+    size_t lds = (size_t)2 * 2 * R * C1_PXP * 2;
+    if (lds < 64 * C1_BN * 4) lds = 64 * C1_BN * 4;          // the staged output half tile
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_conv1d_f16x2_kernel<TAPS, CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * 2 * (C1_TT + 2 * C1_MAXDIL) * C1_PXP * 2);
+        if (e != hipSuccess) {
+            ds_set_error("conv1d_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        attr_set = true;
+    }
+    const long long blocks = (long long)p.B * p.tiles_t * (p.Cout / C1_BN) * (CT ? p.ct_r : 1);
+    DS_CHECK_ARG(blocks < (1ll << 31), "too many tiles");
+    hipLaunchKernelGGL((ds_conv1d_f16x2_kernel<TAPS, CT>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    DS_CHECK_LAUNCH();
+    return 0;
 }
 
 // y[b][t][n] = bias[n] + 2^-s sum_{j < 3} sum_c W2[n][j][c] act(x[b][reflect(t + (j - 1) dil)][c]),  act = LeakyReLU(0.2) if lrelu.
@@ -197,24 +243,25 @@ extern "C" int ds_conv1d_k3_f16x2(const float* x, const void* w2, long long w_ha
     DS_CHECK_ARG((long long)T * Cin < (1ll << 30), "32-bit byte offsets inside a clip");
     Conv1Params p;
     p.x = x; p.w = (const _Float16*)w2; p.bias = bias; p.y = y; p.out_scale = out_scale;
-    p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.dil = dil; p.lrelu = lrelu ? 1 : 0;
-    p.tiles_t = (T + C1_TT - 1) / C1_TT;
-    const int R = C1_TT + 2 * dil;
-    size_t lds = (size_t)2 * 2 * R * C1_PXP * 2;
-    if (lds < 64 * C1_BN * 4) lds = 64 * C1_BN * 4;          // the staged output half tile
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_conv1d_k3_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * 2 * (C1_TT + 2 * C1_MAXDIL) * C1_PXP * 2);
-        if (e != hipSuccess) {
-            ds_set_error("conv1d_k3_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return -2;
-        }
-        attr_set = true;
-    }
-    const long long blocks = (long long)B * p.tiles_t * (Cout / C1_BN);
-    DS_CHECK_ARG(blocks < (1ll << 31), "too many tiles");
-    hipLaunchKernelGGL(ds_conv1d_k3_f16x2_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    DS_CHECK_LAUNCH();
-    return 0;
+    p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.dil = dil; p.lrelu = lrelu ? 1 : 0; p.ct_r = 1; p.ct_pad = 0;
+    return c1_launch<3, false>(p, (hipStream_t)stream);
+}
+
+// ConvTranspose1d(k = 2 r, stride r, padding pad) in polyphase form:  y[b][(q + e_p) r + p - pad][n] = bias[n] + 2^-s sum_c
+// (W[p][n][0][c] act(x[b][q + e_p][c]) + W[p][n][1][c] act(x[b][q + e_p - 1][c])),  e_p = p < pad, source rows outside [0, T) zero.
+// x [B][T][Cin], y [B][T r][Cout] channels-last fp32; w2 = the r phases' weights [Cout][2 Cin] (K ordered [tap][channel]: tap 0 =
+// W[:, :, p], tap 1 = W[:, :, p + r]) each split and fragment-packed with _lib.pack_conv_weights(.., taps = 2), concatenated.
+extern "C" int ds_convt1d_f16x2(const float* x, const void* w2, long long w_halves, float out_scale, const float* bias, float* y,
+                                int B, int T, int Cin, int Cout, int r, int pad, int lrelu, ds_stream_t stream) {
+    DS_CHECK_ARG(x && w2 && y, "null pointer");
+    DS_CHECK_ARG(B > 0 && T > 1 && Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % C1_BN == 0, "Cin % 32 == 0 and Cout % 128 == 0");
+    DS_CHECK_ARG(r >= 1 && pad >= 0 && pad < r, "0 <= pad < r");
+    DS_CHECK_ARG(w_halves == (long long)r * 2 * Cout * 2 * Cin && out_scale > 0.f, "packed weights: r * 2 * Cout * 2 * Cin halves");
+    DS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0,
+                 "operands must be 16-byte aligned");
+    DS_CHECK_ARG((long long)T * Cin < (1ll << 30), "32-bit byte offsets inside a clip");
+    Conv1Params p;
+    p.x = x; p.w = (const _Float16*)w2; p.bias = bias; p.y = y; p.out_scale = out_scale;
+    p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.dil = 1; p.lrelu = lrelu ? 1 : 0; p.ct_r = r; p.ct_pad = pad;
+    return c1_launch<2, true>(p, (hipStream_t)stream);
 }

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
     // (in two halves, work items [0, 4) and [4, 7): 16 instead of 28 registers of halo data in flight next to the 64
     //  accumulators and the two sets of weight fragments)
     f32x4 hv[C3_NF4];
-    auto halo_load = [&](int slab, auto u0_, auto u1_) {
+    // (hv goes in as a parameter and the asm operands are its elements themselves: no register copy between a load and its wait)
+    auto halo_load = [&](f32x4 (&hvr)[C3_NF4], int slab, auto u0_, auto u1_) {
         constexpr int U0 = decltype(u0_)::value, U1 = decltype(u1_)::value;
 #pragma unroll
         for (int u = U0; u < U1; ++u) {
@@ -117,21 +118,16 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
             // asm like the weight loads below (the compiler's own s_waitcnt for a load it knows would be vmcnt(0): it cannot see the
             // asm loads around it, and would drain the weight ring); a pixel outside the image loads pixel 0 and is zeroed below
             const unsigned off = (unsigned)((src < 0 ? 0 : src) + slab * 32) * 4u;
-            f32x4 t;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t) : "v"(off), "s"(xb) : "memory");
-            hv[u] = t;
+            const float* base = xb;      // (a generic lambda's asm operand cannot name the captured variable itself)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hvr[u]) : "v"(off), "s"(base) : "memory");
         }
     };
     // wait_: the loads issued since the matching halo_load (they may stay in flight)
-    auto halo_write = [&](int slab, auto u0_, auto u1_, auto wait_) {
+    auto halo_write = [&](f32x4 (&hvr)[C3_NF4], int slab, auto u0_, auto u1_, auto wait_) {
         constexpr int U0 = decltype(u0_)::value, U1 = decltype(u1_)::value, WAIT = decltype(wait_)::value;
         _Float16* hb = halo + (slab & 1) * (2 * C3_HPL);
 #pragma unroll
-        for (int u = U0; u < U1; ++u) {
-            f32x4 t = hv[u];
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(t) : "n"(WAIT));
-            hv[u] = t;
-        }
+        for (int u = U0; u < U1; ++u) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hvr[u]) : "n"(WAIT));
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};     // the thread's channel quad is the same for every work item
         if (PRO) {
             sc = *(const f32x4*)(scs + slab * 32 + (tid & 7) * 4);
@@ -142,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
             int src, dst;
             h_item(u, src, dst);
             if (dst < 0) continue;
-            f32x4 v = hv[u];
+            f32x4 v = hvr[u];
             if (PRO) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -191,18 +187,18 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
     const std::integral_constant<int, 4> U_B{};
     const std::integral_constant<int, C3_NF4> U_C{};
     const std::integral_constant<int, 12> W12{};
-    halo_load(0, U_A, U_C);
+    halo_load(hv, 0, U_A, U_C);
 #pragma unroll
     for (int q = 0; q < C3_RING - 1; ++q) w_load(q, bq[q]);         // (nq >= 18 > RING - 1)
-    halo_write(0, U_A, U_C, std::integral_constant<int, 2 * (C3_RING - 1)>{});
+    halo_write(hv, 0, U_A, U_C, std::integral_constant<int, 2 * (C3_RING - 1)>{});
     __syncthreads();
     for (int slab = 0; slab < nslab; ++slab) {
         const bool more_slabs = slab + 1 < nslab;
         const _Float16* ab = halo + (slab & 1) * (2 * C3_HPL) + l31 * C3_PXP + hh * 8;    // lane's pixel column and k half
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap == 0 && more_slabs) halo_load(slab + 1, U_A, U_B);      // first half of the next slab: lands under taps 0, 1
-            if (tap == 3 && more_slabs) halo_load(slab + 1, U_B, U_C);      // second half: under taps 3, 4
+            if (tap == 0 && more_slabs) halo_load(hv, slab + 1, U_A, U_B);      // first half of the next slab: lands under taps 0, 1
+            if (tap == 3 && more_slabs) halo_load(hv, slab + 1, U_B, U_C);      // second half: under taps 3, 4
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -228,15 +224,17 @@ __global__ __launch_bounds__(256, 2) void ds_conv3x3_f16x2_kernel(const Conv3Par
                 }
             }
             // the other halo buffer is free: every wave passed the barrier that ended the slab before this one
-            if (tap == 2 && more_slabs) halo_write(slab + 1, U_A, U_B, W12);      // 3 taps x 2 k-steps x 2 loads since its halo_load
-            if (tap == 5 && more_slabs) halo_write(slab + 1, U_B, U_C, W12);
+            if (tap == 2 && more_slabs) halo_write(hv, slab + 1, U_A, U_B, W12);      // 3 taps x 2 k-steps x 2 loads since its halo_load
+            if (tap == 5 && more_slabs) halo_write(hv, slab + 1, U_B, U_C, W12);
         }
         __syncthreads();            // slab s is read, slab s + 1 is written
     }
 
-    // The asm loads still in flight (the ring's clamped refills of the last k-steps, the redundant last halo request) must land
-    // BEFORE the epilogue reuses their registers: hipcc does not know they are outstanding.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The asm loads still in flight (the ring's clamped refills of the last k-steps) must land BEFORE anything reuses their
+    // registers: hipcc does not know they are outstanding.  The ring goes INTO the drain as operands: a load whose result is
+    // never read is dead to the compiler, which then gives every such load the same throw-away register and reuses it at once.
+#pragma unroll
+    for (int q = 0; q < C3_RING; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[q][0]), "+v"(bq[q][1])::"memory");
 
     // ---- epilogue: two passes of 64 tile rows (block rows 2 pass, 2 pass + 1 of every wave) staged as fp32 [64][128] in LDS ----
     const float osc = p.out_scale;

@@ -131,6 +131,12 @@ class Generator(nn.Module):
         pk["first_s"] = sp(pk["first"][0])
         for st in pk["stages"]:
             st["ct_s"] = sp(st["ct"][0])
+            # the phases' planes fragment-packed for the halo-tiled kernel (ds_convt1d_f16x2): [r][Cout/128][Cin/32][2 taps][..]
+            r, cin, cout = st["r"], st["cin"], st["cout"]
+            st["ct_q"] = None
+            if cout % 128 == 0 and cin % 32 == 0:
+                pl = st["ct_s"][0].view(2, r, cout, 2 * cin)
+                st["ct_q"] = torch.cat([_lib.pack_conv_weights(pl[:, g].contiguous(), cout, cin, 2) for g in range(r)])
             for rb in st["res"]:
                 for k in ("c3", "c1", "sc"):
                     rb[k + "_s"] = sp(rb[k][0])
@@ -171,7 +177,10 @@ class Generator(nn.Module):
             r, cin, cout = st["r"], st["cin"], st["cout"]
             w, b = st["ct"]
             y = torch.empty(B, T * r, cout, device=dev)
-            if r == 2 and self.fuse_convt and self.conv_precision == "f16x2" and _lib.lib().ds_melgan_convt2_ok(cin, cout):
+            if self.conv1d_halo and self.conv_precision == "f16x2" and st["ct_q"] is not None:
+                _lib.check(_lib.lib().ds_convt1d_f16x2(_lib.ptr(h), _lib.ptr(st["ct_q"]), st["ct_q"].numel(), st["ct_s"][1], _lib.ptr(b),
+                                                       _lib.ptr(y), B, T, cin, cout, r, r // 2 + r % 2, 1, _lib.stream()))
+            elif r == 2 and self.fuse_convt and self.conv_precision == "f16x2" and _lib.lib().ds_melgan_convt2_ok(cin, cout):
                 _lib.check(_lib.lib().ds_melgan_convt2(_lib.ptr(h), _lib.ptr(st["ct_s"][0]), r * cout * 2 * cin, st["ct_s"][1], _lib.ptr(b),
                                                        _lib.ptr(y), B, T, cin, cout, _lib.stream()))
             else:

@@ -2,7 +2,10 @@
     hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only -o k.s kernel.hip;  python tools/asm_load_audit.py k.s
 A register written by a global_load inside an asm block stays "pending" until an asm s_waitcnt vmcnt(n) that retires it (loads
 retire in order: the n youngest stay pending); any compiler-generated instruction that reads OR overwrites a pending register is reported.
-Linear scan, control flow ignored -- a screen for the v_mov copies hipcc may place between an asm load and its asm wait."""
+The scan is BASIC-BLOCK LOCAL (the pending set is dropped at every label and branch): what it proves is that no block touches a
+register between an asm load it contains and the wait that follows in the same block -- the v_mov copies hipcc may place in front of
+an asm wait, an address temporary allocated over a just-requested register.  Registers that stay in flight across a loop edge
+(a prefetch ring) are covered by the kernels' own wait counts, not by this screen."""
 import sys,re
 s=open(sys.argv[1]).read().split('\n')
 # registers written by asm global_load; flag any non-asm instruction that reads them between the load and the next asm s_waitcnt
@@ -18,10 +21,20 @@ for i,l in enumerate(s):
     t=l.strip()
     if t.startswith(';;#ASMSTART'): inasm=True; continue
     if t.startswith(';;#ASMEND'): inasm=False; continue
+    if t.startswith('.LBB') or re.match(r'^_Z\w+:',t):
+        pending={}                                     # a new basic block
+        continue
     if not t or t.startswith((';','.')) or t.endswith(':'): continue
     parts=re.split(r'[ ,\t]+',t)
     op=parts[0]
+    if op.startswith(('s_cbranch','s_branch')):
+        pending={}
+        continue
     if inasm and op.startswith('global_load'):
+        dup=regs(parts[1]) & set(pending)
+        if dup:                                        # two loads in flight into one register: hipcc thinks both results are dead
+            bad+=1
+            if bad<=12: print('HAZARD (dead load) line',i+1,t,'<- also loaded at line',sorted({pending[r]+1 for r in dup}))
         for r in regs(parts[1]): pending[r]=i
         continue
     if inasm and op=='s_waitcnt':
