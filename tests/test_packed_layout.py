@@ -464,28 +464,32 @@ def test_generic_tile_data_path_emulation():
         assert np.array_equal(C, A1 @ W0.T + A0 @ W1.T + A0 @ W0.T), (BM, BN, WGM, WGN)
 
 
-def test_conv3x3_fragment_packed_weights():
-    """_lib.pack_conv3x3_weights: the host-side layout ds_conv3x3_f16x2 loads straight into MFMA B operands
-    (csrc/conv3x3_f16x2.hip): [Cout/128][Cin/32][9 taps][2 planes][2 wave columns][2 blocks][2 k-steps][64 lanes][8 halves],
-    lane (hh = lane >> 5, l = lane & 31) of fragment (wn, j, ks) holding W[128 nt + 64 wn + 32 j + l][tap][32 slab + 16 ks + 8 hh + e]."""
+def test_conv_fragment_packed_weights():
+    """_lib.pack_conv_weights: the host-side layout ds_conv3x3_f16x2 (9 taps) / ds_conv1d_k3_f16x2 (3) / ds_convt1d_f16x2 (2 per
+    phase) load straight into MFMA B operands: [Cout/128][Cin/32][taps][2 planes][4 blocks of 32 output channels = the wave]
+    [2 k-steps][64 lanes][8 halves], lane (hh = lane >> 5, l = lane & 31) of fragment (wave, ks) holding
+    W[128 nt + 32 wave + l][tap][32 slab + 16 ks + 8 hh + e]."""
     import random
     import torch
     from text_to_sound_synthesis_amd import _lib
     Cout, Cin = 256, 96
-    w = torch.randn(Cout, 9 * Cin)
-    planes, sc = _lib.split_f16x2(w)
-    q = _lib.pack_conv3x3_weights(planes, Cout, Cin)
-    assert q.numel() == 2 * Cout * 9 * Cin
-    q = q.view(Cout // 128, Cin // 32, 9, 2, 2, 2, 2, 64, 8)
-    pl = planes.view(torch.int16).view(2, Cout, 9, Cin)
-    rng = random.Random(3)
-    for _ in range(4000):
-        nt, ns, tap, p_, wn, j, ks, lane, e = [rng.randrange(n) for n in (Cout // 128, Cin // 32, 9, 2, 2, 2, 2, 64, 8)]
-        hh, l = lane >> 5, lane & 31
-        assert q[nt, ns, tap, p_, wn, j, ks, lane, e] == pl[p_, nt * 128 + wn * 64 + j * 32 + l, tap, ns * 32 + ks * 16 + hh * 8 + e]
-    # the planes reconstruct the scaled weights (hi + lo = w * 2^s to fp32 rounding of the split)
-    back = (planes.view(torch.float16)[0].float() + planes.view(torch.float16)[1].float()) * sc
-    assert (back - w).abs().max() <= 2e-7 * w.abs().max()
+    for taps in (9, 3, 2):
+        w = torch.randn(Cout, taps * Cin)
+        planes, sc = _lib.split_f16x2(w)
+        q = _lib.pack_conv_weights(planes, Cout, Cin, taps)
+        assert q.numel() == 2 * Cout * taps * Cin
+        if taps == 9:
+            assert torch.equal(q, _lib.pack_conv3x3_weights(planes, Cout, Cin))
+        q = q.view(Cout // 128, Cin // 32, taps, 2, 4, 2, 64, 8)
+        pl = planes.view(torch.int16).view(2, Cout, taps, Cin)
+        rng = random.Random(taps)
+        for _ in range(3000):
+            nt, ns, tap, p_, wave, ks, lane, e = [rng.randrange(n) for n in (Cout // 128, Cin // 32, taps, 2, 4, 2, 64, 8)]
+            hh, l = lane >> 5, lane & 31
+            assert q[nt, ns, tap, p_, wave, ks, lane, e] == pl[p_, nt * 128 + wave * 32 + l, tap, ns * 32 + ks * 16 + hh * 8 + e]
+        # the planes reconstruct the scaled weights (hi + lo = w * 2^s to fp32 rounding of the split)
+        back = (planes.view(torch.float16)[0].float() + planes.view(torch.float16)[1].float()) * sc
+        assert (back - w).abs().max() <= 2e-7 * w.abs().max()
 
 
 def test_vocoder_args_yml_reader(tmp_path):

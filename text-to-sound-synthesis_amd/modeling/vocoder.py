@@ -3,12 +3,16 @@
 Same constructor, `model.N.*` state-dict keys (weight_g / weight_v / bias, as left by
 torch.nn.utils.weight_norm, :18-23) and forward signature: mel f32[B, 80, T] in [0,1] ->
 waveform f32[B, 1, 256*T].  Weight norm is folded once at pack time (the reference recomputes it on
-every call); activations are channels-last [B, T, C]; every layer is the gather-GEMM -- on the fp16 matrix cores with
-the fp32-class 3-pass split (`conv_precision = "f16x2"`, default; conv_f16x2.hip) or on the exact-fp32 MFMA ("fp32"):
-  Conv1d k7 / dilated k3 (ReflectionPad1d)  -> conv1d loader, LeakyReLU(0.2) applied while staging A
-  ConvTranspose1d(k=2r, s=r)                -> r polyphase GEMMs with K = 2*Cin (no zero-stuffing)
-  ResnetBlock                               -> 3 GEMMs, shortcut added through the residual epilogue
-  final Conv1d(32->1, k7) + tanh            -> N=7 tap GEMM + reflect stencil
+every call); activations are channels-last [B, T, C]; every layer runs on the fp16 matrix cores with
+the fp32-class 3-pass split (`conv_precision = "f16x2"`, default) or as gather-GEMMs on the exact-fp32 MFMA ("fp32"):
+  Conv1d k7 (first layer)                   -> gather-GEMM, conv1d loader (conv_f16x2.hip)
+  ConvTranspose1d(k=2r, s=r)                -> r two-tap convs over one staged tile: halo-tiled kernel (r = 8, conv1d_f16x2.hip),
+                                               single pass with the weights in registers (r = 2, melgan_fused.hip)
+  ResnetBlock, 128 / 256 channels           -> halo-tiled dilated k3 conv (conv1d_f16x2.hip) + ONE GEMM over [LReLU(h) | x] for the
+                                               1x1 conv and the 1x1 shortcut
+  ResnetBlock, 32 / 64 channels             -> ONE kernel per block (melgan_fused.hip): x read once, y written once
+  final Conv1d(32->1, k7) + tanh            -> one pass (melgan_fused.hip)
+(each with a switch back to the polyphase / three-GEMM forms on the gather kernel, see __init__)
 The whole batch goes through at once (the reference vocodes sample by sample,
 evaluation/generate_samples_batch.py:183-187).
 """
