@@ -313,7 +313,7 @@ extern "C" int ds_denoiser_cond_kv(const ds_denoiser* h, const float* cond, int 
 
 // Lp: rows per sample of every activation matrix (d.seq_len, or PS_ROWS in padded-row mode: layout 0 only)
 static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64_t* t, const float* kv, int B,
-                        const Carve& w, float* logits, int layout, hipStream_t s, int Lp) {
+                        const Carve& w, float* logits, int layout, hipStream_t s, int Lp, bool zero_kv_pad = true) {
     const ds_denoiser_desc& d = h->d;
     const int D = d.n_embd, Lv = d.seq_len, L = Lp, M = B * L, Mc = B * d.cond_len, F = D * d.mlp_mult;
     DS_CHECK_ARG(Lp == Lv || (layout == 0 && Lp > Lv), "padded rows need the row-major logits layout");
@@ -348,7 +348,9 @@ static int forward_impl(const ds_denoiser* h, const int64_t* tokens, const int64
     auto attn_ready = [&](const void* imgs, int Lk) {
         return ds_attention_f16x2_ready(w.qkv, qpl, imgs, w.att, D, B, d.n_head, L, Lk, scale, s);
     };
-    if (f16) {   // key slots L..nkey-1 of the self-attention images are never written: they must read as zero
+    // key slots L..nkey-1 of the self-attention images are never written: they must read as zero (a chain of steps over one
+    // workspace zeroes them in its first step only: nothing between two of its steps touches the workspace)
+    if (f16 && zero_kv_pad) {
         hipError_t e = hipMemsetAsync(w.kvimg, 0, attn_img_floats(B, d.n_head, L) * sizeof(float), s);
         if (e != hipSuccess) {
             ds_set_error("forward: hipMemsetAsync: %s", hipGetErrorString(e));
@@ -411,11 +413,12 @@ extern "C" int ds_denoiser_forward(const ds_denoiser* h, const int64_t* tokens, 
 // (sample_fast, diffusion_transformer.py:796-803 calls q_posterior with t - skip_step)
 static int step_impl(const ds_denoiser* h, const int64_t* tokens_in, const int64_t* t, const int64_t* t_post,
                      const float* kv, const float* u, const int64_t* gids, unsigned long long seed, int call, int B,
-                     int initial, float trunc_r, int trunc_k, void* workspace, int64_t* tokens_out, ds_stream_t stream) {
+                     int initial, float trunc_r, int trunc_k, void* workspace, int64_t* tokens_out, ds_stream_t stream,
+                     bool zero_kv_pad = true) {
     Carve w;
     const int Lp = rows_per_sample(h, B);
     carve(h, B, workspace, &w, Lp);
-    TRY(forward_impl(h, tokens_in, t, kv, B, w, w.logits, 0, (hipStream_t)stream, Lp));
+    TRY(forward_impl(h, tokens_in, t, kv, B, w, w.logits, 0, (hipStream_t)stream, Lp, zero_kv_pad));
     return ds_sample_tail_rows(w.logits, Lp, tokens_in, t_post ? t_post : t, u, h->d.sched, tokens_out, nullptr, nullptr,
                                nullptr, B, h->d.seq_len, h->d.n_codes, h->d.n_steps, initial, trunc_r, trunc_k, stream,
                                gids, seed, call);
@@ -456,7 +459,7 @@ extern "C" int ds_denoiser_sample_rng(const ds_denoiser* h, int64_t* tokens, int
     for (int k = 0; k < n_calls; ++k) {
         const int64_t* tk = t_steps + (size_t)k * 2 * B;
         TRY(step_impl(h, cur, tk, tk + B, kv, nullptr, gids, seed, call0 + k, B, initial && k == 0, trunc_r, trunc_k,
-                      workspace, nxt, stream));
+                      workspace, nxt, stream, k == 0));
         int64_t* sw = cur; cur = nxt; nxt = sw;
     }
     if (cur != tokens) {

@@ -193,16 +193,14 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
         int n_keep = 1;
         {
             float cum = 0.f;
-            bool open = true;
-            for (int i = 0; i < K && open; i += 4) {
+            const float r_ = p.trunc_r;
+            for (int i = 0; i < K; i += 4) {
                 const f32x4 p4 = *(const f32x4*)(&s_pr[w][i]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    cum += p4[e];                                                        // mass of ranks 0 .. i + e
-                    if (i + e + 1 < K) {
-                        if (cum < p.trunc_r) ++n_keep; else open = false;
-                    }
-                }
+                const float c0 = cum + p4[0], c1 = c0 + p4[1], c2 = c1 + p4[2], c3 = c2 + p4[3];     // masses of ranks 0 .. i + e
+                // rank i + e + 1 is kept iff c_e < r; the sums do not decrease, so the tests fail from some e on
+                n_keep += (c0 < r_ ? 1 : 0) + (c1 < r_ ? 1 : 0) + (c2 < r_ ? 1 : 0) + ((c3 < r_ && i + 4 < K) ? 1 : 0);
+                cum = c3;
+                if (!(c3 < r_)) break;
             }
         }
         // back to class order: the class at rank rk is kept iff rk < n_keep
