@@ -1,4 +1,6 @@
-// MelGAN tail stages as single-pass kernels (vocoder/modules.py:72-85 ResnetBlock, :119-124 final conv + tanh).
+// MelGAN's HBM-bound layers as single-pass kernels (vocoder/modules.py:72-85 ResnetBlock at 32 / 64 channels, :104-113 the two
+// stride-2 ConvTranspose1d, :119-124 final conv + tanh): ds_melgan_rb32_kernel, ds_melgan_rb64_kernel, ds_melgan_convt2_kernel,
+// ds_melgan_final32_kernel.  Each reads its input tensor once and writes its output once.
 //
 // At 32 channels and 217 088 samples per clip a ResnetBlock is HBM-bound: its tensor is 1.78 GB per 64 clips, and the
 // two-launch form (dilated k3 conv -> h, then [LReLU(h) | x] x [W2 | Ws]^T) moves it five times (x, h out, h in, x, y).
