@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
         // dalle_spec.py:159-172: sort descending, exp, cumsum; rank i is kept iff the mass of ranks 0 .. i-1 is < r (rank 0 always).
         // Round 4: the ranks come from a bitonic sort of the column in LDS (one wave per column, 64-bit keys = order-preserving
         // image of the log-probability | inverted class index: descending value, ascending index among ties) and the mass from
-        // the SEQUENTIAL fp32 sum in rank order -- the order torch's CPU cumsum adds in -- instead of 65 536 pair tests per column
+        // the sum in rank order, accumulated the way torch's CPU cumsum does, instead of 65 536 pair tests per column
         // (the kernel's 173 us per step were 160 us of those: the largest item of a sampling step after the transformer).
         // The kept set is a prefix of the rank order (the masses are non-negative), so the scan only has to find its length.
         unsigned long long* key = s_key[w];
@@ -192,15 +192,28 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
         // n_keep = 1 + #{ i >= 1 : p[0] + .. + p[i-1] < r }, every lane runs the same sequential sum (uniform early exit)
         int n_keep = 1;
         {
-            float cum = 0.f;
+            // torch's CPU cumsum of a float tensor accumulates in DOUBLE and rounds every partial sum to float: the same here
+            // (tests/test_sampler_sort_emulation.py: with this accumulator the restated algorithm equals the reference's
+            // truncation bit for bit; a plain fp32 chain differs in the last place of some partial sums)
+            // float(c) < r, tested on the double: float(c) <= pf = the float below r  <=>  c below the midpoint of pf and r (at the
+            // midpoint itself round-to-nearest-even goes to pf iff pf's last mantissa bit is 0)
+            double cum = 0.0;
             const float r_ = p.trunc_r;
+            const float pf = __uint_as_float(__float_as_uint(r_) - 1u);      // r > 0 (top-r rates are in (0, 1])
+            const double mid = 0.5 * ((double)pf + (double)r_);
+            const bool tie_low = (__float_as_uint(pf) & 1u) == 0u;
+            // c <= mid as ONE comparison: c < the double after mid (mid > 0: its bit pattern + 1)
+            const double lim = tie_low ? __longlong_as_double(__double_as_longlong(mid) + 1) : mid;
+            auto below = [&](double c) { return c < lim; };
+            if (r_ > 0.f)            // (r = 0: no partial sum is below it, rank 0 alone survives)
             for (int i = 0; i < K; i += 4) {
                 const f32x4 p4 = *(const f32x4*)(&s_pr[w][i]);
-                const float c0 = cum + p4[0], c1 = c0 + p4[1], c2 = c1 + p4[2], c3 = c2 + p4[3];     // masses of ranks 0 .. i + e
-                // rank i + e + 1 is kept iff c_e < r; the sums do not decrease, so the tests fail from some e on
-                n_keep += (c0 < r_ ? 1 : 0) + (c1 < r_ ? 1 : 0) + (c2 < r_ ? 1 : 0) + ((c3 < r_ && i + 4 < K) ? 1 : 0);
+                const double c0 = cum + (double)p4[0], c1 = c0 + (double)p4[1], c2 = c1 + (double)p4[2], c3 = c2 + (double)p4[3];
+                // rank i + e + 1 is kept iff float(c_e) < r; the sums do not decrease, so the tests fail from some e on
+                const bool b3 = below(c3);
+                n_keep += (below(c0) ? 1 : 0) + (below(c1) ? 1 : 0) + (below(c2) ? 1 : 0) + ((b3 && i + 4 < K) ? 1 : 0);
                 cum = c3;
-                if (!(c3 < r_)) break;
+                if (!b3) break;
             }
         }
         // back to class order: the class at rank rk is kept iff rk < n_keep
