@@ -1,6 +1,12 @@
 """Benchmark of the Diffsound generation path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL.  Either the driver starts the ranks (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: WORLD_SIZE is in the environment), or
+-- WORLD_SIZE unset -- bench.py starts them ITSELF the same way (launch_ranks below; the reference spawns its own workers
+too, Diffsound/sound_synthesis/distributed/launch.py:26-57).  Asking for more ranks than there are devices, or a
+WORLD_SIZE that contradicts --gpus, is an error, never a silent one-GPU run.
 
 One "step" = one pass of the hot path over one batch: B captions per GPU go through the 100-step
 p_sample loop (19-layer denoiser + fused sampler tail), SpecVQGAN decode and the MelGAN vocoder,
@@ -42,22 +48,25 @@ def parse():
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--n-layer", type=int, default=19)
     ap.add_argument("--codes", type=int, default=256)
-    ap.add_argument("--precision", default=os.environ.get("DIFFSOUND_GEMM", "f16x2"), choices=("fp32", "bf16x3", "f16x2"),
-                    help="denoiser GEMM arithmetic: exact-fp32 MFMA, or an fp32-class split on the 16-bit matrix cores -- "
-                         "f16x2 (default): 2 fp16 planes per operand, 3 MFMA passes; bf16x3: 3 bf16 planes, 6 passes")
+    ap.add_argument("--precision", default=os.environ.get("DIFFSOUND_GEMM", "f16x2"), choices=("fp32", "f16x2"),
+                    help="denoiser GEMM arithmetic: f16x2 (default) = fp32-class split on the fp16 matrix cores, 2 fp16 planes per "
+                         "operand, 3 MFMA passes; fp32 = the exact-fp32 MFMA (strict mode)")
     ap.add_argument("--rng", default="philox", choices=("philox", "torch"),
                     help="philox (default): Gumbel noise drawn in the sampler kernel, keyed by the global caption index -- "
                          "the same NOISE for a caption at every world size / batch (identical tokens as long as the same GEMM "
                          "program serves the local batch: logits differ by ~1e-7 relative between programs, so a near-tie "
                          "can flip); torch: torch.rand per step, the reference's own draw")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DIFFSOUND_STREAMS", "1")), choices=(1, 2),
-                    help="2: the sampling loop runs the batch as two half-batches on two HIP streams")
     ap.add_argument("--transformer-only", action="store_true",
                     help="BASELINE configs[1]: CLIP + sampling loop only (no decode / vocoder); not the default metric")
-    ap.add_argument("--train-leg", action="store_true",
-                    help="also time BASELINE configs[4] (the discrete-diffusion training step, B = 20 per GPU, 19 layers: loss + "
-                         "hand-written backward + all-reduce + clip + AdamW + EMA) after the sampling measurement and add a "
-                         "\"train\" object to the JSON line; off by default (the default line is the sampling metric)")
+    ap.add_argument("--no-train-leg", action="store_true",
+                    help="skip the BASELINE configs[4] leg (the discrete-diffusion training step, B = 20 per GPU, 19 layers: "
+                         "loss + hand-written backward + all-reduce + clip + AdamW + EMA; 3 + 10 iterations AFTER the sampling "
+                         "measurement, outside its timed region), reported as the \"train\" object of the JSON line")
+    ap.add_argument("--train-leg", action="store_true", help=argparse.SUPPRESS)   # (round-4 spelling; the leg is on by default)
+    ap.add_argument("--collectives-selftest", action="store_true",
+                    help="rendezvous + the path's collectives only (all-reduce of ones, caption scatter, waveform gather, one "
+                         "gradient bucket) on stand-in tensors, no HIP kernels: backend nccl on GPUs, gloo without -- what "
+                         "tests/test_shard_gloo.py drives through the self-launcher")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
@@ -67,12 +76,108 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks ourselves, exactly the
+    command the driver uses, and return its exit code (rank 0 of the child job prints the JSON line).  N > visible
+    devices is refused loudly (exit code 2) -- except for --collectives-selftest on a box without GPUs (gloo)."""
+    import subprocess
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not (args.collectives_selftest and n_dev == 0) and n_dev < args.gpus:
+        print("bench.py: %d ranks requested (--gpus %d), %d device(s) visible -- refusing to measure fewer GPUs than asked for"
+              % (args.gpus, args.gpus, n_dev), file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def world_from_env(args):
+    """(world, rank, local_rank) of this process; exits when --gpus and the launcher's WORLD_SIZE disagree."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d -- launch with --nproc-per-node %d (or leave WORLD_SIZE unset and let "
+              "bench.py start the ranks)" % (args.gpus, world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def collectives_check(dev, world, rank):
+    """What the N-rank line reports about its communicator: `rccl_ranks` = an all-reduce of ones over the job's process
+    group (the ranks the collective actually saw), and one round of the path's own collectives on stand-in tensors --
+    caption ids out (616 B per caption), waveforms back (868 KB per clip), one 48 MB gradient bucket -- timed."""
+    import torch.distributed as dist
+    from text_to_sound_synthesis_amd import shard
+    out = {"backend": dist.get_backend() if world > 1 or dist.is_initialized() else None}
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+    ones = torch.ones(1, device=dev)
+    if dist.is_initialized():
+        dist.all_reduce(ones)
+    out["rccl_ranks"] = int(ones.item())
+    n_total = 8 * world
+    ids = torch.arange(n_total * 77, dtype=torch.long).view(n_total, 77) if rank == 0 else None
+    force = dist.is_initialized()
+    sync(); t0 = time.perf_counter()
+    mine = shard.scatter_conditions(ids, n_total, (77,), dev, dtype=torch.long, always_collective=force)
+    sync(); t1 = time.perf_counter()
+    lo, hi = shard.shard_bounds(n_total, world, rank)
+    assert mine.shape == (hi - lo, 77) and int(mine[0, 0]) == lo * 77, "scatter delivered the wrong slice"
+    wave = mine[:, :1].float().expand(-1, 217088).contiguous().unsqueeze(1)
+    sync(); t2 = time.perf_counter()
+    allw = shard.gather_outputs(wave, n_total, always_collective=force)
+    sync(); t3 = time.perf_counter()
+    if rank == 0:
+        assert allw.shape[0] == n_total and allw[:, 0, 0].tolist() == [float(i * 77) for i in range(n_total)], \
+            "gather returned the clips out of caption order"
+    red = shard.GradientReducer(bucket_bytes=48 << 20, always_collective=force)
+    g = {"w%d" % i: torch.full((3 << 20,), float(rank + 1), device=dev) for i in range(5)}     # 5 x 12 MB: two buckets
+    sync(); t4 = time.perf_counter()
+    red.ready({k: g[k] for k in ("w0", "w1", "w2", "w3")})
+    red.finish(g)
+    sync(); t5 = time.perf_counter()
+    want = sum(range(1, world + 1)) / world
+    assert all(abs(float(v[0]) - want) < 1e-6 and abs(float(v[-1]) - want) < 1e-6 for v in g.values()), "gradient average"
+    out.update(scatter_ms=round((t1 - t0) * 1e3, 3), gather_ms=round((t3 - t2) * 1e3, 3),
+               gather_bytes=n_total * 217088 * 4, grad_bucket_ms=round((t5 - t4) * 1e3, 3), grad_bytes=5 * (3 << 20) * 4)
+    return out
+
+
+def selftest_main(args):
+    """--collectives-selftest: the N-rank control flow without the HIP library (see parse())."""
+    import torch.distributed as dist
+    world, rank, local_rank = world_from_env(args)
+    cuda = torch.cuda.is_available()
+    dev = torch.device("cuda", local_rank) if cuda else torch.device("cpu")
+    if cuda:
+        torch.cuda.set_device(local_rank)
+    if world > 1 or os.environ.get("MASTER_ADDR"):
+        dist.init_process_group("nccl" if cuda else "gloo", **({"device_id": dev} if cuda else {}))
+    info = collectives_check(dev, world, rank)
+    info.update(selftest=True, n_gpus=world, device=dev.type)
+    if rank == 0:
+        print(json.dumps(info))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def cpu_baseline(n_layer, codes, T):
     """The path on this box's host cores: the unmodified reference under oracle/ref_harness.py
     when /root/reference exists (`kind: reference`, the build container), else the CPU oracle -- a restatement of the
     reference on the same torch-CPU ops (`kind: port`, the GPU box).  Bounded sample: torch thread count swept on one
-    B=8 denoiser step (a B=1 step is GEMV-like and oversubscribes a many-core host), then at the best count and for
-    B in {1, 8}: 2 timed denoiser steps + 1 decode + 1 vocode, extrapolated to T steps.  Reports the better B."""
+    B=8 denoiser step (a B=1 step is GEMV-like and oversubscribes a many-core host) over every candidate up to the physical
+    core count, then at the best count and for B in {1, 8}: 1 warm-up + 3 timed repeats (2 denoiser steps each), the MEDIAN
+    per step, + decode + vocode, extrapolated to T steps.  Reports the better B; one full-length B=1 clip beside it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import diffsound_oracle as O
     import ref_harness as rh
@@ -120,30 +225,37 @@ def cpu_baseline(n_layer, codes, T):
         return t1 - t0, time.perf_counter() - t1
 
     hw = os.cpu_count() or 8
+    phys = _physical_cores() or max(1, hw // 2)
     default_threads = torch.get_num_threads()
-    cands = sorted({n for n in (8, 16, 32, 64, 128) if 1 <= n <= hw})
+    # thread count swept UP TO the physical core count (and the hardware-thread count beside it),
+    # every point measured -- no early exit -- on one B=8 denoiser step after one warm-up step
+    cands = sorted({n for n in (8, 16, 32, 64, phys, hw) if 1 <= n <= hw})
     sweep = {}
     one = step_fn(8)
-    for n in cands:                                  # upward; stops once more threads are clearly slower (keeps the
-        torch.set_num_threads(n)                     # whole baseline leg within ~30 s of CPU work)
+    for n in cands:
+        torch.set_num_threads(n)
         one(T - 1)                                   # warm-up (thread pool, allocator)
         t0 = time.perf_counter()
         one(T - 2)
         sweep[n] = time.perf_counter() - t0
-        if sweep[n] > 1.3 * min(sweep.values()):
-            break
     best_n = min(sweep, key=sweep.get)
     torch.set_num_threads(best_n)
-    res = {}
-    for B in (1, 8):
+    med = lambda v: sorted(v)[len(v) // 2]
+    res, reps = {}, {}
+    for B in (1, 8):                                 # 1 warm-up + 3 timed repeats, median
         one = step_fn(B)
         one(T - 1)
-        t0 = time.perf_counter()
-        for i in range(2):
-            one(T - 2 - i)
-        t_step = (time.perf_counter() - t0) / 2
-        t_dec, t_voc = tail(B)
+        ts = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            for i in range(2):
+                one(T - 2 - 2 * rep - i)
+            ts.append((time.perf_counter() - t0) / 2)
+        t_step = med(ts)
+        tails = [tail(B) for _ in range(3 if B == 1 else 1)]      # B=8 decode + vocode is ~10 s: timed once (bounded sample)
+        t_dec, t_voc = med([x[0] for x in tails]), med([x[1] for x in tails])
         res[B] = (B / (T * t_step + t_dec + t_voc), t_step, t_dec, t_voc)
+        reps[B] = [round(x, 4) for x in ts]
     # one clip at FULL length (B = 1: all T steps, decode, vocode), when it fits the bounded sample: what the 2-step
     # extrapolation above is worth
     full = None
@@ -159,23 +271,36 @@ def cpu_baseline(n_layer, codes, T):
     torch.set_num_threads(default_threads)
     bB = max(res, key=lambda k: res[k][0])
     value = res[bB][0]
-    note = ""
-    if full is not None and full["clips_per_s"] > value:       # the CPU gets its best measured rate
-        value = full["clips_per_s"]
-        note = "; value = the full-length B=1 clip (%.2f s), faster than the extrapolations" % full["seconds"]
-    elif full is not None:
-        note = "; one full-length B=1 clip measured beside it: %.2f s" % full["seconds"]
     return {"value": value, "unit": "clips/s", "cores": best_n, "kind": "reference" if use_ref else "port",
-            "host_hw_threads": hw,
+            "host_hw_threads": hw, "host_physical_cores": phys,
+            "protocol": "BASELINE.md section 4: B in {1, 8}, 1 warm-up + 3 timed repeats, median; value = the better B",
             "thread_sweep_s_per_B8_step": {str(k): round(v, 3) for k, v in sweep.items()},
             "full_length_B1": full,
-            "per_batch": {"B=%d" % B: {"clips_per_s": round(v[0], 5), "s_per_denoiser_step": round(v[1], 3),
-                                        "s_decode": round(v[2], 2), "s_vocode": round(v[3], 2)} for B, v in res.items()},
-            "sample": "%s, fp32 torch-CPU, %d torch threads (best of the sweep on a B=8 step), B=%d: 2 of %d denoiser "
-                      "steps (%.3f s each) + 1 decode (%.2f s) + 1 vocode (%.2f s), extrapolated to %d steps"
+            "per_batch": {"B=%d" % B: {"clips_per_s": round(v[0], 5), "s_per_denoiser_step_median": round(v[1], 3),
+                                        "s_per_denoiser_step_repeats": reps[B], "s_decode": round(v[2], 2),
+                                        "s_vocode": round(v[3], 2)} for B, v in res.items()},
+            "sample": "%s, fp32 torch-CPU, %d torch threads (best of the sweep %s on a B=8 step; %d physical cores, %d hardware "
+                      "threads), B=%d: median of 3 repeats of 2 of the %d denoiser steps (%.3f s per step) + decode (%.2f s) + "
+                      "vocode (%.2f s), extrapolated to %d steps%s"
                       % ("the unmodified reference under oracle/ref_harness.py" if use_ref else
                          "CPU oracle (restatement of the reference; /root/reference is not on this box)",
-                         best_n, bB, T, res[bB][1], res[bB][2], res[bB][3], T) + note}
+                         best_n, sorted(sweep), phys, hw, bB, T, res[bB][1], res[bB][2], res[bB][3], T,
+                         "; one full-length B=1 clip measured beside it: %.2f s" % full["seconds"] if full else "")}
+
+
+def _physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; None when the file does not say."""
+    try:
+        cores, phys = set(), None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    cores.add((phys, line.split(":")[1].strip()))
+        return len(cores) or None
+    except OSError:
+        return None
 
 
 def pmc_traffic(kernel, template_tail, algorithmic_mb):
@@ -228,10 +353,11 @@ def gemm_algorithmic_mb(B, rows, D=1024, mlp=4):
     return (qkv + 2 * proj + crossq + fc1 + fc2) / 6.0 / 1e6
 
 
-def timed_loop(one_step, warmup, steps, device, world):
+def timed_loop(one_step, warmup, steps, device, world, info=None):
     """W untimed warm-up steps, then EXACTLY K timed steps bracketed by device synchronisation + a barrier on both
     sides; returns (elapsed seconds = MAX over ranks, last step's output).  Shared by main() and the world-size-2
-    gloo test of the control flow (tests/test_shard_gloo.py)."""
+    gloo test of the control flow (tests/test_shard_gloo.py).  `info` (a dict) receives the spread over the ranks of
+    each rank's OWN time to finish its K steps (before the closing barrier): {"rank_s_min", "rank_s_max"}."""
     import torch.distributed as dist
 
     def sync_all():
@@ -249,12 +375,18 @@ def timed_loop(one_step, warmup, steps, device, world):
     out = None
     for _ in range(steps):
         out = one_step()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    own = time.perf_counter() - t0                  # this rank's K steps, before it waits for the others
     sync_all()
     elapsed = time.perf_counter() - t0
+    lo = hi = own
     if world > 1:
-        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        te = torch.tensor([elapsed, own, -own], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        elapsed, hi, lo = float(te[0].item()), float(te[1].item()), -float(te[2].item())
+    if info is not None:
+        info.update(rank_s_min=lo, rank_s_max=hi)
     return elapsed, out
 
 
@@ -267,7 +399,7 @@ def result_line(args, world, elapsed, n_total):
         "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16x3": "f32 via 3-way bf16 split (6 MFMA passes, fp32 accumulate)",
+        "dtype": {"fp32": "f32",
                   "f16x2": "f32 via 2-way fp16 split (3 MFMA passes, fp32 accumulate)"}[args.precision],
         "data": "synthetic captions (5-15 words, BPE-tokenised in the timed region) + seeded random-init weights of the "
                 "reference's shapes",
@@ -286,10 +418,16 @@ def result_line(args, world, elapsed, n_total):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # not under a launcher: start the ranks ourselves
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.collectives_selftest:
+        return selftest_main(args)
+    world, rank, local_rank = world_from_env(args)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: local rank %d but %d device(s) visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -309,7 +447,6 @@ def main():
     dt = model.transformer
     dt.truncation_r = 0.85
     dt.transformer.precision = args.precision
-    dt.sample_streams = args.streams
     n_total = B * world
     # rank 0 owns the captions: synthetic caption STRINGS, tokenised inside the timed region by
     # the package's BPE tokenizer (clip.tokenize semantics: <SOT> word pieces <EOT>, context 77) on the closed-vocabulary
@@ -353,7 +490,8 @@ def main():
                 stage[k] += v
         return allw if allw is not None else wave
 
-    elapsed, w = timed_loop(one_step, args.warmup, args.steps, dev, world)
+    spread = {}
+    elapsed, w = timed_loop(one_step, args.warmup, args.steps, dev, world, info=spread)
     if args.transformer_only:
         assert w.shape[-1] == 265 and int(w.max()) < args.codes       # no [MASK] left at t = 0
     else:
@@ -381,7 +519,6 @@ def main():
         cond = synth.synth_cond_emb(B, key="bench.cond").to(dev)
         # (kernel-symbol prefix, passes of MFMA work per algorithmic flop, MFMA peak of the operand type)
         KIND = {"fp32": ("ds_gemm_kernel<%d,%d,0,0>", 1, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA 32x32x2"),
-                "bf16x3": ("ds_gemm_bf16x3_kernel<%d,%d>", 6, PEAK_16BIT_MFMA_TFLOPS, "6-pass bf16 MFMA 32x32x16"),
                 "f16x2": ("ds_gemm_f16x2_kernel<%d,%d>", 3, PEAK_16BIT_MFMA_TFLOPS, "3-pass fp16 MFMA 32x32x16")}
 
         def leg(precision, warm=None, steps=None):
@@ -435,16 +572,30 @@ def main():
         if args.precision != "fp32":                   # the exact-fp32 MFMA kernel on the same shapes, for reference
             extra["roofline_fp32_mfma_kernel"] = leg("fp32", warm=0, steps=3)    # (a reference point: three steps suffice)
             dt.transformer.precision = args.precision
-    if world == 1 and not args.transformer_only:   # (a lone rank calling the collectives of one_step would hang the others)
-        # one more step with a synchronisation between the stages (outside the timed region): where a batch's time goes
+    if not args.transformer_only:
+        # one more step with a synchronisation between the stages (outside the timed region): where a batch's time goes.
+        # EVERY rank runs it (the step contains the scatter / gather collectives); rank 0 reports its own split and, for
+        # N > 1, the slowest rank's per stage
         one_step(timed_stages=True)
-        extra["stage_ms"] = {k: round(v * 1e3, 2) for k, v in stage.items() if k != "kv"}
+        names = [k for k in stage if k != "kv"]
+        mine = torch.tensor([stage[k] for k in names], device=dev, dtype=torch.float64)
+        worst = mine.clone()
+        if world > 1:
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        extra["stage_ms"] = {k: round(float(v) * 1e3, 2) for k, v in zip(names, mine.tolist())}
+        if world > 1:
+            extra["stage_ms"]["max_over_ranks"] = {k: round(float(v) * 1e3, 2) for k, v in zip(names, worst.tolist())}
         extra["stage_ms"]["note"] = "one extra step, device-synchronised between stages: tokenise+scatter | CLIP + 100-step sampling | SpecVQGAN decode | MelGAN vocode | gather"
-        if args.stage_times:
+        if args.stage_times and rank == 0:
             print("stage seconds (1 step, B=%d): %s" % (B, {k: round(v, 3) for k, v in stage.items()}), file=sys.stderr)
+    if world > 1:
+        # the communicator this line was measured on: ranks an all-reduce saw, the path's collectives on stand-in tensors
+        extra["rccl"] = collectives_check(dev, world, rank)
+        extra["rccl"]["ms_per_step_per_rank"] = {"min": round(spread["rank_s_min"] / args.steps * 1e3, 2),
+                                                 "max": round(spread["rank_s_max"] / args.steps * 1e3, 2)}
 
     train = None
-    if args.train_leg:       # every rank takes part (data-parallel step; one GPU: the iteration replayed as one hipGraph)
+    if not args.no_train_leg:  # every rank takes part (data-parallel step; one GPU: the iteration replayed as one hipGraph)
         del model, voc, dt
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))

@@ -77,12 +77,8 @@ typedef struct ds_gemm_desc {
 
 int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream);
 void ds_gemm_force_tile(int cfg); /* test hook: 0..2 pins the block tile, -1 = auto */
-/* The same dense contraction (DS_LOAD_DENSE, DS_PRO_NONE) on the bf16 matrix cores with fp32-class accuracy:
- * W is pre-split into three bf16 planes (w = w0 + w1 + w2 exactly), A (fp32) is split on the fly, six bf16
- * MFMA passes per k-step accumulate a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 in fp32 (gemm_bf16x3.hip). */
-int ds_gemm_bf16x3(const ds_gemm_desc* d, ds_stream_t stream);
-void ds_gemm_bf16x3_force_tile(int cfg);
-/* Cheaper variant: W*2^s and A are split into two fp16 planes each (22 significant bits), three fp16 MFMA passes
+/* The same dense contraction (DS_LOAD_DENSE, DS_PRO_NONE) on the fp16 matrix cores with fp32-class accuracy:
+ * W*2^s and A are split into two fp16 planes each (22 significant bits), three fp16 MFMA passes
  * a0b0 + a0b1 + a1b0 per k-step, epilogue multiplies by out_scale = 2^-s.  |A| must stay below 65504
  * (gemm_f16x2.hip).  groups > 1 (row-major operands, plain row store, no bias / residual): group g computes
  * A + g a_gstride (floats) times W + g w_gstride (halves, both planes) into C + g c_gstride -- with a_gstride =
@@ -296,11 +292,11 @@ int ds_denoiser_create(const ds_denoiser_desc* desc, const void* const* layer_pt
 void ds_denoiser_destroy(ds_denoiser* h);
 int64_t ds_denoiser_workspace_bytes(const ds_denoiser* h, int B);
 int64_t ds_denoiser_kv_bytes(const ds_denoiser* h, int B);
-/* Switch the denoiser's per-step GEMMs to a split kernel.  mode 1 = bf16x3, 2 = f16x2, 0 = back to fp32 MFMA.
- * split[layer*DS_LP_COUNT + slot] holds the plane-split of that slot's weight for the DS_LP_W_* slots QKV,
- * PROJ1, Q2, PROJ2, FC1, FC2 (other slots NULL), out_scales[same index] the 2^-s of mode 2 (ignored in mode 1);
- * w_logits_split / logits_scale likewise for to_logits.1. */
-enum { DS_SPLIT_NONE = 0, DS_SPLIT_BF16X3 = 1, DS_SPLIT_F16X2 = 2 };
+/* Switch the denoiser's per-step GEMMs to the split kernel.  mode DS_SPLIT_F16X2 = f16x2, DS_SPLIT_NONE = back to fp32
+ * MFMA (the strict mode).  split[layer*DS_LP_COUNT + slot] holds the packed plane-split of that slot's weight for the
+ * DS_LP_W_* slots QKV, PROJ1, Q2, PROJ2, FC1, FC2 (other slots NULL), out_scales[same index] its 2^-s;
+ * w_logits_split / logits_scale likewise for to_logits.1.  (Value 1 was the 6-pass bf16 split of rounds 1-4: removed.) */
+enum { DS_SPLIT_NONE = 0, DS_SPLIT_F16X2 = 2 };
 int ds_denoiser_set_split_weights(ds_denoiser* h, int mode, const void* const* split, const float* out_scales,
                                   const void* w_logits_split, float logits_scale);
 /* Padded-row mode of ds_denoiser_step(_ex) (default on): in f16x2 mode, at batch sizes whose GEMMs run the per-sample

@@ -110,7 +110,8 @@ def test_padded_row_mode_selection_and_workspace():
         assert lib.ds_denoiser_rows_per_sample(h, 64) == 265
         L.check(lib.ds_denoiser_set_row_padding(h, 1))
         assert lib.ds_denoiser_rows_per_sample(h, 64) == 272
-        L.check(lib.ds_denoiser_set_split_weights(h, 1, ptrs, scales, dummy.data_ptr(), 1.0))        # bf16x3 mode: never
+        assert lib.ds_denoiser_set_split_weights(h, 1, ptrs, scales, dummy.data_ptr(), 1.0) != 0     # (the removed bf16 split)
+        L.check(lib.ds_denoiser_set_split_weights(h, 0, None, None, None, 1.0))                      # back to fp32: never
         assert lib.ds_denoiser_rows_per_sample(h, 64) == 265
     finally:
         lib.ds_denoiser_destroy(h)

@@ -93,9 +93,9 @@ def test_conv3x3_halo_vs_float64_and_gather_kernel(L, shape, mode):
         assert (b0 - b1).abs().max().item() <= 2e-6 * max(1.0, b0.abs().max().item())
 
 
-def test_decoder_same_mel_on_both_conv_kernels():
-    """VQModel.decode with the halo-tiled convs + folded GroupNorm statistics against the tap-by-tap kernels: the mel agrees
-    far inside the north-star tolerance (both are fp32-class; only summation orders differ)."""
+def test_decoder_same_mel_in_both_arithmetic_modes():
+    """VQModel.decode in the default mode (halo-tiled split convs + folded GroupNorm statistics) against the strict mode
+    (every conv a gather-GEMM on the exact-fp32 MFMA): the mel agrees far inside the north-star tolerance."""
     from conftest import synth_sd
     from text_to_sound_synthesis_amd.config import build_model, default_config
     m = build_model(default_config(n_layer=1))
@@ -103,19 +103,21 @@ def test_decoder_same_mel_on_both_conv_kernels():
     m = m.cuda().eval()
     tok = synth.synth_tokens(2, mask_frac=0.0, key="c3.codes").cuda()
     codec = m.content_codec
-    codec.conv_halo = True
+    assert codec.conv_precision == "f16x2"
     a = m.decode_to_img(tok, (2, 256, 5, 53)).cpu()
-    codec.conv_halo = False
-    b = m.decode_to_img(tok, (2, 256, 5, 53)).cpu()
-    codec.conv_halo = True
+    codec.conv_precision = "fp32"
+    try:
+        b = m.decode_to_img(tok, (2, 256, 5, 53)).cpu()
+    finally:
+        codec.conv_precision = "f16x2"
     d = (a - b).abs().max().item()
-    print("decode: halo-tiled vs gather convs, mel max-abs difference %.2e (mel range %.2f)" % (d, float(b.abs().max())))
+    print("decode: f16x2 halo-tiled convs vs exact-fp32 gather convs, mel max-abs difference %.2e (mel range %.2f)" % (d, float(b.abs().max())))
     assert torch.isfinite(a).all() and d < 1e-4
 
 
 def test_melgan_resblock_tail_one_gemm():
     """ds_melgan_resblock_tail (vocoder/modules.py:72-85: 1x1 conv on the activated k3 output + 1x1 shortcut as ONE contraction
-    over [LReLU(h) | x]) against float64, and the whole Generator with and without it."""
+    over [LReLU(h) | x]) against float64."""
     from conftest import synth_sd
     from text_to_sound_synthesis_amd import _lib as L
     from text_to_sound_synthesis_amd.modeling.vocoder import Generator
@@ -130,17 +132,6 @@ def test_melgan_resblock_tail_one_gemm():
     L.check(L.lib().ds_melgan_resblock_tail(L.ptr(hc), L.ptr(xc), L.ptr(planes), C * 2 * C, osc, L.ptr(bc), L.ptr(y), M, C,
                                             L.stream()))
     assert relerr(y.cpu(), ref) < 3e-6
-    g = Generator(80, 32, 3)
-    g.load_state_dict(synth_sd("generator"))
-    g = g.cuda().eval()
-    mel = synth.synth_uniform((2, 80, 53), key="rt.mel").cuda()
-    g.fuse_tail = True
-    a = g(mel).cpu()
-    g.fuse_tail = False
-    bb = g(mel).cpu()
-    rms = float((a - bb).pow(2).mean().sqrt())
-    print("MelGAN: one-GEMM block tails vs three launches per block, waveform RMS difference %.2e" % rms)
-    assert torch.isfinite(a).all() and rms < 1e-6
 
 
 def _resblock_ref64(x, w3, b3, w2, b2, ws, bs, dil):
@@ -202,16 +193,6 @@ def test_melgan_final_single_pass_and_generator_ab():
     print("MelGAN final layer, single pass: max abs error vs float64 %.2e" % e)
     assert torch.isfinite(out).all() and e < 2e-6
     assert L.lib().ds_melgan_final(L.ptr(xc), L.ptr(wc), bias, L.ptr(out), B, T, 64, L.stream()) != 0      # not built: loud
-    g = Generator(80, 32, 3)
-    g.load_state_dict(synth_sd("generator"))
-    g = g.cuda().eval()
-    mel = synth.synth_uniform((2, 80, 53), key="rt.mel").cuda()
-    a = g(mel).cpu()
-    g.fuse_block, g.fuse_final = False, False
-    bb = g(mel).cpu()
-    rms = float((a - bb).pow(2).mean().sqrt())
-    print("MelGAN: single-pass 32-channel blocks + final layer vs the GEMM forms, waveform RMS difference %.2e" % rms)
-    assert torch.isfinite(a).all() and rms < 1e-6
 
 
 @pytest.mark.parametrize("C,T,dil", [(128, 700, 1), (128, 512, 9), (256, 300, 3), (128, 1000, 27)])
@@ -237,21 +218,6 @@ def test_conv1d_k3_halo_vs_float64_and_gather_kernel(C, T, dil):
     print("conv1d k3 C %d T %d dil %d: halo kernel %.2e, gather kernel %.2e vs float64; max |a - b| %.2e"
           % (C, T, dil, e1, e2, float((y - y2).abs().max())))
     assert torch.isfinite(y).all() and e1 < 3e-6 and e1 <= 1.5 * e2 + 1e-7
-
-
-def test_generator_conv1d_halo_ab():
-    from conftest import synth_sd
-    from text_to_sound_synthesis_amd.modeling.vocoder import Generator
-    g = Generator(80, 32, 3)
-    g.load_state_dict(synth_sd("generator"))
-    g = g.cuda().eval()
-    mel = synth.synth_uniform((2, 80, 53), key="rt.mel").cuda()
-    a = g(mel).cpu()
-    g.conv1d_halo = False
-    bb = g(mel).cpu()
-    rms = float((a - bb).pow(2).mean().sqrt())
-    print("MelGAN: halo-tiled k3 convs of the 128 / 256-channel blocks vs the gather kernel, waveform RMS difference %.2e" % rms)
-    assert torch.isfinite(a).all() and rms < 1e-6
 
 
 @pytest.mark.parametrize("cin,cout,T", [(128, 64, 300), (64, 32, 1000)])
@@ -281,7 +247,9 @@ def test_melgan_convt2_single_pass(cin, cout, T):
     assert L.lib().ds_melgan_convt2(L.ptr(xc), L.ptr(planes), 2 * cout * 2 * cin, sc, L.ptr(bc), L.ptr(y), B, T, cin, 128, L.stream()) != 0
 
 
-def test_generator_fused_convt_ab():
+def test_generator_default_kernels_vs_strict_fp32_mode():
+    """The whole Generator on its default kernels (one-GEMM block tails, single-pass 32 / 64-channel blocks, halo-tiled k3
+    and transposed convs, fused final layer) against the strict mode (every layer a gather-GEMM on the exact-fp32 MFMA)."""
     from conftest import synth_sd
     from text_to_sound_synthesis_amd.modeling.vocoder import Generator
     g = Generator(80, 32, 3)
@@ -289,10 +257,10 @@ def test_generator_fused_convt_ab():
     g = g.cuda().eval()
     mel = synth.synth_uniform((2, 80, 53), key="rt.mel").cuda()
     a = g(mel).cpu()
-    g.fuse_convt = False
+    g.conv_precision = "fp32"
     bb = g(mel).cpu()
     rms = float((a - bb).pow(2).mean().sqrt())
-    print("MelGAN: single-pass stride-2 ConvTranspose1d layers vs the polyphase GEMMs, waveform RMS difference %.2e" % rms)
+    print("MelGAN: default f16x2 kernels vs the exact-fp32 gather-GEMM forms, waveform RMS difference %.2e" % rms)
     assert torch.isfinite(a).all() and rms < 1e-6
 
 

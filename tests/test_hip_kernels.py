@@ -168,7 +168,15 @@ def test_sample_tail(L, K, t, mask_frac):
                                    int(mask_frac is None), 0.85, L.stream()))
     assert (d[0].cpu() - lp).abs().max() < 1e-5
     kept_h, kept_o = d[1].cpu() > -70, tr > -70
-    assert (kept_h != kept_o).sum().item() <= 1          # a cumsum within 1 ulp of r may flip one class
+    # The kernel's rank-order mass is the reference's CPU cumsum bit for bit GIVEN EQUAL log-probabilities
+    # (tests/test_sampler_sort_emulation.py); here lp itself comes from two libms (device double exp / log vs torch CPU)
+    # and may differ in its last place, so a disagreement is tolerated only in a column whose cut sits within a few ulp
+    # of r (|mass ranked before some class - r| < 4e-7; ulp(0.85) = 6e-8) -- everywhere else the kept sets are EQUAL.
+    bad_cols = (kept_h != kept_o).any(1)                                   # [B, Ln]
+    if bad_cols.any():
+        before = torch.exp(torch.sort(lp, 1, descending=True)[0]).cumsum(1)
+        margin = (before - 0.85).abs().min(1)[0]                           # [B, Ln]
+        assert bool((margin[bad_cols] < 4e-7).all()), "top-r kept sets differ away from a rounding-level cut: %s" % margin[bad_cols]
     same = kept_h == kept_o
     assert (d[1].cpu() - tr)[same].abs().max() < 1e-5
     cols_same = same.all(1)

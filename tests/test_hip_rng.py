@@ -241,3 +241,43 @@ def test_cross_program_agreement_at_the_benchmarked_configuration():
                 "identical, token agreement %.4f" % (same, agree))
     print("one batch of 64 vs 8 x 8: %d of 64 clips identical, token agreement %.4f" % (same, agree))
     assert same >= 32, "most clips must not depend on the sharding (got %d of 64)" % same
+
+
+def test_torch_rng_mode_draws_exactly_rand_like_of_the_logits():
+    """rng_mode = "torch" (the default) promises a reference user's seed: the reference draws `torch.rand_like(logits)` once
+    per step on a [B, K + 1, L] fp32 tensor of the model's device (log_sample_categorical,
+    diffusion_transformer.py:359-368).  Checked here on the device generator itself: with the same torch.manual_seed the
+    uniforms sample() hands to every step ARE the tensors rand_like returns, in order, and the generator ends in the same
+    state (nothing else on the sampling path consumes it) -- so two chains from one seed are identical, and equal the
+    chain fed with those tensors explicitly."""
+    m = build(2, T=10)
+    dt = m.transformer
+    assert dt.rng_mode == "torch"
+    B, K1, L = 3, 257, 265
+    cond = synth.synth_cond_emb(B, key="rng.torch.cond").cuda()
+    seen = []
+    inner = dt.p_sample_tokens
+
+    def spy(x_t, kv, t, u, *a, **k):
+        seen.append(u.clone())
+        return inner(x_t, kv, t, u, *a, **k)
+    dt.p_sample_tokens = spy
+    try:
+        torch.manual_seed(4321)
+        out = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0)["content_token"].clone()
+        state_after = torch.cuda.get_rng_state()
+    finally:
+        del dt.p_sample_tokens                               # back to the class's method
+    assert len(seen) == 10
+    torch.manual_seed(4321)
+    logits_like = torch.empty(B, K1, L, device="cuda")       # what the reference's log_sample_categorical receives
+    want = [torch.rand_like(logits_like) for _ in range(10)]
+    assert torch.equal(torch.cuda.get_rng_state(), state_after), "sample() consumed the device generator differently"
+    for i, (a, b) in enumerate(zip(seen, want)):
+        assert a.shape == b.shape and torch.equal(a, b), "step %d: not the tensor torch.rand_like(logits) returns" % i
+    it = iter(want)
+    again = dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0,
+                      noise_fn=lambda t, shp: next(it))["content_token"]
+    assert torch.equal(again, out)
+    torch.manual_seed(4321)
+    assert torch.equal(dt.sample(condition_token=None, condition_mask=None, condition_embed=cond, filter_ratio=0)["content_token"], out)

@@ -342,3 +342,39 @@ def test_overlapped_gradient_reduction_world2():
         s.step(b)                          # no process group: the reducer is a no-op
     for a, w in zip(got[0]["overlapped"][0], ws):
         assert torch.allclose(a, w, rtol=1e-5, atol=1e-7)
+
+
+# ---- bench.py's own launcher (round 5): `python bench.py --gpus N` with no WORLD_SIZE starts the N ranks itself -----------
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_bench_self_launcher_starts_two_gloo_ranks():
+    """The launcher path end to end on CPU: bench.py --gpus 2 (no WORLD_SIZE) re-executes itself under
+    torch.distributed.run with 2 ranks; rank 0 prints one line whose `rccl_ranks` is what an all-reduce of ones saw, after
+    the path's scatter / gather / gradient-bucket collectives ran on stand-in tensors (gloo here, nccl on GPUs)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--collectives-selftest"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                         # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["rccl_ranks"] == 2 and out["n_gpus"] == 2 and out["backend"] == "gloo"
+    assert out["gather_bytes"] == 16 * 217088 * 4 and out["scatter_ms"] > 0 and out["grad_bucket_ms"] > 0
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """No silent one-GPU run: asking for 2 ranks where fewer devices are visible fails loudly with exit code 2."""
+    r = _run_bench(["--gpus", "2"])
+    assert r.returncode == 2 and "2 ranks requested" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_refuses_world_size_that_contradicts_gpus():
+    r = _run_bench(["--gpus", "2", "--collectives-selftest"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr

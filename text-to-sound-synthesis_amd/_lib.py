@@ -48,8 +48,6 @@ _PROTOS = {
     "ds_last_error_string": (C.c_char_p, []),
     "ds_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_gemm_force_tile": (None, [C.c_int]),
-    "ds_gemm_bf16x3": (C.c_int, [C.POINTER(GemmDesc), _vp]),
-    "ds_gemm_bf16x3_force_tile": (None, [C.c_int]),
     "ds_gemm_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_conv2d_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_gemm_f16x2_force_tile": (None, [C.c_int]),
@@ -155,9 +153,6 @@ def lib():
             fn = getattr(L, name)   # AttributeError here == header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        tile = os.environ.get("DIFFSOUND_F16X2_TILE")        # A/B hook: force a tile / staging candidate of the split GEMM
-        if tile:
-            L.ds_gemm_f16x2_force_tile(int(tile))
         _lib = L
     return _lib
 
@@ -198,10 +193,9 @@ def stream():
 def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=None, ldr=None,
          groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
          act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
-         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split3=False, split2=None,
+         Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split2=None,
          a_plane=0, c_plane=0, attn=None, w_plane=None, conv_split=False):
-    """split3: W is the [3][N][K] bf16 split from split_bf16x3() and the bf16x3 kernel is used.
-    split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used;
+    """split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used;
     a_plane / c_plane > 0 (f16x2 only): A and W are given / C is written as packed split planes (pack_planes())
     that many halves apart."""
     d = GemmDesc()
@@ -217,10 +211,7 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
     d.rows_per_sample, d.Cin, d.H, d.Wd, d.up = rows_per_sample, Cin, H, Wd, up
     d.taps, d.dil, d.ct_r, d.ct_p, d.ct_tin = taps, dil, ct_r, ct_p, ct_tin
     d.f16_round = f16_round
-    if split3:
-        d.w3_plane = N * d.ldw
-        check(lib().ds_gemm_bf16x3(C.byref(d), stream()))
-    elif split2 is not None and conv_split:        # conv-family loaders on the fp16 matrix cores (conv_f16x2.hip)
+    if split2 is not None and conv_split:        # conv-family loaders on the fp16 matrix cores (conv_f16x2.hip)
         d.w3_plane = w_plane if w_plane is not None else max(1, groups) * N * d.ldw
         d.out_scale = split2
         check(lib().ds_conv2d_f16x2(C.byref(d), stream()))
@@ -239,17 +230,6 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
     else:
         check(lib().ds_gemm(C.byref(d), stream()))
     return C_out
-
-
-def split_bf16x3(w):
-    """fp32 [N][K] -> int16 view of [3][N][K] bf16 planes with w == p0 + p1 + p2 (one-time weight prep;
-    torch's fp32->bf16 cast rounds to nearest even, the residual subtractions are exact)."""
-    w = w.detach().float()
-    p0 = w.to(torch.bfloat16)
-    r1 = w - p0.float()
-    p1 = r1.to(torch.bfloat16)
-    p2 = (r1 - p1.float()).to(torch.bfloat16)
-    return torch.stack((p0, p1, p2)).contiguous().view(torch.int16)
 
 
 def pack_conv_weights(planes, Cout, Cin, taps):

@@ -9,12 +9,12 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "obj")
 LIB = os.path.join(HERE, "libdiffsound_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_f16x2.hip", "gemm_f16x2_ps.hip", "conv_f16x2.hip", "conv3x3_f16x2.hip", "conv1d_f16x2.hip", "melgan_fused.hip", "norm.hip", "attention.hip", "attention_bwd.hip", "attention_f16x2.hip", "sampler.hip", "misc.hip", "train.hip", "api.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_f16x2_ps.hip", "conv_f16x2.hip", "conv3x3_f16x2.hip", "conv1d_f16x2.hip", "melgan_fused.hip", "norm.hip", "attention.hip", "attention_bwd.hip", "attention_f16x2.hip", "sampler.hip", "misc.hip", "train.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
          "-I", CSRC, "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
 # kernels that must not touch scratch memory: a register demotion in one of them is a silent 3x slowdown
 # (it happened once: accumulators of the f16x2 GEMM went to scratch when its epilogue grew a second store family)
-NO_SCRATCH = ("ds_gemm_f16x2", "ds_gemm_bf16x3", "ds_attn_f16x2", "ds_gemm_kernel", "ds_sample_tail", "ds_conv2d_f16x2", "ds_conv3x3_f16x2",
+NO_SCRATCH = ("ds_gemm_f16x2", "ds_attn_f16x2", "ds_gemm_kernel", "ds_sample_tail", "ds_conv2d_f16x2", "ds_conv3x3_f16x2",
               "ds_attn_bwd", "ds_melgan_rb", "ds_melgan_convt2", "ds_conv1d_f16x2")
 
 

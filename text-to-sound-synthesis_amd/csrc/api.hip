@@ -51,19 +51,6 @@ extern "C" int ds_gemm(const ds_gemm_desc* d, ds_stream_t stream) {
     return ds_launch_gemm(p, (hipStream_t)stream, d->loader);
 }
 
-extern "C" int ds_gemm_bf16x3(const ds_gemm_desc* d, ds_stream_t stream) {
-    DS_CHECK_ARG(d && d->A && d->W && d->C, "null pointer");
-    DS_CHECK_ARG(d->loader == DS_LOAD_DENSE && d->pro == DS_PRO_NONE && d->groups <= 1 && !d->f16_round,
-                 "bf16x3 is the dense, no-prologue, ungrouped kernel");
-    DS_CHECK_ARG(d->w3_plane > 0, "w3_plane (plane stride of the split weights) is required");
-    DS_CHECK_ARG(d->store != DS_STORE_BATCH_T || d->rows_per_sample > 0, "BATCH_T store needs rows_per_sample");
-    DS_CHECK_ARG(d->R == nullptr || d->store == DS_STORE_ROW, "residual only with row-major store");
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    fill(p, d);
-    return ds_launch_gemm_bf16x3(p, (hipStream_t)stream);
-}
-
 // the conv-family loaders of the descriptor (DS_LOAD_CONV2D / CONV1D / CONVT1D / DENSE) on the fp16 matrix cores; W =
 // split_f16x2 planes.  loader 0 (DS_LOAD_DENSE) in the descriptor of a caller that predates the other loaders meant the
 // 3x3 conv: the conv2d geometry fields (H > 0 and K == 9 Cin) select it.
@@ -115,17 +102,16 @@ extern "C" int ds_denoiser_set_split_weights(ds_denoiser* h, int mode, const voi
         h->split_mode = DS_SPLIT_NONE;
         return 0;
     }
-    DS_CHECK_ARG(mode == DS_SPLIT_BF16X3 || mode == DS_SPLIT_F16X2, "unknown split mode");
-    DS_CHECK_ARG(mode != DS_SPLIT_F16X2 || (out_scales && logits_scale > 0.f), "f16x2 needs the output scales");
+    DS_CHECK_ARG(mode == DS_SPLIT_F16X2, "unknown split mode");
+    DS_CHECK_ARG(out_scales && logits_scale > 0.f, "f16x2 needs the output scales");
     static const int need[6] = {DS_LP_W_QKV, DS_LP_W_PROJ1, DS_LP_W_Q2, DS_LP_W_PROJ2, DS_LP_W_FC1, DS_LP_W_FC2};
     for (int l = 0; l < h->d.n_layer; ++l)
         for (int s : need) DS_CHECK_ARG(split3[(size_t)l * DS_LP_COUNT + s], "missing split weight");
     DS_CHECK_ARG(w_logits3, "missing split logits weight");
     h->lp3.assign(split3, split3 + (size_t)h->d.n_layer * DS_LP_COUNT);
-    if (mode == DS_SPLIT_F16X2) h->osc.assign(out_scales, out_scales + (size_t)h->d.n_layer * DS_LP_COUNT);
-    else h->osc.clear();
+    h->osc.assign(out_scales, out_scales + (size_t)h->d.n_layer * DS_LP_COUNT);
     h->w_logits3 = w_logits3;
-    h->logits_osc = mode == DS_SPLIT_F16X2 ? logits_scale : 1.f;
+    h->logits_osc = logits_scale;
     h->split_mode = mode;
     return 0;
 }
@@ -257,7 +243,7 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
     p.A = A; p.W = W; p.bias = bias; p.R = R; p.C = C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = K; p.ldc = ldc; p.ldr = ldc;
     p.groups = 1; p.act = act; p.store = store; p.rows_per_sample = rps;
-    if (W3) {  // fp32-class GEMM on the bf16 / fp16 matrix cores
+    if (W3) {  // fp32-class GEMM on the fp16 matrix cores
         p.W = (const float*)W3;
         p.w3_plane = (long long)N * K;
         p.out_scale = osc;
@@ -269,7 +255,7 @@ static int dense(const float* A, int lda, const float* W, const float* bias, con
     }
     auto launch = [&]() {
         if (!W3) return ds_launch_gemm(p, s, DS_LOAD_DENSE);
-        return split_mode == DS_SPLIT_F16X2 ? ds_launch_gemm_f16x2(p, s) : ds_launch_gemm_bf16x3(p, s);
+        return ds_launch_gemm_f16x2(p, s);
     };
     if (!g_prof) return launch();
     ProfRec r;

@@ -179,26 +179,26 @@ extern "C" int ds_attention_ex(const float* q, int ldq, const float* k, int ldk,
     const int qtiles = (Lq + 31) / 32;
     const int groups = (qtiles + ATT_WAVES - 1) / ATT_WAVES;
     dim3 grid(groups * heads, B), block(ATT_WAVES * 64);
-    static bool attr9 = false, attr3 = false;
+    static DsOnce attr9, attr3;
     if (Lk <= 96) {
         const size_t lds = 3 * 32 * ATT_LD * sizeof(float);
-        if (!attr3) {
+        if (attr3.need()) {
             (void)hipFuncSetAttribute((const void*)ds_attn_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr3 = true;
+            attr3.done();
         }
         hipLaunchKernelGGL((ds_attn_kernel<3>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
                            heads, scale, causal, f16_round);
     } else {
         DS_CHECK_ARG(Lk <= 288, "at most 288 keys are supported");
         const size_t lds = 9 * 32 * ATT_LD * sizeof(float);
-        if (!attr9) {
+        if (attr9.need()) {
             hipError_t e = hipFuncSetAttribute((const void*)ds_attn_kernel<9>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) {
                 ds_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
                 return -2;
             }
-            attr9 = true;
+            attr9.done();
         }
         hipLaunchKernelGGL((ds_attn_kernel<9>), grid, block, lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Lq, Lk,
                            heads, scale, causal, f16_round);

@@ -299,14 +299,14 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
 }
 
 template <typename KernelT>
-static int ab_set_lds(KernelT kernel, size_t lds, bool& done) {
-    if (done) return 0;
+static int ab_set_lds(KernelT kernel, size_t lds, DsOnce& done) {
+    if (!done.need()) return 0;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         ds_set_error("attention backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return -2;
     }
-    done = true;
+    done.done();
     return 0;
 }
 
@@ -321,7 +321,7 @@ extern "C" int ds_attention_bwd(const float* q, int ldq, const float* k, int ldk
     DS_CHECK_ARG(((ldq | ldk | ldv | ldo | lddo) & 3) == 0, "leading dims of the inputs must be multiples of 4");
     DS_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "16-byte aligned inputs");
     const int qgroups = ((Lq + 31) / 32 + AB_WAVES - 1) / AB_WAVES, kgroups = ((Lk + 31) / 32 + AB_WAVES - 1) / AB_WAVES;
-    static bool a3 = false, a9 = false, akv = false;
+    static DsOnce a3, a9, akv;
     if (Lk <= 96) {
         const size_t lds = 3 * 32 * AB_LD * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_q_kernel<3>, lds, a3)) return -2;

@@ -616,8 +616,10 @@ static int attn_f16x2_launch_n(const float* q, int ldq, const float* k, int ldk,
     constexpr size_t pl_bytes = (size_t)2 * TPC * 32 * 64 * sizeof(unsigned short);       // one operand chunk, both planes
     constexpr size_t lds = XS ? (pl_bytes > stage_bytes ? pl_bytes : stage_bytes) : 2 * pl_bytes;
     static_assert(pl_bytes >= stage_bytes, "the staged output plane fits in the V^T chunk buffer");
-    static int grid_cap = -1;      // persistent launches: workgroups that are resident at once
-    if (grid_cap < 0) {
+    static int grid_cap_dev[64];   // persistent launches: workgroups that are resident at once, per device
+    static DsOnce cap_once;
+    const int devi = DsOnce::dev();
+    if (cap_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<NKT, READY>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -630,8 +632,10 @@ static int attn_f16x2_launch_n(const float* q, int ldq, const float* k, int ldk,
             per_cu = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        grid_cap = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+        grid_cap_dev[devi] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+        cap_once.done();
     }
+    const int grid_cap = grid_cap_dev[devi];
     const int grid = PERSIST && items > grid_cap ? grid_cap : (int)items;
     hipLaunchKernelGGL((ds_attn_f16x2_kernel<NKT, READY>), dim3(grid), dim3(AH_WAVES * 64), lds, stream, q, ldq, k, ldk, v, ldv,
                        o, ldo, Lq, Lk, heads, scale, o_plane, q_plane, groups, (int)items);

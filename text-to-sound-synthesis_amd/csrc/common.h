@@ -91,6 +91,22 @@ void ds_set_error(const char* fmt, ...);
         }                                                                        \
     } while (0)
 
+// Per-DEVICE "done once" flag for launch-side caches (hipFuncSetAttribute(MaxDynamicSharedMemorySize), CU counts,
+// occupancy): a function-local `static DsOnce once;` is consulted with the CURRENT device, so a process that drives several
+// GPUs sets the attribute on each of them (a plain static bool left the 140-161 KB LDS kernels un-launchable on the second
+// device); the bit mask is atomic, a repeated set from two threads is harmless.
+#include <atomic>
+struct DsOnce {
+    std::atomic<unsigned long long> mask{0};
+    static int dev() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 63;
+    }
+    bool need() const { return !((mask.load(std::memory_order_acquire) >> dev()) & 1ull); }
+    void done() { mask.fetch_or(1ull << dev(), std::memory_order_release); }
+};
+
 // ---- gather-GEMM parameter block ----------------------------------------------------------
 // C[m][n] = store( act( sum_k A(m,k) * W[n][k] + bias[n] ) + R[m][n] )
 // A(m,k) is produced by one of the loaders below; W is always K-contiguous ([N][K], nn.Linear
@@ -144,6 +160,5 @@ int ds_sample_tail_rows(const float* logits, int logits_rows, const int64_t* xt,
                         const int64_t* gids = nullptr, unsigned long long seed = 0ull, int call = 0);  // sampler.hip
 
 int ds_launch_gemm(const GemmParams& p, hipStream_t stream, int loader);
-int ds_launch_gemm_bf16x3(const GemmParams& p, hipStream_t stream);  // gemm_bf16x3.hip
 int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream);   // gemm_f16x2.hip
 int ds_launch_conv2d_f16x2(const GemmParams& p, hipStream_t stream, int loader); // conv_f16x2.hip

@@ -213,15 +213,15 @@ static int c1_launch(Conv1Params& p, hipStream_t s) {
     const int R = CT ? C1_TT + 2 : C1_TT + 2 * p.dil;
     size_t lds = (size_t)2 * 2 * R * C1_PXP * 2;
     if (lds < 64 * C1_BN * 4) lds = 64 * C1_BN * 4;          // the staged output half tile
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_conv1d_f16x2_kernel<TAPS, CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            2 * 2 * (C1_TT + 2 * C1_MAXDIL) * C1_PXP * 2);
         if (e != hipSuccess) {
             ds_set_error("conv1d_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const long long blocks = (long long)p.B * p.tiles_t * (p.Cout / C1_BN) * (CT ? p.ct_r : 1);
     DS_CHECK_ARG(blocks < (1ll << 31), "too many tiles");

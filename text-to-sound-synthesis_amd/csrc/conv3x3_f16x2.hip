@@ -308,15 +308,15 @@ static int conv3_launch(const Conv3Params& p, hipStream_t s) {
     // two halo slabs (52 224 bytes) + the sample's [scale | shift] of the prologue
     const size_t lds = (size_t)C3_HALO_BYTES + (PRO ? (size_t)2 * p.Cin * sizeof(float) : 0);
     static_assert((2 * 2 * C3_HPL) * 2 >= 64 * C3_BN * 4, "the staged output half tile fits");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_conv3x3_f16x2_kernel<PRO, UP, STATS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C3_HALO_BYTES + 2 * C3_MAXCIN * 4);
         if (e != hipSuccess) {
             ds_set_error("conv3x3_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const long long blocks = (long long)p.B * p.tiles_x * p.tiles_y * (p.Cout / C3_BN);
     hipLaunchKernelGGL((ds_conv3x3_f16x2_kernel<PRO, UP, STATS>), dim3((unsigned)blocks), dim3(256), lds, s, p);
@@ -342,6 +342,8 @@ extern "C" int ds_conv3x3_f16x2(const float* x, const void* w2, long long w_halv
                      ((uintptr_t)bias & 15) == 0 && ((uintptr_t)pro_scale & 15) == 0 && ((uintptr_t)pro_shift & 15) == 0,
                  "operands must be 16-byte aligned");
     DS_CHECK_ARG((long long)B * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31), "32-bit element offsets");
+    // the halo loads address a sample's source image with a 32-bit BYTE offset ((src + slab * 32) * 4u)
+    DS_CHECK_ARG((long long)(up ? H / 2 : H) * (up ? W / 2 : W) * Cin < (1ll << 30), "32-bit byte offsets inside a sample");
     Conv3Params p;
     p.x = x; p.w = (const _Float16*)w2; p.bias = bias; p.R = residual; p.y = y;
     p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.gn_part = gn_part; p.out_scale = out_scale;

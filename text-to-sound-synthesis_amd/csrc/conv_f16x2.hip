@@ -265,15 +265,15 @@ static int conv_launch(const GemmParams& p, hipStream_t s) {
     const size_t stage = (size_t)2 * 2 * (BM + BN) * CLD * sizeof(unsigned short);
     const size_t tile = (size_t)BM * BN * sizeof(float);
     const size_t lds = stage > tile ? stage : tile;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_conv2d_f16x2_kernel<BM, BN, LOADER, PRO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("conv_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL((ds_conv2d_f16x2_kernel<BM, BN, LOADER, PRO>), dim3(tiles, p.groups > 0 ? p.groups : 1), dim3(256),

@@ -2,7 +2,7 @@
 //
 //   C[m][n] = store( act( out_scale * sum_k A[m][k] * W'[n][k] + bias[n] ) + R[m][n] ),   W' = W * 2^s
 //
-// Same idea as gemm_bf16x3.hip with a cheaper decomposition: fp16 carries an 11-bit significand, so
+// fp16 carries an 11-bit significand, so
 //   a = a0 + a1,  a0 = fp16(a),  a1 = fp16(a - a0)           (a - a0 is exact in fp32)
 // represents a to 22 bits, and  a*b = a0b0 + a0b1 + a1b0 + O(2^-22 |ab|): three v_mfma_f32_32x32x16_f16
 // passes instead of six.  The per-product error (~3e-7 relative, random sign) is far below what the
@@ -492,15 +492,15 @@ static BalancePlan ds_balance_plan(int M, int N, int BM, int BN, int slots, int 
 template <int BM, int BN, int AMODE>
 static int launch_h2(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_kernel<BM, BN, AMODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE>), dim3(tiles, AMODE == 0 && p.groups > 1 ? p.groups : 1),
@@ -552,15 +552,15 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     if (p.R) ps.R = p.R + (size_t)m_off * p.ldr;
     const int nbig = pl.nbig, nsmall = pl.nsmall;
     const size_t lds = (size_t)2 * 2 * (128 + 128) * HLD * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_hybrid_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
     DS_CHECK_LAUNCH();

@@ -638,9 +638,6 @@ static bool ps_serves(const GemmParams& p, bool half) {
 // bytes per MFMA, hence the 0.92.  The floor: below ~0.65 the 4-wave programs (0.29-0.30 of the pipe against 0.46) catch up.
 int ds_gemm_f16x2_ps_choice(long B, long N, bool half_ok) {
     const long tf = B * (N / PS_BN), th = 2 * tf;
-    // measurement hook: DIFFSOUND_PS_MIN_TILES=n takes the full-tile program for every grid of >= n tiles
-    static const int env_min = getenv("DIFFSOUND_PS_MIN_TILES") ? atoi(getenv("DIFFSOUND_PS_MIN_TILES")) : 0;
-    if (env_min > 0) return tf >= env_min ? 1 : 0;
     const double ef = (double)tf / (double)(((tf + 255) / 256) * 256);
     const double eh = half_ok ? 0.92 * (double)th / (double)(((th + 255) / 256) * 256) : 0.0;
     if (ef < 0.65 && eh < 0.65) return 0;
@@ -660,15 +657,15 @@ int ds_gemm_f16x2_ps_pick(const GemmParams& p) {
 
 template <int EPI, bool NB16>
 static int launch_ps(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_ps_kernel<EPI, NB16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2_ps: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const int tiles = (p.M / p.rows_per_sample) * (p.N / PS_BN);
     hipLaunchKernelGGL((ds_gemm_f16x2_ps_kernel<EPI, NB16>), dim3(tiles), dim3(512), PS_LDS_BYTES, s, p);
@@ -686,15 +683,15 @@ int ds_launch_gemm_f16x2_ps(const GemmParams& p, hipStream_t s) {
 
 template <int EPI>
 static int launch_ph(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_ph_kernel<EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2_ph: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const int tiles = 2 * (p.M / p.rows_per_sample) * (p.N / PS_BN);
     hipLaunchKernelGGL((ds_gemm_f16x2_ph_kernel<EPI>), dim3(tiles), dim3(512), PH_LDS_BYTES, s, p);

@@ -278,15 +278,15 @@ __global__ __launch_bounds__(256) void ds_gemm_kernel(const GemmParams p) {
 template <int BM, int BN, int LOADER, int PRO>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_kernel<BM, BN, LOADER, PRO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles, p.groups > 0 ? p.groups : 1);

@@ -402,17 +402,18 @@ extern "C" int ds_melgan_resblock_fused_ok(int T, int C, int dil) {
 
 int ds_launch_melgan_rb(const float* x, const void* w3, long long w3_plane, float w3_scale, const float* b3, const void* wt,
                         long long wt_plane, float wt_scale, const float* bt, float* y, int B, int T, int C, int dil, hipStream_t s) {
-    static int wgs_per_cu = 0, n_cu = 0;
+    static int wgs_per_cu_dev[64], n_cu_dev[64];      // per device (DsOnce rb32_once below)
+    static DsOnce rb32_once;
     if (C == 64) {                                       // one 8-wave workgroup per CU (161 KB of LDS)
-        static int attr_set = 0;
+        static DsOnce attr_set;
         const size_t lds64 = (size_t)MG64_XL + 2 * (size_t)(MG64_TT + 2 * dil) * MG64_PITCH;
-        if (!attr_set) {
+        if (attr_set.need()) {
             if (hipFuncSetAttribute((const void*)ds_melgan_rb64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     MG64_XL + 2 * (MG64_TT + 2 * MG64_MAXDIL) * MG64_PITCH) != hipSuccess) {
                 ds_set_error("ds_melgan_resblock: cannot reserve %d bytes of LDS", MG64_XL + 2 * (MG64_TT + 2 * MG64_MAXDIL) * MG64_PITCH);
                 return -1;
             }
-            attr_set = 1;
+            attr_set.done();
         }
         int dev = 0, cus = 256;
         hipGetDevice(&dev);
@@ -428,18 +429,21 @@ int ds_launch_melgan_rb(const float* x, const void* w3, long long w3_plane, floa
     }
     const int R = MG_TT + 2 * dil;
     const size_t lds = (size_t)2 * R * MG_PITCH + 4 * 2 * 32 * MG_PITCH;
-    if (!n_cu) {
+    const int devi = DsOnce::dev();
+    if (rb32_once.need()) {
         int dev = 0;
         hipGetDevice(&dev);
         hipDeviceProp_t prop;
         hipGetDeviceProperties(&prop, dev);
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        n_cu_dev[devi] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ds_melgan_rb32_kernel, 256,
                                                          (size_t)2 * (MG_TT + 2 * MG_MAXDIL) * MG_PITCH + 8 * 32 * MG_PITCH) != hipSuccess || occ < 1)
             occ = 2;
-        wgs_per_cu = occ;
+        wgs_per_cu_dev[devi] = occ;
+        rb32_once.done();
     }
+    const int n_cu = n_cu_dev[devi], wgs_per_cu = wgs_per_cu_dev[devi];
     const int tiles_per_clip = T / MG_TT;
     const long long n_tiles = (long long)B * tiles_per_clip;
     DS_CHECK_ARG(n_tiles < (1ll << 31), "too many tiles");
@@ -569,14 +573,14 @@ template <int CIN, int COUT>
 static int mg_launch_convt2(const float* x, const void* w, long long w_plane, float osc, const float* bias, float* y, int B, int Tin,
                             hipStream_t s) {
     constexpr int lds = 2 * 130 * (CIN * 2 + 16) + 256 * (COUT * 4 + 16) + COUT * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DsOnce attr_set;
+    if (attr_set.need()) {
         if (hipFuncSetAttribute((const void*)ds_melgan_convt2_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess) {
             ds_set_error("ds_melgan_convt2: cannot reserve %d bytes of LDS", lds);
             return -1;
         }
-        attr_set = true;
+        attr_set.done();
     }
     int dev = 0, cus = 256;
     hipGetDevice(&dev);

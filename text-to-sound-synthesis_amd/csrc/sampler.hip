@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256) void ds_sample_tail_kernel(const SampleParams 
         {
             // torch's CPU cumsum of a float tensor accumulates in DOUBLE and rounds every partial sum to float: the same here
             // (tests/test_sampler_sort_emulation.py: with this accumulator the restated algorithm equals the reference's
-            // truncation bit for bit; a plain fp32 chain differs in the last place of some partial sums)
+            // truncation AS EXECUTED ON THE CPU bit for bit -- the goldens are CPU runs; a plain fp32 chain differs in the
+            // last place of some partial sums, and so does a CUDA execution of dalle_spec.py:163-165, whose cumsum is a
+            // parallel fp32 scan: against a GPU run of the reference a cut at a rounding-level near-tie can differ)
             // float(c) < r, tested on the double: float(c) <= pf = the float below r  <=>  c below the midpoint of pf and r (at the
             // midpoint itself round-to-nearest-even goes to pf iff pf's last mantissa bit is 0)
             double cum = 0.0;

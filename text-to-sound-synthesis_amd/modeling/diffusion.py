@@ -9,7 +9,6 @@ drawn with torch.rand on the reference's [B, K+1, L] shape so that the same seed
 Philox stream as the reference's torch.rand_like(logits) (:360).
 """
 import numpy as np
-import os
 
 import torch
 from torch import nn
@@ -30,14 +29,6 @@ def alpha_schedule(time_step, N=100, att_1=0.99999, att_T=0.000009, ctt_1=0.0000
     ctt = np.concatenate((ctt[1:], [0]))
     btt = (1 - att - ctt) / N
     return at, bt, ct, att, btt, ctt
-
-
-class _nullcontext:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
 
 
 def _log_1_min_a(a):
@@ -67,11 +58,6 @@ class DiffusionTransformer(nn.Module):
         self.truncation_r = None  # set by DALLE.generate_content from sample_type "top{r}r"
         self.truncation_k = None  # ... or "top{k}p" (top-k, dalle_spec.py:147-157); exclusive with truncation_r
         self.repeat_rate = None   # "q{rate}": repeat a step with this probability (dalle_spec.py:135-143)
-        # sampling streams: 2 = the batch is cut in two halves whose steps are enqueued on two HIP streams, so the
-        # ramp / tail of one half's kernels can overlap the other half's (same tokens: every op is per sample).
-        # Measured at B=64: 15.4 clips/s vs 15.9-16.7 on one stream -- no gain (the half-size GEMMs quantise worse
-        # than the overlap recovers), so the default stays 1.
-        self.sample_streams = int(os.environ.get("DIFFSOUND_STREAMS", "1"))
         # Noise source of the samplers.  "torch" (default): torch.rand((B, K+1, L)) per call on the model's device, the
         # reference's own draw (log_sample_categorical, :359-368) -- same seed, same device => same stream, but what a
         # caption draws depends on the batch around it.  "philox" (or passing caption_ids to sample()): the uniforms are
@@ -81,7 +67,7 @@ class DiffusionTransformer(nn.Module):
         # Its tokens are identical across batches as long as the same GEMM program serves the local batch size (the
         # per-sample, half-tile and 4-wave programs agree to ~1e-7 relative on rows 256..264, not bit for bit -- csrc/api.hip
         # rows_per_sample -- so a near-tie can fall differently between, say, one batch of 64 and 8 shards of 8).
-        self.rng_mode = os.environ.get("DIFFSOUND_RNG", "torch")
+        self.rng_mode = "torch"
         self.sample_seed = 1234
         assert alpha_init_type == "alpha1", "Diffsound uses alpha_init_type='alpha1'"
         at, bt, ct, att, btt, ctt = alpha_schedule(self.num_timesteps, N=self.num_classes)
@@ -212,11 +198,16 @@ class DiffusionTransformer(nn.Module):
         ids = torch.as_tensor(caption_ids, dtype=torch.long)
         if ids.shape != (B,):
             raise ValueError("caption_ids must have one entry per caption: got %s for a batch of %d" % (tuple(ids.shape), B))
-        # the range is checked where it costs nothing -- on host lists / CPU tensors.  Ids that already live on the device
-        # (bench.py's timed loop, the partial re-sampling path handing its validated ids on) are taken as they are: a
-        # min / max there would be two host synchronisations per sample() call inside a chain that otherwise has none.
-        if not on_device and B > 0 and (int(ids.min()) < 0 or int(ids.max()) >= 2 ** 32):
-            raise ValueError("caption ids must be in [0, 2^32)")
+        # The range is checked on host lists / CPU tensors every time (it costs nothing there), and on a DEVICE tensor the
+        # first time that very tensor is seen (one host synchronisation; keyed by storage address and version counter, so an
+        # id tensor re-used across sample() calls -- bench.py's timed loop -- is checked once and a modified one again).  An
+        # id outside [0, 2^32) would be truncated into the Philox counter and could share a noise stream with another caption.
+        key = (ids.data_ptr(), ids._version, B) if on_device else None
+        if B > 0 and (not on_device or key != getattr(self, "_gids_checked", None)):
+            if int(ids.min()) < 0 or int(ids.max()) >= 2 ** 32:
+                raise ValueError("caption ids must be in [0, 2^32)")
+            if on_device:
+                self._gids_checked = key
         return ids.to(device).contiguous()
 
     def _cond(self, condition_token, condition_embed):
@@ -356,43 +347,23 @@ class DiffusionTransformer(nn.Module):
             if return_logits:
                 out["logits"] = torch.nn.functional.one_hot(x, K1).permute(0, 2, 1).float()
             return out
-        # sub-batches: one (the whole batch on the current stream) or two halves on two side streams
-        two = self.sample_streams == 2 and B >= 2 and device.type == "cuda"
-        bounds = [(0, B // 2), (B // 2, B)] if two else [(0, B)]
-        main = torch.cuda.current_stream(device) if two else None
-        subs = [torch.cuda.Stream(device) for _ in bounds] if two else [None]
         sched = self._schedule_table()
-        kvs = [self.transformer.condition_kv(cond_emb[a:b].contiguous(), sched) for a, b in bounds]
-        xs = [x[a:b].contiguous() for a, b in bounds]
-        nxts = [torch.empty_like(v) for v in xs]
+        kv = self.transformer.condition_kv(cond_emb.contiguous(), sched)
+        nxt = torch.empty_like(x)
         calls = 0
         for i, (step, step_post) in enumerate(steps):
             repeats = 2 if (self.repeat_rate is not None and random.random() < self.repeat_rate) else 1
             for rep in range(repeats):
+                # the reference's draw: torch.rand_like(logits) on a [B, K+1, L] fp32 tensor of the model's device
+                # (diffusion_transformer.py:359-368) -- torch.rand of that shape consumes the generator identically
                 u = noise_fn(step if self.repeat_rate is None else calls, (B, K1, L)).to(device) \
                     if noise_fn is not None else torch.rand((B, K1, L), device=device)
                 u = u.contiguous()
                 calls += 1
-                ts = [torch.full((b - a,), step, device=device, dtype=torch.long) for a, b in bounds]
-                tps = [None if step_post == step else torch.full((b - a,), step_post, device=device, dtype=torch.long)
-                       for a, b in bounds]
-                ready = main.record_event() if two else None   # everything the side streams read is enqueued by now
-                for h, (a, b) in enumerate(bounds):
-                    t, tp = ts[h], tps[h]
-                    if two:
-                        subs[h].wait_event(ready)          # the noise (and, first time, x / kv) come from the main stream
-                        u.record_stream(subs[h])
-                        t.record_stream(subs[h])
-                        if tp is not None:
-                            tp.record_stream(subs[h])
-                    with torch.cuda.stream(subs[h]) if two else _nullcontext():
-                        self.p_sample_tokens(xs[h], kvs[h], t, u[a:b], initial=(start_tokens is None and i == 0 and rep == 0),
-                                             out=nxts[h], t_post=tp, slot=h)
-                    xs[h], nxts[h] = nxts[h], xs[h]
-        if two:
-            for sub in subs:
-                main.wait_stream(sub)
-        x = torch.cat(xs, 0) if two else xs[0]
+                t = torch.full((B,), step, device=device, dtype=torch.long)
+                tp = None if step_post == step else torch.full((B,), step_post, device=device, dtype=torch.long)
+                self.p_sample_tokens(x, kv, t, u, initial=(start_tokens is None and i == 0 and rep == 0), out=nxt, t_post=tp)
+                x, nxt = nxt, x
         out = {"content_token": x}
         if return_logits:
             out["logits"] = torch.nn.functional.one_hot(x, K1).permute(0, 2, 1).float()

@@ -333,7 +333,14 @@ class TrainStep:
         self._since_check = 0
         m = float(self._amax_live.item())
         self._amax_live.zero_()
-        if m == 0.0:                 # genuinely zero gradients (nothing was scaled): not a reason to re-calibrate / re-capture
+        if m == 0.0:
+            # ds_amax never lets a NaN win and skips non-positive values, so 0 means EITHER genuinely zero gradients (nothing
+            # was scaled: no reason to re-calibrate / re-capture) OR an all-NaN scaled dY (a diverged loss).  The loss of the
+            # same step tells them apart at this very host sync.
+            last = getattr(self, "_last_loss", None)
+            if last is not None and not math.isfinite(float(last)):
+                self.loss_scale_exp, self._calib_norm = None, None
+                return True
             return False
         if math.isfinite(m) and 2.0 ** 6 <= m < 2.0 ** 15:
             return False
@@ -639,6 +646,7 @@ class TrainStep:
             torch._foreach_mul_(small, inv)
         if not calibrating:
             self._steps += 1
+            self._last_loss = loss          # (device scalar; a captured iteration keeps updating this very tensor)
         return loss, g
 
     # ---- optimizer -------------------------------------------------------------------------------------------------------

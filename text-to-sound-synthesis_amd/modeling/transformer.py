@@ -129,13 +129,13 @@ class Text2ImageTransformer(nn.Module):
         self.condition_dim, self.diffusion_step, self.mlp_hidden_times = condition_dim, diffusion_step, mlp_hidden_times
         self.num_codes = out_cls
         self.apply(self._init_weights)
-        # GEMM arithmetic of the denoiser (all three are fp32-class; measured error vs float64 in
-        # tests/test_hip_split_gemm.py: f16x2 1.3e-6 <= bf16x3 1.5e-6 <= fp32 2.1e-6 at K = 1024):
-        #   "f16x2"  2-way fp16 split of both operands, 3 fp16-MFMA passes (csrc/gemm_f16x2.hip)  [default]
-        #   "bf16x3" 3-way bf16 split, 6 bf16-MFMA passes (csrc/gemm_bf16x3.hip)
-        #   "fp32"   v_mfma_f32_32x32x2_f32, the exact fp32 FMA chain (csrc/gemm_f32.hip)
+        # GEMM arithmetic of the denoiser (both are fp32-class; measured error vs float64 in
+        # tests/test_hip_split_gemm.py: f16x2 1.3e-6 <= fp32 2.1e-6 at K = 1024):
+        #   "f16x2"  2-way fp16 split of both operands, 3 fp16-MFMA passes (csrc/gemm_f16x2*.hip)  [default]
+        #   "fp32"   v_mfma_f32_32x32x2_f32, the exact fp32 FMA chain (csrc/gemm_f32.hip): the strict mode
+        # (DIFFSOUND_GEMM=fp32 selects the strict mode for a whole process: the one numerics switch read from the environment)
         self.precision = os.environ.get("DIFFSOUND_GEMM", "f16x2")
-        self.row_padding = os.environ.get("DIFFSOUND_PAD_ROWS", "1") != "0"
+        self.row_padding = True       # padded-row mode of the sampling step (csrc/api.hip rows_per_sample); tests switch it off
         self._packed = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: self.invalidate())
 
@@ -224,13 +224,11 @@ class Text2ImageTransformer(nn.Module):
         d.sched = own(sched_t).data_ptr()
         h = C.c_void_p()
         _lib.check(_lib.lib().ds_denoiser_create(C.byref(d), ptrs, C.byref(h)))
-        if self.precision in ("bf16x3", "f16x2"):
+        if self.precision == "f16x2":
             n = self.n_layer * _lib.LP_COUNT
             ptrs3, scales = (C.c_void_p * n)(), (C.c_float * n)()
 
             def split(w):
-                if self.precision == "bf16x3":
-                    return _lib.split_bf16x3(w), 1.0
                 return _lib.split_f16x2(w, packed=True)   # the denoiser's f16x2 GEMMs take packed operands
             for l in range(self.n_layer):
                 for s in (_lib.LP_W_QKV, _lib.LP_W_PROJ1, _lib.LP_W_Q2, _lib.LP_W_PROJ2, _lib.LP_W_FC1, _lib.LP_W_FC2):
@@ -240,12 +238,11 @@ class Text2ImageTransformer(nn.Module):
                     scales[l * _lib.LP_COUNT + s] = sc
             wl3, lsc = split(self.to_logits[1].weight)
             keep.append(wl3)
-            mode = 1 if self.precision == "bf16x3" else 2
-            _lib.check(_lib.lib().ds_denoiser_set_split_weights(h, mode, ptrs3, scales, wl3.data_ptr(), lsc))
+            _lib.check(_lib.lib().ds_denoiser_set_split_weights(h, 2, ptrs3, scales, wl3.data_ptr(), lsc))
         elif self.precision != "fp32":
-            raise ValueError("precision must be 'fp32', 'bf16x3' or 'f16x2', got %r" % (self.precision,))
+            raise ValueError("precision must be 'fp32' or 'f16x2', got %r" % (self.precision,))
         # padded-row mode of the sampling step (272 rows per sample at batch sizes served by the per-sample GEMM program,
-        # csrc/api.hip rows_per_sample): on by default; `row_padding = False` / DIFFSOUND_PAD_ROWS=0 keeps 265 rows
+        # csrc/api.hip rows_per_sample): on by default; `row_padding = False` keeps 265 rows
         _lib.check(_lib.lib().ds_denoiser_set_row_padding(h, int(self.row_padding)))
         self._packed = {"handle": h, "keep": keep, "sched_src": sched, "ws": {}, "device": dev,
                         "precision": self.precision, "row_padding": self.row_padding}

@@ -12,12 +12,10 @@ the fp32-class 3-pass split (`conv_precision = "f16x2"`, default) or as gather-G
                                                1x1 conv and the 1x1 shortcut
   ResnetBlock, 32 / 64 channels             -> ONE kernel per block (melgan_fused.hip): x read once, y written once
   final Conv1d(32->1, k7) + tanh            -> one pass (melgan_fused.hip)
-(each with a switch back to the polyphase / three-GEMM forms on the gather kernel, see __init__)
+(`conv_precision = "fp32"`: the same layers as gather-GEMMs on the exact-fp32 MFMA, the strict mode)
 The whole batch goes through at once (the reference vocodes sample by sample,
 evaluation/generate_samples_batch.py:183-187).
 """
-import os
-
 import numpy as np
 import torch
 from torch import nn
@@ -77,19 +75,10 @@ class Generator(nn.Module):
         model += [nn.Identity(), nn.Identity(), WNConv1d(ngf, 1, 7), nn.Identity()]
         self.model = nn.Sequential(*model)
         self.n_residual_layers = n_residual_layers
-        self.conv_precision = os.environ.get("DIFFSOUND_VOCODER_CONV", "f16x2")   # "f16x2" | "fp32"
-        # ResnetBlock tail (1x1 conv + 1x1 shortcut) as ONE contraction over [LReLU(h) | x] (ds_melgan_resblock_tail): the
-        # shortcut tensor never goes through HBM.  False / DIFFSOUND_VOCODER_FUSE_TAIL=0: three launches per block.
-        self.fuse_tail = os.environ.get("DIFFSOUND_VOCODER_FUSE_TAIL", "1") != "0"
-        # Single-pass kernels where they are built (melgan_fused.hip): the whole ResnetBlock of the 32-channel stage (its
-        # tensor crosses HBM twice instead of five times) and LReLU + k7 conv + tanh of the last layer.  "0": the GEMM forms.
-        self.fuse_block = os.environ.get("DIFFSOUND_VOCODER_FUSE_BLOCK", "1") != "0"
-        self.fuse_final = os.environ.get("DIFFSOUND_VOCODER_FUSE_FINAL", "1") != "0"
-        # the dilated k3 conv of the 128- / 256-channel blocks on the halo-tiled kernel (conv1d_f16x2.hip: the input tile is
-        # activated and split once for the three taps); "0": the tap-by-tap gather kernel
-        self.conv1d_halo = os.environ.get("DIFFSOUND_VOCODER_CONV1D_HALO", "1") != "0"
-        # the two stride-2 ConvTranspose1d layers as one pass each (ds_melgan_convt2); "0": polyphase GEMMs on the gather kernel
-        self.fuse_convt = os.environ.get("DIFFSOUND_VOCODER_FUSE_CONVT", "1") != "0"
+        # "f16x2" (default): every layer on its best kernel of the 3-pass fp16 split (module docstring); "fp32": the strict
+        # mode, every layer as a gather-GEMM on the exact-fp32 MFMA (three launches per ResnetBlock, polyphase GEMMs for the
+        # transposed convs) -- also what the f16x2 mode falls back to for a shape none of its kernels is built for
+        self.conv_precision = "f16x2"
         self._pk = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_pk", None))
 
@@ -181,10 +170,10 @@ class Generator(nn.Module):
             r, cin, cout = st["r"], st["cin"], st["cout"]
             w, b = st["ct"]
             y = torch.empty(B, T * r, cout, device=dev)
-            if self.conv1d_halo and self.conv_precision == "f16x2" and st["ct_q"] is not None:
+            if self.conv_precision == "f16x2" and st["ct_q"] is not None:
                 _lib.check(_lib.lib().ds_convt1d_f16x2(_lib.ptr(h), _lib.ptr(st["ct_q"]), st["ct_q"].numel(), st["ct_s"][1], _lib.ptr(b),
                                                        _lib.ptr(y), B, T, cin, cout, r, r // 2 + r % 2, 1, _lib.stream()))
-            elif r == 2 and self.fuse_convt and self.conv_precision == "f16x2" and _lib.lib().ds_melgan_convt2_ok(cin, cout):
+            elif r == 2 and self.conv_precision == "f16x2" and _lib.lib().ds_melgan_convt2_ok(cin, cout):
                 _lib.check(_lib.lib().ds_melgan_convt2(_lib.ptr(h), _lib.ptr(st["ct_s"][0]), r * cout * 2 * cin, st["ct_s"][1], _lib.ptr(b),
                                                        _lib.ptr(y), B, T, cin, cout, _lib.stream()))
             else:
@@ -195,14 +184,14 @@ class Generator(nn.Module):
             for rb in st["res"]:
                 M = B * T
                 sc = torch.empty(B, T, cout, device=dev)
-                if self.fuse_tail and self.conv_precision == "f16x2":
+                if self.conv_precision == "f16x2":
                     # the whole block behind one entry: ONE kernel where it is built (h1 = None), else the dilated k3 conv
                     # into h1, then [LReLU(h1) | h] x [W2 | Ws]^T
-                    one_pass = self.fuse_block and _lib.lib().ds_melgan_resblock_fused_ok(T, cout, rb["dil"])
+                    one_pass = _lib.lib().ds_melgan_resblock_fused_ok(T, cout, rb["dil"])
                     h1 = None if one_pass else torch.empty(B, T, cout, device=dev)
                     w3, s3 = rb["c3_s"]
                     w2, osc = rb["tail_s"]
-                    if not one_pass and self.conv1d_halo and rb["c3_q"] is not None and rb["dil"] <= 27:
+                    if not one_pass and rb["c3_q"] is not None and rb["dil"] <= 27:
                         # 128 / 256 channels: the k3 conv on the halo-tiled kernel, then the one-GEMM tail
                         L = _lib.lib()
                         _lib.check(L.ds_conv1d_k3_f16x2(_lib.ptr(h), _lib.ptr(rb["c3_q"]), rb["c3_q"].numel(), s3, _lib.ptr(rb["c3"][1]),
@@ -223,7 +212,7 @@ class Generator(nn.Module):
                 h = sc
         wl, bl = pk["last"]
         out = torch.empty(B, 1, T, device=dev)
-        if self.fuse_final and wl.shape[1] == 32:
+        if self.conv_precision == "f16x2" and wl.shape[1] == 32:
             _lib.check(_lib.lib().ds_melgan_final(_lib.ptr(h), _lib.ptr(wl), bl, _lib.ptr(out), B, T, 32, _lib.stream()))
             return out
         taps = torch.empty(B * T, 8, device=dev)

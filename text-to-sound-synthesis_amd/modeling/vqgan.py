@@ -11,7 +11,6 @@ Device layout: activations are channels-last [B, H, W, C] fp32.  Every conv is t
 while staging its A tile together with swish; nearest-2x upsampling is index math inside the conv
 loader; the 512-channel spatial attention runs as two batched GEMMs around a row softmax.
 """
-import os
 
 import numpy as np
 import torch
@@ -19,6 +18,9 @@ from torch import nn
 
 from .. import _lib
 from ..config import instantiate_from_config
+
+
+HALO_MIN_ROWS = 5      # smallest image height the halo-tiled 3x3 kernel takes (the 5 x 53 token grid)
 
 
 def Normalize(c):
@@ -224,12 +226,12 @@ class VQModel(nn.Module):
         self.ddconfig = dict(ddconfig)
         # arithmetic of the 3x3 convolutions: "f16x2" (default; fp32-class 3-pass fp16 split on the 16-bit matrix
         # cores, csrc/conv_f16x2.hip) or "fp32" (exact fp32 MFMA, csrc/gemm_f32.hip)
-        self.conv_precision = os.environ.get("DIFFSOUND_CONV", "f16x2")
-        # 3x3 convs at >= conv_halo_min_rows image rows on the halo-tiled kernel (csrc/conv3x3_f16x2.hip: the input tile is
-        # activated and split once for all nine taps, the GroupNorm statistics of the output come out of its epilogue);
-        # False / DIFFSOUND_CONV_HALO=0: every conv on the tap-by-tap gather kernel (csrc/conv_f16x2.hip)
-        self.conv_halo = os.environ.get("DIFFSOUND_CONV_HALO", "1") != "0"
-        self.conv_halo_min_rows = int(os.environ.get("DIFFSOUND_CONV_HALO_MIN_ROWS", "5"))
+        self.conv_precision = "f16x2"
+        # In "f16x2" mode every stride-1 3x3 conv (optionally behind a nearest-2x upsample) whose weights are fragment-packed
+        # runs on the halo-tiled kernel (csrc/conv3x3_f16x2.hip: the input tile is activated and split once for all nine
+        # taps, the GroupNorm statistics of the output come out of its epilogue); the shapes it does not take -- the
+        # encoder's stride-2 convs, Cout = 1 (conv_out) -- and the whole "fp32" mode run on the tap-by-tap gather kernel
+        # (csrc/conv_f16x2.hip / gemm_f32.hip).
         self._pk = None
         # samples decoded / encoded at once: bounds the full-resolution workspace (34.7 MB per sample and tensor,
         # ~15 GB live at 64) and the 32-bit element indices inside the kernels ([B][80][848][128] < 2^31 up to B=247);
@@ -340,8 +342,7 @@ class VQModel(nn.Module):
         w, b, w2, sc, wq = wb
         Cout = w.shape[0]
         out = torch.empty(B, H, W, Cout, device=x.device)
-        if (self.conv_precision == "f16x2" and self.conv_halo and H >= self.conv_halo_min_rows and up in (0, 1)
-                and wq is not None):
+        if self.conv_precision == "f16x2" and H >= HALO_MIN_ROWS and up in (0, 1) and wq is not None:
             L = _lib.lib()
             part = torch.empty(B, L.ds_conv3x3_tiles(H, W), 2, Cout, device=x.device, dtype=torch.float64)
             _lib.check(L.ds_conv3x3_f16x2(_lib.ptr(x), _lib.ptr(wq), wq.numel(), sc, _lib.ptr(b), _lib.ptr(R), _lib.ptr(out),

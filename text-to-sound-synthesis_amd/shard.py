@@ -19,10 +19,19 @@ def shard_bounds(n_items, world_size, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def scatter_conditions(cond_all, n_items, feat_shape, device, group=None, dtype=torch.float32):
+def _single(group, always_collective):
+    """True when the call should not touch the process group: none is initialised, or it has one rank and the caller did
+    not ask for the collective anyway (`always_collective`: the world-size-1 RCCL test and bench.py's communicator check
+    run the very same scatter / gather / all-reduce calls an N-rank job issues)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not always_collective
+
+
+def scatter_conditions(cond_all, n_items, feat_shape, device, group=None, dtype=torch.float32, always_collective=False):
     """rank 0 holds cond_all [n_items, *feat_shape] (caption token ids i64[.,77] or embeddings
     f32[.,77,512]); every rank receives its slice."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, always_collective):
         return cond_all.to(device=device, dtype=dtype)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(n_items, world, rank)
@@ -48,9 +57,9 @@ def scatter_conditions(cond_all, n_items, feat_shape, device, group=None, dtype=
     return mine
 
 
-def gather_outputs(local, n_items, group=None):
+def gather_outputs(local, n_items, group=None, always_collective=False):
     """Gather per-rank outputs [n_local, ...] to rank 0 in caption order (None elsewhere)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, always_collective):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     local = local.contiguous()
@@ -118,13 +127,13 @@ def per_caption_noise(global_ids, step, shape_tail, device, base_seed=1234):
     return caption_uniforms(global_ids, step, k1 - 1, length, base_seed).to(device)
 
 
-def allreduce_gradients(grads, bucket_bytes=256 << 20, group=None, average=True):
+def allreduce_gradients(grads, bucket_bytes=256 << 20, group=None, average=True, always_collective=False):
     """Data-parallel gradient reduction for the training step (engine/solver_spec.py:109 wraps the model in DDP):
     the gradient tensors (dict name -> tensor, same keys and shapes on every rank) are packed into flat buckets in
     name order and all-reduced bucket by bucket -- with backend 'nccl' that is RCCL over xGMI; a few large messages
     instead of one per parameter (per-link-bound ring: message count matters) -- then averaged
     over the ranks like DDP does.  In place; returns grads."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, always_collective):
         return grads
     world = dist.get_world_size(group)
     names = sorted(grads)
@@ -166,13 +175,14 @@ class GradientReducer:
     Buckets of ~one block (50 MB) keep the messages large: the xGMI ring is per-link bound.
     Every rank must call ready() with the same names in the same order.  Without a process group it does nothing."""
 
-    def __init__(self, bucket_bytes=48 << 20, group=None, average=True):
+    def __init__(self, bucket_bytes=48 << 20, group=None, average=True, always_collective=False):
         self.bucket_bytes, self.group, self.average = bucket_bytes, group, average
+        self.always_collective = always_collective
         self._pending, self._pending_bytes, self._inflight, self._done = [], 0, [], set()
         self._comm = None
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return not _single(self.group, self.always_collective)
 
     def ready(self, named, streams=()):
         """named: {name: tensor} of gradients that will not change any more; streams: the device streams that wrote them

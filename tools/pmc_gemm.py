@@ -1,5 +1,5 @@
 """One GEMM shape, one tile config, a few launches -- target for rocprofv3 --pmc passes.
-usage: pmc_gemm.py M N K tile [fp32|bf16x3|f16x2]"""
+usage: pmc_gemm.py M N K tile [fp32|f16x2]"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from text_to_sound_synthesis_amd import _lib
@@ -10,8 +10,6 @@ b = torch.randn(N, device="cuda"); C = torch.empty(M, N, device="cuda")
 kw = {}
 if mode == "f16x2":
     W, sc = _lib.split_f16x2(W); kw = dict(split2=sc); _lib.lib().ds_gemm_f16x2_force_tile(tile)
-elif mode == "bf16x3":
-    W = _lib.split_bf16x3(W); kw = dict(split3=True); _lib.lib().ds_gemm_bf16x3_force_tile(tile)
 else:
     _lib.lib().ds_gemm_force_tile(tile)
 for _ in range(5):
