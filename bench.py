@@ -227,9 +227,11 @@ def cpu_baseline(n_layer, codes, T):
     hw = os.cpu_count() or 8
     phys = _physical_cores() or max(1, hw // 2)
     default_threads = torch.get_num_threads()
-    # thread count swept UP TO the physical core count (and the hardware-thread count beside it),
-    # every point measured -- no early exit -- on one B=8 denoiser step after one warm-up step
-    cands = sorted({n for n in (8, 16, 32, 64, phys, hw) if 1 <= n <= hw})
+    # thread count swept UP TO the physical core count, every point measured -- no early exit -- on
+    # one B=8 denoiser step after one warm-up step
+    # (the hardware-thread count itself is not swept: with SMT siblings oversubscribed one B=8 step took 159 s on the 128-core
+    #  box of round 5 against 1.3 s at the best count -- two such steps are the whole budget of this leg many times over)
+    cands = sorted({n for n in (8, 16, 32, 64, phys) if 1 <= n <= hw})
     sweep = {}
     one = step_fn(8)
     for n in cands:
@@ -271,6 +273,8 @@ def cpu_baseline(n_layer, codes, T):
     torch.set_num_threads(default_threads)
     bB = max(res, key=lambda k: res[k][0])
     value = res[bB][0]
+    if full is not None and full["clips_per_s"] > value:       # the CPU gets its best measured rate
+        value = full["clips_per_s"]
     return {"value": value, "unit": "clips/s", "cores": best_n, "kind": "reference" if use_ref else "port",
             "host_hw_threads": hw, "host_physical_cores": phys,
             "protocol": "BASELINE.md section 4: B in {1, 8}, 1 warm-up + 3 timed repeats, median; value = the better B",

@@ -80,9 +80,11 @@ void ds_gemm_force_tile(int cfg); /* test hook: 0..2 pins the block tile, -1 = a
 /* The same dense contraction (DS_LOAD_DENSE, DS_PRO_NONE) on the fp16 matrix cores with fp32-class accuracy:
  * W*2^s and A are split into two fp16 planes each (22 significant bits), three fp16 MFMA passes
  * a0b0 + a0b1 + a1b0 per k-step, epilogue multiplies by out_scale = 2^-s.  |A| must stay below 65504
- * (gemm_f16x2.hip).  groups > 1 (row-major operands, plain row store, no bias / residual): group g computes
- * A + g a_gstride (floats) times W + g w_gstride (halves, both planes) into C + g c_gstride -- with a_gstride =
- * w_gstride = K this is a split-K launch whose partial results the caller sums (ds_colsum). */
+ * (gemm_f16x2.hip).  groups > 1 (plain row store, no bias / residual): group g computes
+ * A + g a_gstride (floats; HALVES for packed operands) times W + g w_gstride (halves, both planes) into C + g c_gstride
+ * -- with a_gstride = w_gstride = K (row-major operands) resp. 16 K (packed operands: K / 32 k-tiles of 512 halves, and
+ * lda = ldw = the FULL contraction length the planes were packed with) this is a split-K launch whose partial results the
+ * caller sums (ds_colsum). */
 int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 /* the conv-family loaders in the same fp32-class 3-pass formulation: A fp32 (split while it is staged), W = the two fp16
    planes [groups][N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart, groups w_gstride apart), out_scale = 2^-s.
@@ -260,6 +262,28 @@ int ds_convert_operand(const float* src, int rows, int cols, long long ld_src, i
                        long long ld_dst, long long plane, int dst_f16, ds_stream_t stream);
 /* *out = max(*out, max_i |x[i]|)  (the caller zeroes *out; calibration of the training step's loss scale) */
 int ds_amax(const float* x, long long n, float* out, ds_stream_t stream);
+/* ONE pass over fp32 X[rows][ld_src] (cols valid, cols % 32 == 0) that writes everything the three GEMMs of an nn.Linear
+ * in the training step (y = x W^T, dX = dY W, dW = dY^T X: engine/solver_spec.py:308-331 over
+ * diffusion_transformer.py:408-476) need of it -- any subset of:
+ *   dst_row      packed split planes (hi | lo, plane_row halves apart) of scale * X as a [rows][cols] GEMM operand;
+ *   dst_t        packed split planes (plane_t apart) of scale * X^T as a [cols][rows_pad] operand: the contraction index
+ *                (X's rows) zero-padded to rows_pad (% 32 == 0; split-K launches need a multiple of 32 * groups);
+ *   colsum_part  [ds_pack_operand_tile_rows(rows, rows_pad)][cols] per-64-row column sums of scale * X, the first
+ *                ceil(rows / 64) rows of which ds_colsum adds up in a fixed order (bias gradients; no atomics);
+ *   amax         *amax = max(*amax, max |scale * X|) (atomicMax on the bit pattern; the caller zeroes it);
+ * with an elementwise prologue: DS_PACK_GELU2 (X := gelu2(X): GELU2 of transformer_utils.py:111-115 between the MLP's
+ * linears) or DS_PACK_GELU2_BWD (X := X * gelu2'(aux), aux fp32 [rows][ld_aux]: its backward).  scale: a power of two. */
+enum { DS_PACK_PLAIN = 0, DS_PACK_GELU2 = 1, DS_PACK_GELU2_BWD = 2 };
+int ds_pack_operand(const float* src, int rows, int cols, long long ld_src, float scale, int pro, const float* aux,
+                    long long ld_aux, void* dst_row, long long plane_row, void* dst_t, long long plane_t, int rows_pad,
+                    float* colsum_part, float* amax, ds_stream_t stream);
+int ds_pack_operand_tile_rows(int rows, int rows_pad);
+/* torch.optim.AdamW (configs/caps.yaml:111-115) on many parameter tensors at once: `tensors` = HOST array of n_tensors
+ * records { p, g, m, v (device pointers), n (int64 element count) } = 5 x 8 bytes each; 64 tensors per launch, their
+ * descriptors passed by value in the kernel arguments (graph-capturable, no table in device memory); hyper and the
+ * arithmetic as for ds_adamw_dev. */
+int ds_adamw_multi(const void* tensors, int n_tensors, const float* hyper, float beta1, float beta2, float eps,
+                   float weight_decay, ds_stream_t stream);
 
 /* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
 enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */

@@ -243,6 +243,134 @@ def test_gemm_f16x2_split_k_groups(L):
         assert (part[g].view(N, K).cpu().double() - 0.5 * pr).abs().max().item() < 2e-6 * scale
 
 
+def _split_planes(a):
+    """ds_split_hi / ds_split_lo (csrc/common.h) in torch: [2][R][K] fp16"""
+    hi = a.clamp(-65504.0, 65504.0).half()
+    lo = (a - hi.float()).clamp(-65504.0, 65504.0).half()
+    return torch.stack((hi, lo)).contiguous()
+
+
+@pytest.mark.parametrize("rows,cols,S", [(531, 1024, 4), (1540, 512, 8), (70, 96, 1), (5300, 256, 8)])
+def test_pack_operand_all_outputs(L, rows, cols, S):
+    """ds_pack_operand (csrc/pack.hip): one pass -> packed row form, packed transposed form with the contraction padded
+    for a split-K launch, per-tile column sums and max |x| -- each bit for bit what torch computes for the same definition
+    (the host packer _lib.pack_planes is the layout the GEMM tests already pin)."""
+    ld = cols + 8
+    src = torch.full((rows, ld), 123.0)
+    src[:, :cols] = rnd((rows, cols), "pk.src%d" % rows, 40.0)
+    src[0, 0], src[1, 1], src[2, 2] = 7.0e4, -9.9e9, 3.0e-7            # saturation and the subnormal low plane
+    scale = 2.0 ** 3
+    want = src[:, :cols] * scale
+    rows_pad = (rows + 32 * S - 1) // (32 * S) * (32 * S)
+    dev = src.cuda()
+    R16, C16 = (rows + 15) // 16 * 16, (cols + 15) // 16 * 16
+    drow = torch.full((2, R16 * cols), 0x7777, dtype=torch.int16, device="cuda")
+    dt = torch.full((2, C16 * rows_pad), 0x7777, dtype=torch.int16, device="cuda")
+    tr = L.lib().ds_pack_operand_tile_rows(rows, rows_pad)
+    part = torch.full((tr, cols), float("nan"), device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    L.check(L.lib().ds_pack_operand(L.ptr(dev), rows, cols, ld, scale, 0, None, 0, L.ptr(drow), R16 * cols, L.ptr(dt),
+                                    C16 * rows_pad, rows_pad, L.ptr(part), L.ptr(amax), L.stream()))
+    got_row = L.unpack_planes(drow.cpu().view(torch.float16).view(2, -1), R16, cols)
+    full = torch.zeros(R16, cols)
+    full[:rows] = want
+    assert torch.equal(got_row, _split_planes(full)), "row form"
+    got_t = L.unpack_planes(dt.cpu().view(torch.float16).view(2, -1), C16, rows_pad)
+    fullt = torch.zeros(C16, rows_pad)
+    fullt[:cols, :rows] = want.t()
+    assert torch.equal(got_t, _split_planes(fullt)), "transposed form (zero-padded contraction)"
+    nr = (rows + 63) // 64
+    sums = part[:nr].cpu().double().sum(0)
+    assert (sums - want.double().sum(0)).abs().max().item() < 1e-5 * want.abs().sum(0).max().item()
+    want_amax = want.abs().max().item()
+    assert amax.item() == want_amax
+
+
+def test_pack_operand_gelu_prologues(L):
+    """The MLP's activation rides in the pack: DS_PACK_GELU2 (x := gelu2(x), transformer_utils.py:111-115) and
+    DS_PACK_GELU2_BWD (x := x * gelu2'(aux)) against float64; the packed value (hi + lo) is the fp32 result to 2^-22."""
+    rows, cols = 300, 128
+    u = rnd((rows, cols), "pkg.u", 4.0)
+    dy = rnd((rows, cols), "pkg.dy", 2.0)
+    uc, dyc = u.cuda(), dy.cuda()
+    R16 = (rows + 15) // 16 * 16
+    for pro, src, aux, ref in ((1, uc, None, u.double() * torch.sigmoid(1.702 * u.double())),
+                               (2, dyc, uc, dy.double() * (torch.sigmoid(1.702 * u.double()) *
+                                                           (1 + 1.702 * u.double() * (1 - torch.sigmoid(1.702 * u.double())))))):
+        d = torch.empty(2, R16 * cols, dtype=torch.int16, device="cuda")
+        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, pro, L.ptr(aux), cols, L.ptr(d), R16 * cols, None, 0, 0,
+                                        None, None, L.stream()))
+        pl = L.unpack_planes(d.cpu().view(torch.float16).view(2, -1), rows, cols)
+        val = pl[0].double() + pl[1].double()
+        assert (val - ref).abs().max().item() < 3e-6 * ref.abs().max().item()
+
+
+def test_gemm_f16x2_packed_split_k_groups(L):
+    """The dW launch of round 5: BOTH operands as packed planes (ds_pack_operand's transposed forms), the contraction split
+    into `groups` K-ranges of one grouped launch (row groups lda / 32 k-tiles apart, group stride 16 K halves), partial
+    products summed by ds_colsum -- against float64, against the ungrouped packed launch and per K-range."""
+    N, K, M, S = 320, 192, 1000, 4
+    Mp = (M + 32 * S - 1) // (32 * S) * (32 * S)
+    dy = rnd((M, N), "psk.dy", 30.0)
+    x = rnd((M, K), "psk.x", 2.0)
+    ref = dy.double().t() @ x.double()
+    dyc, xc = dy.cuda(), x.cuda()
+
+    def tform(src, cols):
+        C16 = (cols + 15) // 16 * 16
+        d = torch.empty(2, C16 * Mp, dtype=torch.int16, device="cuda")
+        L.check(L.lib().ds_pack_operand(L.ptr(src), M, cols, cols, 1.0, 0, None, 0, None, 0, L.ptr(d), C16 * Mp, Mp, None, None,
+                                        L.stream()))
+        return d, C16 * Mp
+    a, apl = tform(dyc, N)
+    w, wpl = tform(xc, K)
+    one = torch.empty(N, K, device="cuda")
+    L.gemm(a, w, one, N, K, Mp, split2=0.5, a_plane=apl, w_plane=wpl)
+    scale = ref.abs().max().item()
+    assert (one.cpu().double() - 0.5 * ref).abs().max().item() < 2e-6 * scale
+    Kc = Mp // S
+    for tile in (-1, 0, 1, 2):
+        L.lib().ds_gemm_f16x2_force_tile(tile)
+        try:
+            part = torch.full((S, N * K), float("nan"), device="cuda")
+            L.gemm(a, w, part, N, K, Kc, lda=Mp, ldw=Mp, ldc=K, groups=S, a_gstride=Kc * 16, w_gstride=Kc * 16, c_gstride=N * K,
+                   split2=0.5, a_plane=apl, w_plane=wpl)
+        finally:
+            L.lib().ds_gemm_f16x2_force_tile(-1)
+        out = torch.empty(N, K, device="cuda")
+        L.check(L.lib().ds_colsum(L.ptr(part), L.ptr(out), 1, S, N * K, N * K, 0, 0, L.stream()))
+        assert (out.cpu().double() - 0.5 * ref).abs().max().item() < 2e-6 * scale, "tile %d" % tile
+        for g in range(S):       # every group is the product over its own K-range (the last one includes the zero padding)
+            lo_, hi_ = g * Kc, min((g + 1) * Kc, M)
+            pr = dy[lo_:hi_].double().t() @ x[lo_:hi_].double() if hi_ > lo_ else torch.zeros(N, K, dtype=torch.float64)
+            assert (part[g].view(N, K).cpu().double() - 0.5 * pr).abs().max().item() < 2e-6 * scale, "tile %d group %d" % (tile, g)
+
+
+def test_adamw_multi_equals_per_tensor_launches(L):
+    """ds_adamw_multi (64 tensor descriptors by value per launch) == ds_adamw_dev tensor by tensor, bit for bit: odd sizes,
+    an unaligned view, more tensors than one batch."""
+    import ctypes
+    import math
+    sizes = [50001, 7, 4096, 1, 123457] + [33 + 17 * i for i in range(70)]
+    hyper = torch.tensor([3e-3, 1.0 - 0.9 ** 2, math.sqrt(1.0 - 0.96 ** 2), 0.25], device="cuda")
+    base = [rnd((n + 1,), "awm.p%d" % i).cuda() for i, n in enumerate(sizes)]
+    ps = [b[1:] if i == 1 else b[:-1] for i, b in enumerate(base)]                 # tensor 1: a 4-byte-offset view
+    gs = [rnd((n,), "awm.g%d" % i, 0.1).cuda() for i, n in enumerate(sizes)]
+    ms = [rnd((n,), "awm.m%d" % i, 0.01).cuda() for i, n in enumerate(sizes)]
+    vs = [rnd((n,), "awm.v%d" % i, 0.01).abs().cuda() for i, n in enumerate(sizes)]
+    pr, mr, vr = [p.clone() for p in ps], [m.clone() for m in ms], [v.clone() for v in vs]
+    for p, g, m, v in zip(pr, gs, mr, vr):
+        L.check(L.lib().ds_adamw_dev(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(hyper), 0.9, 0.96, 1e-8, 4.5e-2, L.stream()))
+    rec = (ctypes.c_int64 * (5 * len(sizes)))()
+    for i, (p, g, m, v) in enumerate(zip(ps, gs, ms, vs)):
+        rec[5 * i:5 * i + 5] = [p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()]
+    L.check(L.lib().ds_adamw_multi(ctypes.cast(rec, ctypes.c_void_p), len(sizes), L.ptr(hyper), 0.9, 0.96, 1e-8, 4.5e-2, L.stream()))
+    torch.cuda.synchronize()
+    for i in range(len(sizes)):
+        assert torch.equal(ps[i], pr[i]) and torch.equal(ms[i], mr[i]) and torch.equal(vs[i], vr[i]), "tensor %d" % i
+        assert float(base[i][0 if i == 1 else -1]) == float(rnd((sizes[i] + 1,), "awm.p%d" % i)[0 if i == 1 else -1])   # neighbours untouched
+
+
 def test_amax_and_adamw_dev(L):
     x = rnd((100003,), "am.x", 3.0)
     x[4711] = -17.25

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "obj")
 LIB = os.path.join(HERE, "libdiffsound_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_f16x2_ps.hip", "conv_f16x2.hip", "conv3x3_f16x2.hip", "conv1d_f16x2.hip", "melgan_fused.hip", "norm.hip", "attention.hip", "attention_bwd.hip", "attention_f16x2.hip", "sampler.hip", "misc.hip", "train.hip", "api.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_f16x2_ps.hip", "conv_f16x2.hip", "conv3x3_f16x2.hip", "conv1d_f16x2.hip", "melgan_fused.hip", "norm.hip", "attention.hip", "attention_bwd.hip", "attention_f16x2.hip", "sampler.hip", "misc.hip", "train.hip", "pack.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
          "-I", CSRC, "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
 # kernels that must not touch scratch memory: a register demotion in one of them is a silent 3x slowdown

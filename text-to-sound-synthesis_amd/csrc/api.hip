@@ -67,7 +67,7 @@ extern "C" int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
 extern "C" int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
     DS_CHECK_ARG(d && d->A && d->W && d->C, "null pointer");
     DS_CHECK_ARG(d->loader == DS_LOAD_DENSE && d->pro == DS_PRO_NONE && !d->f16_round,
-                 "f16x2 is the dense, no-prologue kernel (groups: row-major operands only, see ds_launch_gemm_f16x2)");
+                 "f16x2 is the dense, no-prologue kernel (groups: see ds_launch_gemm_f16x2)");
     DS_CHECK_ARG(d->w3_plane > 0, "w3_plane (plane stride of the split weights) is required");
     DS_CHECK_ARG(d->store != DS_STORE_BATCH_T || d->rows_per_sample > 0, "BATCH_T store needs rows_per_sample");
     DS_CHECK_ARG(d->R == nullptr || d->store == DS_STORE_ROW, "residual only with row-major store");

@@ -230,7 +230,8 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
                 rg = (n0 + r) >> 4; rgs = (p.N + 15) >> 4;
             }
             if (rg >= rgs) rg = rgs - 1;                     // tail groups re-read the last group (never stored)
-            src[i] = base + (size_t)rg * nk * 512 + lane * 8;
+            // row-group stride = the k-tiles the planes were PACKED with (lda = ldw; > K for a K-range of a split-K launch)
+            src[i] = base + (size_t)rg * (p.lda / HBK) * 512 + lane * 8;
         }
 #define H_DMA(stage_, k0_)                                                                          \
     do {                                                                                            \
@@ -438,15 +439,16 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
     }
 }
 
-// blockIdx.y = group (row-major operands only): A / W / C advance by the group strides -- the training step's split-K
-// dW GEMMs are `groups` K-ranges of one product (a_gstride = w_gstride = K per group, partial results c_gstride apart)
+// blockIdx.y = group: A / W / C advance by the group strides -- the training step's split-K dW GEMMs are `groups` K-ranges
+// of one product (a_gstride = w_gstride = K per group for row-major operands; 16 K halves = K / 32 k-tiles for packed
+// operands, whose row groups stay lda / 32 k-tiles apart; partial results c_gstride apart)
 template <int BM, int BN, int AMODE>
 __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    if (AMODE == 0) {                     // blockIdx.y is 0 in an ungrouped launch
+    if (blockIdx.y != 0) {                // (0 in an ungrouped launch)
         GemmParams q = p;
         const size_t g = blockIdx.y;
-        q.A = p.A + g * (size_t)p.a_gstride;
+        q.A = AMODE == 0 ? p.A + g * (size_t)p.a_gstride : (const float*)((const _Float16*)p.A + g * (size_t)p.a_gstride);
         q.W = (const float*)((const _Float16*)p.W + g * (size_t)p.w_gstride);
         q.C = p.C + g * (size_t)p.c_gstride;
         ds_gemm_f16x2_body<BM, BN, AMODE>(q, blockIdx.x, gridDim.x, smem_dyn);
@@ -503,7 +505,7 @@ static int launch_h2(const GemmParams& p, hipStream_t s) {
         attr_set.done();
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE>), dim3(tiles, AMODE == 0 && p.groups > 1 ? p.groups : 1),
+    hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE>), dim3(tiles, p.groups > 1 ? p.groups : 1),
                        dim3(256), lds, s, p);
     DS_CHECK_LAUNCH();
     return 0;
@@ -545,7 +547,7 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
     pb.M = m_off;
     ps.M = p.M - m_off;
     const size_t rg = (size_t)m_off / 16;
-    ps.A = (const float*)((const _Float16*)p.A + rg * (p.K / HBK) * 512);           // packed planes: row-group offset
+    ps.A = (const float*)((const _Float16*)p.A + rg * (p.lda / HBK) * 512);         // packed planes: row-group offset
     if (p.store == DS_STORE_ATTN) ps.row_off = p.row_off + m_off;   // destinations are computed from absolute rows
     else if (p.c_split) ps.C = (float*)((_Float16*)p.C + rg * (p.ldc / 32) * 512);
     else ps.C = p.C + (size_t)m_off * p.ldc;
@@ -584,9 +586,11 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % HBK == 0, "K must be a positive multiple of 32");
     DS_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && p.lda % 4 == 0, "alignment");
     DS_CHECK_ARG(p.ldw >= p.K && p.ldw % 8 == 0 && p.w3_plane % 8 == 0, "split-weight strides must be multiples of 8");
-    DS_CHECK_ARG(!p.a_split || (p.lda == p.K && p.ldw == p.K && p.a_plane >= (long long)((p.M + 15) / 16) * 16 * p.K &&
-                                p.a_plane % 8 == 0 && p.w3_plane >= (long long)((p.N + 15) / 16) * 16 * p.K),
-                 "packed operands: lda = ldw = K, planes of ceil16(rows) * K halves");
+    DS_CHECK_ARG(!p.a_split || (p.lda >= p.K && p.lda % HBK == 0 && p.ldw == p.lda &&
+                                p.a_plane >= (long long)((p.M + 15) / 16) * 16 * p.lda && p.a_plane % 8 == 0 &&
+                                p.w3_plane >= (long long)((p.N + 15) / 16) * 16 * p.lda),
+                 "packed operands: lda = ldw = the packed contraction length (>= K), planes of ceil16(rows) * lda halves");
+    DS_CHECK_ARG(!p.a_split || p.lda == p.K || p.groups > 1, "packed operands: lda > K only for the K-ranges of a split-K launch");
     DS_CHECK_ARG(!p.c_split || (p.ldc % 32 == 0 && p.N <= p.ldc && p.c_plane >= (long long)((p.M + 15) / 16) * 16 * p.ldc &&
                                 p.store == DS_STORE_ROW && !p.R),
                  "packed output: ldc % 32 == 0, plane of ceil16(M) * ldc halves, row store, no residual");
@@ -601,15 +605,16 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     DS_CHECK_ARG(!p.c_split || p.N % 8 == 0, "packed output needs N % 8 == 0");
     DS_CHECK_ARG(p.act == DS_ACT_NONE || p.act == DS_ACT_GELU2, "unsupported activation");
     DS_CHECK_ARG(p.out_scale > 0.f, "out_scale must be set (2^-s of the weight pre-scale)");
-    DS_CHECK_ARG(p.groups <= 1 || (!p.a_split && !p.c_split && p.store == DS_STORE_ROW && !p.R && !p.bias &&
-                                   p.a_gstride % 4 == 0 && p.w_gstride % 8 == 0 && p.c_gstride % 4 == 0),
-                 "groups: row-major operands, plain row store, no bias / residual, 16-byte aligned group strides");
+    DS_CHECK_ARG(p.groups <= 1 || (!p.c_split && p.store == DS_STORE_ROW && !p.R && !p.bias && p.w_gstride % 8 == 0 &&
+                                   p.c_gstride % 4 == 0 && (p.a_split ? p.a_gstride % 512 == 0 && p.w_gstride % 512 == 0
+                                                                      : p.a_gstride % 4 == 0)),
+                 "groups: plain row store, no bias / residual, 16-byte aligned group strides (whole k-tiles for packed operands)");
     // Full-batch denoiser GEMMs (packed operands, one sample = 265 rows, N in 256-column tiles, a grid of whole
     // rounds of the 256 CUs): the per-sample ping-pong program of gemm_f16x2_ps.hip.  force_tile(9) takes it for
     // every shape it can compute (tests: small batches), force_tile(0 / 1 / 2) never.
     // force_tile(10): the half-tile program (272-row samples).
     {
-        const int pick = g_force_tile_h < 0 ? ds_gemm_f16x2_ps_pick(p)
+        const int pick = p.groups > 1 ? 0 : g_force_tile_h < 0 ? ds_gemm_f16x2_ps_pick(p)
                        : g_force_tile_h == 9 ? (ds_gemm_f16x2_ps_applies(p, false) ? 1 : 0)
                        : g_force_tile_h == 10 ? (ds_gemm_f16x2_ph_applies(p) ? 2 : 0) : 0;
         if (pick == 1) {
@@ -634,7 +639,7 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     }
     g_last_tile = best;
     switch (best) {
-        case 0: return p.a_split ? launch_hybrid(p, stream) : launch_h<128, 128>(p, stream);
+        case 0: return p.a_split && p.groups <= 1 ? launch_hybrid(p, stream) : launch_h<128, 128>(p, stream);
         case 1: return launch_h<128, 64>(p, stream);
         default: return launch_h<64, 64>(p, stream);
     }

@@ -12,21 +12,24 @@ cross-attention K | V projections are fused into one linear each (one GEMM of N 
 Two GEMM backends (`TrainStep(precision=...)`), both behind the same step:
 
   "fp32"   exact-fp32 MFMA (`ds_gemm`); transposed / padded operands are made by torch.  The reference arithmetic.
-  "f16x2"  the fp32-class 3-pass fp16 split GEMM (`ds_gemm_f16x2`, fp32 A split by the loader, W operand = two fp16
-           planes) with NOTHING on the host between two launches:
-             * weights are split once per step by `ds_convert_operand` into W planes (forward) and W^T planes (dX), with a
-               per-matrix power-of-two pre-scale refreshed every `rescale_interval` steps (weights move slowly);
-             * dW = dY^T X takes dY^T (fp32) and X^T (planes) from the same kernel (transpose + zero padding fused) and
-               runs as a split-K launch (`groups` K-ranges fill the chip: a 1024 x 1024 dW is only 64 tiles) whose partial
-               sums `ds_colsum` adds in a fixed order;
-             * the gradients' magnitude (|dY| ~ 1e-8 .. 1e-2, far below fp16's range) is handled by ONE loss scale 2^k
-               for the whole backward -- d logits is multiplied by it, every dX carries it, the dW GEMMs' epilogue and
-               one multiply over the small gradients take it out again; k comes from a calibration pass (max |dY| over
-               every GEMM input of one backward, one host sync) -- not from a max + sync in front of every GEMM.
-               A split value keeps an absolute precision of 2^-25, so anything above 2^-3 after scaling is fp32-class;
-               the calibration puts the largest |dY| at 2^12..2^13.
-           The step then has no host synchronisation at all and can be captured in a hipGraph (`capture`): one graph
-           launch per iteration instead of ~3000 kernel launches from Python.
+  "f16x2"  the fp32-class 3-pass fp16 split GEMM with PACKED split planes on both operands of all three GEMMs (LDS-DMA
+           staging, gemm_f16x2.hip AMODE 2: 1.2-1.4x the loader-split program on the step's shapes) and NOTHING on the host
+           between two launches.  Every matrix that enters a GEMM goes through `ds_pack_operand` exactly once (csrc/pack.hip):
+             * an activation x -> its row form (A of y = x W^T) and its transposed form (X^T, W operand of dW = dY^T X);
+             * a gradient dY  -> its row form (A of dX = dY W), its transposed form (A of dW), the per-tile column sums that
+               become the bias gradient, and max |dY| for the loss-scale monitor -- one read of dY instead of four;
+             * a weight W     -> row form (forward) and transposed form (dX), with a per-matrix power-of-two pre-scale
+               refreshed every `rescale_interval` steps (weights move slowly);
+             * GELU2 rides in the pack's prologue in both directions (fc2's input from fc1's output; d fc1-output from
+               d gelu-output), so the MLP's activation and its gradient never exist in fp32.
+           dW runs as a split-K launch on the packed planes (`groups` K-ranges fill the chip: a 1024 x 1024 dW is only 64
+           tiles) whose partial sums `ds_colsum` adds in a fixed order.  The gradients' magnitude (|dY| ~ 1e-8 .. 1e-2, far
+           below fp16's range) is handled by ONE loss scale 2^k for the whole backward -- d logits is multiplied by it, every
+           dX carries it, the dW GEMMs' epilogue and one multiply over the small gradients take it out again; k comes from a
+           calibration pass (max |dY| over every GEMM input of one backward, one host sync).  A split value keeps an absolute
+           precision of 2^-25, so anything above 2^-3 after scaling is fp32-class; the calibration puts the largest |dY| at
+           2^12..2^13.  The step has no host synchronisation at all and is captured in a hipGraph (`capture`): one graph
+           launch per iteration instead of ~2000 kernel launches from Python.
 
 Attention is exact fp32 in both modes: `attention="fused"` (default) = `ds_attention` forward + `ds_attention_bwd`, a
 backward by tile-wise recomputation that reads Q | K | V and writes dQ | dK | dV in place in the fused projection buffers
@@ -68,6 +71,9 @@ def _convert(src, rows, cols, ld_src, transpose, scale, dst, ld_dst, plane, f16)
     return dst
 
 
+PACK_PLAIN, PACK_GELU2, PACK_GELU2_BWD = 0, 1, 2
+
+
 class _Linear:
     """One (possibly fused) nn.Linear of the step: W [N][K] fp32, bias [N], plus what the GEMM backend derived from W."""
 
@@ -77,12 +83,25 @@ class _Linear:
         self.extra = {}
 
 
+def _gelu2(x, dy=None):
+    out = torch.empty_like(x)
+    L_.check(L_.lib().ds_gelu2(L_.ptr(x), L_.ptr(dy), L_.ptr(out), x.numel(), L_.stream()))
+    return out
+
+
 class _Fp32Gemm:
-    """Backend "fp32": every GEMM on the exact-fp32 MFMA kernel; transposes and zero padding by torch."""
+    """Backend "fp32": every GEMM on the exact-fp32 MFMA kernel; transposes and zero padding by torch.  An operand handle is
+    the fp32 matrix itself (after the elementwise prologue, if any)."""
     name = "fp32"
 
     def prepare(self, lin):
         pass
+
+    def prep_x(self, lin, x, pro=PACK_PLAIN):
+        return _gelu2(x) if pro == PACK_GELU2 else x
+
+    def prep_dy(self, lin, dy, pro=PACK_PLAIN, aux=None, amax=None, need_row=True):
+        return _gelu2(aux, dy) if pro == PACK_GELU2_BWD else dy
 
     def fwd(self, lin, x, R=None):
         M = x.shape[0]
@@ -115,9 +134,39 @@ class _Fp32Gemm:
             dW.mul_(inv_scale)
         return dW
 
+    def db(self, lin, dy):
+        return _colsum(dy)[0]
+
+
+class _Packed:
+    """What ds_pack_operand made of one fp32 matrix [rows][cols]: `row` = packed planes of the matrix (int16 [2][plane]),
+    `t` = packed planes of its transpose with the contraction index padded to rows_pad, `part` = per-64-row column sums."""
+    __slots__ = ("rows", "cols", "row", "row_plane", "t", "t_plane", "rows_pad", "part")
+
+
+def _pack(src, rows, cols, *, scale=1.0, pro=PACK_PLAIN, aux=None, want_row=True, rows_pad=0, colsum=False, amax=None, ld=None):
+    """One ds_pack_operand launch (csrc/pack.hip) over src [rows][ld >= cols]."""
+    dev = src.device
+    o = _Packed()
+    o.rows, o.cols, o.rows_pad = rows, cols, rows_pad
+    o.row = o.t = o.part = None
+    o.row_plane = _ceil(rows, 16) * cols
+    o.t_plane = _ceil(cols, 16) * rows_pad
+    if want_row:
+        o.row = torch.empty(2, o.row_plane, dtype=torch.int16, device=dev)
+    if rows_pad:
+        o.t = torch.empty(2, o.t_plane, dtype=torch.int16, device=dev)
+    if colsum:
+        o.part = torch.empty(L_.lib().ds_pack_operand_tile_rows(rows, rows_pad), cols, device=dev)
+    L_.check(L_.lib().ds_pack_operand(L_.ptr(src), rows, cols, cols if ld is None else ld, float(scale), int(pro), L_.ptr(aux),
+                                      cols, L_.ptr(o.row), o.row_plane, L_.ptr(o.t), o.t_plane, rows_pad, L_.ptr(o.part),
+                                      L_.ptr(amax), L_.stream()))
+    return o
+
 
 class _SplitGemm:
-    """Backend "f16x2": every linear-layer GEMM on the 3-pass fp16 split kernel, operands prepared on the device."""
+    """Backend "f16x2": every linear-layer GEMM on the 3-pass fp16 split kernel with packed split planes on both operands
+    (module docstring).  Operand handles are `_Packed` objects."""
     name = "f16x2"
 
     def __init__(self):
@@ -129,29 +178,6 @@ class _SplitGemm:
         for l, m in zip(lins, mx):
             self.wexp[l.key] = 0 if (m == 0.0 or not math.isfinite(m)) else 13 - math.floor(math.log2(m))
 
-    def prepare(self, lin):
-        s = self.wexp[lin.key]
-        N, K = lin.N, lin.K
-        Np = _ceil(N, 32)
-        lin.extra["osc"] = 2.0 ** (-s)
-        lin.extra["Wf"] = _convert(lin.W, N, K, K, 0, 2.0 ** s, torch.empty(2, N, K, dtype=torch.int16, device=lin.W.device),
-                                   K, N * K, 1)
-        lin.extra["Wt"] = _convert(lin.W, N, K, K, 1, 2.0 ** s, torch.empty(2, K, Np, dtype=torch.int16, device=lin.W.device),
-                                   Np, K * Np, 1)
-
-    def fwd(self, lin, x, R=None):
-        M = x.shape[0]
-        y = torch.empty(M, lin.N, device=x.device)
-        return L_.gemm(x, lin.extra["Wf"], y, M, lin.N, lin.K, bias=lin.b, R=R, split2=lin.extra["osc"])
-
-    def dx(self, lin, dy):
-        M, N, K = dy.shape[0], lin.N, lin.K
-        Np = _ceil(N, 32)
-        if Np != N:                                     # K granule of the GEMM: zero-padded copy (not hit by this network)
-            dy = _convert(dy, M, N, N, 0, 1.0, torch.empty(M, Np, device=dy.device), Np, 0, 0)
-        out = torch.empty(M, K, device=dy.device)
-        return L_.gemm(dy, lin.extra["Wt"], out, M, K, Np, split2=lin.extra["osc"])
-
     @staticmethod
     def split_k(N, K):
         """K-ranges of a dW launch: enough 128 x 128 tiles for about two rounds of the 512 resident workgroups."""
@@ -161,22 +187,66 @@ class _SplitGemm:
             s *= 2
         return s
 
-    def dw(self, lin, x, dy, inv_scale):
-        M, N, K = x.shape[0], lin.N, lin.K
+    def rows_pad(self, lin, M):
+        """the padded contraction length of this layer's dW = dY^T X over M rows: a multiple of 32 per K-range"""
+        return _ceil(M, 32 * self.split_k(lin.N, lin.K))
+
+    def prepare(self, lin):
+        """W * 2^s -> row form [N][K] (forward) and transposed form [K][ceil32(N)] (dX), one pass"""
+        s = self.wexp[lin.key]
+        lin.extra["osc"] = 2.0 ** (-s)
+        lin.extra["Wp"] = _pack(lin.W, lin.N, lin.K, scale=2.0 ** s, rows_pad=_ceil(lin.N, 32))
+
+    def prep_x(self, lin, x, pro=PACK_PLAIN):
+        M = x.shape[0]
+        return _pack(x, M, lin.K, pro=pro, rows_pad=self.rows_pad(lin, M))
+
+    def prep_dy(self, lin, dy, pro=PACK_PLAIN, aux=None, amax=None, need_row=True):
+        M = dy.shape[0]
+        return _pack(dy, M, lin.N, pro=pro, aux=aux, want_row=need_row, rows_pad=self.rows_pad(lin, M), colsum=True, amax=amax)
+
+    def fwd(self, lin, xp, R=None):
+        M = xp.rows
+        y = torch.empty(M, lin.N, device=xp.row.device)
+        Wp = lin.extra["Wp"]
+        return L_.gemm(xp.row, Wp.row, y, M, lin.N, lin.K, bias=lin.b, R=R, split2=lin.extra["osc"], a_plane=xp.row_plane,
+                       w_plane=Wp.row_plane)
+
+    def dx(self, lin, dyp):
+        M = dyp.rows
+        Wp = lin.extra["Wp"]
+        out = torch.empty(M, lin.K, device=dyp.row.device)
+        Np = Wp.rows_pad                                       # contraction length of dX = dY W (N, a multiple of 32 here)
+        assert Np == lin.N, "dX needs N % 32 == 0 (true for every linear of this network)"
+        return L_.gemm(dyp.row, Wp.t, out, M, lin.K, Np, split2=lin.extra["osc"], a_plane=dyp.row_plane, w_plane=Wp.t_plane)
+
+    def dw(self, lin, xp, dyp, inv_scale):
+        N, K, Mp = lin.N, lin.K, dyp.rows_pad
+        assert xp.rows_pad == Mp and xp.cols == K and dyp.cols == N
         S = self.split_k(N, K)
-        Mp = _ceil(M, 32 * S)
-        dev = x.device
-        At = _convert(dy, M, N, N, 1, 1.0, torch.empty(N, Mp, device=dev), Mp, 0, 0)                   # dY^T, fp32
-        Xt = _convert(x, M, K, K, 1, 1.0, torch.empty(2, K, Mp, dtype=torch.int16, device=dev), Mp, K * Mp, 1)   # X^T planes
+        dev = dyp.t.device
         dW = torch.empty(N, K, device=dev)
         if S == 1:
-            return L_.gemm(At, Xt, dW, N, K, Mp, split2=inv_scale, w_plane=K * Mp)
+            return L_.gemm(dyp.t, xp.t, dW, N, K, Mp, split2=inv_scale, a_plane=dyp.t_plane, w_plane=xp.t_plane)
         part = torch.empty(S, N * K, device=dev)
         Kc = Mp // S
-        L_.gemm(At, Xt, part, N, K, Kc, lda=Mp, ldw=Mp, ldc=K, groups=S, a_gstride=Kc, w_gstride=Kc, c_gstride=N * K,
-                split2=inv_scale, w_plane=K * Mp)
+        L_.gemm(dyp.t, xp.t, part, N, K, Kc, lda=Mp, ldw=Mp, ldc=K, groups=S, a_gstride=Kc * 16, w_gstride=Kc * 16,
+                c_gstride=N * K, split2=inv_scale, a_plane=dyp.t_plane, w_plane=xp.t_plane)
         L_.check(L_.lib().ds_colsum(L_.ptr(part), L_.ptr(dW), 1, S, N * K, N * K, 0, 0, L_.stream()))
         return dW
+
+    def db(self, lin, dyp):
+        out = torch.empty(1, dyp.cols, device=dyp.part.device)
+        R = (dyp.rows + 63) // 64                              # tile rows that hold data (the rest pad the contraction)
+        L_.check(L_.lib().ds_colsum(L_.ptr(dyp.part), L_.ptr(out), 1, R, dyp.cols, dyp.cols, 0, 0, L_.stream()))
+        return out[0]
+
+
+def _handle_tensors(h):
+    """the device tensors behind an operand handle (fp32 backend: the matrix; f16x2 backend: a _Packed's buffers)"""
+    if torch.is_tensor(h):
+        return [h]
+    return [v for v in (h.row, h.t, h.part) if v is not None]
 
 
 def _norm_fwd(x, mode, L, table=None, t=None, gamma=None, beta=None):
@@ -436,10 +506,7 @@ class TrainStep:
                 self._amax_live = torch.zeros(1, device=dev)
             amax = self._amax_live
 
-        def seen(dy):                                   # every gradient that is about to enter a GEMM: calibration / monitor
-            if amax is not None:
-                L_.check(L_.lib().ds_amax(L_.ptr(dy), dy.numel(), L_.ptr(amax), L_.stream()))
-            return dy
+        # (every gradient that enters a GEMM passes G_.prep_dy, whose pack folds max |dY| into `amax`: calibration / monitor)
 
         sched = dt._schedule_table()
         xt = dt.q_sample_tokens(x0.contiguous(), t, noise)
@@ -449,42 +516,42 @@ class TrainStep:
         L_.check(L_.lib().ds_embed(L_.ptr(xt), L_.ptr(emb.emb.weight), L_.ptr(pos), L_.ptr(x), M, Lx, D, L_.stream()))
         cond = cond_emb.reshape(-1, cond_emb.shape[-1]).float().contiguous()
         Lc = cond_emb.shape[1]
+        # operand handles (G_.prep_x): the forward's GEMM input AND the X^T of the same layer's dW, made in one pass; the
+        # caption embedding feeds every block's cross K | V projection (same K, same padded contraction: one handle)
+        cond_h = G_.prep_x(blocks[0]["kv2"], cond)
         saved = []
         for blk, ls in zip(tr.blocks, blocks):
             s = {"x0": x}
             s["tab1"] = blk.ln1.table()
-            h = _norm_fwd(x, 0, Lx, table=s["tab1"], t=t)
-            s["h1"] = h
+            s["h1"] = h = G_.prep_x(ls["qkv1"], _norm_fwd(x, 0, Lx, table=s["tab1"], t=t))
             qkv = G_.fwd(ls["qkv1"], h)                                             # [M][3D]: q | k | v
             if fused:
                 s["att1"] = _FusedAttn((qkv, 0, 3 * D), (qkv, D, 3 * D), (qkv, 2 * D, 3 * D), B, Lx, Lx, H)
             else:
                 s["att1"] = _Attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, Lx, Lx, H)
-            x = G_.fwd(ls["proj1"], s["att1"].out, R=x)
+            s["o1"] = G_.prep_x(ls["proj1"], s["att1"].out)
+            x = G_.fwd(ls["proj1"], s["o1"], R=x)
             s["x1"] = x
             s["tab2"] = blk.ln1_1.table()
-            h = _norm_fwd(x, 0, Lx, table=s["tab2"], t=t)
-            s["h2"] = h
+            s["h2"] = h = G_.prep_x(ls["q2"], _norm_fwd(x, 0, Lx, table=s["tab2"], t=t))
             q = G_.fwd(ls["q2"], h)
-            kv = G_.fwd(ls["kv2"], cond)                                            # [B*Lc][2D]: k | v
+            kv = G_.fwd(ls["kv2"], cond_h)                                          # [B*Lc][2D]: k | v
             if fused:
                 s["att2"] = _FusedAttn((q, 0, D), (kv, 0, 2 * D), (kv, D, 2 * D), B, Lx, Lc, H)
             else:
                 s["att2"] = _Attn(q, kv[:, :D], kv[:, D:], B, Lx, Lc, H)
-            x = G_.fwd(ls["proj2"], s["att2"].out, R=x)
+            s["o2"] = G_.prep_x(ls["proj2"], s["att2"].out)
+            x = G_.fwd(ls["proj2"], s["o2"], R=x)
             s["x2"] = x
-            h = _norm_fwd(x, 1, Lx, gamma=blk.ln2.weight, beta=blk.ln2.bias)
-            s["h3"] = h
+            s["h3"] = h = G_.prep_x(ls["fc1"], _norm_fwd(x, 1, Lx, gamma=blk.ln2.weight, beta=blk.ln2.bias))
             u = G_.fwd(ls["fc1"], h)
             s["u"] = u
-            gact = torch.empty_like(u)
-            L_.check(L_.lib().ds_gelu2(L_.ptr(u), None, L_.ptr(gact), u.numel(), L_.stream()))
-            s["g"] = gact
-            x = G_.fwd(ls["fc2"], gact, R=x)
+            s["g"] = G_.prep_x(ls["fc2"], u, pro=PACK_GELU2)                        # gelu2(u): the f16x2 backend never stores it in fp32
+            x = G_.fwd(ls["fc2"], s["g"], R=x)
             saved.append(s)
         xf = x
         lnf = tr.to_logits[0]
-        hf = _norm_fwd(xf, 1, Lx, gamma=lnf.weight, beta=lnf.bias)
+        hf = G_.prep_x(lin_logits, _norm_fwd(xf, 1, Lx, gamma=lnf.weight, beta=lnf.bias))
         logits = G_.fwd(lin_logits, hf)                                             # [M, K]
         # ---- loss (forward value) and d loss / d logits
         kl, nll, kl_aux = (torch.empty(B, Lx, device=dev) for _ in range(3))
@@ -516,30 +583,34 @@ class TrainStep:
         side = self._side_stream(dev) if (self.overlap_dw and dev.type == "cuda") else None
         reads_dx = []               # side-stream work that still reads the residual gradient `dx` (updated in place below)
 
-        def lin_bwd(lin, xin, dy, need_dx=True, dy_is_dx=False):
-            """dX on the current stream; dW / db -- off the critical path of the backward, nothing downstream needs them
-            before the clip -- on the side stream when `overlap_dw` is set (the MFMA-bound weight-gradient GEMMs then
-            run beside the latency-bound attention backward / norm kernels of the main chain)."""
-            seen(dy)
+        def lin_bwd(lin, xh, dy, need_dx=True, pro=PACK_PLAIN, aux=None):
+            """The three products of one linear layer for its output gradient dy (fp32; with pro = PACK_GELU2_BWD the
+            gradient of the layer's output is dy * gelu2'(aux)).  dy is packed ONCE on the current stream (G_.prep_dy: row
+            form, transposed form, bias column sums, max |dY| -- after which nothing reads the fp32 dy any more, so the
+            in-place updates of the residual gradient need no ordering against the weight-gradient GEMMs).  dX on the current
+            stream; dW / db -- off the critical path of the backward, nothing downstream needs them before the clip -- on the
+            side stream when `overlap_dw` is set (the MFMA-bound weight-gradient GEMMs then run beside the latency-bound
+            attention backward / norm kernels of the main chain)."""
+            dyh = G_.prep_dy(lin, dy, pro=pro, aux=aux, amax=amax, need_row=need_dx)
             if side is None:
-                dxo = G_.dx(lin, dy) if need_dx else None
-                dW = G_.dw(lin, xin, dy, inv)
-                db = _colsum(dy)[0]
+                dxo = G_.dx(lin, dyh) if need_dx else None
+                dW = G_.dw(lin, xh, dyh, inv)
+                db = G_.db(lin, dyh)
             else:
                 main = torch.cuda.current_stream(dev)
                 ready = torch.cuda.Event()
-                ready.record(main)                          # dy and xin are complete at this point of the main stream
+                ready.record(main)                          # the operand handles are complete at this point of the main stream
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    dW = G_.dw(lin, xin, dy, inv)
-                    db = _colsum(dy)[0]
-                    if dy_is_dx:
+                    dW = G_.dw(lin, xh, dyh, inv)
+                    db = G_.db(lin, dyh)
+                    if self.precision != "f16x2":           # fp32 backend: the handle IS dy, which the caller may update in place
                         done = torch.cuda.Event()
                         done.record(side)
                         reads_dx.append(done)
-                dy.record_stream(side)                      # (allocator: not to be reused before the side stream is done)
-                xin.record_stream(side)
-                dxo = G_.dx(lin, dy) if need_dx else None
+                for tns in _handle_tensors(dyh) + _handle_tensors(xh):
+                    tns.record_stream(side)                 # (allocator: not to be reused before the side stream is done)
+                dxo = G_.dx(lin, dyh) if need_dx else None
             small.append(db)
             return dxo, dW, db
 
@@ -565,37 +636,52 @@ class TrainStep:
 
         Tp = _ceil(T, 32)
 
+        ada = []                    # (AdaLayerNorm module, d scale [B][D], d shift [B][D], parameter prefix): batched below
+
         def adaln_param_grads(ln, d_scale, d_shift, pfx):
+            ada.append((ln, d_scale, d_shift, pfx))
+
+        def adaln_param_grads_all():
             """d table[t_b] rows -> emb.weight / linear.{weight, bias} through  table = Linear(SiLU(emb))  (AdaLayerNorm,
-            transformer_utils.py:134-149): dW = dtab^T silu(e), db = column sums of dtab, de = (dtab W) silu'(e)."""
-            dtab = torch.zeros(T, 2 * D, device=dev)
-            dtab.index_add_(0, t, torch.cat((d_scale, d_shift), dim=1))
+            transformer_utils.py:134-149) for ALL 2 n_layer AdaLN modules at once: dW = dtab^T silu(e), db = column sums of
+            dtab, de = (dtab W) silu'(e) as two GROUPED exact-fp32 GEMMs (one group per module) instead of two small GEMMs,
+            three transposing copies and a dozen elementwise launches per module (4 ms of an 82 ms iteration in round 4)."""
+            G = len(ada)
+            if G == 0:
+                return
+            dmod = torch.stack([torch.cat((dsc, dsh), dim=1) for _, dsc, dsh, _ in ada])            # [G][B][2D]
+            dtab = torch.zeros(G, T, 2 * D, device=dev)
+            dtab.index_add_(1, t, dmod)
             dtab.mul_(inv)
-            e, w = ln.emb.weight.detach(), ln.linear.weight.detach()
-            sg = torch.sigmoid(e)
-            s_ = e * sg
-            dtabT = _convert(dtab, T, 2 * D, 2 * D, 1, 1.0, torch.empty(2 * D, Tp, device=dev), Tp, 0, 0)
-            sT = _convert(s_, T, D, D, 1, 1.0, torch.empty(D, Tp, device=dev), Tp, 0, 0)
-            dw = L_.gemm(dtabT, sT, torch.empty(2 * D, D, device=dev), 2 * D, D, Tp)
-            wT = _convert(w, 2 * D, D, D, 1, 1.0, torch.empty(D, 2 * D, device=dev), 2 * D, 0, 0)
-            ds_ = L_.gemm(dtab, wT, torch.empty(T, D, device=dev), T, D, 2 * D)
-            g[pfx + ".emb.weight"] = ds_ * (sg * (1.0 + e * (1.0 - sg)))
-            g[pfx + ".linear.weight"], g[pfx + ".linear.bias"] = dw, _colsum(dtab)[0]
+            E = torch.stack([ln.emb.weight.detach() for ln, _, _, _ in ada])                       # [G][T][D]
+            sg = torch.sigmoid(E)
+            dtabT = torch.zeros(G, 2 * D, Tp, device=dev)                                          # K = T padded to 32
+            dtabT[:, :, :T] = dtab.transpose(1, 2)
+            sT = torch.zeros(G, D, Tp, device=dev)
+            sT[:, :, :T] = (E * sg).transpose(1, 2)
+            dw = torch.empty(G, 2 * D, D, device=dev)                                              # dW[g] = dtab[g]^T silu(e[g])
+            L_.gemm(dtabT, sT, dw, 2 * D, D, Tp, groups=G, a_gstride=2 * D * Tp, w_gstride=D * Tp, c_gstride=2 * D * D)
+            wT = torch.stack([ln.linear.weight.detach() for ln, _, _, _ in ada]).transpose(1, 2).contiguous()   # [G][D][2D]
+            ds_ = torch.empty(G, T, D, device=dev)                                                 # dtab[g] W[g]
+            L_.gemm(dtab, wT, ds_, T, D, 2 * D, groups=G, a_gstride=T * 2 * D, w_gstride=D * 2 * D, c_gstride=T * D)
+            de = ds_ * (sg * (1.0 + E * (1.0 - sg)))
+            dbias = dtab.sum(1)                                                                    # [G][2D]
+            for i, (_, _, _, pfx) in enumerate(ada):
+                g[pfx + ".emb.weight"], g[pfx + ".linear.weight"], g[pfx + ".linear.bias"] = de[i], dw[i], dbias[i]
 
         for li in reversed(range(len(saved))):
             s, blk, ls = saved[li], tr.blocks[li], blocks[li]
             p = "transformer.blocks.%d." % li
             # x3 = x2 + fc2(gelu(fc1(ln2(x2))))
-            dgact, g[p + "mlp.2.weight"], g[p + "mlp.2.bias"] = lin_bwd(ls["fc2"], s["g"], dx, dy_is_dx=True)
-            du = torch.empty_like(dgact)
-            L_.check(L_.lib().ds_gelu2(L_.ptr(s["u"]), L_.ptr(dgact), L_.ptr(du), du.numel(), L_.stream()))
-            dh, g[p + "mlp.0.weight"], g[p + "mlp.0.bias"] = lin_bwd(ls["fc1"], s["h3"], du)
+            dgact, g[p + "mlp.2.weight"], g[p + "mlp.2.bias"] = lin_bwd(ls["fc2"], s["g"], dx)
+            # d fc1-output = dgact * gelu2'(u): the prologue of fc1's gradient pack
+            dh, g[p + "mlp.0.weight"], g[p + "mlp.0.bias"] = lin_bwd(ls["fc1"], s["h3"], dgact, pro=PACK_GELU2_BWD, aux=s["u"])
             dxn, dgam, dbet = _norm_bwd(s["x2"], dh, 1, Lx, gamma=blk.ln2.weight)
             g[p + "ln2.weight"], g[p + "ln2.bias"] = dgam[0], dbet[0]
             small += [dgam, dbet]
             axpy(dx, dxn)
             # x2 = x1 + proj2(attn2(q(ln1_1(x1)), kv(cond)))
-            dao, g[p + "attn2.proj.weight"], g[p + "attn2.proj.bias"] = lin_bwd(ls["proj2"], s["att2"].out, dx, dy_is_dx=True)
+            dao, g[p + "attn2.proj.weight"], g[p + "attn2.proj.bias"] = lin_bwd(ls["proj2"], s["o2"], dx)
             dq = torch.empty(M, D, device=dev)
             dkv = torch.empty(B * Lc, 2 * D, device=dev)
             if fused:
@@ -603,14 +689,14 @@ class TrainStep:
             else:
                 s["att2"].backward(dao, dq, dkv[:, :D], dkv[:, D:])
             dh, g[p + "attn2.query.weight"], g[p + "attn2.query.bias"] = lin_bwd(ls["q2"], s["h2"], dq)
-            _, dWkv, dbkv = lin_bwd(ls["kv2"], cond, dkv, need_dx=False)
+            _, dWkv, dbkv = lin_bwd(ls["kv2"], cond_h, dkv, need_dx=False)
             g[p + "attn2.key.weight"], g[p + "attn2.value.weight"] = dWkv[:D], dWkv[D:]
             g[p + "attn2.key.bias"], g[p + "attn2.value.bias"] = dbkv[:D], dbkv[D:]
             dxn, dsc, dsh = _norm_bwd(s["x1"], dh, 0, Lx, table=s["tab2"], t=t)
             adaln_param_grads(blk.ln1_1, dsc, dsh, p + "ln1_1")
             axpy(dx, dxn)
             # x1 = x0 + proj1(attn1(qkv(ln1(x0))))
-            dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["att1"].out, dx, dy_is_dx=True)
+            dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["o1"], dx)
             dqkv = torch.empty(M, 3 * D, device=dev)
             if fused:
                 s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D))
@@ -624,8 +710,8 @@ class TrainStep:
             axpy(dx, dxn)
             hand_over([p + n for n in ("mlp.2.weight", "mlp.0.weight", "attn2.proj.weight", "attn2.query.weight",
                                        "attn2.key.weight", "attn2.value.weight", "attn1.proj.weight", "attn1.query.weight",
-                                       "attn1.key.weight", "attn1.value.weight", "ln1.emb.weight", "ln1.linear.weight",
-                                       "ln1.linear.bias", "ln1_1.emb.weight", "ln1_1.linear.weight", "ln1_1.linear.bias")])
+                                       "attn1.key.weight", "attn1.value.weight")])
+        adaln_param_grads_all()
         # ---- embedding
         demb = torch.zeros_like(emb.emb.weight)
         L_.check(L_.lib().ds_embed_bwd(L_.ptr(dx), L_.ptr(xt), L_.ptr(demb), M, D, demb.shape[0], L_.stream()))
@@ -656,18 +742,33 @@ class TrainStep:
         hyper: optional f32[4] device tensor { lr, 1 - beta1^step, sqrt(1 - beta2^step), grad_scale } -- then `step` / `lr`
         are ignored and the launch arguments do not depend on the iteration (captured graphs: `capture`)."""
         params = dict(self.dt.named_parameters())
+        if hyper is not None:
+            # one batched launch per 64 tensors (ds_adamw_multi: descriptors by value in the kernel arguments -- capturable)
+            import ctypes
+            names = list(grads)
+            rec = (ctypes.c_int64 * (5 * len(names)))()
+            keep = []
+            for i, name in enumerate(names):
+                p_ = params[name]
+                if name not in state:
+                    state[name] = (torch.zeros_like(p_), torch.zeros_like(p_))
+                m, v = state[name]
+                gr = grads[name].contiguous()
+                keep.append(gr)
+                assert gr.numel() == p_.numel() and p_.data.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+                rec[5 * i:5 * i + 5] = [p_.data.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), p_.numel()]
+            L_.check(L_.lib().ds_adamw_multi(ctypes.cast(rec, ctypes.c_void_p), len(names), L_.ptr(hyper), betas[0], betas[1], eps,
+                                             weight_decay, L_.stream()))
+            self.tr.invalidate()
+            return
         for name, gr in grads.items():
             p_ = params[name]
             if name not in state:
                 state[name] = (torch.zeros_like(p_), torch.zeros_like(p_))
             m, v = state[name]
             gr = gr.contiguous()
-            if hyper is None:
-                L_.check(L_.lib().ds_adamw(L_.ptr(p_.data), L_.ptr(gr), L_.ptr(m), L_.ptr(v), p_.numel(), lr, betas[0], betas[1],
-                                           eps, weight_decay, step, L_.stream()))
-            else:
-                L_.check(L_.lib().ds_adamw_dev(L_.ptr(p_.data), L_.ptr(gr), L_.ptr(m), L_.ptr(v), p_.numel(), L_.ptr(hyper),
-                                               betas[0], betas[1], eps, weight_decay, L_.stream()))
+            L_.check(L_.lib().ds_adamw(L_.ptr(p_.data), L_.ptr(gr), L_.ptr(m), L_.ptr(v), p_.numel(), lr, betas[0], betas[1],
+                                       eps, weight_decay, step, L_.stream()))
         self.tr.invalidate()       # cached weight packs / AdaLN tables are stale now (frees the native handle too)
 
     # ---- the whole iteration as ONE hipGraph -----------------------------------------------------------------------------
