@@ -347,8 +347,9 @@ def test_gemm_f16x2_packed_split_k_groups(L):
 
 
 def test_adamw_multi_equals_per_tensor_launches(L):
-    """ds_adamw_multi (64 tensor descriptors by value per launch) == ds_adamw_dev tensor by tensor, bit for bit: odd sizes,
-    an unaligned view, more tensors than one batch."""
+    """ds_adamw_multi (64 tensor descriptors by value per launch) against ds_adamw_dev tensor by tensor (the same expressions;
+    hipcc contracts the two kernels' multiply-adds differently, so equal to rounding, not bit for bit): odd sizes, an
+    unaligned view, more tensors than one batch; elements next to a tensor are not touched."""
     import ctypes
     import math
     sizes = [50001, 7, 4096, 1, 123457] + [33 + 17 * i for i in range(70)]
@@ -367,7 +368,8 @@ def test_adamw_multi_equals_per_tensor_launches(L):
     L.check(L.lib().ds_adamw_multi(ctypes.cast(rec, ctypes.c_void_p), len(sizes), L.ptr(hyper), 0.9, 0.96, 1e-8, 4.5e-2, L.stream()))
     torch.cuda.synchronize()
     for i in range(len(sizes)):
-        assert torch.equal(ps[i], pr[i]) and torch.equal(ms[i], mr[i]) and torch.equal(vs[i], vr[i]), "tensor %d" % i
+        assert close(ps[i].cpu(), pr[i].cpu(), 1e-6) and close(ms[i].cpu(), mr[i].cpu(), 1e-6) and close(vs[i].cpu(), vr[i].cpu(), 1e-6), \
+            "tensor %d" % i
         assert float(base[i][0 if i == 1 else -1]) == float(rnd((sizes[i] + 1,), "awm.p%d" % i)[0 if i == 1 else -1])   # neighbours untouched
 
 

@@ -329,11 +329,15 @@ class _FusedAttn:
     recomputation: the probabilities are never stored), reading Q / K / V and writing dQ / dK / dV IN PLACE in the fused
     projection buffers -- an operand is (tensor, first column, row stride).  Exact-fp32 MFMA, like the composed version."""
 
-    def __init__(self, q, k, v, B, Lq, Lk, H):
+    def __init__(self, q, k, v, B, Lq, Lk, H, split=False):
+        """split: the forward on the streamed fp16-split attention kernel of the sampling path (ds_attention_f16x2: fp32-class,
+        2e-5 max-abs against float64 where the exact-fp32 kernel has 1e-6; 3-4x faster) -- the "f16x2" backend's choice; the
+        backward recomputes the probabilities in exact fp32 either way."""
         self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H = q, k, v, B, Lq, Lk, H
         self.out = torch.empty(B * Lq, H * 64, device=q[0].device)
-        L_.check(L_.lib().ds_attention(L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2],
-                                       L_.ptr(self.out), H * 64, B, H, Lq, Lk, 0.125, L_.stream()))
+        fn = L_.lib().ds_attention_f16x2 if split else L_.lib().ds_attention
+        L_.check(fn(L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2],
+                    L_.ptr(self.out), H * 64, B, H, Lq, Lk, 0.125, L_.stream()))
 
     def backward(self, dO, dq, dk, dv):
         q, k, v, B, Lq, Lk, H = self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H
@@ -348,6 +352,9 @@ class TrainStep:
     def __init__(self, diffusion_transformer, precision="fp32", rescale_interval=100, attention="fused", overlap_dw=False):
         assert precision in ("f16x2", "fp32") and attention in ("fused", "composed")
         self.attention = attention
+        # fused attention FORWARD on the streamed fp16-split kernel of the sampling path (ds_attention_f16x2) in the "f16x2"
+        # backend: 122 -> ~35 us per self-attention launch at B = 20; gradient parity unchanged (tests/test_hip_train_kernels.py)
+        self.split_attention = precision == "f16x2"
         self.overlap_dw = overlap_dw      # weight-gradient GEMMs on a second HIP stream, beside the dX / attention chain
         self._side = None
         self.dt = diffusion_transformer
@@ -519,25 +526,34 @@ class TrainStep:
         # operand handles (G_.prep_x): the forward's GEMM input AND the X^T of the same layer's dW, made in one pass; the
         # caption embedding feeds every block's cross K | V projection (same K, same padded contraction: one handle)
         cond_h = G_.prep_x(blocks[0]["kv2"], cond)
+        # the 2 n_layer AdaLN tables  Linear(SiLU(Emb))  (transformer_utils.py:145-147) as ONE grouped exact-fp32 GEMM (the
+        # per-module AdaLayerNorm.table() is the same kernel with the bias in its epilogue: identical values)
+        lns = [ln for blk in tr.blocks for ln in (blk.ln1, blk.ln1_1)]
+        ada_E = torch.stack([ln.emb.weight.detach() for ln in lns])                    # [G][T][D]
+        ada_W = torch.stack([ln.linear.weight.detach() for ln in lns])                 # [G][2D][D]
+        tabs = torch.empty(len(lns), T, 2 * D, device=dev)
+        L_.gemm(torch.nn.functional.silu(ada_E), ada_W, tabs, T, 2 * D, D, groups=len(lns), a_gstride=T * D,
+                w_gstride=2 * D * D, c_gstride=T * 2 * D)
+        tabs += torch.stack([ln.linear.bias.detach() for ln in lns])[:, None, :]
         saved = []
-        for blk, ls in zip(tr.blocks, blocks):
+        for li, (blk, ls) in enumerate(zip(tr.blocks, blocks)):
             s = {"x0": x}
-            s["tab1"] = blk.ln1.table()
+            s["tab1"] = tabs[2 * li]
             s["h1"] = h = G_.prep_x(ls["qkv1"], _norm_fwd(x, 0, Lx, table=s["tab1"], t=t))
             qkv = G_.fwd(ls["qkv1"], h)                                             # [M][3D]: q | k | v
             if fused:
-                s["att1"] = _FusedAttn((qkv, 0, 3 * D), (qkv, D, 3 * D), (qkv, 2 * D, 3 * D), B, Lx, Lx, H)
+                s["att1"] = _FusedAttn((qkv, 0, 3 * D), (qkv, D, 3 * D), (qkv, 2 * D, 3 * D), B, Lx, Lx, H, split=self.split_attention)
             else:
                 s["att1"] = _Attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, Lx, Lx, H)
             s["o1"] = G_.prep_x(ls["proj1"], s["att1"].out)
             x = G_.fwd(ls["proj1"], s["o1"], R=x)
             s["x1"] = x
-            s["tab2"] = blk.ln1_1.table()
+            s["tab2"] = tabs[2 * li + 1]
             s["h2"] = h = G_.prep_x(ls["q2"], _norm_fwd(x, 0, Lx, table=s["tab2"], t=t))
             q = G_.fwd(ls["q2"], h)
             kv = G_.fwd(ls["kv2"], cond_h)                                          # [B*Lc][2D]: k | v
             if fused:
-                s["att2"] = _FusedAttn((q, 0, D), (kv, 0, 2 * D), (kv, D, 2 * D), B, Lx, Lc, H)
+                s["att2"] = _FusedAttn((q, 0, D), (kv, 0, 2 * D), (kv, D, 2 * D), B, Lx, Lc, H, split=self.split_attention)
             else:
                 s["att2"] = _Attn(q, kv[:, :D], kv[:, D:], B, Lx, Lc, H)
             s["o2"] = G_.prep_x(ls["proj2"], s["att2"].out)
@@ -653,7 +669,8 @@ class TrainStep:
             dtab = torch.zeros(G, T, 2 * D, device=dev)
             dtab.index_add_(1, t, dmod)
             dtab.mul_(inv)
-            E = torch.stack([ln.emb.weight.detach() for ln, _, _, _ in ada])                       # [G][T][D]
+            order = [lns.index(ln) for ln, _, _, _ in ada]                                         # (the backward visits the blocks last first)
+            E = ada_E[order]                                                                       # [G][T][D]
             sg = torch.sigmoid(E)
             dtabT = torch.zeros(G, 2 * D, Tp, device=dev)                                          # K = T padded to 32
             dtabT[:, :, :T] = dtab.transpose(1, 2)
@@ -661,7 +678,7 @@ class TrainStep:
             sT[:, :, :T] = (E * sg).transpose(1, 2)
             dw = torch.empty(G, 2 * D, D, device=dev)                                              # dW[g] = dtab[g]^T silu(e[g])
             L_.gemm(dtabT, sT, dw, 2 * D, D, Tp, groups=G, a_gstride=2 * D * Tp, w_gstride=D * Tp, c_gstride=2 * D * D)
-            wT = torch.stack([ln.linear.weight.detach() for ln, _, _, _ in ada]).transpose(1, 2).contiguous()   # [G][D][2D]
+            wT = ada_W[order].transpose(1, 2).contiguous()                                         # [G][D][2D]
             ds_ = torch.empty(G, T, D, device=dev)                                                 # dtab[g] W[g]
             L_.gemm(dtab, wT, ds_, T, D, 2 * D, groups=G, a_gstride=T * 2 * D, w_gstride=D * 2 * D, c_gstride=T * D)
             de = ds_ * (sg * (1.0 + E * (1.0 - sg)))

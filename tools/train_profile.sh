@@ -2,7 +2,7 @@
 # Per-kernel time of the training iteration (BASELINE configs[4] on one GPU, run ON THE GPU BOX): rocprofv3 --kernel-trace --stats over
 # tools/bench_train.py (eager f16x2 iterations); prints the top kernels.  usage: tools/train_profile.sh <out dir>
 set -u
-OUT=$1
+OUT=$(mkdir -p "$1" && cd "$1" && pwd)       # absolute: rocprofv3 runs from /tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
