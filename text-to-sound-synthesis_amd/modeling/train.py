@@ -670,7 +670,7 @@ class TrainStep:
             dtab.index_add_(1, t, dmod)
             dtab.mul_(inv)
             order = [lns.index(ln) for ln, _, _, _ in ada]                                         # (the backward visits the blocks last first)
-            E = ada_E[order]                                                                       # [G][T][D]
+            E = torch.stack([ada_E[i] for i in order])         # [G][T][D]  (views + stack: no host index tensor, capturable)
             sg = torch.sigmoid(E)
             dtabT = torch.zeros(G, 2 * D, Tp, device=dev)                                          # K = T padded to 32
             dtabT[:, :, :T] = dtab.transpose(1, 2)
@@ -678,7 +678,7 @@ class TrainStep:
             sT[:, :, :T] = (E * sg).transpose(1, 2)
             dw = torch.empty(G, 2 * D, D, device=dev)                                              # dW[g] = dtab[g]^T silu(e[g])
             L_.gemm(dtabT, sT, dw, 2 * D, D, Tp, groups=G, a_gstride=2 * D * Tp, w_gstride=D * Tp, c_gstride=2 * D * D)
-            wT = ada_W[order].transpose(1, 2).contiguous()                                         # [G][D][2D]
+            wT = torch.stack([ada_W[i].t() for i in order])    # [G][D][2D] (stack of transposed views = one transposing copy)
             ds_ = torch.empty(G, T, D, device=dev)                                                 # dtab[g] W[g]
             L_.gemm(dtab, wT, ds_, T, D, 2 * D, groups=G, a_gstride=T * 2 * D, w_gstride=D * 2 * D, c_gstride=T * D)
             de = ds_ * (sg * (1.0 + E * (1.0 - sg)))
