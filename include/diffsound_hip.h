@@ -239,6 +239,12 @@ int ds_softmax_bwd_rows(const float* P, float* dP, int rows, int n, int ld, floa
 int ds_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                      const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                      float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
+/* The same backward with every tile product on the fp16 matrix cores (operands split into fp16 hi + lo on the fly, three
+ * v_mfma_f32_32x32x16_f16 passes, fp32 accumulate: fp32-class, 5.3x less matrix-pipe time than the exact-fp32 MFMA); |dO|
+ * must stay below 65504 (the training step's loss scale puts it at <= 2^13).  The "f16x2" training backend's choice. */
+int ds_attention_bwd_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                           const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                           float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
 /* d emb[tokens[m]] += dx[m] (atomic) */
 int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
 /* y += a * x, n % 4 == 0 */

@@ -109,11 +109,13 @@ def test_softmax_backward_rows(L):
     assert close(dPc.cpu()[:, :n], s.grad) and (dPc[:, n:] == 0).all()
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("B,H,Lq,Lk,fusedkv", [(2, 16, 265, 265, 3), (2, 16, 265, 77, 2), (1, 2, 40, 33, 2), (3, 4, 288, 96, 2)])
-def test_attention_backward_recompute(L, B, H, Lq, Lk, fusedkv):
-    """ds_attention_bwd (two kernels, tile-wise recomputation, nothing stored between forward and backward but O):
-    dQ / dK / dV written in place into fused projection gradients, against float64 autograd of softmax(q k^T / 8) v;
-    the forward it differentiates is ds_attention on the same in-place operands."""
+def test_attention_backward_recompute(L, B, H, Lq, Lk, fusedkv, split):
+    """ds_attention_bwd / ds_attention_bwd_f16x2 (two kernels, tile-wise recomputation, nothing stored between forward and
+    backward but O): dQ / dK / dV written in place into fused projection gradients, against float64 autograd of
+    softmax(q k^T / 8) v; the forward it differentiates is ds_attention on the same in-place operands.  split: every tile
+    product on the fp16 matrix cores (3-pass split) with dO at the magnitude the training step's loss scale gives it."""
     D = H * 64
     if fusedkv == 3:            # self-attention: q | k | v columns of one [B*L][3D] buffer
         qkv = rnd((B * Lq, 3 * D), "ab.qkv.%d" % Lq, 1.5)
@@ -121,7 +123,7 @@ def test_attention_backward_recompute(L, B, H, Lq, Lk, fusedkv):
     else:                       # cross-attention: q [B*Lq][D], k | v columns of [B*Lk][2D]
         q, kv = rnd((B * Lq, D), "ab.q.%d" % Lq, 1.5), rnd((B * Lk, 2 * D), "ab.kv.%d" % Lk, 1.5)
         srcs = [(q, 0, D), (kv, 0, 2 * D), (kv, D, 2 * D)]
-    dO = rnd((B * Lq, D), "ab.do.%d" % Lq, 0.7)
+    dO = rnd((B * Lq, D), "ab.do.%d" % Lq, 0.7 * (4096.0 if split else 1.0))      # (split: |dO| up to 2^11.5, as under the loss scale)
 
     def heads(t, col, Lx):
         return t[:, col:col + D].reshape(B, Lx, H, 64).permute(0, 2, 1, 3)
@@ -139,7 +141,8 @@ def test_attention_backward_recompute(L, B, H, Lq, Lk, fusedkv):
     gops = [(grads[id(t)], col, ld) for t, col, ld in srcs]
     stats = torch.empty(2 * B * H * ((Lq + 31) // 32 * 32), device="cuda")
     dOc = dO.cuda()
-    L.check(L.lib().ds_attention_bwd(
+    bwd = L.lib().ds_attention_bwd_f16x2 if split else L.lib().ds_attention_bwd
+    L.check(bwd(
         L.ptr_off(*ops[0][:2]), ops[0][2], L.ptr_off(*ops[1][:2]), ops[1][2], L.ptr_off(*ops[2][:2]), ops[2][2], L.ptr(o), D,
         L.ptr(dOc), D, L.ptr_off(*gops[0][:2]), gops[0][2], L.ptr_off(*gops[1][:2]), gops[1][2], L.ptr_off(*gops[2][:2]), gops[2][2],
         L.ptr(stats), B, H, Lq, Lk, 0.125, L.stream()))

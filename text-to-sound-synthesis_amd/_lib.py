@@ -93,6 +93,8 @@ _PROTOS = {
     "ds_softmax_bwd_rows": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_attention_bwd": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                    _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
+    "ds_attention_bwd_f16x2": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                   _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_embed_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_axpy": (C.c_int, [_vp, _vp, _f, _i64, _vp]),
     "ds_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, C.c_int, _vp]),

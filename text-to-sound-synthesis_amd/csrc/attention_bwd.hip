@@ -16,7 +16,17 @@
 // (7 tile products instead of the 5 of a formulation with cross-lane transposes; the exact-fp32 MFMA makes them the
 // cost of the kernels: 2 Lq Lk 64 flops each at 157 TFLOP/s peak.)  One LDS buffer per workgroup, re-staged between
 // the phases (K, V, K  /  Q, dO, Q), two workgroups per CU.
+//
+// SPLIT = true (round 5, ds_attention_bwd_f16x2: the "f16x2" training backend): the same kernels, the same data movement
+// (fp32 rows in LDS, fp32 fragments from global memory), but every tile product runs on v_mfma_f32_32x32x16_f16 with both
+// operands split into fp16 hi + lo on the fly (a0b0 + a0b1 + a1b0, fp32 accumulate -- the arithmetic of gemm_f16x2.hip):
+// 12 MFMAs of 8 passes per 64-deep tile product instead of 32 of 16 passes, i.e. 5.3x less matrix-pipe time for ~100 VALU
+// conversions per product.  Only the k-index mapping of the fragments changes (a lane holds 8 consecutive d / 8 of its own
+// accumulator rows per MFMA instead of 1).  P in [0, 1] is multiplied by 2^10 before it is split (its lo plane would sit in
+// fp16's subnormal range otherwise) and dV by 2^-10 when it is stored; dO / dS carry the step's loss scale (|.| < 2^16).
 #include "common.h"
+
+typedef _Float16 ab_h8 __attribute__((ext_vector_type(8)));
 
 #define AB_LD 68
 #define AB_WAVES 3
@@ -51,6 +61,7 @@ __device__ __forceinline__ void ab_stage(float* __restrict__ lds, const float* _
 
 // tile product with the register index on the ROWS of the result: acc[i = lds row (tile * 32 + lane & 31)][j = the
 // lane's own row of the register operand]:  acc += X_lds[tile rows][d] * Y_reg[d]   (attention.hip pass 1)
+struct AbFragF;
 __device__ __forceinline__ void ab_rows_times_reg(f32x16& acc, const float* __restrict__ lds, int tile, int l31, int hh,
                                                   const f32x4 (&yf)[8]) {
     const float* xr = lds + (tile * 32 + l31) * AB_LD + 4 * hh;
@@ -76,26 +87,129 @@ __device__ __forceinline__ void ab_reg_times_rows(f32x16& o0, f32x16& o1, const 
 }
 
 // lane (row = lane & 31, half hh) keeps X[row][8c + 4hh + j], c = 0..7, j = 0..3
-__device__ __forceinline__ void ab_load_frag(f32x4 (&f)[8], const float* __restrict__ rowp, int hh) {
+struct AbFragF {
+    f32x4 v[8];
+};
+__device__ __forceinline__ void ab_load_frag(AbFragF& f, const float* __restrict__ rowp, int hh) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) f[c] = *(const f32x4*)(rowp + 4 * hh + 8 * c);
+    for (int c = 0; c < 8; ++c) f.v[c] = *(const f32x4*)(rowp + 4 * hh + 8 * c);
 }
 
-// result tile [32 rows over registers][lane & 31 (+32) = d] -> dst rows row0 + .., for rows < limit
+// ---- SPLIT forms: the register fragment of a 64-deep row as fp16 hi / lo, k-block c (16 k) = X[row][16c + 8hh + 0..7] ----
+struct AbFragH {
+    ab_h8 hi[4], lo[4];
+};
+__device__ __forceinline__ void ab_split8(const f32x4& a, const f32x4& b, ab_h8& hi, ab_h8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = ds_split_hi(a[e]);
+        lo[e] = ds_split_lo(a[e], hi[e]);
+        hi[4 + e] = ds_split_hi(b[e]);
+        lo[4 + e] = ds_split_lo(b[e], hi[4 + e]);
+    }
+}
+__device__ __forceinline__ void ab_load_frag(AbFragH& f, const float* __restrict__ rowp, int hh) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 a = *(const f32x4*)(rowp + 8 * hh + 16 * c), b = *(const f32x4*)(rowp + 8 * hh + 16 * c + 4);
+        ab_split8(a, b, f.hi[c], f.lo[c]);
+    }
+}
+// delta_q = sum_d dO[q][d] O[q][d] needs the fp32 dO values of this lane's k-slots next to the split fragment
+__device__ __forceinline__ float ab_frag_dot(const float* __restrict__ ap, const float* __restrict__ bp, int hh, bool split) {
+    float acc = 0.f;
+    if (split) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 a = *(const f32x4*)(ap + 8 * hh + 16 * c + 4 * h), b = *(const f32x4*)(bp + 8 * hh + 16 * c + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += a[j] * b[j];
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 a = *(const f32x4*)(ap + 4 * hh + 8 * c), b = *(const f32x4*)(bp + 4 * hh + 8 * c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += a[j] * b[j];
+        }
+    }
+    return acc;
+}
+// acc[i = lds row][j = the lane's own register-operand row] += X_lds[tile rows][d] * Y_reg[d], three split passes per k-block
+__device__ __forceinline__ void ab_rows_times_reg(f32x16& acc, const float* __restrict__ lds, int tile, int l31, int hh,
+                                                  const AbFragH& y) {
+    const float* xr = lds + (tile * 32 + l31) * AB_LD + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 a = *(const f32x4*)(xr + 16 * c), b = *(const f32x4*)(xr + 16 * c + 4);
+        ab_h8 xh, xl;
+        ab_split8(a, b, xh, xl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, y.hi[c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, y.lo[c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, y.hi[c], acc, 0, 0, 0);
+    }
+}
+// out[i = lane's own index][d] += sum over the 32 register rows of `tile`: (wscale W[i][row]) * Z_lds[row][d].  MFMA m (0, 1)
+// contracts the 16 rows held in accumulator registers 8m .. 8m+7 of the two lane halves: k-slot (hh, e) <-> row
+// (e & 3) + 8 (2m + (e >> 2)) + 4 hh -- the A operand is the lane's own registers, the B operand 8 scalar LDS reads.
+__device__ __forceinline__ void ab_reg_times_rows_split(f32x16& o0, f32x16& o1, const f32x16& w, const float* __restrict__ lds,
+                                                        int tile, int l31, int hh, float wscale) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        ab_h8 wh, wl, z0h, z0l, z1h, z1l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float wv = w[8 * m + e] * wscale;
+            wh[e] = ds_split_hi(wv);
+            wl[e] = ds_split_lo(wv, wh[e]);
+            const int row = tile * 32 + (e & 3) + 8 * (2 * m + (e >> 2)) + 4 * hh;
+            const float* zr = lds + row * AB_LD + l31;
+            const float za = zr[0], zb = zr[32];
+            z0h[e] = ds_split_hi(za);
+            z0l[e] = ds_split_lo(za, z0h[e]);
+            z1h[e] = ds_split_hi(zb);
+            z1l[e] = ds_split_lo(zb, z1h[e]);
+        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, z0h, o0, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, z0l, o0, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, z0h, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, z1h, o1, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, z1l, o1, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, z1h, o1, 0, 0, 0);
+    }
+}
+
+// result tile [32 rows over registers][lane & 31 (+32) = d] -> dst rows row0 + .., for rows < limit (oscale: a power of two)
 __device__ __forceinline__ void ab_store_tile(float* __restrict__ dst, int ld, int row0, int limit, const f32x16& o0, const f32x16& o1,
-                                              int l31, int hh) {
+                                              int l31, int hh, float oscale = 1.f) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (row < limit) {
             float* p = dst + (size_t)row * ld + l31;
-            p[0] = o0[r];
-            p[32] = o1[r];
+            p[0] = o0[r] * oscale;
+            p[32] = o1[r] * oscale;
         }
     }
 }
 
-template <int NKT>
+template <bool SPLIT> struct AbSel { typedef AbFragF Frag; };
+template <> struct AbSel<true> { typedef AbFragH Frag; };
+__device__ __forceinline__ void ab_rows_times_reg(f32x16& acc, const float* __restrict__ lds, int tile, int l31, int hh,
+                                                  const AbFragF& y) {
+    ab_rows_times_reg(acc, lds, tile, l31, hh, y.v);
+}
+template <bool SPLIT>
+__device__ __forceinline__ void ab_reg_times_rows_any(f32x16& o0, f32x16& o1, const f32x16& w, const float* __restrict__ lds, int tile,
+                                                      int l31, int hh, float wscale = 1.f) {
+    if (SPLIT) ab_reg_times_rows_split(o0, o1, w, lds, tile, l31, hh, wscale);
+    else ab_reg_times_rows(o0, o1, w, lds, tile, l31, hh);       // (wscale is 1 in the exact-fp32 form)
+}
+#define AB_PSCALE 1024.f      // SPLIT: P * 2^10 is what gets split (its lo plane stays in fp16's normal range), dV * 2^-10 stored
+
+template <int NKT, bool SPLIT>
 __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
                                                                 int ldk, const float* __restrict__ Vp, int ldv,
                                                                 const float* __restrict__ O, int ldo, const float* __restrict__ dO,
@@ -116,7 +230,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
     ab_stage<NKT, 4>(kv, kb, ldk, Lk, tid);
     f32x16 s[NKT];
     {
-        f32x4 qf[8];
+        typename AbSel<SPLIT>::Frag qf;
         ab_load_frag(qf, Q + qrow * ldq + head * 64, hh);
         __syncthreads();
         if (active) {
@@ -165,19 +279,10 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
     // dO fragment and delta_q = sum_d dO O  (loaded only now: with the Q fragment still live the kernel would not fit
     // its 256 registers; the fence keeps the scheduler from hoisting the loads over the softmax)
     AB_FENCE();
-    f32x4 dof[8];
+    typename AbSel<SPLIT>::Frag dof;
     ab_load_frag(dof, dO + qrow * lddo + head * 64, hh);
-    float delta = 0.f;
-    {
-        const float* op = O + qrow * ldo + head * 64 + 4 * hh;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 o4 = *(const f32x4*)(op + 8 * c);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) delta += dof[c][j] * o4[j];
-        }
-        delta += __shfl_xor(delta, 32);
-    }
+    float delta = ab_frag_dot(dO + qrow * lddo + head * 64, O + qrow * ldo + head * 64, hh, SPLIT);   // (fp32 values, L1-hot)
+    delta += __shfl_xor(delta, 32);
     if (active && hh == 0 && q0 + l31 < Lq) {
         const int lqs = ((Lq + 31) >> 5) << 5;
         float* st = stats + ((size_t)b * heads + head) * lqs + q0 + l31;
@@ -205,12 +310,12 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) ab_reg_times_rows(o0, o1, s[kt], kv, kt, l31, hh);   // dQ = dS K
+        for (int kt = 0; kt < NKT; ++kt) ab_reg_times_rows_any<SPLIT>(o0, o1, s[kt], kv, kt, l31, hh);   // dQ = dS K
         ab_store_tile(dQ + (size_t)b * Lq * lddq + head * 64, lddq, q0, Lq, o0, o1, l31, hh);
     }
 }
 
-template <int NQT>
+template <int NQT, bool SPLIT>
 __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ Kp,
                                                                  int ldk, const float* __restrict__ Vp, int ldv,
                                                                  const float* __restrict__ dO, int lddo, float* __restrict__ dK, int lddk,
@@ -242,7 +347,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
     }
     f32x16 t[NQT];
     {
-        f32x4 kf[8];
+        typename AbSel<SPLIT>::Frag kf;
         ab_load_frag(kf, Kp + krow * ldk + head * 64, hh);
         __syncthreads();
         if (active) {
@@ -267,9 +372,10 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows(o0, o1, t[qt], qs, qt, l31, hh);   // dV = P^T dO
-        ab_store_tile(dV + (size_t)b * Lk * lddv + head * 64, lddv, k0, Lk, o0, o1, l31, hh);
-        f32x4 vf[8];
+        for (int qt = 0; qt < NQT; ++qt)
+            ab_reg_times_rows_any<SPLIT>(o0, o1, t[qt], qs, qt, l31, hh, SPLIT ? AB_PSCALE : 1.f);   // dV = P^T dO
+        ab_store_tile(dV + (size_t)b * Lk * lddv + head * 64, lddv, k0, Lk, o0, o1, l31, hh, SPLIT ? 1.f / AB_PSCALE : 1.f);
+        typename AbSel<SPLIT>::Frag vf;
         ab_load_frag(vf, Vp + krow * ldv + head * 64, hh);
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
@@ -293,7 +399,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows(o0, o1, t[qt], qs, qt, l31, hh);   // dK = dS^T Q
+        for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows_any<SPLIT>(o0, o1, t[qt], qs, qt, l31, hh);   // dK = dS^T Q
         ab_store_tile(dK + (size_t)b * Lk * lddk + head * 64, lddk, k0, Lk, o0, o1, l31, hh);
     }
 }
@@ -312,10 +418,10 @@ static int ab_set_lds(KernelT kernel, size_t lds, DsOnce& done) {
 
 // Q / O / dO / dQ: [B*Lq][ld] (head h at columns h*64..), K / V / dK / dV: [B*Lk][ld]; any row strides (column ranges of
 // fused projections are addressed in place).  stats: 2 * B * heads * ceil32(Lq) floats of workspace.
-extern "C" int ds_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
-                                const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
-                                float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+template <bool SPLIT>
+static int ab_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                     const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, float* stats, int B,
+                     int heads, int Lq, int Lk, float scale, hipStream_t stream) {
     DS_CHECK_ARG(q && k && v && o && d_o && dq && dk && dv && stats, "null pointer");
     DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lq <= 288 && Lk <= 288, "at most 288 queries / keys are supported");
     DS_CHECK_ARG(((ldq | ldk | ldv | ldo | lddo) & 3) == 0, "leading dims of the inputs must be multiples of 4");
@@ -324,22 +430,38 @@ extern "C" int ds_attention_bwd(const float* q, int ldq, const float* k, int ldk
     static DsOnce a3, a9, akv;
     if (Lk <= 96) {
         const size_t lds = 3 * 32 * AB_LD * sizeof(float);
-        if (ab_set_lds(ds_attn_bwd_q_kernel<3>, lds, a3)) return -2;
-        hipLaunchKernelGGL((ds_attn_bwd_q_kernel<3>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o, ldo,
-                           d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
+        if (ab_set_lds(ds_attn_bwd_q_kernel<3, SPLIT>, lds, a3)) return -2;
+        hipLaunchKernelGGL((ds_attn_bwd_q_kernel<3, SPLIT>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o,
+                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
     } else {
         const size_t lds = 9 * 32 * AB_LD * sizeof(float);
-        if (ab_set_lds(ds_attn_bwd_q_kernel<9>, lds, a9)) return -2;
-        hipLaunchKernelGGL((ds_attn_bwd_q_kernel<9>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o, ldo,
-                           d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
+        if (ab_set_lds(ds_attn_bwd_q_kernel<9, SPLIT>, lds, a9)) return -2;
+        hipLaunchKernelGGL((ds_attn_bwd_q_kernel<9, SPLIT>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o,
+                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
     }
     DS_CHECK_LAUNCH();
     {
         const size_t lds = (9 * 32 * AB_LD + 2 * 9 * 32) * sizeof(float);
-        if (ab_set_lds(ds_attn_bwd_kv_kernel<9>, lds, akv)) return -2;
-        hipLaunchKernelGGL((ds_attn_bwd_kv_kernel<9>), dim3(kgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, d_o,
-                           lddo, dk, lddk, dv, lddv, stats, Lq, Lk, heads, scale);
+        if (ab_set_lds(ds_attn_bwd_kv_kernel<9, SPLIT>, lds, akv)) return -2;
+        hipLaunchKernelGGL((ds_attn_bwd_kv_kernel<9, SPLIT>), dim3(kgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv,
+                           d_o, lddo, dk, lddk, dv, lddv, stats, Lq, Lk, heads, scale);
     }
     DS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ds_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                                const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                                float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
+    return ab_launch<false>(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, dq, lddq, dk, lddk, dv, lddv, stats, B, heads, Lq, Lk, scale,
+                            (hipStream_t)stream_);
+}
+
+// the same backward with every tile product on the fp16 matrix cores (3-pass split, fp32-class; |dO| must stay below 65504:
+// the training step's loss scale sees to it)
+extern "C" int ds_attention_bwd_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                      int ldo, const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv,
+                                      int lddv, float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
+    return ab_launch<true>(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, dq, lddq, dk, lddk, dv, lddv, stats, B, heads, Lq, Lk, scale,
+                           (hipStream_t)stream_);
 }

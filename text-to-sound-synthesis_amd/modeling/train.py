@@ -31,11 +31,12 @@ Two GEMM backends (`TrainStep(precision=...)`), both behind the same step:
            2^12..2^13.  The step has no host synchronisation at all and is captured in a hipGraph (`capture`): one graph
            launch per iteration instead of ~2000 kernel launches from Python.
 
-Attention is exact fp32 in both modes: `attention="fused"` (default) = `ds_attention` forward + `ds_attention_bwd`, a
-backward by tile-wise recomputation that reads Q | K | V and writes dQ | dK | dV in place in the fused projection buffers
-and never stores the probabilities; `attention="composed"` = grouped fp32 GEMMs + row softmax with materialised
-probabilities and torch head split / merge / transposes (the first version, kept as a cross-check).  The norms and the
-loss tail are exact fp32 too.  Worst per-tensor gradient error against autograd through the oracle, all 63 tensors of the
+Attention: `attention="fused"` (default) = a fused forward + a backward by tile-wise recomputation that reads Q | K | V and
+writes dQ | dK | dV in place in the fused projection buffers and never stores the probabilities -- `ds_attention` +
+`ds_attention_bwd` on the exact-fp32 MFMA in the "fp32" backend, `ds_attention_f16x2` + `ds_attention_bwd_f16x2` (every tile
+product on the fp16 matrix cores, 3-pass split, fp32-class) in the "f16x2" backend; `attention="composed"` = grouped fp32
+GEMMs + row softmax with materialised probabilities and torch head split / merge / transposes (the first version, kept as a
+cross-check).  The norms and the loss tail are exact fp32.  Worst per-tensor gradient error against autograd through the oracle, all 63 tensors of the
 2-layer test model: see tests/test_hip_train_kernels.py.
 """
 import math
@@ -333,16 +334,21 @@ class _FusedAttn:
         """split: the forward on the streamed fp16-split attention kernel of the sampling path (ds_attention_f16x2: fp32-class,
         2e-5 max-abs against float64 where the exact-fp32 kernel has 1e-6; 3-4x faster) -- the "f16x2" backend's choice; the
         backward recomputes the probabilities in exact fp32 either way."""
-        self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H = q, k, v, B, Lq, Lk, H
+        self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H, self.split = q, k, v, B, Lq, Lk, H, split
         self.out = torch.empty(B * Lq, H * 64, device=q[0].device)
         fn = L_.lib().ds_attention_f16x2 if split else L_.lib().ds_attention
         L_.check(fn(L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2],
                     L_.ptr(self.out), H * 64, B, H, Lq, Lk, 0.125, L_.stream()))
 
-    def backward(self, dO, dq, dk, dv):
+    def backward(self, dO, dq, dk, dv, amax=None):
+        """split: the tile products of the recomputation on the fp16 matrix cores too (ds_attention_bwd_f16x2); dO enters
+        them as an fp16-split operand, so its magnitude is folded into the step's saturation monitor (`amax`)."""
         q, k, v, B, Lq, Lk, H = self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H
         stats = torch.empty(2 * B * H * _ceil(Lq, 32), device=dO.device)
-        L_.check(L_.lib().ds_attention_bwd(
+        if self.split and amax is not None:
+            L_.check(L_.lib().ds_amax(L_.ptr(dO), dO.numel(), L_.ptr(amax), L_.stream()))
+        bwd = L_.lib().ds_attention_bwd_f16x2 if self.split else L_.lib().ds_attention_bwd
+        L_.check(bwd(
             L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2], L_.ptr(self.out), H * 64,
             L_.ptr(dO), H * 64, L_.ptr_off(dq[0], dq[1]), dq[2], L_.ptr_off(dk[0], dk[1]), dk[2], L_.ptr_off(dv[0], dv[1]), dv[2],
             L_.ptr(stats), B, H, Lq, Lk, 0.125, L_.stream()))
@@ -702,7 +708,7 @@ class TrainStep:
             dq = torch.empty(M, D, device=dev)
             dkv = torch.empty(B * Lc, 2 * D, device=dev)
             if fused:
-                s["att2"].backward(dao, (dq, 0, D), (dkv, 0, 2 * D), (dkv, D, 2 * D))
+                s["att2"].backward(dao, (dq, 0, D), (dkv, 0, 2 * D), (dkv, D, 2 * D), amax=amax)
             else:
                 s["att2"].backward(dao, dq, dkv[:, :D], dkv[:, D:])
             dh, g[p + "attn2.query.weight"], g[p + "attn2.query.bias"] = lin_bwd(ls["q2"], s["h2"], dq)
@@ -716,7 +722,7 @@ class TrainStep:
             dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["o1"], dx)
             dqkv = torch.empty(M, 3 * D, device=dev)
             if fused:
-                s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D))
+                s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D), amax=amax)
             else:
                 s["att1"].backward(dao, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
             dh, dWqkv, dbqkv = lin_bwd(ls["qkv1"], s["h1"], dqkv)
