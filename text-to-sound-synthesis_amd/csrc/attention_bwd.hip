@@ -17,11 +17,11 @@
 // cost of the kernels: 2 Lq Lk 64 flops each at 157 TFLOP/s peak.)  One LDS buffer per workgroup, re-staged between
 // the phases (K, V, K  /  Q, dO, Q), two workgroups per CU.
 //
-// SPLIT = true (round 5, ds_attention_bwd_f16x2: the "f16x2" training backend): the same kernels, the same data movement
-// (fp32 rows in LDS, fp32 fragments from global memory), but every tile product runs on v_mfma_f32_32x32x16_f16 with both
-// operands split into fp16 hi + lo on the fly (a0b0 + a0b1 + a1b0, fp32 accumulate -- the arithmetic of gemm_f16x2.hip):
-// 12 MFMAs of 8 passes per 64-deep tile product instead of 32 of 16 passes, i.e. 5.3x less matrix-pipe time for ~100 VALU
-// conversions per product.  Only the k-index mapping of the fragments changes (a lane holds 8 consecutive d / 8 of its own
+// SPLIT = true (round 5, ds_attention_bwd_f16x2: the "f16x2" training backend): the same two kernels and phases, but every
+// tile product runs on v_mfma_f32_32x32x16_f16 with both operands as fp16 hi + lo (a0b0 + a0b1 + a1b0, fp32 accumulate -- the
+// arithmetic of gemm_f16x2.hip): 12 MFMAs of 8 passes per 64-deep tile product instead of 32 of 16 passes, i.e. 5.3x less
+// matrix-pipe time.  The LDS operand is split ONCE when it is staged (two swizzled fp16 planes, ab_stage_split), register
+// fragments when they are loaded, the score / dS tiles right at the MFMA.  Only the k-index mapping of the fragments changes (a lane holds 8 consecutive d / 8 of its own
 // accumulator rows per MFMA instead of 1).  P in [0, 1] is multiplied by 2^10 before it is split (its lo plane would sit in
 // fp16's subnormal range otherwise) and dV by 2^-10 when it is stored; dO / dS carry the step's loss scale (|.| < 2^16).
 #include "common.h"
@@ -137,15 +137,53 @@ __device__ __forceinline__ float ab_frag_dot(const float* __restrict__ ap, const
     }
     return acc;
 }
+// SPLIT staging: the operand rows go to LDS ALREADY SPLIT -- two fp16 planes [rows][64 halves] (hi, then lo `AB_HPLANE(NT)`
+// halves further), 128-byte rows without padding, the 16-byte chunk c of row r at chunk position c ^ (r & 7) (the 32 lanes
+// of a fragment read cover all banks; 73.7 KB per workgroup against 78.3 KB of padded fp32 rows).  An element is converted
+// ONCE per workgroup here instead of once per wave and use in the products (the first form of this kernel -- fp32 rows,
+// conversion at the MFMA -- was VALU-bound: 104 / 115 us per launch against 143 / 160 on the fp32 MFMA).
+#define AB_HPLANE(NT_) ((NT_) * 32 * 64)
+__device__ __forceinline__ int ab_hoff(int row, int d) { return row * 64 + ((((d >> 3) ^ (row & 7))) << 3) + (d & 7); }
+typedef _Float16 ab_h4 __attribute__((ext_vector_type(4)));
+template <int NT, int INFLIGHT>
+__device__ __forceinline__ void ab_stage_split(_Float16* __restrict__ lds, const float* __restrict__ src, int ld, int valid, int tid) {
+    static_assert((NT * 32 * 16) % (AB_NT * INFLIGHT) == 0, "staging trip count");
+    asm volatile("" : "+v"(tid));
+    for (int it0 = 0; it0 < NT * 32 * 16 / AB_NT; it0 += INFLIGHT) {
+        f32x4 t8[INFLIGHT];
+#pragma unroll
+        for (int u = 0; u < INFLIGHT; ++u) {
+            const int f = tid + (it0 + u) * AB_NT;
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            t8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < valid) t8[u] = *(const f32x4*)(src + (size_t)row * ld + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < INFLIGHT; ++u) {
+            const int f = tid + (it0 + u) * AB_NT;
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            ab_h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = ds_split_hi(t8[u][e]);
+                lo[e] = ds_split_lo(t8[u][e], hi[e]);
+            }
+            _Float16* d = lds + ab_hoff(row, c4);          // 4 consecutive d stay inside one 8-half chunk
+            *(ab_h4*)d = hi;
+            *(ab_h4*)(d + AB_HPLANE(NT)) = lo;
+        }
+    }
+}
 // acc[i = lds row][j = the lane's own register-operand row] += X_lds[tile rows][d] * Y_reg[d], three split passes per k-block
-__device__ __forceinline__ void ab_rows_times_reg(f32x16& acc, const float* __restrict__ lds, int tile, int l31, int hh,
-                                                  const AbFragH& y) {
-    const float* xr = lds + (tile * 32 + l31) * AB_LD + 8 * hh;
+template <int NT>
+__device__ __forceinline__ void ab_rows_times_reg_h(f32x16& acc, const _Float16* __restrict__ lds, int tile, int l31, int hh,
+                                                    const AbFragH& y) {
+    const int row = tile * 32 + l31;
+    const _Float16* xr = lds + row * 64;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const f32x4 a = *(const f32x4*)(xr + 16 * c), b = *(const f32x4*)(xr + 16 * c + 4);
-        ab_h8 xh, xl;
-        ab_split8(a, b, xh, xl);
+        const int off = ((2 * c + hh) ^ (row & 7)) << 3;                       // k-block c: d = 16c + 8hh + 0..7
+        const ab_h8 xh = *(const ab_h8*)(xr + off), xl = *(const ab_h8*)(xr + AB_HPLANE(NT) + off);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, y.hi[c], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, y.lo[c], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, y.hi[c], acc, 0, 0, 0);
@@ -154,8 +192,10 @@ __device__ __forceinline__ void ab_rows_times_reg(f32x16& acc, const float* __re
 // out[i = lane's own index][d] += sum over the 32 register rows of `tile`: (wscale W[i][row]) * Z_lds[row][d].  MFMA m (0, 1)
 // contracts the 16 rows held in accumulator registers 8m .. 8m+7 of the two lane halves: k-slot (hh, e) <-> row
 // (e & 3) + 8 (2m + (e >> 2)) + 4 hh -- the A operand is the lane's own registers, the B operand 8 scalar LDS reads.
-__device__ __forceinline__ void ab_reg_times_rows_split(f32x16& o0, f32x16& o1, const f32x16& w, const float* __restrict__ lds,
+template <int NT>
+__device__ __forceinline__ void ab_reg_times_rows_split(f32x16& o0, f32x16& o1, const f32x16& w, const _Float16* __restrict__ lds,
                                                         int tile, int l31, int hh, float wscale) {
+    const int c0 = l31 >> 3, d7 = l31 & 7;                 // d = l31 (o0) and 32 + l31 (o1): chunks c0 and 4 + c0
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         ab_h8 wh, wl, z0h, z0l, z1h, z1l;
@@ -165,12 +205,12 @@ __device__ __forceinline__ void ab_reg_times_rows_split(f32x16& o0, f32x16& o1, 
             wh[e] = ds_split_hi(wv);
             wl[e] = ds_split_lo(wv, wh[e]);
             const int row = tile * 32 + (e & 3) + 8 * (2 * m + (e >> 2)) + 4 * hh;
-            const float* zr = lds + row * AB_LD + l31;
-            const float za = zr[0], zb = zr[32];
-            z0h[e] = ds_split_hi(za);
-            z0l[e] = ds_split_lo(za, z0h[e]);
-            z1h[e] = ds_split_hi(zb);
-            z1l[e] = ds_split_lo(zb, z1h[e]);
+            const _Float16* zr = lds + row * 64 + d7;
+            const int o0f = (c0 ^ (row & 7)) << 3, o1f = ((4 + c0) ^ (row & 7)) << 3;
+            z0h[e] = zr[o0f];
+            z0l[e] = zr[AB_HPLANE(NT) + o0f];
+            z1h[e] = zr[o1f];
+            z1l[e] = zr[AB_HPLANE(NT) + o1f];
         }
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, z0h, o0, 0, 0, 0);
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, z0l, o0, 0, 0, 0);
@@ -201,12 +241,26 @@ __device__ __forceinline__ void ab_rows_times_reg(f32x16& acc, const float* __re
                                                   const AbFragF& y) {
     ab_rows_times_reg(acc, lds, tile, l31, hh, y.v);
 }
-template <bool SPLIT>
+// the same LDS buffer is fp32 rows (exact form) or fp16 planes (SPLIT): the *_any forms dispatch at compile time
+template <bool SPLIT, int NT>
 __device__ __forceinline__ void ab_reg_times_rows_any(f32x16& o0, f32x16& o1, const f32x16& w, const float* __restrict__ lds, int tile,
                                                       int l31, int hh, float wscale = 1.f) {
-    if (SPLIT) ab_reg_times_rows_split(o0, o1, w, lds, tile, l31, hh, wscale);
+    if constexpr (SPLIT) ab_reg_times_rows_split<NT>(o0, o1, w, (const _Float16*)lds, tile, l31, hh, wscale);
     else ab_reg_times_rows(o0, o1, w, lds, tile, l31, hh);       // (wscale is 1 in the exact-fp32 form)
 }
+template <bool SPLIT, int NT, typename Frag>
+__device__ __forceinline__ void ab_rows_times_reg_any(f32x16& acc, const float* __restrict__ lds, int tile, int l31, int hh,
+                                                      const Frag& y) {
+    if constexpr (SPLIT) ab_rows_times_reg_h<NT>(acc, (const _Float16*)lds, tile, l31, hh, y);
+    else ab_rows_times_reg(acc, lds, tile, l31, hh, y);
+}
+template <bool SPLIT, int NT, int INFLIGHT>
+__device__ __forceinline__ void ab_stage_any(float* __restrict__ lds, const float* __restrict__ src, int ld, int valid, int tid) {
+    if constexpr (SPLIT) ab_stage_split<NT, INFLIGHT>((_Float16*)lds, src, ld, valid, tid);
+    else ab_stage<NT, INFLIGHT>(lds, src, ld, valid, tid);
+}
+// floats of the operand buffer for NT row tiles
+template <bool SPLIT> __host__ __device__ constexpr int ab_buf_floats(int nt) { return SPLIT ? nt * 32 * 64 : nt * 32 * AB_LD; }
 #define AB_PSCALE 1024.f      // SPLIT: P * 2^10 is what gets split (its lo plane stays in fp16's normal range), dV * 2^-10 stored
 
 template <int NKT, bool SPLIT>
@@ -227,7 +281,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
     if (qr >= Lq) qr = Lq - 1;
     const size_t qrow = (size_t)b * Lq + qr;
 
-    ab_stage<NKT, 4>(kv, kb, ldk, Lk, tid);
+    ab_stage_any<SPLIT, NKT, 4>(kv, kb, ldk, Lk, tid);
     f32x16 s[NKT];
     {
         typename AbSel<SPLIT>::Frag qf;
@@ -238,12 +292,12 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
             for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-                ab_rows_times_reg(s[kt], kv, kt, l31, hh, qf);          // S^T tile: rows = keys, lane = query
+                ab_rows_times_reg_any<SPLIT, NKT>(s[kt], kv, kt, l31, hh, qf);          // S^T tile: rows = keys, lane = query
             }
         }
     }
     __syncthreads();                          // everyone is done reading K
-    ab_stage<NKT, 2>(kv, vb, ldv, Lk, tid);  // V into the same buffer (its latency runs under the softmax)
+    ab_stage_any<SPLIT, NKT, 2>(kv, vb, ldv, Lk, tid);  // V into the same buffer (its latency runs under the softmax)
 
     // softmax over the keys of query l31, exactly as the forward (attention.hip)
     float Lrow = 0.f;
@@ -296,21 +350,21 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
             f32x16 dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = 0.f;
-            ab_rows_times_reg(dp, kv, kt, l31, hh, dof);                // dP^T tile = V dO^T
+            ab_rows_times_reg_any<SPLIT, NKT>(dp, kv, kt, l31, hh, dof);                // dP^T tile = V dO^T
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = scale * s[kt][r] * (dp[r] - delta);   // dS^T (0 for masked keys: P = 0)
             AB_FENCE();                       // one dP tile live at a time
         }
     }
     __syncthreads();
-    ab_stage<NKT, 2>(kv, kb, ldk, Lk, tid);  // K again
+    ab_stage_any<SPLIT, NKT, 2>(kv, kb, ldk, Lk, tid);  // K again
     __syncthreads();
     if (active) {
         f32x16 o0, o1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) ab_reg_times_rows_any<SPLIT>(o0, o1, s[kt], kv, kt, l31, hh);   // dQ = dS K
+        for (int kt = 0; kt < NKT; ++kt) ab_reg_times_rows_any<SPLIT, NKT>(o0, o1, s[kt], kv, kt, l31, hh);   // dQ = dS K
         ab_store_tile(dQ + (size_t)b * Lq * lddq + head * 64, lddq, q0, Lq, o0, o1, l31, hh);
     }
 }
@@ -322,7 +376,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
                                                                  float* __restrict__ dV, int lddv, const float* __restrict__ stats, int Lq,
                                                                  int Lk, int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQT*32][AB_LD] operand rows, then L[NQT*32], delta[NQT*32]
-    float* Ls = qs + NQT * 32 * AB_LD;
+    float* Ls = qs + ab_buf_floats<SPLIT>(NQT);
     float* Ds = Ls + NQT * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -336,7 +390,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
     if (kr >= Lk) kr = Lk - 1;
     const size_t krow = (size_t)b * Lk + kr;
 
-    ab_stage<NQT, 4>(qs, qb, ldq, Lq, tid);
+    ab_stage_any<SPLIT, NQT, 4>(qs, qb, ldq, Lq, tid);
     {
         const int lqs = ((Lq + 31) >> 5) << 5;
         const float* st = stats + ((size_t)b * heads + head) * lqs;
@@ -355,7 +409,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
             for (int qt = 0; qt < NQT; ++qt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t[qt][r] = 0.f;
-                ab_rows_times_reg(t[qt], qs, qt, l31, hh, kf);          // S tile: rows = queries, lane = key
+                ab_rows_times_reg_any<SPLIT, NQT>(t[qt], qs, qt, l31, hh, kf);          // S tile: rows = queries, lane = key
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -365,7 +419,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
         }
     }
     __syncthreads();                          // everyone is done reading Q
-    ab_stage<NQT, 2>(qs, dob, lddo, Lq, tid);
+    ab_stage_any<SPLIT, NQT, 2>(qs, dob, lddo, Lq, tid);
     __syncthreads();
     if (active) {
         f32x16 o0, o1;
@@ -373,7 +427,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt)
-            ab_reg_times_rows_any<SPLIT>(o0, o1, t[qt], qs, qt, l31, hh, SPLIT ? AB_PSCALE : 1.f);   // dV = P^T dO
+            ab_reg_times_rows_any<SPLIT, NQT>(o0, o1, t[qt], qs, qt, l31, hh, SPLIT ? AB_PSCALE : 1.f);   // dV = P^T dO
         ab_store_tile(dV + (size_t)b * Lk * lddv + head * 64, lddv, k0, Lk, o0, o1, l31, hh, SPLIT ? 1.f / AB_PSCALE : 1.f);
         typename AbSel<SPLIT>::Frag vf;
         ab_load_frag(vf, Vp + krow * ldv + head * 64, hh);
@@ -382,7 +436,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
             f32x16 dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = 0.f;
-            ab_rows_times_reg(dp, qs, qt, l31, hh, vf);                 // dP tile = dO V^T
+            ab_rows_times_reg_any<SPLIT, NQT>(dp, qs, qt, l31, hh, vf);                 // dP tile = dO V^T
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -392,14 +446,14 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
         }
     }
     __syncthreads();
-    ab_stage<NQT, 2>(qs, qb, ldq, Lq, tid);   // Q again
+    ab_stage_any<SPLIT, NQT, 2>(qs, qb, ldq, Lq, tid);   // Q again
     __syncthreads();
     if (active) {
         f32x16 o0, o1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows_any<SPLIT>(o0, o1, t[qt], qs, qt, l31, hh);   // dK = dS^T Q
+        for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows_any<SPLIT, NQT>(o0, o1, t[qt], qs, qt, l31, hh);   // dK = dS^T Q
         ab_store_tile(dK + (size_t)b * Lk * lddk + head * 64, lddk, k0, Lk, o0, o1, l31, hh);
     }
 }
@@ -429,19 +483,19 @@ static int ab_launch(const float* q, int ldq, const float* k, int ldk, const flo
     const int qgroups = ((Lq + 31) / 32 + AB_WAVES - 1) / AB_WAVES, kgroups = ((Lk + 31) / 32 + AB_WAVES - 1) / AB_WAVES;
     static DsOnce a3, a9, akv;
     if (Lk <= 96) {
-        const size_t lds = 3 * 32 * AB_LD * sizeof(float);
+        const size_t lds = ab_buf_floats<SPLIT>(3) * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_q_kernel<3, SPLIT>, lds, a3)) return -2;
         hipLaunchKernelGGL((ds_attn_bwd_q_kernel<3, SPLIT>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o,
                            ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
     } else {
-        const size_t lds = 9 * 32 * AB_LD * sizeof(float);
+        const size_t lds = ab_buf_floats<SPLIT>(9) * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_q_kernel<9, SPLIT>, lds, a9)) return -2;
         hipLaunchKernelGGL((ds_attn_bwd_q_kernel<9, SPLIT>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o,
                            ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
     }
     DS_CHECK_LAUNCH();
     {
-        const size_t lds = (9 * 32 * AB_LD + 2 * 9 * 32) * sizeof(float);
+        const size_t lds = (ab_buf_floats<SPLIT>(9) + 2 * 9 * 32) * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_kv_kernel<9, SPLIT>, lds, akv)) return -2;
         hipLaunchKernelGGL((ds_attn_bwd_kv_kernel<9, SPLIT>), dim3(kgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv,
                            d_o, lddo, dk, lddk, dv, lddv, stats, Lq, Lk, heads, scale);
