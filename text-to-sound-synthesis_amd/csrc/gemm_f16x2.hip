@@ -634,8 +634,10 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
         best = g_force_tile_h;
     } else {
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.groups > 1 ? p.groups : 1);
-        // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups
-        best = t128 >= (p.a_split ? 1000 : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
+        // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups; a packed split-K
+        // launch (the training step's dW) from 1.5 rounds on (3072 x 1024 in 4 K-ranges: 118 vs 128 us,
+        // profiles/r05g_train_gemm_packed_sweep.txt)
+        best = t128 >= (p.a_split ? (p.groups > 1 ? 700 : 1000) : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
     }
     g_last_tile = best;
     switch (best) {

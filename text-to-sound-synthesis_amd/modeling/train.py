@@ -180,17 +180,20 @@ class _SplitGemm:
             self.wexp[l.key] = 0 if (m == 0.0 or not math.isfinite(m)) else 13 - math.floor(math.log2(m))
 
     @staticmethod
-    def split_k(N, K):
-        """K-ranges of a dW launch: enough 128 x 128 tiles for about two rounds of the 512 resident workgroups."""
+    def split_k(N, K, M=4096):
+        """K-ranges of a dW = dY^T X launch over M rows, from the measured sweep of the packed kernel INCLUDING the fixed-order
+        reduction of the partial results (tools/train_gemm_ab.py -> profiles/r05g_train_gemm_packed_sweep.txt, M = 5300 / 1540):
+        >= 256 tiles of 128 x 128 (fc1 / fc2: half a round of the chip) run unsplit -- the partials' write + re-read costs more
+        than the idle slots (133 vs 148 us); smaller products take 4 ranges (1024 x 1024: 48 us against 52 at 8, 83 unsplit;
+        3072 x 1024: 118 against 124 unsplit), 2 when the contraction itself is short (the caption rows: 22 us against 31 at 8)."""
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        s = 1
-        while s < 8 and tiles * s * 2 <= 1024:
-            s *= 2
-        return s
+        if tiles >= 256:
+            return 1
+        return 4 if M >= 4096 else 2
 
     def rows_pad(self, lin, M):
         """the padded contraction length of this layer's dW = dY^T X over M rows: a multiple of 32 per K-range"""
-        return _ceil(M, 32 * self.split_k(lin.N, lin.K))
+        return _ceil(M, 32 * self.split_k(lin.N, lin.K, M))
 
     def prepare(self, lin):
         """W * 2^s -> row form [N][K] (forward) and transposed form [K][ceil32(N)] (dX), one pass"""
@@ -224,7 +227,7 @@ class _SplitGemm:
     def dw(self, lin, xp, dyp, inv_scale):
         N, K, Mp = lin.N, lin.K, dyp.rows_pad
         assert xp.rows_pad == Mp and xp.cols == K and dyp.cols == N
-        S = self.split_k(N, K)
+        S = self.split_k(N, K, dyp.rows)
         dev = dyp.t.device
         dW = torch.empty(N, K, device=dev)
         if S == 1:

@@ -1,6 +1,7 @@
-"""The training step's GEMM shapes (batch 20: M = 5300 rows) on the split kernel's two operand paths: A fp32 split by the
-loader + row-major fp16-plane W (what modeling/train.py uses) against packed split planes for both operands staged by
-LDS-DMA (what the sampling path uses), per tile configuration.  Decides whether packing the training operands pays.
+"""The training step's GEMM shapes (batch 20: M = 5300 rows; cross K|V: 1540 rows) on the packed-operand split kernel
+(gemm_f16x2.hip AMODE 2), per tile configuration -- and, for the weight-gradient products dW = dY^T X, per number of K-ranges
+S of the split-K launch INCLUDING the fixed-order reduction of the S partial results (ds_colsum).  Decides the dispatch
+thresholds of ds_launch_gemm_f16x2 for packed operands and modeling/train.py's _SplitGemm.split_k rule.
 Run on the GPU box:  python tools/train_gemm_ab.py"""
 import os
 import sys
@@ -9,17 +10,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from text_to_sound_synthesis_amd import _lib as L
 
-M0 = 20 * 265
-MP = 5376                      # the dW contraction length (M padded to 32 * 8 K-ranges)
-SHAPES = [("fwd/dX qkv   ", M0, 3072, 1024, 1), ("fwd/dX proj  ", M0, 1024, 1024, 1), ("fwd fc1/dX fc2", M0, 4096, 1024, 1),
-          ("fwd fc2/dX fc1", M0, 1024, 4096, 1), ("dX qkv (K=3072)", M0, 1024, 3072, 1),
-          ("dW proj  x8  ", 1024, 1024, MP, 8), ("dW qkv   x4  ", 3072, 1024, MP, 4), ("dW fc1   x4  ", 4096, 1024, MP, 4),
-          ("dW fc2   x4  ", 1024, 4096, MP, 4)]
+M0, MC = 20 * 265, 20 * 77
+FWD = [("fwd qkv / dX fc-like N=3072", M0, 3072, 1024), ("fwd proj / q2 / dX proj   ", M0, 1024, 1024),
+       ("fwd fc1 / dX fc2          ", M0, 4096, 1024), ("fwd fc2 / dX fc1          ", M0, 1024, 4096),
+       ("dX qkv (K = 3072)         ", M0, 1024, 3072), ("fwd kv2 (cond rows)       ", MC, 2048, 512)]
+DW = [("dW proj / q2 ", 1024, 1024, M0), ("dW qkv       ", 3072, 1024, M0), ("dW fc1       ", 4096, 1024, M0),
+      ("dW fc2       ", 1024, 4096, M0), ("dW kv2       ", 2048, 512, MC)]
 
 
-def split(a):
-    hi = a.clamp(-65504.0, 65504.0).half()
-    return torch.stack((hi, (a - hi.float()).clamp(-65504.0, 65504.0).half())).contiguous()
+def pack(src, rows, cols, rows_pad=0):
+    """ds_pack_operand: (row planes, plane stride) if rows_pad == 0 else (transposed planes, plane stride)"""
+    if rows_pad == 0:
+        pl = (rows + 15) // 16 * 16 * cols
+        d = torch.empty(2, pl, dtype=torch.int16, device="cuda")
+        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, 0, None, 0, L.ptr(d), pl, None, 0, 0, None, None, L.stream()))
+    else:
+        pl = (cols + 15) // 16 * 16 * rows_pad
+        d = torch.empty(2, pl, dtype=torch.int16, device="cuda")
+        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, 0, None, 0, None, 0, L.ptr(d), pl, rows_pad, None, None, L.stream()))
+    return d, pl
 
 
 def timeit(fn, n=10):
@@ -34,43 +43,47 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-tot = {}
-for name, M, N, K, S in SHAPES:
+for name, M, N, K in FWD:
     A = torch.randn(M, K, device="cuda")
-    W = torch.randn(N, K, device="cuda") * 0.05
-    fl = 2.0 * M * N * K
-    Wrow = split(W * 2.0 ** 4).view(torch.int16)                     # row-major planes [2][N][K]
-    A2 = L.pack_planes(split(A))
-    W2p = L.pack_planes(split(W * 2.0 ** 4)).view(torch.int16)
-    M16 = (M + 15) // 16 * 16
+    W = torch.randn(N, K, device="cuda")
+    Ap, apl = pack(A, M, K)
+    Wp, wpl = pack(W, N, K)
     out = torch.empty(M, N, device="cuda")
-    part = torch.empty(S, M * N, device="cuda")
-    row = []
-    # (a) the training step's launch: fp32 A, row-major planes, split-K groups for dW
-    if S == 1:
-        cur = lambda: L.gemm(A, Wrow, out, M, N, K, split2=2.0 ** -4)
-    else:
-        Kc = K // S
-        def cur():
-            L.gemm(A, Wrow, part, M, N, Kc, lda=K, ldw=K, ldc=N, groups=S, a_gstride=Kc, w_gstride=Kc, c_gstride=M * N,
-                   split2=2.0 ** -4, w_plane=N * K)
-            L.check(L.lib().ds_colsum(L.ptr(part), L.ptr(out), 1, S, M * N, M * N, 0, 0, L.stream()))
-    t = timeit(cur)
-    row.append("loader-split%s %7.1f us %6.1f TF" % (" x%d" % S if S > 1 else "   ", t, fl / t / 1e6))
-    tot.setdefault("cur", 0.0)
-    tot["cur"] += t
-    ref = out.clone()
-    # (b) packed operands, LDS-DMA staging, unsplit K, every tile configuration
-    best = None
-    for tile in (0, 1, 2):
+    fl, row = 2.0 * M * N * K, []
+    for tile in (-1, 0, 1, 2):
         L.lib().ds_gemm_f16x2_force_tile(tile)
-        run = lambda: L.gemm(A2, W2p, out, M, N, K, split2=2.0 ** -4, a_plane=M16 * K)
-        t = timeit(run)
-        err = (out - ref).abs().max().item() / ref.abs().max().item()
-        row.append("packed t%d %7.1f us %6.1f TF%s" % (tile, t, fl / t / 1e6, "" if err < 1e-5 else " ERR %.1e" % err))
-        best = t if best is None else min(best, t)
+        t = timeit(lambda: L.gemm(Ap, Wp, out, M, N, K, split2=1.0, a_plane=apl, w_plane=wpl))
+        row.append("%s %6.1f us %5.1f TF" % ("auto" if tile < 0 else "t%d" % tile, t, fl / t / 1e6))
     L.lib().ds_gemm_f16x2_force_tile(-1)
-    tot.setdefault("packed", 0.0)
-    tot["packed"] += best
     print("%s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
-print("sum over the listed shapes: loader-split %.0f us, best packed %.0f us" % (tot["cur"], tot["packed"]))
+
+for name, N, K, M in DW:
+    dY = torch.randn(M, N, device="cuda")
+    X = torch.randn(M, K, device="cuda")
+    fl = 2.0 * M * N * K
+    dW = torch.empty(N, K, device="cuda")
+    best = None
+    for S in (1, 2, 3, 4, 6, 8):
+        Mp = (M + 32 * S - 1) // (32 * S) * (32 * S)
+        a, apl = pack(dY, M, N, Mp)
+        w, wpl = pack(X, M, K, Mp)
+        part = torch.empty(S, N * K, device="cuda")
+        Kc = Mp // S
+        row = []
+        for tile in (0, 1, 2):
+            L.lib().ds_gemm_f16x2_force_tile(tile)
+
+            def run():
+                if S == 1:
+                    L.gemm(a, w, dW, N, K, Mp, split2=1.0, a_plane=apl, w_plane=wpl)
+                else:
+                    L.gemm(a, w, part, N, K, Kc, lda=Mp, ldw=Mp, ldc=K, groups=S, a_gstride=Kc * 16, w_gstride=Kc * 16,
+                           c_gstride=N * K, split2=1.0, a_plane=apl, w_plane=wpl)
+                    L.check(L.lib().ds_colsum(L.ptr(part), L.ptr(dW), 1, S, N * K, N * K, 0, 0, L.stream()))
+            t = timeit(run)
+            row.append("t%d %6.1f us" % (tile, t))
+            if best is None or t < best[0]:
+                best = (t, S, tile)
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+        print("%s N=%4d K=%4d M=%4d S=%d (Mp %4d) | %s" % (name, N, K, M, S, Mp, " | ".join(row)), flush=True)
+    print("%s best: %.1f us = %.1f TF-eq at S=%d tile %d" % (name, best[0], fl / best[0] / 1e6, best[1], best[2]), flush=True)
