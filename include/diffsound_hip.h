@@ -220,6 +220,9 @@ int ds_loss_tail_bwd(const float* logits, const int64_t* x0, const int64_t* xt, 
  * gradient (NULL to skip); D = 1024 */
 int ds_layernorm_bwd(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
                      const float* table, const int64_t* t, const float* gamma, ds_stream_t stream);
+/* the same, accumulating: dx += ... (the residual connection's gradient; replaces ds_layernorm_bwd + ds_axpy) */
+int ds_layernorm_bwd_acc(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
+                     const float* table, const int64_t* t, const float* gamma, ds_stream_t stream);
 /* out[g][c] (+)= sum over R rows of x[(g*gstride) + r*ld + c]: bias / scale / per-sample AdaLN gradients */
 int ds_colsum(const float* x, float* out, int G, int R, int C, long long ld, long long gstride, int accumulate,
               ds_stream_t stream);

@@ -48,6 +48,12 @@ def test_layernorm_backward(L, mode):
     L.check(L.lib().ds_layernorm_bwd(L.ptr(xc), L.ptr(dyc), L.ptr(dx), L.ptr(dyxn), M, Lr, D, mode, L.ptr(tabc), L.ptr(tc),
                                      L.ptr(gc), L.stream()))
     assert close(dx.cpu(), x.grad)
+    # the accumulating form: dx_res += d norm-input (what ds_layernorm_bwd followed by ds_axpy(dx_res, dx) gave, bit for bit)
+    res = rnd((M, D), "lnb.res", 2.0).cuda()
+    want = res + dx
+    L.check(L.lib().ds_layernorm_bwd_acc(L.ptr(xc), L.ptr(dyc), L.ptr(res), L.ptr(dyxn), M, Lr, D, mode, L.ptr(tabc), L.ptr(tc),
+                                         L.ptr(gc), L.stream()))
+    assert torch.equal(res, want)
     if mode == 0:   # per-sample scale / shift gradients = the rows of d tab[t]
         ds_ = torch.empty(2, D, device="cuda")
         db_ = torch.empty(2, D, device="cuda")

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void ds_layernorm_bwd_kernel(const float* __re
                                                                float* __restrict__ dx, float* __restrict__ dyxn, int M,
                                                                int L, int mode, const float* __restrict__ tab,
                                                                const int64_t* __restrict__ t,
-                                                               const float* __restrict__ gamma, float eps) {
+                                                               const float* __restrict__ gamma, float eps, int accumulate) {
     constexpr int NV = D / 256;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -68,18 +68,29 @@ __global__ __launch_bounds__(256) void ds_layernorm_bwd_kernel(const float* __re
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = rstd * (g[j][k] - mg - v[j][k] * mgx);
+        if (accumulate) o += *(const f32x4*)(dx + (size_t)row * D + c);     // the residual stream's gradient: dx += d norm-input
         *(f32x4*)(dx + (size_t)row * D + c) = o;
     }
 }
 
-extern "C" int ds_layernorm_bwd(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
-                                const float* table, const int64_t* t, const float* gamma, ds_stream_t stream) {
+static int ln_bwd_launch(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode, const float* table,
+                         const int64_t* t, const float* gamma, int accumulate, ds_stream_t stream) {
     DS_CHECK_ARG(x && dy && dx && M > 0 && D == 1024, "bad arguments (D = 1024 is built)");
     DS_CHECK_ARG(mode == 0 ? (table && t && L > 0) : (mode == 1 && gamma), "mode 0 needs table / t / L, mode 1 gamma");
     hipLaunchKernelGGL((ds_layernorm_bwd_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, dyxn,
-                       M, mode == 0 ? L : 1, mode, table, t, gamma, 1e-5f);
+                       M, mode == 0 ? L : 1, mode, table, t, gamma, 1e-5f, accumulate);
     DS_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int ds_layernorm_bwd(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
+                                const float* table, const int64_t* t, const float* gamma, ds_stream_t stream) {
+    return ln_bwd_launch(x, dy, dx, dyxn, M, L, D, mode, table, t, gamma, 0, stream);
+}
+// the same with dx += (the block's residual connection: x_out = x + f(norm(x)) => d x = d x_out + d norm-input), saving the
+// separate ds_axpy pass over the residual gradient
+extern "C" int ds_layernorm_bwd_acc(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
+                                    const float* table, const int64_t* t, const float* gamma, ds_stream_t stream) {
+    return ln_bwd_launch(x, dy, dx, dyxn, M, L, D, mode, table, t, gamma, 1, stream);
 }
 
 // ---- column sums:  out[g][c] (+)= sum_{r < R} x[(g * R + r) * ld + c]   (bias / scale / embedding gradients) ----------

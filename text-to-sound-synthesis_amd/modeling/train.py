@@ -263,10 +263,14 @@ def _norm_fwd(x, mode, L, table=None, t=None, gamma=None, beta=None):
     return y
 
 
-def _norm_bwd(x, dy, mode, L, table=None, t=None, gamma=None):
+def _norm_bwd(x, dy, mode, L, table=None, t=None, gamma=None, add_to=None):
+    """add_to: the residual stream's gradient -- the norm-input gradient is ADDED to it in place (ds_layernorm_bwd_acc) instead
+    of being returned and added by a separate pass"""
     M, D = x.shape
-    dx, dyxn = torch.empty_like(x), torch.empty_like(x)
-    L_.check(L_.lib().ds_layernorm_bwd(L_.ptr(x), L_.ptr(dy), L_.ptr(dx), L_.ptr(dyxn), M, L, D, mode, L_.ptr(table),
+    dx = torch.empty_like(x) if add_to is None else add_to
+    dyxn = torch.empty_like(x)
+    fn = L_.lib().ds_layernorm_bwd if add_to is None else L_.lib().ds_layernorm_bwd_acc
+    L_.check(fn(L_.ptr(x), L_.ptr(dy), L_.ptr(dx), L_.ptr(dyxn), M, L, D, mode, L_.ptr(table),
                                        L_.ptr(t), L_.ptr(gamma), L_.stream()))
     G = M // L if mode == 0 else 1
     return dx, _colsum(dyxn, G), _colsum(dy, G)               # d scale, d shift per sample (AdaLN) or summed (LN)
@@ -655,10 +659,6 @@ class TrainStep:
         g["transformer.to_logits.0.weight"], g["transformer.to_logits.0.bias"] = dgam[0], dbet[0]
         small += [dgam, dbet]
 
-        def axpy(y, x_):
-            dx_readers_done()
-            L_.check(L_.lib().ds_axpy(L_.ptr(y), L_.ptr(x_), 1.0, y.numel(), L_.stream()))
-
         Tp = _ceil(T, 32)
 
         ada = []                    # (AdaLayerNorm module, d scale [B][D], d shift [B][D], parameter prefix): batched below
@@ -702,10 +702,10 @@ class TrainStep:
             dgact, g[p + "mlp.2.weight"], g[p + "mlp.2.bias"] = lin_bwd(ls["fc2"], s["g"], dx)
             # d fc1-output = dgact * gelu2'(u): the prologue of fc1's gradient pack
             dh, g[p + "mlp.0.weight"], g[p + "mlp.0.bias"] = lin_bwd(ls["fc1"], s["h3"], dgact, pro=PACK_GELU2_BWD, aux=s["u"])
-            dxn, dgam, dbet = _norm_bwd(s["x2"], dh, 1, Lx, gamma=blk.ln2.weight)
+            dx_readers_done()
+            _, dgam, dbet = _norm_bwd(s["x2"], dh, 1, Lx, gamma=blk.ln2.weight, add_to=dx)
             g[p + "ln2.weight"], g[p + "ln2.bias"] = dgam[0], dbet[0]
             small += [dgam, dbet]
-            axpy(dx, dxn)
             # x2 = x1 + proj2(attn2(q(ln1_1(x1)), kv(cond)))
             dao, g[p + "attn2.proj.weight"], g[p + "attn2.proj.bias"] = lin_bwd(ls["proj2"], s["o2"], dx)
             dq = torch.empty(M, D, device=dev)
@@ -718,9 +718,9 @@ class TrainStep:
             _, dWkv, dbkv = lin_bwd(ls["kv2"], cond_h, dkv, need_dx=False)
             g[p + "attn2.key.weight"], g[p + "attn2.value.weight"] = dWkv[:D], dWkv[D:]
             g[p + "attn2.key.bias"], g[p + "attn2.value.bias"] = dbkv[:D], dbkv[D:]
-            dxn, dsc, dsh = _norm_bwd(s["x1"], dh, 0, Lx, table=s["tab2"], t=t)
+            dx_readers_done()
+            _, dsc, dsh = _norm_bwd(s["x1"], dh, 0, Lx, table=s["tab2"], t=t, add_to=dx)
             adaln_param_grads(blk.ln1_1, dsc, dsh, p + "ln1_1")
-            axpy(dx, dxn)
             # x1 = x0 + proj1(attn1(qkv(ln1(x0))))
             dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["o1"], dx)
             dqkv = torch.empty(M, 3 * D, device=dev)
@@ -731,9 +731,9 @@ class TrainStep:
             dh, dWqkv, dbqkv = lin_bwd(ls["qkv1"], s["h1"], dqkv)
             for j, nm in enumerate(("query", "key", "value")):
                 g[p + "attn1.%s.weight" % nm], g[p + "attn1.%s.bias" % nm] = dWqkv[j * D:(j + 1) * D], dbqkv[j * D:(j + 1) * D]
-            dxn, dsc, dsh = _norm_bwd(s["x0"], dh, 0, Lx, table=s["tab1"], t=t)
+            dx_readers_done()
+            _, dsc, dsh = _norm_bwd(s["x0"], dh, 0, Lx, table=s["tab1"], t=t, add_to=dx)
             adaln_param_grads(blk.ln1, dsc, dsh, p + "ln1")
-            axpy(dx, dxn)
             hand_over([p + n for n in ("mlp.2.weight", "mlp.0.weight", "attn2.proj.weight", "attn2.query.weight",
                                        "attn2.key.weight", "attn2.value.weight", "attn1.proj.weight", "attn1.query.weight",
                                        "attn1.key.weight", "attn1.value.weight")])
