@@ -87,6 +87,8 @@ _PROTOS = {
     "ds_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _f,
                                    C.c_int, _vp]),
     "ds_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "ds_layernorm_bwd_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ds_layernorm_bwd_sums": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "ds_layernorm_bwd_acc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "ds_colsum": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _i64, C.c_int, _vp]),
     "ds_colsum_ws": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _i64, C.c_int, _vp, _i64, _vp]),

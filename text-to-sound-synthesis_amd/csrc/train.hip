@@ -93,6 +93,110 @@ extern "C" int ds_layernorm_bwd_acc(const float* x, const float* dy, float* dx, 
     return ln_bwd_launch(x, dy, dx, dyxn, M, L, D, mode, table, t, gamma, 1, stream);
 }
 
+// ---- the same backward with the scale / shift gradient sums folded in (round 5) ------------------------------------------
+// d scale = column sums of dy * xn, d shift = column sums of dy, per sample (AdaLN) or over all rows (LayerNorm).  The form
+// above writes dy * xn to HBM for ds_colsum_ws (one write + two reads of an [M][D] matrix and four launches per norm); here a
+// workgroup walks a CHUNK of <= 64 consecutive rows of one group, its four waves keep the two sums of their rows' columns in
+// registers, combine them through LDS and write ONE partial row pair part[chunk][2][D]; ds_colsum adds the chunks of a group
+// in a fixed order (deterministic).  chunks per group = ceil(rows per group / 64), rows per chunk = ceil(rows / chunks).
+extern "C" int ds_layernorm_bwd_chunks(int M, int L, int mode) {
+    const int rows = mode == 0 ? L : M;
+    return rows > 0 ? (rows + 63) / 64 : 0;
+}
+template <int D>
+__global__ __launch_bounds__(256) void ds_layernorm_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    float* __restrict__ dx, float* __restrict__ part, int M, int L,
+                                                                    int mode, const float* __restrict__ tab,
+                                                                    const int64_t* __restrict__ t, const float* __restrict__ gamma,
+                                                                    float eps, int accumulate, int rows_per_group, int cpg, int rpc) {
+    constexpr int NV = D / 256;
+    __shared__ float red[4][2][D];
+    const int grp = blockIdx.x / cpg, ck = blockIdx.x - grp * cpg;
+    const int g0 = grp * rows_per_group;
+    const int r_lo = g0 + ck * rpc;
+    int r_hi = r_lo + rpc;
+    if (r_hi > g0 + rows_per_group) r_hi = g0 + rows_per_group;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* sc = mode == 0 ? tab + (size_t)t[grp] * 2 * D : gamma;      // (mode 0: one group = one sample)
+    f32x4 a[NV], sx[NV], sd[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        a[j] = *(const f32x4*)(sc + (j * 64 + lane) * 4);
+        sx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = r_lo + wave; row < r_hi; row += 4) {
+        f32x4 v[NV], g[NV];
+        const float* xr = x + (size_t)row * D;
+        const float* dr = dy + (size_t)row * D;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = *(const f32x4*)(xr + (j * 64 + lane) * 4);
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mean = tr_wsum(s) * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = v[j][k] - mean;
+                q += d * d;
+            }
+        const float rstd = 1.f / sqrtf(tr_wsum(q) * (1.f / D) + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const f32x4 d4 = *(const f32x4*)(dr + (j * 64 + lane) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xn = (v[j][k] - mean) * rstd;
+                v[j][k] = xn;
+                g[j][k] = d4[k] * (mode == 0 ? 1.f + a[j][k] : a[j][k]);
+                sx[j][k] += d4[k] * xn;
+                sd[j][k] += d4[k];
+                sg += g[j][k];
+                sgx += g[j][k] * xn;
+            }
+        }
+        const float mg = tr_wsum(sg) * (1.f / D), mgx = tr_wsum(sgx) * (1.f / D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (j * 64 + lane) * 4;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = rstd * (g[j][k] - mg - v[j][k] * mgx);
+            if (accumulate) o += *(const f32x4*)(dx + (size_t)row * D + c);
+            *(f32x4*)(dx + (size_t)row * D + c) = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        *(f32x4*)(&red[wave][0][(j * 64 + lane) * 4]) = sx[j];
+        *(f32x4*)(&red[wave][1][(j * 64 + lane) * 4]) = sd[j];
+    }
+    __syncthreads();
+    float* out = part + (size_t)blockIdx.x * 2 * D;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int which = i / D, c = i - which * D;
+        out[i] = ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+    }
+}
+// part: [G * chunks][2][D] floats with G = M / L (mode 0) or 1 (mode 1), chunks = ds_layernorm_bwd_chunks(M, L, mode);
+// accumulate != 0: dx += (the residual connection), else dx =.
+extern "C" int ds_layernorm_bwd_sums(const float* x, const float* dy, float* dx, float* part, int M, int L, int D, int mode,
+                                     const float* table, const int64_t* t, const float* gamma, int accumulate, ds_stream_t stream) {
+    DS_CHECK_ARG(x && dy && dx && part && M > 0 && D == 1024, "bad arguments (D = 1024 is built)");
+    DS_CHECK_ARG(mode == 0 ? (table && t && L > 0 && M % L == 0) : (mode == 1 && gamma), "mode 0 needs table / t / L | M, mode 1 gamma");
+    const int rows = mode == 0 ? L : M, G = mode == 0 ? M / L : 1;
+    const int cpg = (rows + 63) / 64, rpc = (rows + cpg - 1) / cpg;
+    hipLaunchKernelGGL((ds_layernorm_bwd_sums_kernel<1024>), dim3(G * cpg), dim3(256), 0, (hipStream_t)stream, x, dy, dx, part, M,
+                       mode == 0 ? L : 1, mode, table, t, gamma, 1e-5f, accumulate, rows, cpg, rpc);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- column sums:  out[g][c] (+)= sum_{r < R} x[(g * R + r) * ld + c]   (bias / scale / embedding gradients) ----------
 // grid (ceil(C/256), G); each thread owns one column and walks the rows: coalesced, deterministic order
 __global__ __launch_bounds__(256) void ds_colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C,

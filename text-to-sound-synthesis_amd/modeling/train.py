@@ -264,16 +264,19 @@ def _norm_fwd(x, mode, L, table=None, t=None, gamma=None, beta=None):
 
 
 def _norm_bwd(x, dy, mode, L, table=None, t=None, gamma=None, add_to=None):
-    """add_to: the residual stream's gradient -- the norm-input gradient is ADDED to it in place (ds_layernorm_bwd_acc) instead
-    of being returned and added by a separate pass"""
+    """-> (dx, d scale, d shift): per sample [B][D] (AdaLN, mode 0) or summed [1][D] (LayerNorm, mode 1).  One kernel computes dx
+    and per-chunk column sums of dy * xn and dy (ds_layernorm_bwd_sums), one ds_colsum adds the chunks.
+    add_to: the residual stream's gradient -- the norm-input gradient is ADDED to it in place instead of being returned."""
     M, D = x.shape
     dx = torch.empty_like(x) if add_to is None else add_to
-    dyxn = torch.empty_like(x)
-    fn = L_.lib().ds_layernorm_bwd if add_to is None else L_.lib().ds_layernorm_bwd_acc
-    L_.check(fn(L_.ptr(x), L_.ptr(dy), L_.ptr(dx), L_.ptr(dyxn), M, L, D, mode, L_.ptr(table),
-                                       L_.ptr(t), L_.ptr(gamma), L_.stream()))
     G = M // L if mode == 0 else 1
-    return dx, _colsum(dyxn, G), _colsum(dy, G)               # d scale, d shift per sample (AdaLN) or summed (LN)
+    chunks = L_.lib().ds_layernorm_bwd_chunks(M, L, mode)
+    part = torch.empty(G * chunks, 2 * D, device=x.device)
+    L_.check(L_.lib().ds_layernorm_bwd_sums(L_.ptr(x), L_.ptr(dy), L_.ptr(dx), L_.ptr(part), M, L, D, mode, L_.ptr(table), L_.ptr(t),
+                                            L_.ptr(gamma), int(add_to is not None), L_.stream()))
+    sums = torch.empty(G, 2 * D, device=x.device)
+    L_.check(L_.lib().ds_colsum(L_.ptr(part), L_.ptr(sums), G, chunks, 2 * D, 2 * D, chunks * 2 * D, 0, L_.stream()))
+    return dx, sums[:, :D], sums[:, D:]
 
 
 def _heads(x, B, Lx, H, Lp):
