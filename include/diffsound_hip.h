@@ -220,7 +220,7 @@ int ds_loss_tail_bwd(const float* logits, const int64_t* x0, const int64_t* xt, 
  * gradient (NULL to skip); D = 1024 */
 int ds_layernorm_bwd(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
                      const float* table, const int64_t* t, const float* gamma, ds_stream_t stream);
-/* The backward with the scale / shift gradient sums folded in: part[G * chunks][2][D] receives, per chunk of <= 64 rows of a
+/* The backward with the scale / shift gradient sums folded in: part[G * chunks][2][D] receives, per chunk of <= 16 rows of a
  * group (G = M / L samples for mode 0, one group for mode 1; chunks = ds_layernorm_bwd_chunks(M, L, mode)), the column sums of
  * dy * xn and of dy; ds_colsum over a group's chunks (R = chunks, C = 2 D) gives [d scale | d shift].  No [M][D] dyxn matrix. */
 int ds_layernorm_bwd_chunks(int M, int L, int mode);

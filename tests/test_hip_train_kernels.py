@@ -57,12 +57,12 @@ def test_layernorm_backward(L, mode):
     # the form with the scale / shift sums folded in (no dyxn matrix): same dx, sums per sample (mode 0) / over all rows (mode 1)
     G = 2 if mode == 0 else 1
     chunks = L.lib().ds_layernorm_bwd_chunks(M, Lr, mode)
-    assert chunks == ((Lr if mode == 0 else M) + 63) // 64
+    assert chunks == ((Lr if mode == 0 else M) + 15) // 16
     part = torch.full((G * chunks, 2 * D), float("nan"), device="cuda")
     dx2 = torch.full((M, D), float("nan"), device="cuda")
     L.check(L.lib().ds_layernorm_bwd_sums(L.ptr(xc), L.ptr(dyc), L.ptr(dx2), L.ptr(part), M, Lr, D, mode, L.ptr(tabc), L.ptr(tc),
                                           L.ptr(gc), 0, L.stream()))
-    assert torch.equal(dx2, dx)
+    assert close(dx2.cpu(), dx.cpu(), 2e-6)            # (the same expressions; hipcc contracts the two kernels' multiply-adds differently)
     sums = torch.empty(G, 2 * D, device="cuda")
     L.check(L.lib().ds_colsum(L.ptr(part), L.ptr(sums), G, chunks, 2 * D, 2 * D, chunks * 2 * D, 0, L.stream()))
     if mode == 0:
@@ -72,7 +72,7 @@ def test_layernorm_backward(L, mode):
     res2 = rnd((M, D), "lnb.res", 2.0).cuda()
     L.check(L.lib().ds_layernorm_bwd_sums(L.ptr(xc), L.ptr(dyc), L.ptr(res2), L.ptr(part), M, Lr, D, mode, L.ptr(tabc), L.ptr(tc),
                                           L.ptr(gc), 1, L.stream()))
-    assert torch.equal(res2, want)
+    assert close(res2.cpu(), want.cpu(), 2e-6)
     if mode == 0:   # per-sample scale / shift gradients = the rows of d tab[t]
         ds_ = torch.empty(2, D, device="cuda")
         db_ = torch.empty(2, D, device="cuda")

@@ -96,12 +96,15 @@ extern "C" int ds_layernorm_bwd_acc(const float* x, const float* dy, float* dx, 
 // ---- the same backward with the scale / shift gradient sums folded in (round 5) ------------------------------------------
 // d scale = column sums of dy * xn, d shift = column sums of dy, per sample (AdaLN) or over all rows (LayerNorm).  The form
 // above writes dy * xn to HBM for ds_colsum_ws (one write + two reads of an [M][D] matrix and four launches per norm); here a
-// workgroup walks a CHUNK of <= 64 consecutive rows of one group, its four waves keep the two sums of their rows' columns in
-// registers, combine them through LDS and write ONE partial row pair part[chunk][2][D]; ds_colsum adds the chunks of a group
-// in a fixed order (deterministic).  chunks per group = ceil(rows per group / 64), rows per chunk = ceil(rows / chunks).
+// workgroup walks a CHUNK of <= LNB_CHUNK consecutive rows of one group, its four waves keep the two sums of their rows'
+// columns in registers, combine them through LDS and write ONE partial row pair part[chunk][2][D]; ds_colsum adds the chunks of
+// a group in a fixed order (deterministic).  chunks per group = ceil(rows per group / LNB_CHUNK), rows per chunk = ceil(rows /
+// chunks).  LNB_CHUNK = 16: at B = 20 that is 340 workgroups (64-row chunks were 100 workgroups on 256 CUs: 61 us per launch
+// against 18 us for the plain kernel, profiles/r05j_train_kernel_top.txt).
+#define LNB_CHUNK 16
 extern "C" int ds_layernorm_bwd_chunks(int M, int L, int mode) {
     const int rows = mode == 0 ? L : M;
-    return rows > 0 ? (rows + 63) / 64 : 0;
+    return rows > 0 ? (rows + LNB_CHUNK - 1) / LNB_CHUNK : 0;
 }
 template <int D>
 __global__ __launch_bounds__(256) void ds_layernorm_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -190,7 +193,7 @@ extern "C" int ds_layernorm_bwd_sums(const float* x, const float* dy, float* dx,
     DS_CHECK_ARG(x && dy && dx && part && M > 0 && D == 1024, "bad arguments (D = 1024 is built)");
     DS_CHECK_ARG(mode == 0 ? (table && t && L > 0 && M % L == 0) : (mode == 1 && gamma), "mode 0 needs table / t / L | M, mode 1 gamma");
     const int rows = mode == 0 ? L : M, G = mode == 0 ? M / L : 1;
-    const int cpg = (rows + 63) / 64, rpc = (rows + cpg - 1) / cpg;
+    const int cpg = (rows + LNB_CHUNK - 1) / LNB_CHUNK, rpc = (rows + cpg - 1) / cpg;
     hipLaunchKernelGGL((ds_layernorm_bwd_sums_kernel<1024>), dim3(G * cpg), dim3(256), 0, (hipStream_t)stream, x, dy, dx, part, M,
                        mode == 0 ? L : 1, mode, table, t, gamma, 1e-5f, accumulate, rows, cpg, rpc);
     DS_CHECK_LAUNCH();
