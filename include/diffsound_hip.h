@@ -282,7 +282,11 @@ int ds_amax(const float* x, long long n, float* out, ds_stream_t stream);
  * diffusion_transformer.py:408-476) need of it -- any subset of:
  *   dst_row      packed split planes (hi | lo, plane_row halves apart) of scale * X as a [rows][cols] GEMM operand;
  *   dst_t        packed split planes (plane_t apart) of scale * X^T as a [cols][rows_pad] operand: the contraction index
- *                (X's rows) zero-padded to rows_pad (% 32 == 0; split-K launches need a multiple of 32 * groups);
+ *                (X's rows) zero-padded to rows_pad (% 32 == 0; split-K launches need a multiple of 32 * groups); with
+ *                t_cols > 0 the destination is [cols][t_cols] and this matrix fills its k-range [t_col0, t_col0 + rows_pad)
+ *                (t_col0, t_cols % 32 == 0; 0, 0 = the matrix is the whole destination) -- row ranges of the ROW form are
+ *                reached by offsetting dst_row by whole 16-row groups: the parts of a fused projection weight need no
+ *                concatenated copy;
  *   colsum_part  [ds_pack_operand_tile_rows(rows, rows_pad)][cols] per-64-row column sums of scale * X, the first
  *                ceil(rows / 64) rows of which ds_colsum adds up in a fixed order (bias gradients; no atomics);
  *   amax         *amax = max(*amax, max |scale * X|) (atomicMax on the bit pattern; the caller zeroes it);
@@ -291,7 +295,7 @@ int ds_amax(const float* x, long long n, float* out, ds_stream_t stream);
 enum { DS_PACK_PLAIN = 0, DS_PACK_GELU2 = 1, DS_PACK_GELU2_BWD = 2 };
 int ds_pack_operand(const float* src, int rows, int cols, long long ld_src, float scale, int pro, const float* aux,
                     long long ld_aux, void* dst_row, long long plane_row, void* dst_t, long long plane_t, int rows_pad,
-                    float* colsum_part, float* amax, ds_stream_t stream);
+                    int t_col0, int t_cols, float* colsum_part, float* amax, ds_stream_t stream);
 int ds_pack_operand_tile_rows(int rows, int rows_pad);
 /* torch.optim.AdamW (configs/caps.yaml:111-115) on many parameter tensors at once: `tensors` = HOST array of n_tensors
  * records { p, g, m, v (device pointers), n (int64 element count) } = 5 x 8 bytes each; 64 tensors per launch, their

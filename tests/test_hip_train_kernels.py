@@ -298,7 +298,7 @@ def test_pack_operand_all_outputs(L, rows, cols, S):
     part = torch.full((tr, cols), float("nan"), device="cuda")
     amax = torch.zeros(1, device="cuda")
     L.check(L.lib().ds_pack_operand(L.ptr(dev), rows, cols, ld, scale, 0, None, 0, L.ptr(drow), R16 * cols, L.ptr(dt),
-                                    C16 * rows_pad, rows_pad, L.ptr(part), L.ptr(amax), L.stream()))
+                                    C16 * rows_pad, rows_pad, 0, 0, L.ptr(part), L.ptr(amax), L.stream()))
     got_row = L.unpack_planes(drow.cpu().view(torch.float16).view(2, -1), R16, cols)
     full = torch.zeros(R16, cols)
     full[:rows] = want
@@ -314,6 +314,32 @@ def test_pack_operand_all_outputs(L, rows, cols, S):
     assert amax.item() == want_amax
 
 
+def test_pack_operand_parts_into_a_fused_operand(L):
+    """The sub-range form: query | key | value weights packed straight into their row groups (row form) and k-ranges
+    (transposed form) of ONE fused operand == packing the concatenated matrix (what the training step did with torch.cat)."""
+    K, Ns = 256, (64, 96, 32)
+    parts = [rnd((n, K), "pkp.w%d" % i, 0.3).cuda() for i, n in enumerate(Ns)]
+    N = sum(Ns)
+    fused = torch.cat(parts)
+    K16 = (K + 15) // 16 * 16
+
+    def alloc():
+        return (torch.full((2, N * K), 0x7777, dtype=torch.int16, device="cuda"),
+                torch.full((2, K16 * N), 0x7777, dtype=torch.int16, device="cuda"))
+    row_a, t_a = alloc()
+    L.check(L.lib().ds_pack_operand(L.ptr(fused), N, K, K, 4.0, 0, None, 0, L.ptr(row_a), N * K, L.ptr(t_a), K16 * N, N, 0, 0, None, None,
+                                    L.stream()))
+    row_b, t_b = alloc()
+    n0 = 0
+    for w in parts:
+        n = w.shape[0]
+        L.check(L.lib().ds_pack_operand(L.ptr(w), n, K, K, 4.0, 0, None, 0, L.ptr_off(row_b, n0 * K), N * K, L.ptr(t_b), K16 * N, n, n0, N,
+                                        None, None, L.stream()))
+        n0 += n
+    assert torch.equal(row_a, row_b) and torch.equal(t_a, t_b)
+    assert int((row_a == 0x7777).sum()) < 8 and int((t_a == 0x7777).sum()) < 8        # (everything was written)
+
+
 def test_pack_operand_gelu_prologues(L):
     """The MLP's activation rides in the pack: DS_PACK_GELU2 (x := gelu2(x), transformer_utils.py:111-115) and
     DS_PACK_GELU2_BWD (x := x * gelu2'(aux)) against float64; the packed value (hi + lo) is the fp32 result to 2^-22."""
@@ -326,7 +352,7 @@ def test_pack_operand_gelu_prologues(L):
                                (2, dyc, uc, dy.double() * (torch.sigmoid(1.702 * u.double()) *
                                                            (1 + 1.702 * u.double() * (1 - torch.sigmoid(1.702 * u.double())))))):
         d = torch.empty(2, R16 * cols, dtype=torch.int16, device="cuda")
-        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, pro, L.ptr(aux), cols, L.ptr(d), R16 * cols, None, 0, 0,
+        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, pro, L.ptr(aux), cols, L.ptr(d), R16 * cols, None, 0, 0, 0, 0,
                                         None, None, L.stream()))
         pl = L.unpack_planes(d.cpu().view(torch.float16).view(2, -1), rows, cols)
         val = pl[0].double() + pl[1].double()
@@ -347,7 +373,7 @@ def test_gemm_f16x2_packed_split_k_groups(L):
     def tform(src, cols):
         C16 = (cols + 15) // 16 * 16
         d = torch.empty(2, C16 * Mp, dtype=torch.int16, device="cuda")
-        L.check(L.lib().ds_pack_operand(L.ptr(src), M, cols, cols, 1.0, 0, None, 0, None, 0, L.ptr(d), C16 * Mp, Mp, None, None,
+        L.check(L.lib().ds_pack_operand(L.ptr(src), M, cols, cols, 1.0, 0, None, 0, None, 0, L.ptr(d), C16 * Mp, Mp, 0, 0, None, None,
                                         L.stream()))
         return d, C16 * Mp
     a, apl = tform(dyc, N)

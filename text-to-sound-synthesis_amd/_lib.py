@@ -104,7 +104,8 @@ _PROTOS = {
     "ds_adamw_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
     "ds_convert_operand": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, _f, _vp, _i64, _i64, C.c_int, _vp]),
     "ds_amax": (C.c_int, [_vp, _i64, _vp, _vp]),
-    "ds_pack_operand": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f, C.c_int, _vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _vp, _vp, _vp]),
+    "ds_pack_operand": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f, C.c_int, _vp, _i64, _vp, _i64, _vp, _i64, C.c_int, C.c_int, C.c_int,
+                                  _vp, _vp, _vp]),
     "ds_pack_operand_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "ds_adamw_multi": (C.c_int, [_vp, C.c_int, _vp, _f, _f, _f, _f, _vp]),
     "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),

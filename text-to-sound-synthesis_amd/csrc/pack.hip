@@ -5,7 +5,10 @@
 //                     need of it, so that all of them run on packed split planes staged by LDS-DMA (gemm_f16x2.hip AMODE 2):
 //                       * the ROW form   -- packed planes of X   (A operand of y = x W^T / dX = dY W;  W operand: W itself)
 //                       * the TRANSPOSED form -- packed planes of X^T with the contraction index (the rows of X) zero-padded
-//                         to rows_pad (A / W operands of dW = dY^T X;  W operand of dX: W^T)
+//                         to rows_pad (A / W operands of dW = dY^T X;  W operand of dX: W^T); optionally as the k-range
+//                         [t_col0, t_col0 + rows_pad) of a WIDER destination (t_cols): the query | key | value weights of a
+//                         fused projection are packed straight into their row / k ranges of the fused operand -- no
+//                         concatenated fp32 copy of the weights per step
 //                       * per-tile-row column sums (bias gradients: db = column sums of dY), summed by ds_colsum afterwards
 //                         in a fixed order -- no atomics, the gradients stay bit-reproducible
 //                       * max |x| (the loss-scale calibration / saturation monitor of the step)
@@ -36,6 +39,7 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
                                                               float scale, const float* __restrict__ aux, long long ld_aux,
                                                               _Float16* __restrict__ dst_row, long long plane_row,
                                                               _Float16* __restrict__ dst_t, long long plane_t, int rows_pad,
+                                                              int t_col0, int t_cols,
                                                               float* __restrict__ colsum_part, unsigned* __restrict__ amax) {
     __shared__ float t[64][65];
     __shared__ float wm[4];
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
     }
     // TRANSPOSED form: logical X^T[cols][rows_pad]; a chunk = 8 consecutive source rows of one source column
     if (dst_t && r0 < rows_pad) {
-        const int ktiles = rows_pad >> 5;
+        const int ktiles = t_cols >> 5;                      // the destination's full contraction length (>= t_col0 + rows_pad)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int w = tid + 256 * it;                    // 512 chunks: source column (64) x row chunk (8)
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
                     hi[e] = ds_split_hi(v);
                     lo[e] = ds_split_lo(v, hi[e]);
                 }
-                _Float16* d = dst_t + ds_packed_off(trow, tcol, ktiles);
+                _Float16* d = dst_t + ds_packed_off(trow, t_col0 + tcol, ktiles);
                 *(pk_h8*)d = hi;
                 *(pk_h8*)(d + plane_t) = lo;
             }
@@ -144,7 +148,7 @@ extern "C" int ds_pack_operand_tile_rows(int rows, int rows_pad) {
 
 extern "C" int ds_pack_operand(const float* src, int rows, int cols, long long ld_src, float scale, int pro, const float* aux,
                                long long ld_aux, void* dst_row, long long plane_row, void* dst_t, long long plane_t,
-                               int rows_pad, float* colsum_part, float* amax, ds_stream_t stream) {
+                               int rows_pad, int t_col0, int t_cols, float* colsum_part, float* amax, ds_stream_t stream) {
     DS_CHECK_ARG(src && rows > 0 && cols > 0 && cols % 32 == 0 && ld_src >= cols && ld_src % 4 == 0, "src: cols % 32 == 0, ld % 4 == 0");
     DS_CHECK_ARG((((uintptr_t)src) & 15) == 0, "src must be 16-byte aligned");
     DS_CHECK_ARG(dst_row || dst_t || colsum_part || amax, "nothing to produce");
@@ -154,15 +158,18 @@ extern "C" int ds_pack_operand(const float* src, int rows, int cols, long long l
     DS_CHECK_ARG(!dst_row || ((((uintptr_t)dst_row) & 15) == 0 && plane_row % 8 == 0 &&
                               plane_row >= (long long)((rows + 15) & ~15) * cols),
                  "row form: 16-byte aligned, plane stride >= ceil16(rows) * cols halves");
+    if (t_cols == 0) { t_cols = rows_pad; t_col0 = 0; }      // the matrix is the whole destination
     DS_CHECK_ARG(!dst_t || ((((uintptr_t)dst_t) & 15) == 0 && rows_pad >= rows && rows_pad % 32 == 0 && plane_t % 8 == 0 &&
-                            plane_t >= (long long)((cols + 15) & ~15) * rows_pad),
-                 "transposed form: rows_pad % 32 == 0 and >= rows, plane stride >= ceil16(cols) * rows_pad halves");
+                            t_col0 >= 0 && t_col0 % 32 == 0 && t_cols % 32 == 0 && t_col0 + rows_pad <= t_cols &&
+                            plane_t >= (long long)((cols + 15) & ~15) * t_cols),
+                 "transposed form: rows_pad % 32 == 0 and >= rows, k-range [t_col0, t_col0 + rows_pad) inside t_cols, plane stride "
+                 ">= ceil16(cols) * t_cols halves");
     if (!dst_t) rows_pad = 0;
     const dim3 grid((unsigned)ds_pack_operand_tile_rows(rows, rows_pad), (unsigned)((cols + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
 #define PK_LAUNCH(P)                                                                                                       \
     hipLaunchKernelGGL(ds_pack_operand_kernel<P>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, aux, ld_aux,      \
-                       (_Float16*)dst_row, plane_row, (_Float16*)dst_t, plane_t, rows_pad, colsum_part, (unsigned*)amax)
+                       (_Float16*)dst_row, plane_row, (_Float16*)dst_t, plane_t, rows_pad, t_col0, t_cols, colsum_part, (unsigned*)amax)
     if (pro == DS_PACK_GELU2) PK_LAUNCH(DS_PACK_GELU2);
     else if (pro == DS_PACK_GELU2_BWD) PK_LAUNCH(DS_PACK_GELU2_BWD);
     else PK_LAUNCH(DS_PACK_PLAIN);

@@ -76,12 +76,24 @@ PACK_PLAIN, PACK_GELU2, PACK_GELU2_BWD = 0, 1, 2
 
 
 class _Linear:
-    """One (possibly fused) nn.Linear of the step: W [N][K] fp32, bias [N], plus what the GEMM backend derived from W."""
+    """One (possibly fused) nn.Linear of the step: the weights of its parts (each [N_i][K] fp32; query | key | value of a fused
+    projection), bias [N], plus what the GEMM backend derived from them.  `W` (the concatenated fp32 matrix) is only built
+    when somebody asks for it -- the "fp32" backend; the "f16x2" backend packs every part straight into its range of the
+    fused operand (ds_pack_operand's sub-range form)."""
 
     def __init__(self, key, W, b):
-        self.key, self.W, self.b = key, W, b
-        self.N, self.K = W.shape
+        self.key = key
+        self.parts = [w.detach() for w in W] if isinstance(W, (list, tuple)) else [W.detach()]
+        self.b = torch.cat([x.detach() for x in b]) if isinstance(b, (list, tuple)) else b.detach()
+        self.N, self.K = sum(w.shape[0] for w in self.parts), self.parts[0].shape[1]
+        self._W = self.parts[0] if len(self.parts) == 1 else None
         self.extra = {}
+
+    @property
+    def W(self):
+        if self._W is None:
+            self._W = torch.cat(self.parts)
+        return self._W
 
 
 def _gelu2(x, dy=None):
@@ -160,8 +172,29 @@ def _pack(src, rows, cols, *, scale=1.0, pro=PACK_PLAIN, aux=None, want_row=True
     if colsum:
         o.part = torch.empty(L_.lib().ds_pack_operand_tile_rows(rows, rows_pad), cols, device=dev)
     L_.check(L_.lib().ds_pack_operand(L_.ptr(src), rows, cols, cols if ld is None else ld, float(scale), int(pro), L_.ptr(aux),
-                                      cols, L_.ptr(o.row), o.row_plane, L_.ptr(o.t), o.t_plane, rows_pad, L_.ptr(o.part),
+                                      cols, L_.ptr(o.row), o.row_plane, L_.ptr(o.t), o.t_plane, rows_pad, 0, 0, L_.ptr(o.part),
                                       L_.ptr(amax), L_.stream()))
+    return o
+
+
+def _pack_parts(parts, K, scale):
+    """The parts [N_i][K] of a fused weight (N = sum N_i, every N_i % 32 == 0) -> ONE _Packed of the fused matrix [N][K]: part i
+    goes to the row groups [n0 / 16, ..) of the row form and to the k-range [n0, n0 + N_i) of the transposed form [K][N]."""
+    dev = parts[0].device
+    N = sum(w.shape[0] for w in parts)
+    assert all(w.shape[0] % 32 == 0 and w.shape[1] == K and w.is_contiguous() for w in parts)
+    o = _Packed()
+    o.rows, o.cols, o.rows_pad, o.part = N, K, N, None
+    o.row_plane, o.t_plane = N * K, _ceil(K, 16) * N
+    o.row = torch.empty(2, o.row_plane, dtype=torch.int16, device=dev)
+    o.t = torch.empty(2, o.t_plane, dtype=torch.int16, device=dev)
+    n0 = 0
+    for w in parts:
+        Ni = w.shape[0]
+        L_.check(L_.lib().ds_pack_operand(L_.ptr(w), Ni, K, K, float(scale), PACK_PLAIN, None, 0,
+                                          L_.ptr_off(o.row, n0 * K), o.row_plane,       # row group n0 / 16: (n0 / 16) * (K / 32) * 512 halves
+                                          L_.ptr(o.t), o.t_plane, Ni, n0, N, None, None, L_.stream()))
+        n0 += Ni
     return o
 
 
@@ -175,7 +208,7 @@ class _SplitGemm:
 
     def refresh_scales(self, lins):
         """One host sync for all matrices: s = 13 - floor(log2 max|W|)."""
-        mx = torch.stack([l.W.detach().abs().max() for l in lins]).tolist()
+        mx = torch.stack([torch.stack([w.abs().max() for w in l.parts]).max() for l in lins]).tolist()
         for l, m in zip(lins, mx):
             self.wexp[l.key] = 0 if (m == 0.0 or not math.isfinite(m)) else 13 - math.floor(math.log2(m))
 
@@ -199,7 +232,10 @@ class _SplitGemm:
         """W * 2^s -> row form [N][K] (forward) and transposed form [K][ceil32(N)] (dX), one pass"""
         s = self.wexp[lin.key]
         lin.extra["osc"] = 2.0 ** (-s)
-        lin.extra["Wp"] = _pack(lin.W, lin.N, lin.K, scale=2.0 ** s, rows_pad=_ceil(lin.N, 32))
+        if len(lin.parts) > 1 or lin.N % 32 == 0:
+            lin.extra["Wp"] = _pack_parts(lin.parts, lin.K, 2.0 ** s)
+        else:
+            lin.extra["Wp"] = _pack(lin.W, lin.N, lin.K, scale=2.0 ** s, rows_pad=_ceil(lin.N, 32))
 
     def prep_x(self, lin, x, pro=PACK_PLAIN):
         M = x.shape[0]
@@ -465,12 +501,11 @@ class TrainStep:
             a1, a2 = blk.attn1, blk.attn2
             p = "b%d." % li
             out.append({
-                "qkv1": _Linear(p + "qkv1", torch.cat((a1.query.weight, a1.key.weight, a1.value.weight)).detach(),
-                                torch.cat((a1.query.bias, a1.key.bias, a1.value.bias)).detach()),
+                "qkv1": _Linear(p + "qkv1", (a1.query.weight, a1.key.weight, a1.value.weight),
+                                (a1.query.bias, a1.key.bias, a1.value.bias)),
                 "proj1": _Linear(p + "proj1", a1.proj.weight.detach(), a1.proj.bias.detach()),
                 "q2": _Linear(p + "q2", a2.query.weight.detach(), a2.query.bias.detach()),
-                "kv2": _Linear(p + "kv2", torch.cat((a2.key.weight, a2.value.weight)).detach(),
-                               torch.cat((a2.key.bias, a2.value.bias)).detach()),
+                "kv2": _Linear(p + "kv2", (a2.key.weight, a2.value.weight), (a2.key.bias, a2.value.bias)),
                 "proj2": _Linear(p + "proj2", a2.proj.weight.detach(), a2.proj.bias.detach()),
                 "fc1": _Linear(p + "fc1", blk.mlp[0].weight.detach(), blk.mlp[0].bias.detach()),
                 "fc2": _Linear(p + "fc2", blk.mlp[2].weight.detach(), blk.mlp[2].bias.detach()),

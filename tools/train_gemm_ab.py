@@ -23,11 +23,11 @@ def pack(src, rows, cols, rows_pad=0):
     if rows_pad == 0:
         pl = (rows + 15) // 16 * 16 * cols
         d = torch.empty(2, pl, dtype=torch.int16, device="cuda")
-        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, 0, None, 0, L.ptr(d), pl, None, 0, 0, None, None, L.stream()))
+        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, 0, None, 0, L.ptr(d), pl, None, 0, 0, 0, 0, None, None, L.stream()))
     else:
         pl = (cols + 15) // 16 * 16 * rows_pad
         d = torch.empty(2, pl, dtype=torch.int16, device="cuda")
-        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, 0, None, 0, None, 0, L.ptr(d), pl, rows_pad, None, None, L.stream()))
+        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, 0, None, 0, None, 0, L.ptr(d), pl, rows_pad, 0, 0, None, None, L.stream()))
     return d, pl
 
 
