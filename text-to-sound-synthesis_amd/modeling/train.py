@@ -702,7 +702,9 @@ class TrainStep:
         ada = []                    # (AdaLayerNorm module, d scale [B][D], d shift [B][D], parameter prefix): batched below
 
         def adaln_param_grads(ln, d_scale, d_shift, pfx):
-            ada.append((ln, d_scale, d_shift, pfx))
+            # (d_scale / d_shift are the two column halves of _norm_bwd's [B][2D] sums: ._base is [d scale | d shift] itself)
+            both = d_scale._base if d_scale._base is not None and d_scale._base is d_shift._base else torch.cat((d_scale, d_shift), dim=1)
+            ada.append((ln, both, None, pfx))
 
         def adaln_param_grads_all():
             """d table[t_b] rows -> emb.weight / linear.{weight, bias} through  table = Linear(SiLU(emb))  (AdaLayerNorm,
@@ -712,7 +714,7 @@ class TrainStep:
             G = len(ada)
             if G == 0:
                 return
-            dmod = torch.stack([torch.cat((dsc, dsh), dim=1) for _, dsc, dsh, _ in ada])            # [G][B][2D]
+            dmod = torch.stack([both for _, both, _, _ in ada])                                     # [G][B][2D]
             dtab = torch.zeros(G, T, 2 * D, device=dev)
             dtab.index_add_(1, t, dmod)
             dtab.mul_(inv)
