@@ -49,11 +49,15 @@ for name, M, N, K in FWD:
     Ap, apl = pack(A, M, K)
     Wp, wpl = pack(W, N, K)
     out = torch.empty(M, N, device="cuda")
-    fl, row = 2.0 * M * N * K, []
-    for tile in (-1, 0, 1, 2):
+    fl, row, ref = 2.0 * M * N * K, [], None
+    for tile in (-1, 0, 1, 2, 3):          # 3 = the 2-wave 128 x 64 program
         L.lib().ds_gemm_f16x2_force_tile(tile)
+        out.fill_(float("nan"))
         t = timeit(lambda: L.gemm(Ap, Wp, out, M, N, K, split2=1.0, a_plane=apl, w_plane=wpl))
-        row.append("%s %6.1f us %5.1f TF" % ("auto" if tile < 0 else "t%d" % tile, t, fl / t / 1e6))
+        if ref is None:
+            ref = out.clone()
+        bad = "" if torch.equal(out, ref) else " DIFF %.1e" % float((out - ref).abs().max())
+        row.append("%s %6.1f us %5.1f TF%s" % ("auto" if tile < 0 else "t%d" % tile, t, fl / t / 1e6, bad))
     L.lib().ds_gemm_f16x2_force_tile(-1)
     print("%s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
 
@@ -63,14 +67,14 @@ for name, N, K, M in DW:
     fl = 2.0 * M * N * K
     dW = torch.empty(N, K, device="cuda")
     best = None
-    for S in (1, 2, 3, 4, 6, 8):
+    for S in (1, 2, 4):
         Mp = (M + 32 * S - 1) // (32 * S) * (32 * S)
         a, apl = pack(dY, M, N, Mp)
         w, wpl = pack(X, M, K, Mp)
         part = torch.empty(S, N * K, device="cuda")
         Kc = Mp // S
         row = []
-        for tile in (0, 1, 2):
+        for tile in (0, 1, 2, 3):
             L.lib().ds_gemm_f16x2_force_tile(tile)
 
             def run():
