@@ -45,11 +45,12 @@ typedef __attribute__((address_space(3))) void* ds_lptr;
 // two LDS stages.  (Round 2 measured the 8-wave big-tile, register-staged and deeper-ring variants of this loop
 // against it and against the per-sample ping-pong program of gemm_f16x2_ps.hip -- profiles/r02_probe_*.txt -- and
 // removed them: none beat this loop by more than a few per cent on the shapes it still serves.)
-template <int BM, int BN, int AMODE, int WGM = 2, int WGN = 2>
+// (Round 5 measured a 2-wave form of the 128 x 64 tile -- wave tile 64 x 64, a third fewer LDS fragment bytes per MFMA -- on the
+// training step's packed shapes: 15-25 % SLOWER than this 4-wave form everywhere, profiles/r05n_*; removed.)
+template <int BM, int BN, int AMODE>
 __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid, const int nblk,
                                                    unsigned char* smem_raw) {
-    constexpr int NS = 2;
-    static_assert(AMODE == 2 || (WGM == 2 && WGN == 2), "the register-staging loader is written for 256 threads");
+    constexpr int WGM = 2, WGN = 2, NS = 2;
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave tiles are made of 32x32 blocks");
@@ -458,24 +459,6 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
     ds_gemm_f16x2_body<BM, BN, AMODE>(p, blockIdx.x, gridDim.x, smem_dyn);
 }
 
-// The 128 x 64 tile with TWO waves (wave tile 64 x 64: 2 x 2 MFMA blocks per wave instead of 2 x 1), packed operands only.
-// The 4-wave 128 x 64 program reads 48 KB of fragments from LDS per k-tile for 48 MFMAs (+ 24 KB of LDS-DMA writes): as many
-// LDS cycles as matrix cycles; the 64 x 64 wave tile reads 32 KB for the same MFMAs.  force_tile(3) / see ds_launch_gemm_f16x2.
-template <int BM, int BN>
-__global__ __launch_bounds__(128, 2) void ds_gemm_f16x2_w2_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    if (blockIdx.y != 0) {
-        GemmParams q = p;
-        const size_t g = blockIdx.y;
-        q.A = (const float*)((const _Float16*)p.A + g * (size_t)p.a_gstride);
-        q.W = (const float*)((const _Float16*)p.W + g * (size_t)p.w_gstride);
-        q.C = p.C + g * (size_t)p.c_gstride;
-        ds_gemm_f16x2_body<BM, BN, 2, 2, 1>(q, blockIdx.x, gridDim.x, smem_dyn);
-        return;
-    }
-    ds_gemm_f16x2_body<BM, BN, 2, 2, 1>(p, blockIdx.x, gridDim.x, smem_dyn);
-}
-
 // Balanced launch for packed operands: the first `nbig` workgroups compute 128x128 tiles of the leading rows
 // (pb: a whole number of rounds of the chip's resident-workgroup slots), the rest 64x64 tiles of the remaining
 // rows (ps: the same problem with the row origin moved).  At M = 16960, N = 1024 a plain 128x128 grid is 1064
@@ -526,24 +509,6 @@ static int launch_h2(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE>), dim3(tiles, p.groups > 1 ? p.groups : 1),
                        dim3(256), lds, s, p);
-    DS_CHECK_LAUNCH();
-    return 0;
-}
-template <int BM, int BN>
-static int launch_w2(const GemmParams& p, hipStream_t s) {
-    const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * sizeof(unsigned short);
-    static DsOnce attr_set;
-    if (attr_set.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_w2_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) {
-            ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return -2;
-        }
-        attr_set.done();
-    }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((ds_gemm_f16x2_w2_kernel<BM, BN>), dim3(tiles, p.groups > 1 ? p.groups : 1), dim3(128), lds, s, p);
     DS_CHECK_LAUNCH();
     return 0;
 }
@@ -667,10 +632,6 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     // ~235-250 TF-eq once the grid has >= 3 rounds of 512 resident blocks; below that 128x64 (3 blocks/CU,
     // ~205-230 TF-eq) quantises better; 64x64 (~190) only wins for tiny grids.
     int best;
-    if (g_force_tile_h == 3 && p.a_split) {       // experiment: the 2-wave 128 x 64 program (packed operands)
-        g_last_tile = 1;
-        return launch_w2<128, 64>(p, stream);
-    }
     if (g_force_tile_h >= 0 && g_force_tile_h <= 2) {
         best = g_force_tile_h;
     } else {

@@ -50,7 +50,7 @@ for name, M, N, K in FWD:
     Wp, wpl = pack(W, N, K)
     out = torch.empty(M, N, device="cuda")
     fl, row, ref = 2.0 * M * N * K, [], None
-    for tile in (-1, 0, 1, 2, 3):          # 3 = the 2-wave 128 x 64 program
+    for tile in (-1, 0, 1, 2):
         L.lib().ds_gemm_f16x2_force_tile(tile)
         out.fill_(float("nan"))
         t = timeit(lambda: L.gemm(Ap, Wp, out, M, N, K, split2=1.0, a_plane=apl, w_plane=wpl))
@@ -74,7 +74,7 @@ for name, N, K, M in DW:
         part = torch.empty(S, N * K, device="cuda")
         Kc = Mp // S
         row = []
-        for tile in (0, 1, 2, 3):
+        for tile in (0, 1, 2):
             L.lib().ds_gemm_f16x2_force_tile(tile)
 
             def run():
