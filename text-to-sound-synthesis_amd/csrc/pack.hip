@@ -33,7 +33,9 @@ __device__ __forceinline__ float pk_gelu2_grad(float v) {
 
 // 64 x 64 source tile per workgroup through LDS (rows padded to 65 words).  grid = (row tiles over max(rows_pad,
 // ceil16(rows)), column tiles).  Source elements outside [rows) x [cols) read as zero, so the padding rows / k-slots of
-// both forms are written as zeros.
+// both forms are written as zeros.  Every element is split ONCE, when it is loaded (hi | lo << 16 in one LDS word, the
+// staging format of the GEMM epilogues); the two forms are byte shuffles of those words (v_perm), the column sums come from
+// the fp32 values still in registers (per-thread partials over its 4 rows, added across the 16 row groups in a fixed order).
 template <int PRO>
 __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __restrict__ src, int rows, int cols, long long ld_src,
                                                               float scale, const float* __restrict__ aux, long long ld_aux,
@@ -41,16 +43,18 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
                                                               _Float16* __restrict__ dst_t, long long plane_t, int rows_pad,
                                                               int t_col0, int t_cols,
                                                               float* __restrict__ colsum_part, unsigned* __restrict__ amax) {
-    __shared__ float t[64][65];
+    __shared__ unsigned t[64][65];
+    __shared__ float cs[16][64];
     __shared__ float wm[4];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
     float m = 0.f;
     {
-        const int c4 = (tid & 15) * 4;
+        const int c4 = (tid & 15) * 4, rq = tid >> 4;
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int r = (tid >> 4) + 16 * it;
+            const int r = rq + 16 * it;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (r0 + r < rows && c0 + c4 < cols) {          // cols % 4 == 0: a 4-column unit is inside or outside
                 v = *(const f32x4*)(src + (size_t)(r0 + r) * ld_src + c0 + c4);
@@ -69,8 +73,13 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
                     m = a > m ? a : m;                      // NaN never wins (a calibration quantity, not a validity check)
                 }
             }
+            sum += v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[r][c4 + e] = v[e];
+            for (int e = 0; e < 4; ++e) t[r][c4 + e] = ds_split_pack(v[e]);
+        }
+        if (colsum_part) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs[rq][c4 + e] = sum[e];
         }
     }
     if (amax) {
@@ -88,13 +97,22 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
         for (int w = 1; w < 4; ++w) b = wm[w] > b ? wm[w] : b;
         if (b > 0.f) atomicMax(amax, __float_as_uint(b));
     }
-    // column sums of this tile row (rows r0 .. r0+63 in a fixed order): partial[blockIdx.x][c]
+    // column sums of this tile row: the 16 row-group partials in a fixed order -> partial[blockIdx.x][c]
     if (colsum_part && tid < 64 && c0 + tid < cols && r0 < rows) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) s += t[r][tid];
-        colsum_part[(size_t)blockIdx.x * cols + c0 + tid] = s;
+        float s_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_ += cs[q][tid];
+        colsum_part[(size_t)blockIdx.x * cols + c0 + tid] = s_;
     }
+    // 8 packed words -> the 8 halves of plane 0 (low halves) and of plane 1 (high halves): one v_perm_b32 per output word
+#define PK_UNZIP(x_, hi_, lo_)                                                                   \
+    do {                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
+            hi_[e] = __builtin_amdgcn_perm((x_)[2 * e + 1], (x_)[2 * e], 0x05040100u);           \
+            lo_[e] = __builtin_amdgcn_perm((x_)[2 * e + 1], (x_)[2 * e], 0x07060302u);           \
+        }                                                                                        \
+    } while (0)
+    typedef unsigned pk_u4 __attribute__((ext_vector_type(4)));
     // ROW form: 4 row groups x 2 k-tiles; one 16-byte chunk (8 consecutive columns of a row) per thread and iteration
     if (dst_row && r0 < ((rows + 15) & ~15)) {
         const int ktiles = cols >> 5;
@@ -104,20 +122,18 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
             const int ch = w & 7, r = w >> 3;
             const int row = r0 + r, col = c0 + ch * 8;
             if (row < ((rows + 15) & ~15) && col < cols) {
-                pk_h8 hi, lo;
+                unsigned x[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = t[r][ch * 8 + e];
-                    hi[e] = ds_split_hi(v);
-                    lo[e] = ds_split_lo(v, hi[e]);
-                }
+                for (int e = 0; e < 8; ++e) x[e] = t[r][ch * 8 + e];
+                pk_u4 hi, lo;
+                PK_UNZIP(x, hi, lo);
                 _Float16* d = dst_row + ds_packed_off(row, col, ktiles);
-                *(pk_h8*)d = hi;
-                *(pk_h8*)(d + plane_row) = lo;
+                *(pk_u4*)d = hi;
+                *(pk_u4*)(d + plane_row) = lo;
             }
         }
     }
-    // TRANSPOSED form: logical X^T[cols][rows_pad]; a chunk = 8 consecutive source rows of one source column
+    // TRANSPOSED form: logical X^T[cols][t_cols]; a chunk = 8 consecutive source rows of one source column
     if (dst_t && r0 < rows_pad) {
         const int ktiles = t_cols >> 5;                      // the destination's full contraction length (>= t_col0 + rows_pad)
 #pragma unroll
@@ -126,19 +142,18 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
             const int ch = w & 7, cl = w >> 3;
             const int trow = c0 + cl, tcol = r0 + ch * 8;    // row / column of X^T
             if (trow < ((cols + 15) & ~15) && tcol < rows_pad) {
-                pk_h8 hi, lo;
+                unsigned x[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = t[ch * 8 + e][cl];
-                    hi[e] = ds_split_hi(v);
-                    lo[e] = ds_split_lo(v, hi[e]);
-                }
+                for (int e = 0; e < 8; ++e) x[e] = t[ch * 8 + e][cl];
+                pk_u4 hi, lo;
+                PK_UNZIP(x, hi, lo);
                 _Float16* d = dst_t + ds_packed_off(trow, t_col0 + tcol, ktiles);
-                *(pk_h8*)d = hi;
-                *(pk_h8*)(d + plane_t) = lo;
+                *(pk_u4*)d = hi;
+                *(pk_u4*)(d + plane_t) = lo;
             }
         }
     }
+#undef PK_UNZIP
 }
 
 extern "C" int ds_pack_operand_tile_rows(int rows, int rows_pad) {
