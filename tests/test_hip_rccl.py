@@ -72,3 +72,51 @@ def test_bench_refuses_more_ranks_than_devices_on_the_box():
     n = torch.cuda.device_count()
     r = _bench(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0"])
     assert r.returncode == 2 and ("%d ranks requested" % (n + 1)) in r.stderr and not r.stdout.strip()
+
+
+def test_graphed_training_iteration_with_rccl_allreduce_between_the_graphs():
+    """The data-parallel form of the captured training iteration (engine/solver_spec.py:109: DDP reduces before the optimizer
+    step) with the REAL reduction: GraphSolver(reduce=shard.allreduce_gradients) replays gradients | bucketed all-reduce over
+    RCCL (world 1, forced through the communicator) | clip + AdamW -- two iterations, against the one-graph solver."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from conftest import synth_sd
+    from text_to_sound_synthesis_amd import shard, synth
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    from text_to_sound_synthesis_amd.modeling.solver import GradClipWindow, GraphSolver
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        def make():
+            m = build_model(default_config(n_layer=2, diffusion_step=100))
+            m.load_state_dict({**dict(synth_sd("dalle", 2)), **synth_sd("encoder")}, strict=False)
+            dt = m.cuda().eval().transformer
+            dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]
+            return dt
+        x0 = synth.synth_tokens(3, mask_frac=0.0, key="tl.x0").cuda()
+        cond = synth.synth_cond_emb(3, key="tl.c").cuda()
+        pt = (torch.ones(3) / 100).cuda()
+        batches = [(torch.tensor([57, 0, 93]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u").cuda()),
+                   (torch.tensor([3, 99, 41]).cuda(), synth.synth_uniform((3, 257, 265), key="tl.u2").cuda())]
+        calls = []
+
+        def reduce(grads):
+            calls.append(len(grads))
+            shard.allreduce_gradients(grads, bucket_bytes=8 << 20, always_collective=True)
+        with torch.no_grad():
+            a = GraphSolver(TrainStep(make(), precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5))
+            b = GraphSolver(TrainStep(make(), precision="f16x2"), lr=1e-3, clip_grad_norm=GradClipWindow(0, 5000, 0.5), reduce=reduce)
+            for t, u in batches:
+                oa, ob = a.step(x0, cond, t, pt, u), b.step(x0, cond, t, pt, u)
+                la, lb, na, nb = float(oa["loss"]), float(ob["loss"]), float(oa["grad_norm"]), float(ob["grad_norm"])
+                assert abs(la - lb) <= 1e-6 * abs(la) and abs(na - nb) <= 1e-5 * abs(na), (la, lb, na, nb)
+        assert calls == [63, 63] and b.iteration_graph.update_graph is not None
+    finally:
+        dist.destroy_process_group()
