@@ -226,9 +226,6 @@ int ds_layernorm_bwd(const float* x, const float* dy, float* dx, float* dyxn, in
 int ds_layernorm_bwd_chunks(int M, int L, int mode);
 int ds_layernorm_bwd_sums(const float* x, const float* dy, float* dx, float* part, int M, int L, int D, int mode,
                           const float* table, const int64_t* t, const float* gamma, int accumulate, ds_stream_t stream);
-/* the same, accumulating: dx += ... (the residual connection's gradient; replaces ds_layernorm_bwd + ds_axpy) */
-int ds_layernorm_bwd_acc(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
-                     const float* table, const int64_t* t, const float* gamma, ds_stream_t stream);
 /* out[g][c] (+)= sum over R rows of x[(g*gstride) + r*ld + c]: bias / scale / per-sample AdaLN gradients */
 int ds_colsum(const float* x, float* out, int G, int R, int C, long long ld, long long gstride, int accumulate,
               ds_stream_t stream);
@@ -256,8 +253,6 @@ int ds_attention_bwd_f16x2(const float* q, int ldq, const float* k, int ldk, con
                            float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
 /* d emb[tokens[m]] += dx[m] (atomic) */
 int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
-/* y += a * x, n % 4 == 0 */
-int ds_axpy(float* y, const float* x, float a, long long n, ds_stream_t stream);
 /* fused AdamW update (torch.optim.AdamW semantics), step >= 1 */
 int ds_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int step, ds_stream_t stream);
@@ -266,15 +261,6 @@ int ds_adamw(float* p, const float* g, float* m, float* v, long long n, float lr
  * hipGraph replays fixed kernel arguments, so what changes per iteration is read through this pointer. */
 int ds_adamw_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2,
                  float eps, float weight_decay, ds_stream_t stream);
-/* Operand preparation for the training step's split GEMMs (forward  y = x W^T,  dX = dY W,  dW = dY^T X -- what
- * loss.backward() runs for every nn.Linear of Text2ImageTransformer, engine/solver_spec.py:308-331):
- *   dst = scale * src   (transpose 0)   or   scale * src^T   (transpose 1),   src fp32 [rows][ld_src] (cols valid),
- * written as fp32 [drows][ld_dst] (dst_f16 0) or as two row-major fp16 planes hi | lo, `plane` halves apart
- * (dst_f16 1: the W operand of ds_gemm_f16x2 with a_split 0).  drows = transpose ? cols : rows; destination columns past
- * the valid ones up to ld_dst (ld_dst % 8 == 0) are written as zeros.  scale must be a power of two for the split to be
- * exact. */
-int ds_convert_operand(const float* src, int rows, int cols, long long ld_src, int transpose, float scale, void* dst,
-                       long long ld_dst, long long plane, int dst_f16, ds_stream_t stream);
 /* *out = max(*out, max_i |x[i]|)  (the caller zeroes *out; calibration of the training step's loss scale) */
 int ds_amax(const float* x, long long n, float* out, ds_stream_t stream);
 /* ONE pass over fp32 X[rows][ld_src] (cols valid, cols % 32 == 0) that writes everything the three GEMMs of an nn.Linear

@@ -48,12 +48,7 @@ def test_layernorm_backward(L, mode):
     L.check(L.lib().ds_layernorm_bwd(L.ptr(xc), L.ptr(dyc), L.ptr(dx), L.ptr(dyxn), M, Lr, D, mode, L.ptr(tabc), L.ptr(tc),
                                      L.ptr(gc), L.stream()))
     assert close(dx.cpu(), x.grad)
-    # the accumulating form: dx_res += d norm-input (what ds_layernorm_bwd followed by ds_axpy(dx_res, dx) gave, bit for bit)
-    res = rnd((M, D), "lnb.res", 2.0).cuda()
-    want = res + dx
-    L.check(L.lib().ds_layernorm_bwd_acc(L.ptr(xc), L.ptr(dyc), L.ptr(res), L.ptr(dyxn), M, Lr, D, mode, L.ptr(tabc), L.ptr(tc),
-                                         L.ptr(gc), L.stream()))
-    assert torch.equal(res, want)
+    want = rnd((M, D), "lnb.res", 2.0).cuda() + dx                    # what accumulating into a residual gradient must give
     # the form with the scale / shift sums folded in (no dyxn matrix): same dx, sums per sample (mode 0) / over all rows (mode 1)
     G = 2 if mode == 0 else 1
     chunks = L.lib().ds_layernorm_bwd_chunks(M, Lr, mode)
@@ -210,51 +205,16 @@ def test_adamw_matches_torch(L):
     assert close(p.cpu(), ref.detach(), 2e-6)
 
 
-@pytest.mark.parametrize("transpose", [0, 1])
-@pytest.mark.parametrize("f16", [0, 1])
-def test_convert_operand(L, transpose, f16):
-    """ds_convert_operand: scale * src or its transpose, as fp32 or as the hi | lo fp16 planes of the split GEMM's W
-    operand, zero padding up to ld_dst -- exactly what torch computes for the same definition (RNE casts)."""
-    rows, cols, ld_src = 531, 1003, 1008
-    src = torch.zeros(rows, ld_src)
-    src[:, :cols] = rnd((rows, cols), "cv.src", 40.0)
-    src[0, 0], src[1, 1], src[2, 2] = 7.0e4, -9.9e9, 3.0e-7            # saturation and the subnormal low plane
-    src[:, cols:] = 123.0                                               # columns past `cols` must not be read as data
-    scale = 2.0 ** 3
-    want = (src[:, :cols] * scale).t() if transpose else src[:, :cols] * scale
-    drows, dvalid = want.shape
-    ld_dst = (dvalid + 31) // 32 * 32
-    full = torch.zeros(drows, ld_dst)
-    full[:, :dvalid] = want
-    dev_src = src.cuda()
-    if f16:
-        dst = torch.full((2, drows, ld_dst), 0x7777, dtype=torch.int16, device="cuda")
-        plane = drows * ld_dst
-    else:
-        dst = torch.full((drows, ld_dst), float("nan"), device="cuda")
-        plane = 0
-    L.check(L.lib().ds_convert_operand(L.ptr(dev_src), rows, cols, ld_src, transpose, scale, L.ptr(dst), ld_dst, plane, f16,
-                                       L.stream()))
-    if f16:
-        hi = full.clamp(-65504.0, 65504.0).half()
-        lo = (full - hi.float()).clamp(-65504.0, 65504.0).half()
-        got = dst.cpu().view(torch.float16)
-        assert torch.equal(got[0], hi) and torch.equal(got[1], lo)
-    else:
-        assert torch.equal(dst.cpu(), full)
-
-
 def test_gemm_f16x2_split_k_groups(L):
-    """The dW launch of the training step: C = A W^T with the contraction split into `groups` K-ranges of one grouped
-    ds_gemm_f16x2 launch (row-major fp32 A, fp16-plane W), partial products summed by ds_colsum -- against float64 and
-    against the ungrouped launch."""
+    """The row-major form of a split-K launch (fp32 A split by the loader, row-major fp16-plane W -- the training step itself
+    uses the packed form below): C = A W^T with the contraction split into `groups` K-ranges of one grouped ds_gemm_f16x2
+    launch, partial products summed by ds_colsum -- against float64 and against the ungrouped launch."""
     N, K, Mp, S = 320, 192, 1024, 4
     a = rnd((N, Mp), "sk.a", 30.0)
     x = rnd((K, Mp), "sk.x", 2.0)
     ref = a.double() @ x.double().t()
     ac, xc = a.cuda(), x.cuda()
-    planes = torch.empty(2, K, Mp, dtype=torch.int16, device="cuda")
-    L.check(L.lib().ds_convert_operand(L.ptr(xc), K, Mp, Mp, 0, 1.0, L.ptr(planes), Mp, K * Mp, 1, L.stream()))
+    planes = _split_planes(x).view(torch.int16).cuda()          # row-major hi | lo fp16 planes [2][K][Mp]
     one = torch.empty(N, K, device="cuda")
     L.gemm(ac, planes, one, N, K, Mp, split2=0.5, w_plane=K * Mp)
     part = torch.full((S, N * K), float("nan"), device="cuda")

@@ -89,7 +89,6 @@ _PROTOS = {
     "ds_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "ds_layernorm_bwd_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ds_layernorm_bwd_sums": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
-    "ds_layernorm_bwd_acc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "ds_colsum": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _i64, C.c_int, _vp]),
     "ds_colsum_ws": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _i64, C.c_int, _vp, _i64, _vp]),
     "ds_gelu2": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
@@ -99,10 +98,8 @@ _PROTOS = {
     "ds_attention_bwd_f16x2": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                    _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_embed_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
-    "ds_axpy": (C.c_int, [_vp, _vp, _f, _i64, _vp]),
     "ds_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, C.c_int, _vp]),
     "ds_adamw_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
-    "ds_convert_operand": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, _f, _vp, _i64, _i64, C.c_int, _vp]),
     "ds_amax": (C.c_int, [_vp, _i64, _vp, _vp]),
     "ds_pack_operand": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f, C.c_int, _vp, _i64, _vp, _i64, _vp, _i64, C.c_int, C.c_int, C.c_int,
                                   _vp, _vp, _vp]),

@@ -15,7 +15,7 @@
 //                     with an optional elementwise prologue, so that the MLP's activation never exists in fp32:
 //                       DS_PACK_GELU2      x := gelu2(x)                  (forward: fc2's input from fc1's output)
 //                       DS_PACK_GELU2_BWD  x := x * gelu2'(aux)           (backward: d fc1-output from d gelu-output)
-//                     It replaces ds_convert_operand (two transposing passes per linear layer and backward GEMM), the bias
+//                     It replaces the round-2 ds_convert_operand (two transposing passes per linear layer and backward GEMM), the bias
 //                     ds_colsum_ws launches and the ds_amax probes of rounds 2-4.
 //   ds_adamw_multi    the AdamW update of 64 parameter tensors per launch (descriptors by value in the kernel arguments),
 //                     16-byte accesses -- rounds 2-4 launched ds_adamw_dev once per tensor (462 launches per iteration).

@@ -86,13 +86,6 @@ extern "C" int ds_layernorm_bwd(const float* x, const float* dy, float* dx, floa
                                 const float* table, const int64_t* t, const float* gamma, ds_stream_t stream) {
     return ln_bwd_launch(x, dy, dx, dyxn, M, L, D, mode, table, t, gamma, 0, stream);
 }
-// the same with dx += (the block's residual connection: x_out = x + f(norm(x)) => d x = d x_out + d norm-input), saving the
-// separate ds_axpy pass over the residual gradient
-extern "C" int ds_layernorm_bwd_acc(const float* x, const float* dy, float* dx, float* dyxn, int M, int L, int D, int mode,
-                                    const float* table, const int64_t* t, const float* gamma, ds_stream_t stream) {
-    return ln_bwd_launch(x, dy, dx, dyxn, M, L, D, mode, table, t, gamma, 1, stream);
-}
-
 // ---- the same backward with the scale / shift gradient sums folded in (round 5) ------------------------------------------
 // d scale = column sums of dy * xn, d shift = column sums of dy, per sample (AdaLN) or over all rows (LayerNorm).  The form
 // above writes dy * xn to HBM for ds_colsum_ws (one write + two reads of an [M][D] matrix and four launches per norm); here a
@@ -370,126 +363,7 @@ extern "C" int ds_adamw(float* p, const float* g, float* m, float* v, long long 
     return 0;
 }
 
-// ---- y += a * x (residual-stream gradient accumulation), n % 4 == 0 ----------------------------------------------------
-__global__ __launch_bounds__(256) void ds_axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long long n) {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
-    f32x4 yy = *(const f32x4*)(y + i);
-    const f32x4 xx = *(const f32x4*)(x + i);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) yy[k] += a * xx[k];
-    *(f32x4*)(y + i) = yy;
-}
 
-extern "C" int ds_axpy(float* y, const float* x, float a, long long n, ds_stream_t stream) {
-    DS_CHECK_ARG(y && x && n > 0 && n % 4 == 0, "bad arguments (n % 4 == 0)");
-    hipLaunchKernelGGL(ds_axpy_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
-    DS_CHECK_LAUNCH();
-    return 0;
-}
-
-
-// ---- operand preparation for the training step's split GEMMs (modeling/train.py, precision "f16x2") ---------------------
-// dst = scale * src  or  scale * src^T, written either as fp32 or as the two row-major fp16 planes (hi, lo) that
-// ds_gemm_f16x2 takes as its W operand.  The destination has drows rows of ld_dst elements: columns [0, dvalid) carry
-// data, columns [dvalid, ld_dst) are written as zeros (the GEMM's K granule / the split-K padding).  One kernel for the
-// four uses of the backward (dX: W^T planes;  dW: X^T planes and dY^T in fp32) and for the forward's weight planes, so
-// that no torch transpose / pad / cast and no host-side scale search sits between two GEMMs.
-//   non-transposed: a thread converts 8 consecutive elements of a row (2 x 16-byte loads, one 16-byte store per plane)
-//   transposed:     64 x 64 tiles through LDS (rows padded to 65 words: conflict-free both ways); 8 consecutive lanes
-//                   write one 128-byte (fp16) / 256-byte (fp32) run of a destination row
-typedef _Float16 tr_h8 __attribute__((ext_vector_type(8)));
-
-template <bool F16>
-__device__ __forceinline__ void tr_store8(const float (&v)[8], void* dst, long long idx, long long plane) {
-    if (F16) {
-        tr_h8 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            hi[e] = ds_split_hi(v[e]);
-            lo[e] = ds_split_lo(v[e], hi[e]);
-        }
-        _Float16* d = (_Float16*)dst + idx;
-        *(tr_h8*)d = hi;
-        *(tr_h8*)(d + plane) = lo;
-    } else {
-        float* d = (float*)dst + idx;
-        *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    }
-}
-
-template <bool F16>
-__global__ __launch_bounds__(256) void ds_convert_rows_kernel(const float* __restrict__ src, int rows, int cols,
-                                                              long long ld_src, float scale, void* __restrict__ dst,
-                                                              long long ld_dst, long long plane) {
-    const int chunks = (int)(ld_dst >> 3);
-    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (w >= (long long)rows * chunks) return;
-    const int r = (int)(w / chunks), c0 = (int)(w - (long long)r * chunks) * 8;
-    float v[8];
-    const float* s = src + (size_t)r * ld_src + c0;
-    if (c0 + 8 <= cols && (((uintptr_t)s) & 15) == 0) {
-        const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = a[e] * scale; v[4 + e] = b[e] * scale; }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = c0 + e < cols ? s[e] * scale : 0.f;
-    }
-    tr_store8<F16>(v, dst, (long long)r * ld_dst + c0, plane);
-}
-
-template <bool F16>
-__global__ __launch_bounds__(256) void ds_convert_transpose_kernel(const float* __restrict__ src, int rows, int cols,
-                                                                   long long ld_src, float scale, void* __restrict__ dst,
-                                                                   long long ld_dst, long long plane) {
-    __shared__ float t[64][65];
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;     // source tile; destination rows c0.., columns r0..
-    const int tid = threadIdx.x;
-    {
-        const int c = tid & 63;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int r = (tid >> 6) + 4 * it;
-            t[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * ld_src + c0 + c] * scale : 0.f;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int w = tid + 256 * it, chunk = w & 7, cl = w >> 3;        // destination row c0 + cl, columns r0 + 8 chunk ..
-        if (c0 + cl >= cols || r0 + chunk * 8 >= ld_dst) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = t[chunk * 8 + e][cl];
-        tr_store8<F16>(v, dst, (long long)(c0 + cl) * ld_dst + r0 + chunk * 8, plane);
-    }
-}
-
-// dst_f16 != 0: dst = fp16 planes [2][drows][ld_dst] (plane halves apart), else fp32 [drows][ld_dst];
-// drows = transpose ? cols : rows.  ld_dst % 8 == 0 and >= the number of valid destination columns.
-extern "C" int ds_convert_operand(const float* src, int rows, int cols, long long ld_src, int transpose, float scale,
-                                  void* dst, long long ld_dst, long long plane, int dst_f16, ds_stream_t stream) {
-    DS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols, "bad arguments");
-    DS_CHECK_ARG(ld_dst % 8 == 0 && ld_dst >= (transpose ? rows : cols), "ld_dst: a multiple of 8 covering the valid columns");
-    DS_CHECK_ARG(((uintptr_t)dst & 15) == 0 && (!dst_f16 || (plane % 8 == 0 && plane >= (long long)(transpose ? cols : rows) * ld_dst)),
-                 "dst alignment / plane stride");
-    hipStream_t s = (hipStream_t)stream;
-    if (!transpose) {
-        const long long work = (long long)rows * (ld_dst >> 3);
-        const dim3 grid((unsigned)((work + 255) / 256));
-        if (dst_f16) hipLaunchKernelGGL(ds_convert_rows_kernel<true>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, dst, ld_dst, plane);
-        else hipLaunchKernelGGL(ds_convert_rows_kernel<false>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, dst, ld_dst, plane);
-    } else {
-        // tiles over [0, ld_dst) source rows (rows past `rows` produce the zero padding) x the source columns
-        const dim3 grid((unsigned)((ld_dst + 63) / 64), (unsigned)((cols + 63) / 64));
-        if (dst_f16) hipLaunchKernelGGL(ds_convert_transpose_kernel<true>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, dst, ld_dst, plane);
-        else hipLaunchKernelGGL(ds_convert_transpose_kernel<false>, grid, dim3(256), 0, s, src, rows, cols, ld_src, scale, dst, ld_dst, plane);
-    }
-    DS_CHECK_LAUNCH();
-    return 0;
-}
 
 // ---- max |x| into *out (caller zeroes it): non-negative floats order like their bit patterns -------------------------
 // ONE atomic per workgroup, at most 512 workgroups, 16-byte loads.  (Round 3: one atomic per WAVE of 2048 workgroups -- 8192

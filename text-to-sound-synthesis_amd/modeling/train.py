@@ -66,12 +66,6 @@ def _colsum(x, G=1, R=None, accumulate_into=None):
     return out
 
 
-def _convert(src, rows, cols, ld_src, transpose, scale, dst, ld_dst, plane, f16):
-    L_.check(L_.lib().ds_convert_operand(L_.ptr(src), rows, cols, ld_src, int(transpose), float(scale), L_.ptr(dst), ld_dst,
-                                         plane, int(f16), L_.stream()))
-    return dst
-
-
 PACK_PLAIN, PACK_GELU2, PACK_GELU2_BWD = 0, 1, 2
 
 
