@@ -276,13 +276,6 @@ class _SplitGemm:
         return out[0]
 
 
-def _handle_tensors(h):
-    """the device tensors behind an operand handle (fp32 backend: the matrix; f16x2 backend: a _Packed's buffers)"""
-    if torch.is_tensor(h):
-        return [h]
-    return [v for v in (h.row, h.t, h.part) if v is not None]
-
-
 def _norm_fwd(x, mode, L, table=None, t=None, gamma=None, beta=None):
     M, D = x.shape
     y = torch.empty_like(x)
@@ -395,14 +388,12 @@ class _FusedAttn:
 
 
 class TrainStep:
-    def __init__(self, diffusion_transformer, precision="fp32", rescale_interval=100, attention="fused", overlap_dw=False):
+    def __init__(self, diffusion_transformer, precision="fp32", rescale_interval=100, attention="fused"):
         assert precision in ("f16x2", "fp32") and attention in ("fused", "composed")
         self.attention = attention
         # fused attention FORWARD on the streamed fp16-split kernel of the sampling path (ds_attention_f16x2) in the "f16x2"
         # backend: 122 -> ~35 us per self-attention launch at B = 20; gradient parity unchanged (tests/test_hip_train_kernels.py)
         self.split_attention = precision == "f16x2"
-        self.overlap_dw = overlap_dw      # weight-gradient GEMMs on a second HIP stream, beside the dX / attention chain
-        self._side = None
         self.dt = diffusion_transformer
         self.tr = diffusion_transformer.transformer
         self.precision = precision
@@ -423,11 +414,6 @@ class TrainStep:
         # weight swaps outside this class (checkpoint / EMA loads: solver._invalidate) must drop the cached pre-scales
         import weakref
         diffusion_transformer.__dict__.setdefault("_scale_clients", []).append(weakref.ref(self))
-
-    def _side_stream(self, dev):
-        if self._side is None:
-            self._side = torch.cuda.Stream(dev)
-        return self._side
 
     def reset_scales(self):
         """Forget the per-matrix weight pre-scales 2^s and the loss scale: the next step re-derives both (one calibration
@@ -641,49 +627,22 @@ class TrainStep:
         # ---- backward (every d* below carries the loss scale; `small` collects what one multiply un-scales at the end)
         g, small = {}, []
 
-        side = self._side_stream(dev) if (self.overlap_dw and dev.type == "cuda") else None
-        reads_dx = []               # side-stream work that still reads the residual gradient `dx` (updated in place below)
-
         def lin_bwd(lin, xh, dy, need_dx=True, pro=PACK_PLAIN, aux=None):
             """The three products of one linear layer for its output gradient dy (fp32; with pro = PACK_GELU2_BWD the
-            gradient of the layer's output is dy * gelu2'(aux)).  dy is packed ONCE on the current stream (G_.prep_dy: row
-            form, transposed form, bias column sums, max |dY| -- after which nothing reads the fp32 dy any more, so the
-            in-place updates of the residual gradient need no ordering against the weight-gradient GEMMs).  dX on the current
-            stream; dW / db -- off the critical path of the backward, nothing downstream needs them before the clip -- on the
-            side stream when `overlap_dw` is set (the MFMA-bound weight-gradient GEMMs then run beside the latency-bound
-            attention backward / norm kernels of the main chain)."""
+            gradient of the layer's output is dy * gelu2'(aux)).  dy is packed ONCE (G_.prep_dy: row form, transposed form,
+            bias column sums, max |dY|), then dX, dW and db.  (Rounds 2-4 could put dW / db on a second HIP stream; measured
+            slower in both rounds it was tried -- 15.6 vs 15.9 and 16.2 vs 16.6 it/s, the GEMMs fill the power-capped chip -- and
+            removed in round 5.)"""
             dyh = G_.prep_dy(lin, dy, pro=pro, aux=aux, amax=amax, need_row=need_dx)
-            if side is None:
-                dxo = G_.dx(lin, dyh) if need_dx else None
-                dW = G_.dw(lin, xh, dyh, inv)
-                db = G_.db(lin, dyh)
-            else:
-                main = torch.cuda.current_stream(dev)
-                ready = torch.cuda.Event()
-                ready.record(main)                          # the operand handles are complete at this point of the main stream
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    dW = G_.dw(lin, xh, dyh, inv)
-                    db = G_.db(lin, dyh)
-                    if self.precision != "f16x2":           # fp32 backend: the handle IS dy, which the caller may update in place
-                        done = torch.cuda.Event()
-                        done.record(side)
-                        reads_dx.append(done)
-                for tns in _handle_tensors(dyh) + _handle_tensors(xh):
-                    tns.record_stream(side)                 # (allocator: not to be reused before the side stream is done)
-                dxo = G_.dx(lin, dyh) if need_dx else None
+            dxo = G_.dx(lin, dyh) if need_dx else None
+            dW = G_.dw(lin, xh, dyh, inv)
+            db = G_.db(lin, dyh)
             small.append(db)
             return dxo, dW, db
 
-        def dx_readers_done():
-            """before `dx` is modified in place: the weight-gradient GEMMs that read it as their dY have finished"""
-            for ev in reads_dx:
-                torch.cuda.current_stream(dev).wait_event(ev)
-            reads_dx.clear()
-
         def hand_over(names):
             if on_grads is not None and not calibrating:
-                on_grads({n: g[n] for n in names}, (side,) if side is not None else ())
+                on_grads({n: g[n] for n in names}, ())
 
         dh, g["transformer.to_logits.1.weight"], g["transformer.to_logits.1.bias"] = lin_bwd(lin_logits, hf, dlog)
         hand_over(["transformer.to_logits.1.weight"])
@@ -736,7 +695,6 @@ class TrainStep:
             dgact, g[p + "mlp.2.weight"], g[p + "mlp.2.bias"] = lin_bwd(ls["fc2"], s["g"], dx)
             # d fc1-output = dgact * gelu2'(u): the prologue of fc1's gradient pack
             dh, g[p + "mlp.0.weight"], g[p + "mlp.0.bias"] = lin_bwd(ls["fc1"], s["h3"], dgact, pro=PACK_GELU2_BWD, aux=s["u"])
-            dx_readers_done()
             _, dgam, dbet = _norm_bwd(s["x2"], dh, 1, Lx, gamma=blk.ln2.weight, add_to=dx)
             g[p + "ln2.weight"], g[p + "ln2.bias"] = dgam[0], dbet[0]
             small += [dgam, dbet]
@@ -752,7 +710,6 @@ class TrainStep:
             _, dWkv, dbkv = lin_bwd(ls["kv2"], cond_h, dkv, need_dx=False)
             g[p + "attn2.key.weight"], g[p + "attn2.value.weight"] = dWkv[:D], dWkv[D:]
             g[p + "attn2.key.bias"], g[p + "attn2.value.bias"] = dbkv[:D], dbkv[D:]
-            dx_readers_done()
             _, dsc, dsh = _norm_bwd(s["x1"], dh, 0, Lx, table=s["tab2"], t=t, add_to=dx)
             adaln_param_grads(blk.ln1_1, dsc, dsh, p + "ln1_1")
             # x1 = x0 + proj1(attn1(qkv(ln1(x0))))
@@ -765,7 +722,6 @@ class TrainStep:
             dh, dWqkv, dbqkv = lin_bwd(ls["qkv1"], s["h1"], dqkv)
             for j, nm in enumerate(("query", "key", "value")):
                 g[p + "attn1.%s.weight" % nm], g[p + "attn1.%s.bias" % nm] = dWqkv[j * D:(j + 1) * D], dbqkv[j * D:(j + 1) * D]
-            dx_readers_done()
             _, dsc, dsh = _norm_bwd(s["x0"], dh, 0, Lx, table=s["tab1"], t=t, add_to=dx)
             adaln_param_grads(blk.ln1, dsc, dsh, p + "ln1")
             hand_over([p + n for n in ("mlp.2.weight", "mlp.0.weight", "attn2.proj.weight", "attn2.query.weight",
@@ -786,8 +742,6 @@ class TrainStep:
         L_.check(L_.lib().ds_colsum(L_.ptr(dpos), L_.ptr(dw), Ww, Hh, D, Ww * D, D, 0, L_.stream()))   # sum over h
         g["transformer.content_emb.width_emb.weight"] = dw
         small += [demb, dhh, dw]
-        if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)      # every dW / db is complete from here on
         if inv != 1.0:
             torch._foreach_mul_(small, inv)
         if not calibrating:

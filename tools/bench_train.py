@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 
 def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", ema_device="cuda", attention="fused",
-        overlap_dw=False, graph=True, world=1, rank=0, dev=None):
+        graph=True, world=1, rank=0, dev=None):
     """Time `steps` training iterations (after `warmup`) and return the result dict (see the module docstring).  (Per-kernel
     rates: tools/train_profile.sh -- rocprofv3 --stats over this script.)"""
     from text_to_sound_synthesis_amd import shard, synth
@@ -74,11 +74,11 @@ def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", e
         # one GPU: the whole iteration is one hipGraph.  Data parallel: two graphs per rank (gradients | clip + AdamW) with the
         # bucketed all-reduce over RCCL enqueued between the replays (tests/test_hip_rccl.py runs exactly this at world 1)
         from text_to_sound_synthesis_amd.modeling.solver import GraphSolver
-        solver = GraphSolver(TrainStep(dt, precision=precision, attention=attention, overlap_dw=overlap_dw), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = GraphSolver(TrainStep(dt, precision=precision, attention=attention), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                              scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
                              reduce=timed_allreduce if world > 1 else None)
     else:
-        solver = Solver(Timed(dt, precision=precision, attention=attention, overlap_dw=overlap_dw), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = Solver(Timed(dt, precision=precision, attention=attention), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                         scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
                         allreduce=timed_allreduce if world > 1 else None)
 
@@ -113,7 +113,7 @@ def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", e
         "data": "synthetic", "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
         "ms": {k: 1e3 * v / steps for k, v in times.items()},
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-        "graph": use_graph, "attention": attention, "overlap_dw": overlap_dw,
+        "graph": use_graph, "attention": attention,
         "loss_scale_exp": solver.train_step.loss_scale_exp,
         "config": {"workload": "BASELINE configs[4]: training step, B=%d per GPU, %d layers, K=%d" % (B, n_layer, codes),
                    "parallelism": "dp%d" % world}}
@@ -131,7 +131,6 @@ def main():
     ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
     ap.add_argument("--attention", default="fused", choices=("fused", "composed"),
                     help="fused: ds_attention + ds_attention_bwd (recompute); composed: grouped GEMMs with stored probabilities")
-    ap.add_argument("--overlap-dw", action="store_true", help="weight-gradient GEMMs on a second HIP stream")
     ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,7 +141,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     out = run(args.batch, args.steps, args.warmup, args.n_layer, args.codes, args.precision, args.ema_device, args.attention,
-              args.overlap_dw, args.graph, world, rank, dev)
+              args.graph, world, rank, dev)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
