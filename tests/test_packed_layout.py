@@ -502,3 +502,36 @@ def test_vocoder_args_yml_reader(tmp_path):
     assert read_vocoder_args(str(f)) == (80, 48, 4)
     f.write_text("ngf: 32\n")
     assert read_vocoder_args(str(f)) == (80, 32, 3)          # missing fields keep the reference configuration's values
+
+
+def test_pack_operand_forms_and_subrange_arithmetic_host_mirror():
+    """The host mirror of ds_pack_operand (csrc/pack.hip; the GPU test compares the kernel to exactly these expressions): the ROW
+    form is pack_planes(split(X)), the TRANSPOSED form pack_planes(split(X^T zero-padded to rows_pad)); and the sub-range
+    arithmetic modeling/train.py's _pack_parts relies on -- part i of a fused weight lands (row form) n0 * K halves into each
+    plane and (transposed form) in k-range [n0, n0 + N_i) of X^T [K][N] -- holds in the documented layout."""
+    from text_to_sound_synthesis_amd import _lib as L
+
+    def split(a):
+        hi = a.clamp(-65504.0, 65504.0).half()
+        return torch.stack((hi, (a - hi.float()).clamp(-65504.0, 65504.0).half()))
+
+    K, Ns = 64, (32, 96, 64)
+    g = torch.Generator().manual_seed(5)
+    parts = [torch.randn(n, K, generator=g) for n in Ns]
+    fused = torch.cat(parts)
+    N = fused.shape[0]
+    row = L.pack_planes(split(fused)).reshape(2, -1)                     # [2][N * K]
+    tr = L.pack_planes(split(fused.t().contiguous())).reshape(2, -1)     # X^T [K][N]: [2][ceil16(K) * N]
+    n0 = 0
+    for w in parts:
+        n = w.shape[0]
+        # row form: the part's own packing, dropped n0 * K halves into each plane of the fused operand
+        own = L.pack_planes(split(w)).reshape(2, -1)
+        assert torch.equal(row[:, n0 * K:(n0 + n) * K], own)
+        # transposed form: element (k, n0 + j) of X^T sits at ds_packed_off(k, n0 + j, N / 32)
+        own_t = split(w.t().contiguous())                                # [2][K][n]
+        for k, j in ((0, 0), (5, 9), (17, n - 1), (K - 1, n // 2)):
+            col = n0 + j
+            off = ((k // 16) * (N // 32) + col // 32) * 512 + (k % 16) * 32 + (((col // 8) % 4) ^ ((k // 4) % 4)) * 8 + col % 8
+            assert tr[0, off] == own_t[0, k, j] and tr[1, off] == own_t[1, k, j]
+        n0 += n
