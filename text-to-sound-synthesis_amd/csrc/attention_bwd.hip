@@ -23,7 +23,9 @@
 // matrix-pipe time.  The LDS operand is split ONCE when it is staged (two swizzled fp16 planes, ab_stage_split), register
 // fragments when they are loaded, the score / dS tiles right at the MFMA.  Only the k-index mapping of the fragments changes (a lane holds 8 consecutive d / 8 of its own
 // accumulator rows per MFMA instead of 1).  P in [0, 1] is multiplied by 2^10 before it is split (its lo plane would sit in
-// fp16's subnormal range otherwise) and dV by 2^-10 when it is stored; dO / dS carry the step's loss scale (|.| < 2^16).
+// fp16's subnormal range otherwise) and dV by 2^-10 when it is stored; dO / dS carry the step's loss scale: |dO| is folded into
+// the step's saturation monitor (modeling/train.py), |dS| = scale P |dP - delta| is not monitored itself -- it is bounded by the
+// monitored |dQ|, |dK| it sums into in practice, and the split SATURATES at 65504 instead of overflowing.
 #include "common.h"
 
 typedef _Float16 ab_h8 __attribute__((ext_vector_type(8)));
