@@ -77,7 +77,6 @@ extern "C" int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
     return ds_launch_gemm_f16x2(p, (hipStream_t)stream);
 }
 
-int ds_launch_gemm_f16x2_pair(const GemmParams& p1, const GemmParams& p2, hipStream_t stream);   // gemm_f16x2.hip
 extern "C" int ds_gemm_f16x2_pair(const ds_gemm_desc* d1, const ds_gemm_desc* d2, ds_stream_t stream) {
     DS_CHECK_ARG(d1 && d2 && d1->A && d1->W && d1->C && d2->A && d2->W && d2->C, "null pointer");
     DS_CHECK_ARG(d1->loader == DS_LOAD_DENSE && d2->loader == DS_LOAD_DENSE && d1->pro == DS_PRO_NONE && d2->pro == DS_PRO_NONE &&

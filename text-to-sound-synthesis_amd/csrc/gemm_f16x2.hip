@@ -474,20 +474,17 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_hybrid_kernel(const Gemm
 
 // TWO packed-operand problems in ONE grid of 128 x 128 tiles (round 5: the training step's dX = dY W and dW = dY^T X of a
 // 1024 x 1024 layer).  Alone, each is ~0.5-0.66 of a round of the 512 resident workgroups (336 and 128-256 tiles), which is why
-// the dispatcher gives them the LDS-bound 128 x 64 tile; together they are about one round of the better tile.  Problem 2 may be
-// a split-K launch: its K-range groups are laid out after one another (tpg2 tiles per group, n2 in all).  second_first puts
-// problem 2's workgroups at the front of the grid -- the problem with the longer contraction per tile goes first so that the
-// short tiles fill the slots the long ones leave.
+// the dispatcher gives them the LDS-bound 128 x 64 tile; together they are one round of the better tile.  Workgroups [0, n1)
+// run problem 1; the rest run problem 2, whose K-range groups (split-K) are laid out after one another (tpg2 tiles per group).
 __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_pair_kernel(const GemmParams p1, const GemmParams p2, const int n1,
-                                                                   const int tpg2, const int n2, const int second_first) {
+                                                                   const int tpg2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     const int bid = blockIdx.x;   // uniform branch: a workgroup runs one of the two problems
-    const int b1 = second_first ? bid - n2 : bid;
-    if (b1 >= 0 && b1 < n1) {
-        ds_gemm_f16x2_body<128, 128, 2>(p1, b1, n1, smem_dyn);
+    if (bid < n1) {
+        ds_gemm_f16x2_body<128, 128, 2>(p1, bid, n1, smem_dyn);
         return;
     }
-    const int b2 = second_first ? bid : bid - n1, g = b2 / tpg2;
+    const int b2 = bid - n1, g = b2 / tpg2;
     GemmParams q = p2;
     q.A = (const float*)((const _Float16*)p2.A + (size_t)g * (size_t)p2.a_gstride);
     q.W = (const float*)((const _Float16*)p2.W + (size_t)g * (size_t)p2.w_gstride);
@@ -625,7 +622,7 @@ int ds_launch_gemm_f16x2_pair(const GemmParams& p1, const GemmParams& p2, hipStr
         }
         attr_set.done();
     }
-    hipLaunchKernelGGL(ds_gemm_f16x2_pair_kernel, dim3(n1 + n2), dim3(256), lds, s, p1, p2, n1, tpg2, n2, p2.K > p1.K ? 1 : 0);
+    hipLaunchKernelGGL(ds_gemm_f16x2_pair_kernel, dim3(n1 + n2), dim3(256), lds, s, p1, p2, n1, tpg2);
     DS_CHECK_LAUNCH();
     return 0;
 }

@@ -200,7 +200,6 @@ class _SplitGemm:
     def __init__(self):
         self.wexp = {}              # key -> s: the weight is split as W * 2^s (max |W| 2^s in [2^13, 2^14))
         self.pair_small = True      # dX + dW of the small layers as one launch (pairs / dx_dw_pair)
-        self.pair_ranges = 4        # ... with this many K-ranges of dW when the padded contraction allows (else 2)
 
     def refresh_scales(self, lins):
         """One host sync for all matrices: s = 13 - floor(log2 max|W|)."""
@@ -218,7 +217,7 @@ class _SplitGemm:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         if tiles >= 256:
             return 1
-        return 4 if M >= 4096 else 2      # (a PAIRED launch, `pairs`, uses 4 or 2 ranges of the same padded contraction)
+        return 4 if M >= 4096 else 2      # (a PAIRED launch uses 2 ranges of the same padded contraction: 32 * 4 | Mp)
 
     def rows_pad(self, lin, M):
         """the padded contraction length of this layer's dW = dY^T X over M rows: a multiple of 32 per K-range"""
@@ -272,28 +271,21 @@ class _SplitGemm:
         return dW
 
     def pairs(self, lin, M):
-        """K-ranges of dW when dX and dW of this layer go out as ONE launch (ds_gemm_f16x2_pair), else 0.  Both are well under
-        a round of the 512 resident 128 x 128 tiles alone (N = K = 1024 at M = 5300: 336 tiles and 64 per K-range), which is
-        where the dispatcher falls back to the LDS-bound 128 x 64 tile.  pair_ranges K-ranges when that keeps the contraction
-        whole k-tiles and the grid within 1.25 rounds (dW's tiles are then about as long as dX's and the compute units stay
-        evenly loaded), else 2."""
+        """Whether dX and dW of this layer go out as ONE launch (ds_gemm_f16x2_pair): both are well under a round of 128 x 128
+        tiles alone (N = K = 1024 at M = 5300: 336 + 128 tiles = one round together), which is where the dispatcher falls
+        back to the LDS-bound 128 x 64 tile."""
         t_dx = ((M + 127) // 128) * ((lin.K + 127) // 128)
         t_dw = ((lin.N + 127) // 128) * ((lin.K + 127) // 128)
-        if not self.pair_small or lin.N % 32 or t_dx > 400 or t_dw > 128:
-            return 0
-        Mp = self.rows_pad(lin, M)
-        for S in (self.pair_ranges, 2):
-            if S >= 2 and Mp % (32 * S) == 0 and t_dx + S * t_dw <= (640 if S > 2 else 512):
-                return S
-        return 0
+        return self.pair_small and lin.N % 32 == 0 and t_dx <= 400 and t_dw <= 128 and t_dx + 2 * t_dw <= 512
 
-    def dx_dw_pair(self, lin, xp, dyp, inv_scale, S):
-        """dX = dY W and dW = dY^T X (S K-ranges) in one grid; -> (dX, dW)"""
+    def dx_dw_pair(self, lin, xp, dyp, inv_scale):
+        """dX = dY W and dW = dY^T X (2 K-ranges) in one grid; -> (dX, dW)"""
         M, N, K, Mp = dyp.rows, lin.N, lin.K, dyp.rows_pad
         Wp = lin.extra["Wp"]
         dev = dyp.row.device
         out = torch.empty(M, K, device=dev)
         d1 = L_.gemm(dyp.row, Wp.t, out, M, K, N, split2=lin.extra["osc"], a_plane=dyp.row_plane, w_plane=Wp.t_plane, launch=False)
+        S = 2
         assert Mp % (32 * S) == 0 and xp.rows_pad == Mp
         part = torch.empty(S, N * K, device=dev)
         Kc = Mp // S
@@ -669,9 +661,8 @@ class TrainStep:
             slower in both rounds it was tried -- 15.6 vs 15.9 and 16.2 vs 16.6 it/s, the GEMMs fill the power-capped chip -- and
             removed in round 5.)"""
             dyh = G_.prep_dy(lin, dy, pro=pro, aux=aux, amax=amax, need_row=need_dx)
-            S = G_.pairs(lin, dyh.rows) if need_dx and getattr(G_, "pairs", None) is not None else 0
-            if S:
-                dxo, dW = G_.dx_dw_pair(lin, xh, dyh, inv, S)
+            if need_dx and getattr(G_, "pairs", None) is not None and G_.pairs(lin, dyh.rows):
+                dxo, dW = G_.dx_dw_pair(lin, xh, dyh, inv)
             else:
                 dxo = G_.dx(lin, dyh) if need_dx else None
                 dW = G_.dw(lin, xh, dyh, inv)

@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 
 def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", ema_device="cuda", attention="fused",
-        graph=True, world=1, rank=0, dev=None, pair_ranges=None):
+        graph=True, world=1, rank=0, dev=None):
     """Time `steps` training iterations (after `warmup`) and return the result dict (see the module docstring).  (Per-kernel
     rates: tools/train_profile.sh -- rocprofv3 --stats over this script.)"""
     from text_to_sound_synthesis_amd import shard, synth
@@ -70,18 +70,15 @@ def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", e
     sched = PlateauWarmupLR(3.0e-6, factor=0.5, patience=25000, min_lr=1.0e-6, threshold=1.0e-1, warmup_lr=4.5e-4, warmup=1000)
     ema = EMA(dt, decay=0.99, update_interval=25, device=ema_device)
     use_graph = bool(graph)
-    step = (TrainStep if use_graph else Timed)(dt, precision=precision, attention=attention)
-    if pair_ranges is not None and hasattr(step.gemm, "pair_small"):   # A/B of the paired dX + dW launch: 0 = two launches
-        step.gemm.pair_small, step.gemm.pair_ranges = pair_ranges > 0, max(pair_ranges, 2)
     if use_graph:
         # one GPU: the whole iteration is one hipGraph.  Data parallel: two graphs per rank (gradients | clip + AdamW) with the
         # bucketed all-reduce over RCCL enqueued between the replays (tests/test_hip_rccl.py runs exactly this at world 1)
         from text_to_sound_synthesis_amd.modeling.solver import GraphSolver
-        solver = GraphSolver(step, lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = GraphSolver(TrainStep(dt, precision=precision, attention=attention), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                              scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
                              reduce=timed_allreduce if world > 1 else None)
     else:
-        solver = Solver(step, lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = Solver(Timed(dt, precision=precision, attention=attention), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                         scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
                         allreduce=timed_allreduce if world > 1 else None)
 
@@ -134,8 +131,6 @@ def main():
     ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
     ap.add_argument("--attention", default="fused", choices=("fused", "composed"),
                     help="fused: ds_attention + ds_attention_bwd (recompute); composed: grouped GEMMs with stored probabilities")
-    ap.add_argument("--pair-ranges", type=int, default=None,
-                    help="A/B: K-ranges of dW in the paired dX + dW launch of the small layers (0: two launches; default: 4)")
     ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,7 +141,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     out = run(args.batch, args.steps, args.warmup, args.n_layer, args.codes, args.precision, args.ema_device, args.attention,
-              args.graph, world, rank, dev, args.pair_ranges)
+              args.graph, world, rank, dev)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
