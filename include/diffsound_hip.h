@@ -86,9 +86,6 @@ void ds_gemm_force_tile(int cfg); /* test hook: 0..2 pins the block tile, -1 = a
  * lda = ldw = the FULL contraction length the planes were packed with) this is a split-K launch whose partial results the
  * caller sums (ds_colsum). */
 int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
-/* TWO packed-operand problems (a_split, plain row store; d2 may be a split-K launch: groups) in ONE grid of 128 x 128 tiles:
- * the training step's dX = dY W and dW = dY^T X of one nn.Linear, each too small to fill the chip with that tile alone. */
-int ds_gemm_f16x2_pair(const ds_gemm_desc* d1, const ds_gemm_desc* d2, ds_stream_t stream);
 /* the conv-family loaders in the same fp32-class 3-pass formulation: A fp32 (split while it is staged), W = the two fp16
    planes [groups][N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart, groups w_gstride apart), out_scale = 2^-s.
    d->loader: DS_LOAD_CONV2D (3x3 conv over a channels-last image: Cin, H, Wd, up; prologue none or GroupNorm affine +

@@ -360,47 +360,6 @@ def test_gemm_f16x2_packed_split_k_groups(L):
             assert (part[g].view(N, K).cpu().double() - 0.5 * pr).abs().max().item() < 2e-6 * scale, "tile %d group %d" % (tile, g)
 
 
-def test_gemm_f16x2_pair_equals_two_launches(L):
-    """ds_gemm_f16x2_pair: dX = dY W and dW = dY^T X (2 K-ranges) of one layer in ONE grid of 128 x 128 tiles == the two separate
-    launches with the 128 x 128 tile forced, bit for bit (the same tile program computes every output element)."""
-    M, N, K = 795, 320, 256
-    Mp = (M + 63) // 64 * 64
-    dy, x, w = rnd((M, N), "pr.dy", 20.0), rnd((M, K), "pr.x", 2.0), rnd((N, K), "pr.w", 0.3)
-    dyc, xc, wc = dy.cuda(), x.cuda(), w.cuda()
-
-    def pack(src, rows, cols, rows_pad):
-        R16, C16 = (rows + 15) // 16 * 16, (cols + 15) // 16 * 16
-        r = torch.empty(2, R16 * cols, dtype=torch.int16, device="cuda")
-        t = torch.empty(2, C16 * rows_pad, dtype=torch.int16, device="cuda")
-        L.check(L.lib().ds_pack_operand(L.ptr(src), rows, cols, cols, 1.0, 0, None, 0, L.ptr(r), R16 * cols, L.ptr(t), C16 * rows_pad,
-                                        rows_pad, 0, 0, None, None, L.stream()))
-        return r, R16 * cols, t, C16 * rows_pad
-    dy_r, dy_rp, dy_t, dy_tp = pack(dyc, M, N, Mp)
-    _, _, x_t, x_tp = pack(xc, M, K, Mp)
-    _, _, w_t, w_tp = pack(wc, N, K, N)                              # W^T [K][N]: the W operand of dX
-    Kc = Mp // 2
-
-    def descs(dx, part, launch):
-        a = L.gemm(dy_r, w_t, dx, M, K, N, split2=0.5, a_plane=dy_rp, w_plane=w_tp, launch=launch)
-        b = L.gemm(dy_t, x_t, part, N, K, Kc, lda=Mp, ldw=Mp, ldc=K, groups=2, a_gstride=Kc * 16, w_gstride=Kc * 16,
-                   c_gstride=N * K, split2=0.25, a_plane=dy_tp, w_plane=x_tp, launch=launch)
-        return a, b
-    dx1, part1 = torch.full((M, K), float("nan"), device="cuda"), torch.full((2, N * K), float("nan"), device="cuda")
-    L.lib().ds_gemm_f16x2_force_tile(0)
-    try:
-        descs(dx1, part1, True)
-    finally:
-        L.lib().ds_gemm_f16x2_force_tile(-1)
-    dx2, part2 = torch.full((M, K), float("nan"), device="cuda"), torch.full((2, N * K), float("nan"), device="cuda")
-    d1, d2 = descs(dx2, part2, False)
-    L.gemm_pair(d1, d2)
-    assert torch.equal(dx2, dx1) and torch.equal(part2, part1)
-    ref = 0.5 * (dy.double() @ w.double())
-    assert (dx2.cpu().double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
-    refw = 0.25 * (dy.double().t() @ x.double())
-    assert (part2.sum(0).view(N, K).cpu().double() - refw).abs().max().item() < 2e-6 * refw.abs().max().item()
-
-
 def test_adamw_multi_equals_per_tensor_launches(L):
     """ds_adamw_multi (64 tensor descriptors by value per launch) against ds_adamw_dev tensor by tensor (the same expressions;
     hipcc contracts the two kernels' multiply-adds differently, so equal to rounding, not bit for bit): odd sizes, an

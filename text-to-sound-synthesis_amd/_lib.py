@@ -49,7 +49,6 @@ _PROTOS = {
     "ds_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_gemm_force_tile": (None, [C.c_int]),
     "ds_gemm_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
-    "ds_gemm_f16x2_pair": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _vp]),
     "ds_conv2d_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_gemm_f16x2_force_tile": (None, [C.c_int]),
     "ds_gemm_f16x2_set_balance_slots": (None, [C.c_int]),
@@ -201,7 +200,7 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
          groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
          act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
          Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split2=None,
-         a_plane=0, c_plane=0, attn=None, w_plane=None, conv_split=False, launch=True):
+         a_plane=0, c_plane=0, attn=None, w_plane=None, conv_split=False):
     """split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used;
     a_plane / c_plane > 0 (f16x2 only): A and W are given / C is written as packed split planes (pack_planes())
     that many halves apart."""
@@ -233,17 +232,10 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
             d.w3_plane = w_plane
         if attn is not None:        # (kv images tensor or None, heads, nkey, q plane stride): STORE_ATTN
             d.attn_kv, d.attn_heads, d.attn_nkey, d.attn_qplane = ptr(attn[0]), attn[1], attn[2], attn[3]
-        if not launch:              # the filled descriptor, for gemm_pair (the caller keeps the operand tensors alive)
-            return d
         check(lib().ds_gemm_f16x2(C.byref(d), stream()))
     else:
         check(lib().ds_gemm(C.byref(d), stream()))
     return C_out
-
-
-def gemm_pair(d1, d2):
-    """Two packed-operand f16x2 problems (descriptors from gemm(..., launch=False)) in one grid: ds_gemm_f16x2_pair."""
-    check(lib().ds_gemm_f16x2_pair(C.byref(d1), C.byref(d2), stream()))
 
 
 def pack_conv_weights(planes, Cout, Cin, taps):

@@ -77,19 +77,6 @@ extern "C" int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
     return ds_launch_gemm_f16x2(p, (hipStream_t)stream);
 }
 
-extern "C" int ds_gemm_f16x2_pair(const ds_gemm_desc* d1, const ds_gemm_desc* d2, ds_stream_t stream) {
-    DS_CHECK_ARG(d1 && d2 && d1->A && d1->W && d1->C && d2->A && d2->W && d2->C, "null pointer");
-    DS_CHECK_ARG(d1->loader == DS_LOAD_DENSE && d2->loader == DS_LOAD_DENSE && d1->pro == DS_PRO_NONE && d2->pro == DS_PRO_NONE &&
-                     !d1->f16_round && !d2->f16_round && d1->w3_plane > 0 && d2->w3_plane > 0,
-                 "pair: two dense, no-prologue f16x2 problems with split weights");
-    GemmParams p1, p2;
-    memset(&p1, 0, sizeof(p1));
-    memset(&p2, 0, sizeof(p2));
-    fill(p1, d1);
-    fill(p2, d2);
-    return ds_launch_gemm_f16x2_pair(p1, p2, (hipStream_t)stream);
-}
-
 // ---- denoiser ---------------------------------------------------------------------------------------
 struct ds_denoiser {
     ds_denoiser_desc d;

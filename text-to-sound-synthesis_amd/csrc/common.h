@@ -161,5 +161,4 @@ int ds_sample_tail_rows(const float* logits, int logits_rows, const int64_t* xt,
 
 int ds_launch_gemm(const GemmParams& p, hipStream_t stream, int loader);
 int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream);   // gemm_f16x2.hip
-int ds_launch_gemm_f16x2_pair(const GemmParams& p1, const GemmParams& p2, hipStream_t stream);   // gemm_f16x2.hip
 int ds_launch_conv2d_f16x2(const GemmParams& p, hipStream_t stream, int loader); // conv_f16x2.hip

@@ -472,26 +472,6 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_hybrid_kernel(const Gemm
     else ds_gemm_f16x2_body<64, 64, 2>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
 }
 
-// TWO packed-operand problems in ONE grid of 128 x 128 tiles (round 5: the training step's dX = dY W and dW = dY^T X of a
-// 1024 x 1024 layer).  Alone, each is ~0.5-0.66 of a round of the 512 resident workgroups (336 and 128-256 tiles), which is why
-// the dispatcher gives them the LDS-bound 128 x 64 tile; together they are one round of the better tile.  Workgroups [0, n1)
-// run problem 1; the rest run problem 2, whose K-range groups (split-K) are laid out after one another (tpg2 tiles per group).
-__global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_pair_kernel(const GemmParams p1, const GemmParams p2, const int n1,
-                                                                   const int tpg2) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    const int bid = blockIdx.x;   // uniform branch: a workgroup runs one of the two problems
-    if (bid < n1) {
-        ds_gemm_f16x2_body<128, 128, 2>(p1, bid, n1, smem_dyn);
-        return;
-    }
-    const int b2 = bid - n1, g = b2 / tpg2;
-    GemmParams q = p2;
-    q.A = (const float*)((const _Float16*)p2.A + (size_t)g * (size_t)p2.a_gstride);
-    q.W = (const float*)((const _Float16*)p2.W + (size_t)g * (size_t)p2.w_gstride);
-    q.C = p2.C + (size_t)g * (size_t)p2.c_gstride;
-    ds_gemm_f16x2_body<128, 128, 2>(q, b2 - g * tpg2, tpg2, smem_dyn);
-}
-
 // Row partition of a balanced launch: the first m_off rows go to BM x BN tiles (nbig of them = a whole number of rounds
 // of `slots` resident workgroups), the rows after them to tbm x tbn tail tiles (nsmall of them) in the same grid.
 // nsmall == 0: one program over all rows.  Pure arithmetic (ds_gemm_f16x2_plan exposes it to the CPU tests).
@@ -587,42 +567,6 @@ static int launch_hybrid(const GemmParams& p, hipStream_t s) {
         attr_set.done();
     }
     hipLaunchKernelGGL(ds_gemm_f16x2_hybrid_kernel, dim3(nbig + nsmall), dim3(256), lds, s, pb, ps, nbig);
-    DS_CHECK_LAUNCH();
-    return 0;
-}
-
-static int f16x2_check_packed_plain(const GemmParams& p) {
-    DS_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % HBK == 0, "K must be a positive multiple of 32");
-    DS_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "alignment");
-    DS_CHECK_ARG(p.a_split && p.lda >= p.K && p.lda % HBK == 0 && p.ldw == p.lda &&
-                     p.a_plane >= (long long)((p.M + 15) / 16) * 16 * p.lda && p.a_plane % 8 == 0 &&
-                     p.w3_plane >= (long long)((p.N + 15) / 16) * 16 * p.lda && p.w3_plane % 8 == 0,
-                 "pair: packed operands, lda = ldw = the packed contraction length, planes of ceil16(rows) * lda halves");
-    DS_CHECK_ARG(p.store == DS_STORE_ROW && !p.c_split && p.act == DS_ACT_NONE && p.out_scale > 0.f, "pair: plain row store");
-    DS_CHECK_ARG(p.groups <= 1 || (!p.R && !p.bias && p.a_gstride % 512 == 0 && p.w_gstride % 512 == 0 && p.c_gstride % 4 == 0),
-                 "pair: groups without bias / residual, whole k-tiles apart");
-    DS_CHECK_ARG(p.lda == p.K || p.groups > 1, "pair: lda > K only for the K-ranges of a split-K problem");
-    return 0;
-}
-// both problems: packed operands, row store; p2 may be a split-K launch (groups)
-int ds_launch_gemm_f16x2_pair(const GemmParams& p1, const GemmParams& p2, hipStream_t s) {
-    if (int rc = f16x2_check_packed_plain(p1)) return rc;
-    if (int rc = f16x2_check_packed_plain(p2)) return rc;
-    DS_CHECK_ARG(p1.groups <= 1, "pair: only the second problem may be a split-K launch");
-    const int n1 = ((p1.M + 127) / 128) * ((p1.N + 127) / 128);
-    const int tpg2 = ((p2.M + 127) / 128) * ((p2.N + 127) / 128);
-    const int n2 = tpg2 * (p2.groups > 1 ? p2.groups : 1);
-    const size_t lds = (size_t)2 * 2 * (128 + 128) * HLD * sizeof(unsigned short);
-    static DsOnce attr_set;
-    if (attr_set.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return -2;
-        }
-        attr_set.done();
-    }
-    hipLaunchKernelGGL(ds_gemm_f16x2_pair_kernel, dim3(n1 + n2), dim3(256), lds, s, p1, p2, n1, tpg2);
     DS_CHECK_LAUNCH();
     return 0;
 }

@@ -199,7 +199,6 @@ class _SplitGemm:
 
     def __init__(self):
         self.wexp = {}              # key -> s: the weight is split as W * 2^s (max |W| 2^s in [2^13, 2^14))
-        self.pair_small = True      # dX + dW of the small layers as one launch (pairs / dx_dw_pair)
 
     def refresh_scales(self, lins):
         """One host sync for all matrices: s = 13 - floor(log2 max|W|)."""
@@ -217,7 +216,7 @@ class _SplitGemm:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         if tiles >= 256:
             return 1
-        return 4 if M >= 4096 else 2      # (a PAIRED launch uses 2 ranges of the same padded contraction: 32 * 4 | Mp)
+        return 4 if M >= 4096 else 2
 
     def rows_pad(self, lin, M):
         """the padded contraction length of this layer's dW = dY^T X over M rows: a multiple of 32 per K-range"""
@@ -269,32 +268,6 @@ class _SplitGemm:
                 c_gstride=N * K, split2=inv_scale, a_plane=dyp.t_plane, w_plane=xp.t_plane)
         L_.check(L_.lib().ds_colsum(L_.ptr(part), L_.ptr(dW), 1, S, N * K, N * K, 0, 0, L_.stream()))
         return dW
-
-    def pairs(self, lin, M):
-        """Whether dX and dW of this layer go out as ONE launch (ds_gemm_f16x2_pair): both are well under a round of 128 x 128
-        tiles alone (N = K = 1024 at M = 5300: 336 + 128 tiles = one round together), which is where the dispatcher falls
-        back to the LDS-bound 128 x 64 tile."""
-        t_dx = ((M + 127) // 128) * ((lin.K + 127) // 128)
-        t_dw = ((lin.N + 127) // 128) * ((lin.K + 127) // 128)
-        return self.pair_small and lin.N % 32 == 0 and t_dx <= 400 and t_dw <= 128 and t_dx + 2 * t_dw <= 512
-
-    def dx_dw_pair(self, lin, xp, dyp, inv_scale):
-        """dX = dY W and dW = dY^T X (2 K-ranges) in one grid; -> (dX, dW)"""
-        M, N, K, Mp = dyp.rows, lin.N, lin.K, dyp.rows_pad
-        Wp = lin.extra["Wp"]
-        dev = dyp.row.device
-        out = torch.empty(M, K, device=dev)
-        d1 = L_.gemm(dyp.row, Wp.t, out, M, K, N, split2=lin.extra["osc"], a_plane=dyp.row_plane, w_plane=Wp.t_plane, launch=False)
-        S = 2
-        assert Mp % (32 * S) == 0 and xp.rows_pad == Mp
-        part = torch.empty(S, N * K, device=dev)
-        Kc = Mp // S
-        d2 = L_.gemm(dyp.t, xp.t, part, N, K, Kc, lda=Mp, ldw=Mp, ldc=K, groups=S, a_gstride=Kc * 16, w_gstride=Kc * 16,
-                     c_gstride=N * K, split2=inv_scale, a_plane=dyp.t_plane, w_plane=xp.t_plane, launch=False)
-        L_.gemm_pair(d1, d2)
-        dW = torch.empty(N, K, device=dev)
-        L_.check(L_.lib().ds_colsum(L_.ptr(part), L_.ptr(dW), 1, S, N * K, N * K, 0, 0, L_.stream()))
-        return out, dW
 
     def db(self, lin, dyp):
         out = torch.empty(1, dyp.cols, device=dyp.part.device)
@@ -661,11 +634,8 @@ class TrainStep:
             slower in both rounds it was tried -- 15.6 vs 15.9 and 16.2 vs 16.6 it/s, the GEMMs fill the power-capped chip -- and
             removed in round 5.)"""
             dyh = G_.prep_dy(lin, dy, pro=pro, aux=aux, amax=amax, need_row=need_dx)
-            if need_dx and getattr(G_, "pairs", None) is not None and G_.pairs(lin, dyh.rows):
-                dxo, dW = G_.dx_dw_pair(lin, xh, dyh, inv)
-            else:
-                dxo = G_.dx(lin, dyh) if need_dx else None
-                dW = G_.dw(lin, xh, dyh, inv)
+            dxo = G_.dx(lin, dyh) if need_dx else None
+            dW = G_.dw(lin, xh, dyh, inv)
             db = G_.db(lin, dyh)
             small.append(db)
             return dxo, dW, db
