@@ -409,6 +409,8 @@ class TrainStep:
         # scalar (ds_amax, the calibration's own probe; captured into the graph like any other launch), and
         # check_loss_scale() reads it on the host every `monitor_interval` steps -- whether or not clipping is configured.
         self.monitor_interval = 16
+        self.monitor_window = (6, 15)           # log2 bounds of max |scaled dY| outside which the calibration is dropped
+        self.monitor_log = []                   # log2 of the last readings (host floats; tools/bench_train.py prints them)
         self._amax_live = None
         self._since_check = 0
         # weight swaps outside this class (checkpoint / EMA loads: solver._invalidate) must drop the cached pre-scales
@@ -442,6 +444,7 @@ class TrainStep:
         self._since_check = 0
         m = float(self._amax_live.item())
         self._amax_live.zero_()
+        self.monitor_log = self.monitor_log[-63:] + [round(math.log2(m), 2) if m > 0.0 and math.isfinite(m) else m]
         if m == 0.0:
             # ds_amax never lets a NaN win and skips non-positive values, so 0 means EITHER genuinely zero gradients (nothing
             # was scaled: no reason to re-calibrate / re-capture) OR an all-NaN scaled dY (a diverged loss).  The loss of the
@@ -451,7 +454,7 @@ class TrainStep:
                 self.loss_scale_exp, self._calib_norm = None, None
                 return True
             return False
-        if math.isfinite(m) and 2.0 ** 6 <= m < 2.0 ** 15:
+        if math.isfinite(m) and 2.0 ** self.monitor_window[0] <= m < 2.0 ** self.monitor_window[1]:
             return False
         self.loss_scale_exp, self._calib_norm = None, None
         return True
@@ -873,6 +876,7 @@ class GraphedIteration:
         if static is not None:
             for dst, src in zip(self.static, static):
                 dst.copy_(src)
+        self.recaptures = getattr(self, "recaptures", 0) + 1
         self.step.reset_scales()
         keep_state = {k: (m.clone(), v.clone()) for k, (m, v) in self.opt_state.items()}
         self._capture()

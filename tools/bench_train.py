@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 
 def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", ema_device="cuda", attention="fused",
-        graph=True, world=1, rank=0, dev=None):
+        graph=True, world=1, rank=0, dev=None, monitor_hi=None):
     """Time `steps` training iterations (after `warmup`) and return the result dict (see the module docstring).  (Per-kernel
     rates: tools/train_profile.sh -- rocprofv3 --stats over this script.)"""
     from text_to_sound_synthesis_amd import shard, synth
@@ -70,15 +70,18 @@ def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", e
     sched = PlateauWarmupLR(3.0e-6, factor=0.5, patience=25000, min_lr=1.0e-6, threshold=1.0e-1, warmup_lr=4.5e-4, warmup=1000)
     ema = EMA(dt, decay=0.99, update_interval=25, device=ema_device)
     use_graph = bool(graph)
+    step = (TrainStep if use_graph else Timed)(dt, precision=precision, attention=attention)
+    if monitor_hi is not None:           # experiment: the upper bound (log2) of the saturation monitor's window
+        step.monitor_window = (step.monitor_window[0], monitor_hi)
     if use_graph:
         # one GPU: the whole iteration is one hipGraph.  Data parallel: two graphs per rank (gradients | clip + AdamW) with the
         # bucketed all-reduce over RCCL enqueued between the replays (tests/test_hip_rccl.py runs exactly this at world 1)
         from text_to_sound_synthesis_amd.modeling.solver import GraphSolver
-        solver = GraphSolver(TrainStep(dt, precision=precision, attention=attention), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = GraphSolver(step, lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                              scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
                              reduce=timed_allreduce if world > 1 else None)
     else:
-        solver = Solver(Timed(dt, precision=precision, attention=attention), lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
+        solver = Solver(step, lr=3.0e-6, betas=(0.9, 0.96), weight_decay=4.5e-2,
                         scheduler=sched, clip_grad_norm=GradClipWindow(0, 5000, 0.5), ema=ema,
                         allreduce=timed_allreduce if world > 1 else None)
 
@@ -115,6 +118,8 @@ def run(batch=20, steps=5, warmup=2, n_layer=19, codes=256, precision="f16x2", e
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         "graph": use_graph, "attention": attention,
         "loss_scale_exp": solver.train_step.loss_scale_exp,
+        # the saturation monitor over the run: log2 of max |scaled dY| at each check, and how often the iteration was re-captured
+        "monitor_log2": list(step.monitor_log), "recaptures": getattr(getattr(solver, "iteration_graph", None), "recaptures", 0),
         "config": {"workload": "BASELINE configs[4]: training step, B=%d per GPU, %d layers, K=%d" % (B, n_layer, codes),
                    "parallelism": "dp%d" % world}}
 
@@ -131,6 +136,7 @@ def main():
     ap.add_argument("--ema-device", default="cuda", help="the reference keeps the EMA on the CPU (configs/caps.yaml:101)")
     ap.add_argument("--attention", default="fused", choices=("fused", "composed"),
                     help="fused: ds_attention + ds_attention_bwd (recompute); composed: grouped GEMMs with stored probabilities")
+    ap.add_argument("--monitor-hi", type=int, default=None, help="experiment: log2 upper bound of the saturation monitor's window")
     ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,7 +147,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     out = run(args.batch, args.steps, args.warmup, args.n_layer, args.codes, args.precision, args.ema_device, args.attention,
-              args.graph, world, rank, dev)
+              args.graph, world, rank, dev, args.monitor_hi)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
