@@ -200,11 +200,14 @@ class _SplitGemm:
     def __init__(self):
         self.wexp = {}              # key -> s: the weight is split as W * 2^s (max |W| 2^s in [2^13, 2^14))
 
-    def refresh_scales(self, lins):
-        """One host sync for all matrices: s = 13 - floor(log2 max|W|)."""
+    @staticmethod
+    def scales_of(lins):
+        """{key: s} with s = 13 - floor(log2 max|W|) for every matrix; one host sync for all of them"""
         mx = torch.stack([torch.stack([w.abs().max() for w in l.parts]).max() for l in lins]).tolist()
-        for l, m in zip(lins, mx):
-            self.wexp[l.key] = 0 if (m == 0.0 or not math.isfinite(m)) else 13 - math.floor(math.log2(m))
+        return {l.key: 0 if (m == 0.0 or not math.isfinite(m)) else 13 - math.floor(math.log2(m)) for l, m in zip(lins, mx)}
+
+    def refresh_scales(self, lins):
+        self.wexp.update(self.scales_of(lins))
 
     @staticmethod
     def split_k(N, K, M=4096):
@@ -411,6 +414,11 @@ class TrainStep:
         self.monitor_interval = 16
         self.monitor_window = (6, 15)           # log2 bounds of max |scaled dY| outside which the calibration is dropped
         self.monitor_log = []                   # log2 of the last readings (host floats; tools/bench_train.py prints them)
+        # what a HIGH reading teaches: the largest exponent that keeps the batches seen so far inside fp16 (None: no bound).
+        # A calibration looks at ONE batch; batches differ (B = 20, random init: every fifth or so has a largest |dY| 5-10x the
+        # usual one -- 4 re-captures in 100 iterations, profiles/r05last_monitor_ab.txt), so without this memory the next
+        # calibration picks the scale that has just saturated.  Dropped again when a reading falls under the window.
+        self._scale_cap = None
         self._amax_live = None
         self._since_check = 0
         # weight swaps outside this class (checkpoint / EMA loads: solver._invalidate) must drop the cached pre-scales
@@ -454,10 +462,39 @@ class TrainStep:
                 self.loss_scale_exp, self._calib_norm = None, None
                 return True
             return False
-        if math.isfinite(m) and 2.0 ** self.monitor_window[0] <= m < 2.0 ** self.monitor_window[1]:
+        lo, hi = self.monitor_window
+        if math.isfinite(m) and 2.0 ** lo <= m < 2.0 ** hi:
             return False
+        if math.isfinite(m) and m >= 2.0 ** hi and self.loss_scale_exp is not None:
+            cap = self.loss_scale_exp - (math.floor(math.log2(m)) - 12)        # this window's largest value -> 2^12..2^13
+            self._scale_cap = cap if self._scale_cap is None else min(self._scale_cap, cap)
+        elif math.isfinite(m):
+            self._scale_cap = None                                             # gradients have shrunk: calibrate freely again
         self.loss_scale_exp, self._calib_norm = None, None
         return True
+
+    def _exp_from_amax(self, m):
+        """loss-scale exponent k for a calibration batch whose largest unscaled |dY| is m: m 2^k in [2^12, 2^13), no larger than
+        what the saturation monitor has learnt (`_scale_cap`)"""
+        if m == 0.0 or not math.isfinite(m):
+            return 0
+        k = 12 - math.floor(math.log2(m))
+        return k if self._scale_cap is None else min(k, self._scale_cap)
+
+    @torch.no_grad()
+    def prescales_drifted(self):
+        """Host check of the weight pre-scales 2^s a CAPTURED iteration froze (the eager step simply refreshes them every
+        `rescale_interval` steps): one host sync over max |W| of every matrix.  True when a matrix has outgrown its place --
+        max |W| 2^s has reached 2^14, one bit of fp16's range left for the replays until the next check -- or has fallen more
+        than two bits under it (2 of the split's 22 bits lost), or when there are no pre-scales at all (weights were swapped)."""
+        if self.precision != "f16x2":
+            return False
+        old = self.gemm.wexp
+        if not old:
+            return True
+        blocks, lin_logits = self._linears()
+        new = self.gemm.scales_of([l for b in blocks for l in b.values()] + [lin_logits])
+        return any(k not in old or s < old[k] or s > old[k] + 2 for k, s in new.items())
 
     def observe_grad_norm(self, norm):
         """Guard of the calibrated loss scale ("f16x2" backend): the calibration leaves 8x of headroom below fp16's range
@@ -521,7 +558,7 @@ class TrainStep:
         self._run(x0, cond_emb, t, pt, noise, calibrating=True, amax=amax)
         m = float(amax.item())
         self.calibrated_amax = m
-        self.loss_scale_exp = 0 if (m == 0.0 or not math.isfinite(m)) else 12 - math.floor(math.log2(m))
+        self.loss_scale_exp = self._exp_from_amax(m)
         return self.loss_scale_exp
 
     def _run(self, x0, cond_emb, t, pt, noise, calibrating, amax=None, on_grads=None):
@@ -925,13 +962,20 @@ class GraphedIteration:
         return {"loss": self.loss, "grad_norm": self.grad_norm, "lr": lr}
 
     def check_loss_scale(self):
-        """Host-side guards of the frozen constants of a captured iteration.  (1) The weight pre-scales 2^s and the loss
-        scale are those of capture time -- the eager step refreshes the pre-scales every `rescale_interval` steps, a
-        replay cannot: re-capture after that many replays (one calibration backward + one capture).  (2) The saturation
-        monitor (max |scaled dY|, TrainStep.check_loss_scale) is read every `monitor_interval` replays -- one host sync
-        then, none in between -- and re-captures when the gradients have left the calibrated window."""
+        """Host-side guards of the frozen constants of a captured iteration.  (1) The weight pre-scales 2^s are those of
+        capture time -- the eager step refreshes them every `rescale_interval` steps, a replay cannot: after that many
+        replays the weights are looked at (TrainStep.prescales_drifted, one host sync) and the iteration is re-captured only
+        if a matrix has left its place.  (Until round 5 this re-captured unconditionally: ~1.9 s per 100 replays of 57 ms,
+        a quarter of a long run -- profiles/r05last_monitor_ab.txt.)  (2) The saturation monitor (max |scaled dY|,
+        TrainStep.check_loss_scale) is read every `monitor_interval` replays -- one host sync then, none in between -- and
+        re-captures when the gradients have left the calibrated window."""
         st = self.step
-        if getattr(self, "_replays", 0) >= max(1, st.rescale_interval) or st.check_loss_scale():
+        if getattr(self, "_replays", 0) >= max(1, st.rescale_interval):
+            self._replays = 0
+            if st.prescales_drifted():
+                self.recapture()
+                return True
+        if st.check_loss_scale():
             self.recapture()
             return True
         return False
