@@ -21,6 +21,10 @@ Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).  `roofline
 HIP events around every denoiser GEMM launch in a separate profiled batch (ds_profile_*), algorithmic
 flops 2*M*N*K per launch.  `cpu_baseline` times the reference itself (when /root/reference exists) or the CPU oracle (a
 restatement of the reference path) on a bounded sample on this box's host cores, thread count swept.
+
+Everything after the timed region is a side leg (run_side_legs): a leg that raises is filed as {"error": ...} under its
+name, and a leg that hangs -- N ranks, one of them gone inside a collective -- is cut off by HeadlineGuard after
+--side-leg-limit seconds: the line is printed with what it has ("incomplete": reason) and every rank exits 0.
 """
 import argparse
 import ctypes
@@ -67,6 +71,9 @@ def parse():
                     help="rendezvous + the path's collectives only (all-reduce of ones, caption scatter, waveform gather, one "
                          "gradient bucket) on stand-in tensors, no HIP kernels: backend nccl on GPUs, gloo without -- what "
                          "tests/test_shard_gloo.py drives through the self-launcher")
+    ap.add_argument("--side-leg-limit", type=float, default=480.0,
+                    help="seconds the legs AFTER the timed region may take (roofline, stage split, communicator check, training "
+                         "leg, CPU baseline) before the line is printed without what is missing (HeadlineGuard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
@@ -394,6 +401,66 @@ def timed_loop(one_step, warmup, steps, device, world, info=None):
     return elapsed, out
 
 
+class HeadlineGuard:
+    """The measurement is over when timed_loop returns; everything after it (profiled roofline leg, the stage split, the
+    communicator check, the training leg, the CPU baseline) is a side leg and must never cost the line.  Started on EVERY
+    rank right after the timed region: if the side legs have not finished `limit_s` later -- a rank died inside a leg's
+    collective and the others wait for it -- `emit(reason)` prints the line as far as it got (rank 0) and the process
+    exits 0 without tearing the process group down.  finish() is the normal path: True = the caller prints the line."""
+
+    def __init__(self, limit_s, emit, exit_fn=None):
+        import threading
+        self.limit_s, self.emit, self.exit_fn = limit_s, emit, exit_fn or os._exit
+        self.lock, self.closed = threading.Lock(), False
+        self.timer = threading.Timer(limit_s, self._fire)
+        self.timer.daemon = True
+
+    def start(self):
+        self.timer.start()
+        return self
+
+    def _fire(self):
+        with self.lock:
+            if self.closed:
+                return
+            self.closed = True
+            try:
+                self.emit("side legs unfinished after %d s" % self.limit_s)
+            finally:
+                sys.stdout.flush()
+                sys.stderr.flush()
+                self.exit_fn(0)
+
+    def finish(self):
+        with self.lock:
+            if self.closed:            # the timer is printing / has printed: it ends the process
+                return False
+            self.closed = True
+        self.timer.cancel()
+        return True
+
+
+def run_side_legs(legs, world, rank, line):
+    """legs = [(name, fn, runs_on_this_rank, contains_collectives)], in order.  An exception inside a leg is filed as
+    line[name] = {"error": ...} (rank 0) and reported on stderr instead of propagating.  With N ranks a rank that left a
+    COLLECTIVE leg early must not enter another collective (the others are still inside the failed one): every later
+    collective leg is skipped on it and False is returned -- the caller then prints and exits without tearing the process
+    group down; the other ranks are ended by their HeadlineGuard."""
+    in_step = True
+    for name, fn, mine, collective in legs:
+        if not mine or (collective and not in_step):
+            continue
+        try:
+            fn()
+        except Exception as e:
+            if rank == 0:
+                line[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            print("bench.py: side leg %r failed on rank %d: %s: %s" % (name, rank, type(e).__name__, e), file=sys.stderr)
+            if collective and world > 1:
+                in_step = False
+    return in_step
+
+
 def result_line(args, world, elapsed, n_total):
     """The driver's one-line JSON contract (whole-job aggregate over all ranks)."""
     value = n_total * args.steps / elapsed
@@ -501,9 +568,21 @@ def main():
     else:
         assert torch.isfinite(w).all() and w.shape[-1] == 217088
 
-    roof = None
-    extra = {}
-    if rank == 0 and world == 1 and not args.transformer_only:
+    # ---- the measurement is done: from here on only side legs, each of which may fail without costing the line ----------
+    line = result_line(args, world, elapsed, n_total) if rank == 0 else {}
+    bare = json.dumps(dict(line, incomplete="side legs did not finish"))
+
+    def emit(reason=None):
+        if rank != 0:
+            return
+        try:
+            text = json.dumps(dict(line, incomplete=reason) if reason else line)
+        except Exception:                       # (the timer thread caught the dict mid-update)
+            text = bare
+        print(text, flush=True)
+    guard = HeadlineGuard(args.side_leg_limit, emit).start()
+
+    def leg_host_copy():
         # what handing the result over to the host costs (generate_sample does it before writing .wav files): the batch's
         # waveforms HBM -> pinned host memory, timed on its own -- reported beside `value`, never part of it
         host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
@@ -513,11 +592,11 @@ def main():
             host.copy_(w, non_blocking=True)
         torch.cuda.synchronize()
         copy_s = (time.perf_counter() - t0) / 5
-        extra["host_copy"] = {"bytes_per_step": w.numel() * w.element_size(), "ms_per_step": round(copy_s * 1e3, 3),
-                              "GB_per_s": round(w.numel() * w.element_size() / copy_s / 1e9, 1),
-                              "clips_per_s_incl_copy": round(n_total * args.steps / (elapsed + copy_s * args.steps), 4)}
-        del host
-    if rank == 0 and not args.no_roofline:
+        line["host_copy"] = {"bytes_per_step": w.numel() * w.element_size(), "ms_per_step": round(copy_s * 1e3, 3),
+                             "GB_per_s": round(w.numel() * w.element_size() / copy_s / 1e9, 1),
+                             "clips_per_s_incl_copy": round(n_total * args.steps / (elapsed + copy_s * args.steps), 4)}
+
+    def leg_roofline():
         # profiled legs of a few denoiser steps: HIP events around every GEMM launch (ds_profile_*)
         L = _lib.lib()
         cond = synth.synth_cond_emb(B, key="bench.cond").to(dev)
@@ -572,11 +651,15 @@ def main():
                                                   "tflops": round(fl[c] / max(ms[c], 1e-9) / 1e9, 2)}
                                        for c in range(5) if n[c]},
                     "all_gemm_tflops": round(sum(fl) / (sum(ms) * 1e-3) / 1e12, 2)}
-        roof = leg(args.precision)
-        if args.precision != "fp32":                   # the exact-fp32 MFMA kernel on the same shapes, for reference
-            extra["roofline_fp32_mfma_kernel"] = leg("fp32", warm=0, steps=3)    # (a reference point: three steps suffice)
+        try:
+            line["roofline"] = leg(args.precision)
+            if args.precision != "fp32":               # the exact-fp32 MFMA kernel on the same shapes, for reference
+                line["roofline_fp32_mfma_kernel"] = leg("fp32", warm=0, steps=3)    # (a reference point: three steps suffice)
+        finally:
+            L.ds_profile_enable(0)
             dt.transformer.precision = args.precision
-    if not args.transformer_only:
+
+    def leg_stage_split():
         # one more step with a synchronisation between the stages (outside the timed region): where a batch's time goes.
         # EVERY rank runs it (the step contains the scatter / gather collectives); rank 0 reports its own split and, for
         # N > 1, the slowest rank's per stage
@@ -586,50 +669,57 @@ def main():
         worst = mine.clone()
         if world > 1:
             dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-        extra["stage_ms"] = {k: round(float(v) * 1e3, 2) for k, v in zip(names, mine.tolist())}
+        split = {k: round(float(v) * 1e3, 2) for k, v in zip(names, mine.tolist())}
         if world > 1:
-            extra["stage_ms"]["max_over_ranks"] = {k: round(float(v) * 1e3, 2) for k, v in zip(names, worst.tolist())}
-        extra["stage_ms"]["note"] = "one extra step, device-synchronised between stages: tokenise+scatter | CLIP + 100-step sampling | SpecVQGAN decode | MelGAN vocode | gather"
+            split["max_over_ranks"] = {k: round(float(v) * 1e3, 2) for k, v in zip(names, worst.tolist())}
+        split["note"] = "one extra step, device-synchronised between stages: tokenise+scatter | CLIP + 100-step sampling | SpecVQGAN decode | MelGAN vocode | gather"
+        if rank == 0:
+            line["stage_ms"] = split
         if args.stage_times and rank == 0:
             print("stage seconds (1 step, B=%d): %s" % (B, {k: round(v, 3) for k, v in stage.items()}), file=sys.stderr)
-    if world > 1:
-        # the communicator this line was measured on: ranks an all-reduce saw, the path's collectives on stand-in tensors
-        extra["rccl"] = collectives_check(dev, world, rank)
-        extra["rccl"]["ms_per_step_per_rank"] = {"min": round(spread["rank_s_min"] / args.steps * 1e3, 2),
-                                                 "max": round(spread["rank_s_max"] / args.steps * 1e3, 2)}
 
-    train = None
-    if not args.no_train_leg:  # every rank takes part (data-parallel step; one GPU: the iteration replayed as one hipGraph)
-        del model, voc, dt
+    def leg_communicator():
+        # the communicator this line was measured on: ranks an all-reduce saw, the path's collectives on stand-in tensors
+        info = collectives_check(dev, world, rank)
+        info["ms_per_step_per_rank"] = {"min": round(spread["rank_s_min"] / args.steps * 1e3, 2),
+                                        "max": round(spread["rank_s_max"] / args.steps * 1e3, 2)}
+        if rank == 0:
+            line["rccl"] = info
+
+    def leg_train():    # every rank takes part (data-parallel step; one GPU: the iteration replayed as one hipGraph)
+        nonlocal model, voc, dt
+        model = voc = dt = None                   # the sampling model makes room for the training step's activations
         torch.cuda.empty_cache()
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_train
-        try:
-            r = bench_train.run(batch=20, steps=10, warmup=3, n_layer=args.n_layer, codes=args.codes, precision="f16x2",
-                                graph=True, world=world, rank=rank, dev=dev)
-            train = {"it_per_s": round(r["value"], 3), "samples_per_s": round(r["samples_per_s"], 2), "ms_per_it": round(r["ms_per_step"], 2),
-                     "allreduce_ms": round(r["ms"]["allreduce"], 3) if world > 1 else None,
-                     "batch_per_gpu": 20, "graph": r["graph"], "dtype": r["dtype"], "loss": r["loss"],
-                     "workload": r["config"]["workload"], "parallelism": r["config"]["parallelism"]}
-        except Exception as e:          # a side leg must never cost the headline line (it is printed below either way)
-            if world > 1:
-                raise                   # (N ranks: the others are inside the leg's collectives -- fail loudly together)
-            train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    if rank == 0:
-        line = result_line(args, world, elapsed, n_total)
-        if train is not None:
-            line["train"] = train
-        if roof is not None:
-            line["roofline"] = roof
-        line.update(extra)
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                line["cpu_baseline"] = cpu_baseline(args.n_layer, args.codes, T)
-            except Exception as e:      # the host-side leg is reported, never required for the GPU line
-                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        print(json.dumps(line))
-    if world > 1:
+        r = bench_train.run(batch=20, steps=10, warmup=3, n_layer=args.n_layer, codes=args.codes, precision="f16x2",
+                            graph=True, world=world, rank=rank, dev=dev)
+        if rank == 0:
+            line["train"] = {"it_per_s": round(r["value"], 3), "samples_per_s": round(r["samples_per_s"], 2),
+                             "ms_per_it": round(r["ms_per_step"], 2),
+                             "allreduce_ms": round(r["ms"]["allreduce"], 3) if world > 1 else None,
+                             "batch_per_gpu": 20, "graph": r["graph"], "dtype": r["dtype"], "loss": r["loss"],
+                             "workload": r["config"]["workload"], "parallelism": r["config"]["parallelism"]}
+
+    def leg_cpu_baseline():
+        line["cpu_baseline"] = cpu_baseline(args.n_layer, args.codes, T)
+
+    # (name the error is filed under, the leg, who runs it, whether it contains collectives)
+    legs = [("host_copy", leg_host_copy, rank == 0 and world == 1 and not args.transformer_only, False),
+            ("roofline", leg_roofline, rank == 0 and not args.no_roofline, False),
+            ("stage_ms", leg_stage_split, not args.transformer_only, True),
+            ("rccl", leg_communicator, world > 1, True),
+            ("train", leg_train, not args.no_train_leg, True),
+            ("cpu_baseline", leg_cpu_baseline, rank == 0 and world == 1 and not args.no_cpu_baseline, False)]
+    in_step = run_side_legs(legs, world, rank, line)
+    if not guard.finish():
+        time.sleep(3600)                          # the guard's timer is printing the line and ends the process
+    emit()
+    if world > 1 and in_step:
         dist.destroy_process_group()
+    elif world > 1:
+        sys.stdout.flush()
+        os._exit(0)                               # the others wait inside a collective until their own guards end them
 
 
 if __name__ == "__main__":

@@ -378,3 +378,68 @@ def test_bench_refuses_more_ranks_than_devices():
 def test_bench_refuses_world_size_that_contradicts_gpus():
     r = _run_bench(["--gpus", "2", "--collectives-selftest"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+# ---- after the timed region: side legs may fail or hang, the line is printed regardless (round 5) ------------------------
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_side_legs_file_their_errors_and_stop_entering_collectives(capsys):
+    """bench.run_side_legs: a failing leg becomes line[name] = {"error": ...}; one GPU: the remaining legs still run; N ranks:
+    after a failed COLLECTIVE leg this rank enters no further collective (the others are still inside the failed one) but
+    still runs its local legs, and the caller is told (False) not to tear the process group down."""
+    bench = _bench_module()
+    ran = []
+
+    def ok(name):
+        return lambda: ran.append(name)
+
+    def boom():
+        raise RuntimeError("rank 1 went away")
+    legs = [("host_copy", ok("host_copy"), True, False), ("roofline", boom, True, False), ("stage_ms", ok("stage_ms"), True, True),
+            ("rccl", boom, True, True), ("train", ok("train"), True, True), ("skipped", ok("skipped"), False, False),
+            ("cpu_baseline", ok("cpu_baseline"), True, False)]
+    line = {"value": 1.0}
+    assert bench.run_side_legs(legs, 1, 0, line) is True              # one GPU: every leg is attempted
+    assert ran == ["host_copy", "stage_ms", "train", "cpu_baseline"]
+    assert line["roofline"]["error"].startswith("RuntimeError") and "rccl" in line and line["value"] == 1.0
+    ran.clear()
+    line = {"value": 1.0}
+    assert bench.run_side_legs(legs, 2, 0, line) is False             # N ranks: nothing collective after the failed one
+    assert ran == ["host_copy", "stage_ms", "cpu_baseline"] and "error" in line["rccl"] and "train" not in line
+    line = {}
+    assert bench.run_side_legs(legs[:3], 2, 1, line) is True and line == {}   # a local leg's failure on rank 1: filed on stderr only
+    assert "side leg 'roofline' failed on rank 1" in capsys.readouterr().err
+
+
+def test_headline_guard_prints_the_line_when_a_side_leg_hangs():
+    """bench.HeadlineGuard: the normal path (finish() -> True, timer cancelled, nothing emitted), and the hang: the timer emits
+    the line with the reason and ends the process with exit code 0 -- run for real in a child process whose "side leg" sleeps."""
+    import json
+    import subprocess
+    import sys
+    import time
+    bench = _bench_module()
+    got = []
+    g = bench.HeadlineGuard(30.0, got.append, exit_fn=got.append).start()
+    assert g.finish() is True and not got and g.finish() is False
+    g = bench.HeadlineGuard(0.05, got.append, exit_fn=got.append).start()
+    time.sleep(0.5)
+    assert got == ["side legs unfinished after 0 s", 0] and g.finish() is False
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = ("import importlib.util, json, sys, time\n"
+             "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+             "line = {'metric': 'clips/s', 'value': 23.0}\n"
+             "g = b.HeadlineGuard(0.3, lambda why: print(json.dumps(dict(line, incomplete=why)), flush=True)).start()\n"
+             "time.sleep(30)\n"
+             "print('never reached')\n") % os.path.join(root, "bench.py")
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "never reached" not in r.stdout
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["value"] == 23.0 and out["incomplete"].startswith("side legs unfinished")
