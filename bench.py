@@ -719,6 +719,7 @@ def main():
         dist.destroy_process_group()
     elif world > 1:
         sys.stdout.flush()
+        sys.stderr.flush()
         os._exit(0)                               # the others wait inside a collective until their own guards end them
 
 
