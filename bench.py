@@ -24,7 +24,7 @@ restatement of the reference path) on a bounded sample on this box's host cores,
 
 Everything after the timed region is a side leg (run_side_legs): a leg that raises is filed as {"error": ...} under its
 name, and a leg that hangs -- N ranks, one of them gone inside a collective -- is cut off by HeadlineGuard after
---side-leg-limit seconds: the line is printed with what it has ("incomplete": reason) and every rank exits 0.
+--side-leg-limit seconds (N > 1 only): the line is printed with what it has ("incomplete": reason) and every rank exits 0.
 """
 import argparse
 import ctypes
@@ -72,8 +72,8 @@ def parse():
                          "gradient bucket) on stand-in tensors, no HIP kernels: backend nccl on GPUs, gloo without -- what "
                          "tests/test_shard_gloo.py drives through the self-launcher")
     ap.add_argument("--side-leg-limit", type=float, default=480.0,
-                    help="seconds the legs AFTER the timed region may take (roofline, stage split, communicator check, training "
-                         "leg, CPU baseline) before the line is printed without what is missing (HeadlineGuard)")
+                    help="N > 1: seconds the legs AFTER the timed region may take (roofline, stage split, communicator check, "
+                         "training leg) before the line is printed without what is missing (HeadlineGuard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print a per-stage split to stderr")
@@ -580,7 +580,9 @@ def main():
         except Exception:                       # (the timer thread caught the dict mid-update)
             text = bare
         print(text, flush=True)
-    guard = HeadlineGuard(args.side_leg_limit, emit).start()
+    guard = HeadlineGuard(args.side_leg_limit, emit)
+    if world > 1:           # one rank cannot wait for another: its legs end by themselves (cpu_baseline alone takes minutes)
+        guard.start()
 
     def leg_host_copy():
         # what handing the result over to the host costs (generate_sample does it before writing .wav files): the batch's
