@@ -63,9 +63,11 @@ def parse():
     ap.add_argument("--transformer-only", action="store_true",
                     help="BASELINE configs[1]: CLIP + sampling loop only (no decode / vocoder); not the default metric")
     ap.add_argument("--no-train-leg", action="store_true",
-                    help="skip the BASELINE configs[4] leg (the discrete-diffusion training step, B = 20 per GPU, 19 layers: "
-                         "loss + hand-written backward + all-reduce + clip + AdamW + EMA; 3 + 10 iterations AFTER the sampling "
-                         "measurement, outside its timed region), reported as the \"train\" object of the JSON line")
+                    help="skip the BASELINE configs[4] leg (the training iteration from the reference's batch, B = 20 per GPU, 19 "
+                         "layers: mel + captions -> BPE + CLIP + VQ encode -> loss + hand-written backward + all-reduce + clip + "
+                         "AdamW + EMA; 5 + --train-steps iterations AFTER the sampling measurement, outside its timed region), "
+                         "reported as the \"train\" object of the JSON line (text_to_sound_synthesis_amd/train_bench.py)")
+    ap.add_argument("--train-steps", type=int, default=200, help="timed iterations of the training leg (sustained rate; ~15 s)")
     ap.add_argument("--train-leg", action="store_true", help=argparse.SUPPRESS)   # (round-4 spelling; the leg is on by default)
     ap.add_argument("--collectives-selftest", action="store_true",
                     help="rendezvous + the path's collectives only (all-reduce of ones, caption scatter, waveform gather, one "
@@ -233,12 +235,16 @@ def cpu_baseline(n_layer, codes, T):
 
     hw = os.cpu_count() or 8
     phys = _physical_cores() or max(1, hw // 2)
+    host = host_cpu_info()
+    # what the host GIVES this process: a cgroup CPU quota or an affinity mask below the core count makes every thread count
+    # above it slower, not faster (round 5's 128-core box: 1.65 s per step at 16 threads, 9.99 s at 128) -- sweep up to it
+    usable = min(x for x in (phys, host["affinity_cpus"], host["cgroup_quota_cpus"]) if x)
     default_threads = torch.get_num_threads()
     # thread count swept UP TO the physical core count, every point measured -- no early exit -- on
     # one B=8 denoiser step after one warm-up step
     # (the hardware-thread count itself is not swept: with SMT siblings oversubscribed one B=8 step took 159 s on the 128-core
     #  box of round 5 against 1.3 s at the best count -- two such steps are the whole budget of this leg many times over)
-    cands = sorted({n for n in (8, 16, 32, 64, phys) if 1 <= n <= hw})
+    cands = sorted({n for n in (4, 8, 16, 32, 64, usable) if 1 <= n <= min(hw, max(usable, 8))})
     sweep = {}
     one = step_fn(8)
     for n in cands:
@@ -283,7 +289,7 @@ def cpu_baseline(n_layer, codes, T):
     if full is not None and full["clips_per_s"] > value:       # the CPU gets its best measured rate
         value = full["clips_per_s"]
     return {"value": value, "unit": "clips/s", "cores": best_n, "kind": "reference" if use_ref else "port",
-            "host_hw_threads": hw, "host_physical_cores": phys,
+            "host_hw_threads": hw, "host_physical_cores": phys, "host": host, "usable_cpus": usable,
             "protocol": "BASELINE.md section 4: B in {1, 8}, 1 warm-up + 3 timed repeats, median; value = the better B",
             "thread_sweep_s_per_B8_step": {str(k): round(v, 3) for k, v in sweep.items()},
             "full_length_B1": full,
@@ -297,6 +303,51 @@ def cpu_baseline(n_layer, codes, T):
                          "CPU oracle (restatement of the reference; /root/reference is not on this box)",
                          best_n, sorted(sweep), phys, hw, bB, T, res[bB][1], res[bB][2], res[bB][3], T,
                          "; one full-length B=1 clip measured beside it: %.2f s" % full["seconds"] if full else "")}
+
+
+def host_cpu_info():
+    """What the box gives this process: CPU model (BASELINE.md section 4 asks for it), the scheduler affinity, the cgroup
+    CPU quota (v2 cpu.max, else v1 cfs quota / period) as a CPU count (None = unlimited), NUMA nodes of the affinity mask."""
+    info = {"model": None, "affinity_cpus": None, "cgroup_cpu_max": None, "cgroup_quota_cpus": None, "numa_nodes_online": None}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    info["model"] = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    info["cgroup_cpu_max"], info["cgroup_quota_cpus"] = _cgroup_quota()
+    try:
+        with open("/sys/devices/system/node/online") as f:
+            info["numa_nodes_online"] = f.read().strip()
+    except OSError:
+        pass
+    return info
+
+
+def _cgroup_quota(root="/sys/fs/cgroup"):
+    """(raw text, quota in CPUs rounded up or None)"""
+    import math
+    try:
+        with open(os.path.join(root, "cpu.max")) as f:                     # cgroup v2: "<quota|max> <period>"
+            raw = f.read().strip()
+        q, per = raw.split()
+        return raw, (None if q == "max" else max(1, math.ceil(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(os.path.join(root, "cpu", "cpu.cfs_quota_us")) as f:
+            q = int(f.read())
+        with open(os.path.join(root, "cpu", "cpu.cfs_period_us")) as f:
+            per = int(f.read())
+        return "%d %d" % (q, per), (None if q <= 0 else max(1, math.ceil(q / per)))
+    except (OSError, ValueError):
+        return None, None
 
 
 def _physical_cores():
@@ -488,6 +539,12 @@ def result_line(args, world, elapsed, n_total):
 
 
 def main():
+    # dmabuf IPC.  The host driver of this pool only supports dmabuf handles: with the legacy IPC mode RCCL's intra-node
+    # transport setup (and any CUDA-tensor sharing across processes) fails with `hipIpcGetMemHandle: invalid argument` as soon
+    # as two ranks exchange buffer handles -- an N-rank job then dies in its first collective.  Set BEFORE the first HIP call
+    # and on every entry path: the self-launcher's children inherit it, ranks started by the driver's own
+    # `torch.distributed.run ... bench.py --gpus N` get it here.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -519,14 +576,17 @@ def main():
     dt.truncation_r = 0.85
     dt.transformer.precision = args.precision
     n_total = B * world
-    # rank 0 owns the captions: synthetic caption STRINGS, tokenised inside the timed region by
-    # the package's BPE tokenizer (clip.tokenize semantics: <SOT> word pieces <EOT>, context 77) on the closed-vocabulary
-    # merge table text-to-sound-synthesis_amd/data/bpe_closed_vocab.json (tokenizer.CLOSED_VOCAB_PATH) -- the part of CLIP's table these captions exercise, ids checked
-    # against the reference's tokenizer when the file was made (the 1.3 MB full table is not on the GPU box).  Every
-    # rank gets a slice of the ids and runs the CLIP text tower on it.
+    # Every rank holds the caption list -- synthetic caption STRINGS; the reference's sharded sampler
+    # opens the same dataset on every rank, Codebook/evaluation/generate_samples_caps.py:147-153 --, rank 0 scatters caption
+    # INDICES, and each rank tokenises ITS captions inside the timed region (shard.scatter_captions; rank 0's host work does
+    # not grow with N) with the package's BPE tokenizer (clip.tokenize semantics: <SOT> word pieces <EOT>, context 77) on
+    # the closed-vocabulary merge table text-to-sound-synthesis_amd/data/bpe_closed_vocab.json (tokenizer.CLOSED_VOCAB_PATH)
+    # -- the part of CLIP's table these captions exercise, ids checked against the reference's tokenizer when the file was
+    # made (the 1.3 MB full table is not on the GPU box) --, then runs the CLIP text tower on them.
     from text_to_sound_synthesis_amd import tokenizer as tz
-    captions = synth.synth_captions(n_total, seed=7) if rank == 0 else None
-    bpe = tz.SimpleTokenizer(bpe_path=tz.CLOSED_VOCAB_PATH) if rank == 0 else None
+    captions = synth.synth_captions(n_total, seed=7)
+    bpe = tz.SimpleTokenizer(bpe_path=tz.CLOSED_VOCAB_PATH)
+    bpe_ids = lambda strings: tz.tokenize(strings, context_length=77, add_start_and_end=True, tokenizer=bpe)["token"]
     torch.manual_seed(1234 + rank)
     lo_id, hi_id = shard.shard_bounds(n_total, world, rank)
     my_ids = torch.arange(lo_id, hi_id, device=dev, dtype=torch.long)
@@ -538,9 +598,7 @@ def main():
                 torch.cuda.synchronize()
             return time.perf_counter()
         t0 = mark()
-        tok_all = tz.tokenize(captions, context_length=77, add_start_and_end=True, tokenizer=bpe)["token"] \
-            if rank == 0 else None
-        toks = shard.scatter_conditions(tok_all, n_total, (77,), dev, dtype=torch.long)
+        toks, _ = shard.scatter_captions(captions, n_total, dev, bpe_ids)
         t1 = mark()
         # per-caption in-kernel noise keyed by the GLOBAL caption index: a caption's clip is the same at every world size
         out = dt.sample(condition_token=toks, condition_mask=None, condition_embed=None, filter_ratio=0,
@@ -581,6 +639,17 @@ def main():
             text = bare
         print(text, flush=True)
     guard = HeadlineGuard(args.side_leg_limit, emit)
+    if rank == 0:
+        # a rank that DIES inside a side leg makes torch.distributed.run SIGTERM the others long before the guard's timer: the
+        # measurement is complete at this point, so rank 0 prints it on the way out (exit code 3 = line printed, legs cut short)
+        import signal
+
+        def on_term(signum, frame):
+            if guard.finish():
+                emit("SIGTERM during the side legs (another rank exited)")
+                sys.stdout.flush()
+            os._exit(3)
+        signal.signal(signal.SIGTERM, on_term)
     if world > 1:           # one rank cannot wait for another: its legs end by themselves (cpu_baseline alone takes minutes)
         guard.start()
 
@@ -692,16 +761,20 @@ def main():
         nonlocal model, voc, dt
         model = voc = dt = None                   # the sampling model makes room for the training step's activations
         torch.cuda.empty_cache()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_train
-        r = bench_train.run(batch=20, steps=10, warmup=3, n_layer=args.n_layer, codes=args.codes, precision="f16x2",
-                            graph=True, world=world, rank=rank, dev=dev)
+        from text_to_sound_synthesis_amd import train_bench
+        torch.set_grad_enabled(False)
+        r = train_bench.run(batch=20, steps=args.train_steps, warmup=5, n_layer=args.n_layer, codes=args.codes,
+                            precision="f16x2", graph=True, world=world, rank=rank, dev=dev)
         if rank == 0:
-            line["train"] = {"it_per_s": round(r["value"], 3), "samples_per_s": round(r["samples_per_s"], 2),
-                             "ms_per_it": round(r["ms_per_step"], 2),
-                             "allreduce_ms": round(r["ms"]["allreduce"], 3) if world > 1 else None,
+            line["train"] = {"it_per_s_sustained": round(r["it_per_s_sustained"], 3), "it_per_s_replay": round(r["it_per_s_replay"], 3),
+                             "iterations": r["steps"], "recaptures": r["recaptures"], "recapture_reasons": r["recapture_reasons"],
+                             "monitor_log2": r["monitor_log2"], "loss_scale_exp": r["loss_scale_exp"],
+                             "samples_per_s": round(r["samples_per_s"], 2), "ms_per_it": round(r["ms_per_step"], 2),
+                             "ms_per_replay_median": round(r["ms_per_replay_median"], 2),
+                             "ms_per_iteration_max": round(r["ms_per_iteration_max"], 2),
                              "batch_per_gpu": 20, "graph": r["graph"], "dtype": r["dtype"], "loss": r["loss"],
-                             "workload": r["config"]["workload"], "parallelism": r["config"]["parallelism"]}
+                             "grad_norm": r["grad_norm"], "workload": r["config"]["workload"],
+                             "parallelism": r["config"]["parallelism"]}
 
     def leg_cpu_baseline():
         line["cpu_baseline"] = cpu_baseline(args.n_layer, args.codes, T)

@@ -251,6 +251,13 @@ int ds_attention_bwd(const float* q, int ldq, const float* k, int ldk, const flo
 int ds_attention_bwd_f16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                            const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                            float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
+/* ... with the training step's saturation monitor folded in (round 6): *amax -- a device float the caller zeroes when it
+ * reads it; the kernels only ever raise it -- takes max(|dO|, |dS|), i.e. everything these kernels split to fp16 under the
+ * step's loss scale (dS = scale P (dP - delta) exists only in registers: no other pass could see it).  Replaces the
+ * separate ds_amax over dO of rounds 3-5.  Reference: the same loss.backward() lines as above. */
+int ds_attention_bwd_f16x2_mon(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                               const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                               float* stats, int B, int heads, int Lq, int Lk, float scale, float* amax, ds_stream_t stream);
 /* d emb[tokens[m]] += dx[m] (atomic) */
 int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
 /* fused AdamW update (torch.optim.AdamW semantics), step >= 1 */

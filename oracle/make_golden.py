@@ -290,6 +290,72 @@ def train_loss():
          **{"gradnorm_" + n.replace(".", "_"): v for n, v in gn.items()})
 
 
+TRAIN_BATCH_T = (57, 0, 93, 12, 99, 3, 71, 40, 88, 25, 64, 1, 97, 50, 33, 79, 8, 18, 45, 60)
+
+
+def train_batch(name="train_batch_L19_b20", profile="init", n_layer=19, B=20):
+    """Round 6: BASELINE configs[4] as the reference runs it -- the UNMODIFIED `DALLE.forward(batch,
+    return_loss=True)` (dalle_spec.py:389-400 -> prepare_input :93-133: Tokenize + VQModel.encode of the mel; then
+    diffusion_transformer.py:539-577: CLIPTextEmbedding of the caption ids, _train_loss) and `loss.backward()`
+    (engine/solver_spec.py:308-331) at 19 layers, B = 20, on `image ~ U(-1, 1) f32[20,1,80,848]` + 20 synthetic captions
+    (SURVEY.md section 8d row 5), with the sampled timesteps and the q_sample noise injected.  Stored: what every stage
+    hands to the next (caption ids, CLIP embedding, VQ token ids + the argmin margin of every code), the loss, the norm
+    of EVERY parameter gradient + the global norm, two gradient slices, and the importance-sampling statistics after."""
+    torch.manual_seed(0)
+    m = rh.build_dalle(n_layer=n_layer, diffusion_step=100, n_embed=256, with_encoder=True, with_clip=True)
+    if profile != "init":
+        synth.synth_init_(m, seed=0, skip=("content_codec.", "transformer.condition_emb."), profile=profile)
+    dt = m.transformer
+    mel = synth.synth_uniform((B, 1, 80, 848), key="tb.mel") * 2 - 1
+    caps = synth.synth_captions(B, seed=17)
+    t = torch.tensor(TRAIN_BATCH_T[:B])
+    pt = torch.ones(B) / 100
+    dt.sample_time = lambda b, device, method="uniform": (t, pt)
+    u = synth.synth_uniform((B, 257, 265), key="tb.u")
+    params = {k: p_ for k, p_ in dt.named_parameters() if not k.startswith("condition_emb.")}
+    for p_ in params.values():
+        p_.requires_grad_(True)
+        p_.grad = None
+    # what the stages hand over (recorded by calling the reference's own methods once more, outside the measured call)
+    with torch.no_grad():
+        inp = m.prepare_input({"image": mel, "text": caps})
+        cond = dt.condition_emb(inp["condition_token"]).float()
+        codec = m.content_codec
+        h = codec.quant_conv(codec.encoder(mel))
+        E = codec.quantize.embedding.weight
+        zf = h.permute(0, 2, 3, 1).reshape(-1, 256)
+        d = (zf ** 2).sum(1, keepdim=True) + (E ** 2).sum(1) - 2 * zf @ E.t()
+        top2 = d.topk(2, dim=1, largest=False).values
+        vq_gap = m.first_stage_permuter((top2[:, 1] - top2[:, 0]).view(B, -1))
+    assert torch.equal(cond, cond.half().float())
+    t0 = time.time()
+    with torch.enable_grad(), InjectNoise(lambda shp: u):
+        out = m({"image": mel, "text": caps}, return_loss=True)
+        out["loss"].backward()
+    print("reference DALLE.forward + backward, %d layers, B=%d, profile %s: %.1f s, loss %.6f"
+          % (n_layer, B, profile, time.time() - t0, float(out["loss"])))
+    names = sorted(k for k, p_ in params.items() if p_.grad is not None)
+    norms = torch.stack([params[k].grad.double().norm() for k in names])
+    total = torch.sqrt((norms ** 2).sum())
+    amax = torch.stack([params[k].grad.abs().max() for k in names])
+    with open(os.path.join(OUT, name + "_names.json"), "w") as f:
+        json.dump({"captions": caps, "grad_names": names}, f)
+    last = "transformer.blocks.%d." % (n_layer - 1)
+    save(name, t=t, caption_tokens=inp["condition_token"].to(torch.int32), cond_emb=cond.half(),
+         tokens=inp["content_token"].to(torch.int16), vq_gap=vq_gap, loss=out["loss"].detach().double(),
+         grad_norms=norms, grad_amax=amax, grad_total=total,
+         grad_logits_w_sample=params["transformer.to_logits.1.weight"].grad[::37, ::53].clone(),
+         grad_first_q_sample=params["transformer.blocks.0.attn1.query.weight"].grad[::97, ::89].clone(),
+         grad_last_fc1_sample=params[last + "mlp.0.weight"].grad[::211, ::89].clone(),
+         Lt_history=dt.Lt_history.detach(), Lt_count=dt.Lt_count.detach())
+
+
+def train_batch_trained():
+    """The same iteration on trained-like denoiser weights (synth.py profile="trained"): the single 2^k loss scale and the
+    saturation monitor meet a heavy-tailed dY."""
+    train_batch("train_batch_L19_b20_trainedlike", profile="trained")
+
+
 def solver_schedule():
     """SURVEY.md section 8f-3, the host logic around the training step (engine/solver_spec.py:308-331): the reference's
     own ReduceLROnPlateauWithWarmup, ClipGradNorm and EMA classes driven over a short deterministic run."""
@@ -361,7 +427,11 @@ class _StopAfter(Exception):
     pass
 
 
-def traj_full(name="traj_T100_L19", n_embed=256, n_clips=N1_B, caption_seed=11, n_steps=100, with_decode=True):
+N1_WAVE_FULL = (0, 7)   # clips whose waveform is stored at full length (fp32): the MelGAN tail of a sampled clip
+
+
+def traj_full(name="traj_T100_L19", n_embed=256, n_clips=N1_B, caption_seed=11, n_steps=100, with_decode=True,
+              profile="init"):
     """N1 (judge's row): end-to-end same-seed parity AT THE BENCHMARKED CONFIGURATION -- 19 layers, T = 100, K = 256,
     top0.85r, 8 captions.  Runs the reference's own loop (diffusion_transformer.py:587-659: 100 x p_sample :639-641)
     with the per-step noise injected, then dalle_spec.py:80-91 decode_to_img and vocoder/modules.py:129 forward.
@@ -383,6 +453,8 @@ def traj_full(name="traj_T100_L19", n_embed=256, n_clips=N1_B, caption_seed=11, 
     cond = clip(tk["token"].clone()).float()
     assert torch.equal(cond, cond.half().float())
     m = rh.build_dalle(n_layer=19, diffusion_step=100, n_embed=n_embed)
+    if profile != "init":      # round 6: the denoiser off the N(0, 0.02) manifold (synth.py profile="trained"), as trained_like()
+        synth.synth_init_(m, seed=0, skip=("content_codec.",), profile=profile)
     voc = rh.build_vocoder()
     dt = m.transformer
     inner = dt.predict_start
@@ -433,7 +505,40 @@ def traj_full(name="traj_T100_L19", n_embed=256, n_clips=N1_B, caption_seed=11, 
         return save(name, tokens=tokens.to(torch.int16), **common)
     mel = m.decode_to_img(tokens, (n_clips, 256, 5, 53))
     wave = voc((mel[:, 0] + 1) / 2)
-    save(name, tokens=tokens.to(torch.int16), mel=mel[:, 0], wave_head=wave[:, 0, :N1_WAVE_HEAD], **common)
+    save(name, tokens=tokens.to(torch.int16), mel=mel[:, 0], wave_head=wave[:, 0, :N1_WAVE_HEAD],
+         wave_full=wave[list(N1_WAVE_FULL), 0], wave_full_clips=torch.tensor(N1_WAVE_FULL), **common)
+
+
+def traj_add_full_wave(name, n_embed):
+    """Round 6: add `wave_full` (clips N1_WAVE_FULL, all 217 088 samples, fp32) to a chain golden written by an earlier
+    round WITHOUT re-running its 100-step loop: the reference's decode_to_img + Generator.forward on the file's own final
+    tokens.  The rebuilt models must reproduce the stored mel and waveform heads (to run-to-run rounding of torch-CPU), or nothing is written."""
+    path = os.path.join(OUT, name + ".npz")
+    z = dict(np.load(path))
+    m = rh.build_dalle(n_layer=2, diffusion_step=100, n_embed=n_embed)      # (decode_to_img does not touch the denoiser)
+    voc = rh.build_vocoder()
+    tokens = torch.from_numpy(z["tokens"].astype(np.int64))
+    with torch.no_grad():
+        mel = m.decode_to_img(tokens, (tokens.shape[0], 256, 5, 53))
+        wave = voc((mel[:, 0] + 1) / 2)
+    # (not bit for bit: torch-CPU conv reductions depend on the thread count of the run; the two runs of the reference must
+    # agree far inside the parity tolerances -- mel 1e-3 max-abs, waveform 1e-4 RMS -- or nothing is written)
+    d_mel = float(np.abs(mel[:, 0].numpy() - z["mel"]).max())
+    d_wav = float(np.sqrt(np.mean((wave[:, 0, :N1_WAVE_HEAD].numpy() - z["wave_head"]) ** 2)))
+    print("re-run of the reference vs the stored vectors: mel max-abs %.2e, wave-head rms %.2e" % (d_mel, d_wav))
+    assert d_mel < 2e-5 and d_wav < 2e-6, "rebuilt decoder / vocoder do not reproduce the stored vectors"
+    z["wave_full"] = wave[list(N1_WAVE_FULL), 0].numpy()
+    z["wave_full_clips"] = np.asarray(N1_WAVE_FULL)
+    np.savez_compressed(path, **z)
+    print("added wave_full to %-24s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def traj_trained():
+    """Round 6: the chain golden on TRAINED-LIKE denoiser weights -- GELU2 outputs in the 1e4s, hot
+    residual channels, LayerNorm gains over two decades, peaky posteriors whose top-r cut falls after rank 1-3 -- 8
+    captions, 100 steps, same hooks / noise keys as traj_full."""
+    traj_full("traj_T100_L19_trainedlike", n_embed=256, n_clips=8, caption_seed=11, n_steps=100, with_decode=True,
+              profile="trained")
 
 
 def traj_k512():
@@ -547,6 +652,17 @@ def main():
         return traj_full()
     if "--n1-k512-only" in sys.argv:
         return traj_k512()
+    if "--n1-trained-only" in sys.argv:
+        return traj_trained()
+    if "--full-wave-only" in sys.argv:
+        traj_add_full_wave("traj_T100_L19", 256)
+        return traj_add_full_wave("traj_T100_L19_k512", 512)
+    if "--train-batch-only" in sys.argv:
+        return train_batch()
+    if "--train-batch-trained-only" in sys.argv:
+        return train_batch_trained()
+    if "--train-batch-small" in sys.argv:      # plumbing check of the generator itself (not committed)
+        return train_batch("_scratch_train_batch_L2_b3", n_layer=2, B=3)
     if "--n1-b64-only" in sys.argv:
         return traj_b64()
     if "--dsample-only" in sys.argv:
@@ -657,6 +773,9 @@ def main():
     traj_full()
     traj_k512()
     traj_b64()
+    traj_trained()
+    train_batch()
+    train_batch_trained()
     print("done in %.1fs" % (time.time() - t0))
 
 

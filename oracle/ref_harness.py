@@ -63,10 +63,11 @@ def install():
     _installed = True
 
 
-def ref_config(n_layer=19, diffusion_step=100, n_embed=256):
+def ref_config(n_layer=19, diffusion_step=100, n_embed=256, with_clip=False):
     """The reference's own evaluation/caps_text.yaml, with the absent checkpoint
-    path removed and CLIP replaced by 'condition_embed' injection (the CLIP text
-    encoder is SURVEY §8(f)-1, not part of this path)."""
+    path removed and -- unless with_clip -- CLIP replaced by 'condition_embed' injection.
+    with_clip keeps the file's condition_emb_config (CLIPTextEmbedding inside the
+    DiffusionTransformer, caps_text.yaml:67-76): the training batch's own route."""
     import yaml
     with open(os.path.join(REF_ROOT, "evaluation", "caps_text.yaml")) as f:
         cfg = yaml.full_load(f)
@@ -77,18 +78,24 @@ def ref_config(n_layer=19, diffusion_step=100, n_embed=256):
     d["diffusion_step"] = diffusion_step
     d["transformer_config"]["params"]["n_layer"] = n_layer
     d["content_emb_config"]["params"]["num_embed"] = n_embed
-    d["condition_emb_config"] = None
+    if not with_clip:
+        d["condition_emb_config"] = None
     return cfg
 
 
-def build_dalle(n_layer=19, diffusion_step=100, n_embed=256, seed=0, with_encoder=False):
-    """Reference DALLE (without CLIP) carrying synth weights keyed by state-dict name.  with_encoder also gives the
-    VQ encoder + quant_conv synth weights (scope row 8f-2); weights are keyed by name, so nothing else changes."""
+def build_dalle(n_layer=19, diffusion_step=100, n_embed=256, seed=0, with_encoder=False, with_clip=False):
+    """Reference DALLE carrying synth weights keyed by state-dict name.  with_encoder also gives the VQ encoder +
+    quant_conv synth weights (scope row 8f-2); with_clip builds the reference's CLIPTextEmbedding inside the
+    DiffusionTransformer (random-init ViT-B/32 text tower, see build_clip_text; its keys are
+    transformer.condition_emb.*, the same synth values build_clip_text pours).  Weights are keyed by name, so nothing
+    else changes."""
     install()
     from sound_synthesis.modeling.build import build_model
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from text_to_sound_synthesis_amd.synth import synth_init_
-    cfg = ref_config(n_layer, diffusion_step, n_embed)
+    cfg = ref_config(n_layer, diffusion_step, n_embed, with_clip=with_clip)
+    if with_clip:
+        _redirect_clip_load()
     model = build_model(cfg).eval()
     # the VQ encoder / loss are not on the path; leave them at their defaults
     synth_init_(model, seed=seed, skip=("content_codec.loss.",) if with_encoder else
@@ -109,15 +116,19 @@ def build_vocoder(seed=0):
     return g
 
 
+def _redirect_clip_load():
+    from sound_synthesis.modeling.modules.clip import clip as clip_mod
+    from sound_synthesis.modeling.modules.clip import model as clip_model
+    clip_mod.load = lambda *a, **k: (clip_model.CLIP(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12), None)
+
+
 def build_clip_text(seed=0):
     """The reference's CLIPTextEmbedding (fp16 ViT-B/32 text tower, per-token output) with synth weights.
     clip.load is redirected to a random-init CLIP of the ViT-B/32 shape: the real ViT-B-32.pt path is
     hard-coded to the authors' cluster (modules/clip/clip.py:96)."""
     install()
-    from sound_synthesis.modeling.modules.clip import clip as clip_mod
-    from sound_synthesis.modeling.modules.clip import model as clip_model
     from text_to_sound_synthesis_amd.synth import synth_init_
-    clip_mod.load = lambda *a, **k: (clip_model.CLIP(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12), None)
+    _redirect_clip_load()
     from sound_synthesis.modeling.embeddings.clip_text_embedding import CLIPTextEmbedding
     m = CLIPTextEmbedding(clip_name="ViT-B/32", num_embed=49408, normalize=True, pick_last_embedding=False,
                           keep_seq_len_dim=False, additional_last_embedding=False, embed_dim=512).eval()

@@ -115,3 +115,25 @@ def test_padded_row_mode_selection_and_workspace():
         assert lib.ds_denoiser_rows_per_sample(h, 64) == 265
     finally:
         lib.ds_denoiser_destroy(h)
+
+
+def test_cpu_baseline_reports_what_the_host_gives(tmp_path):
+    """the cpu_baseline object names the CPU model, the affinity count and the cgroup CPU quota, and the
+    thread sweep stops at what the process may actually use."""
+    import os
+    import bench
+    info = bench.host_cpu_info()
+    assert set(info) == {"model", "affinity_cpus", "cgroup_cpu_max", "cgroup_quota_cpus", "numa_nodes_online"}
+    assert info["affinity_cpus"] is None or 1 <= info["affinity_cpus"] <= (os.cpu_count() or 1)
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("1600000 100000\n")
+    assert bench._cgroup_quota(str(v2)) == ("1600000 100000", 16)
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert bench._cgroup_quota(str(v2)) == ("max 100000", None)
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench._cgroup_quota(str(v1)) == ("250000 100000", 3)
+    assert bench._cgroup_quota(str(tmp_path / "none")) == (None, None)

@@ -1,0 +1,231 @@
+"""BASELINE configs[4] as the reference runs it: the training iteration FROM THE REFERENCE'S BATCH
+{'image': mel f32[20,1,80,848], 'text': 20 captions} at the benchmarked shape -- 19 layers, B = 20 -- against
+tests/golden/train_batch_L19_b20{,_trainedlike}.npz, which oracle/make_golden.py train_batch() produced by calling the
+UNMODIFIED reference's `DALLE.forward(batch, return_loss=True)` (dalle_spec.py:389-400 -> prepare_input :93-133 ->
+diffusion_transformer.py:539-577, 408-476) and `loss.backward()` (engine/solver_spec.py:308-331) with the timesteps and the
+q_sample noise injected.  The golden keeps what every stage hands to the next, the loss, the norm and the largest element
+of EVERY parameter gradient (539 tensors), the global norm and three gradient slices.  GPU only (-m gpu).
+
+Two weight profiles: "init" (N(0, 0.02)-like) and "trained" (synth.py: heavy-tailed weights, hot residual channels, GELU2
+outputs in the 1e4s) -- the second is where ONE 2^k loss scale for the whole backward and the saturation monitor meet a
+heavy-tailed dY."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, golden, parity_line, synth_sd
+from text_to_sound_synthesis_amd import synth
+
+pytestmark = pytest.mark.gpu
+NO_GRAD = True
+
+B = 20
+GRAD_NORM_TOL = 2e-4        # per-tensor |norm - reference norm| / reference norm (fp32 autograd on the CPU is the yardstick)
+SLICE_TOL = 2e-4            # elementwise, relative to the slice's largest element
+LOSS_TOL = 2e-5             # relative
+VQ_TIE = 2e-4               # nearest-code margin (squared distance) under which the argmin is a rounding-level tie
+
+
+def names(profile):
+    tag = "train_batch_L19_b20" + ("_trainedlike" if profile == "trained" else "")
+    with open(os.path.join(GOLDEN, tag + "_names.json")) as f:
+        return tag, json.load(f)
+
+
+def build(profile):
+    from text_to_sound_synthesis_amd import tokenizer as tz
+    from text_to_sound_synthesis_amd.config import build_model, default_config
+    m = build_model(default_config(n_layer=19, diffusion_step=100, with_clip=True, bpe_path=tz.CLOSED_VOCAB_PATH))
+    with open(os.path.join(GOLDEN, "state_dict_keys_clip.json")) as f:
+        clip_sd = synth.synth_state_dict(json.load(f))
+    sd = {**synth_sd("dalle", 19, profile=profile), **synth_sd("encoder"), **clip_sd}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected
+    m = m.cuda().eval()
+    dt = m.transformer
+    dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]     # caps_text.yaml:46-48
+    return m
+
+
+def batch_of(meta):
+    mel = synth.synth_uniform((B, 1, 80, 848), key="tb.mel") * 2 - 1
+    return {"image": mel.cuda(), "text": meta["captions"]}
+
+
+def injected(g):
+    return g["t"].long().cuda(), (torch.ones(B) / 100).cuda(), synth.synth_uniform((B, 257, 265), key="tb.u").cuda()
+
+
+@pytest.fixture(scope="module")
+def model_init():
+    return build("init")
+
+
+def test_prologue_stages_vs_reference(model_init):
+    """mel + captions -> BPE ids (exact), CLIP embedding (fp16 tower: 5e-4 on unit-norm rows), VQ token ids (exact except
+    where the reference's own nearest-code margin is a rounding-level tie)."""
+    from text_to_sound_synthesis_amd.modeling.train import training_inputs
+    tag, meta = names("init")
+    g = golden(tag)
+    m = model_init
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x0, cond, t, pt, u = training_inputs(m, batch_of(meta), generator=gen)
+    ids = m.prepare_condition(batch_of(meta))["condition_token"]
+    assert torch.equal(ids.cpu().long(), g["caption_tokens"].long()), "BPE ids differ from the reference's"
+    cond_err = float((cond.cpu() - g["cond_emb"].float()).abs().max())
+    diff = x0.cpu() != g["tokens"].long()
+    gaps = g["vq_gap"][diff]
+    assert x0.shape == (B, 265) and cond.shape == (B, 77, 512) and t.shape == pt.shape == (B,) and u.shape == (B, 257, 265)
+    assert x0.dtype == torch.long and int(x0.min()) >= 0 and int(x0.max()) < 256
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and torch.equal(pt.cpu(), torch.full((B,), 0.01))     # uniform branch: Lt_count is empty
+    parity_line("train batch prologue: BPE ids identical, CLIP max-abs %.2e, VQ tokens %d of %d differ (largest reference margin there %.1e; "
+                "%d reference margins are under %.0e)" % (cond_err, int(diff.sum()), diff.numel(), float(gaps.max()) if gaps.numel() else 0.0,
+                                                          int((g["vq_gap"] < VQ_TIE).sum()), VQ_TIE))
+    assert cond_err < 5e-4
+    assert bool((gaps < VQ_TIE).all()), "a VQ code differs away from a near-tie: margins %s" % gaps[gaps >= VQ_TIE][:4]
+    assert int(diff.sum()) <= int((g["vq_gap"] < VQ_TIE).sum())
+
+
+def check_grads(g, meta, loss, grads, what):
+    ref_names = meta["grad_names"]
+    got_norm = {k: float(v.double().norm()) for k, v in grads.items()}
+    missing = [n for n in ref_names if n not in grads]
+    assert not missing, missing[:4]
+    worst = []
+    for n, want, amax in zip(ref_names, g["grad_norms"].tolist(), g["grad_amax"].tolist()):
+        if amax < 1e-7:      # analytically zero (the attention key biases: softmax is invariant to them): rounding noise on both sides
+            assert got_norm[n] < 1e-5, n
+            continue
+        worst.append((abs(got_norm[n] - want) / want, n, want))
+    worst.sort(reverse=True)
+    total = math.sqrt(sum(v * v for v in got_norm.values()))
+    loss_err = abs(float(loss) - float(g["loss"])) / float(g["loss"])
+    tot_err = abs(total - float(g["grad_total"])) / float(g["grad_total"])
+    sl = []
+    for key, name, idx in (("grad_logits_w_sample", "transformer.to_logits.1.weight", (slice(None, None, 37), slice(None, None, 53))),
+                           ("grad_first_q_sample", "transformer.blocks.0.attn1.query.weight", (slice(None, None, 97), slice(None, None, 89))),
+                           ("grad_last_fc1_sample", "transformer.blocks.18.mlp.0.weight", (slice(None, None, 211), slice(None, None, 89)))):
+        got, want = grads[name][idx].cpu().double(), g[key].double()
+        sl.append(float((got - want).abs().max() / want.abs().max()))
+    parity_line("%s: loss rel %.1e (%.6f vs reference %.6f), global grad norm rel %.1e, worst of %d per-tensor norms %.1e (%s), "
+                "slices %s" % (what, loss_err, float(loss), float(g["loss"]), tot_err, len(worst), worst[0][0], worst[0][1],
+                               ["%.1e" % e for e in sl]))
+    for err, n, want in worst[:6]:
+        print("  grad-norm rel err %.2e  |g| %.3e  %s" % (err, want, n))
+    assert loss_err < LOSS_TOL
+    assert tot_err < GRAD_NORM_TOL
+    assert worst[0][0] < GRAD_NORM_TOL, worst[:4]
+    assert max(sl) < SLICE_TOL, sl
+
+
+@pytest.mark.parametrize("profile", ["init", "trained"])
+def test_loss_and_gradients_L19_b20_vs_reference(model_init, profile):
+    """The loss and every parameter gradient of the benchmarked training shape against the reference's own loss.backward(),
+    entered at what the reference's prologue produced (its VQ token ids and its CLIP embedding, so that the comparison is
+    the denoiser's alone) -- at the default loss-scale calibration and at 2^8 / 2^13 (the policy constant `calib_log2`
+    must not be what the precision hangs on)."""
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    tag, meta = names(profile)
+    g = golden(tag)
+    m = model_init if profile == "init" else build("trained")
+    dt = m.transformer
+    t, pt, u = injected(g)
+    x0, cond = g["tokens"].long().cuda(), g["cond_emb"].float().cuda()
+    for calib in (None, 8, 13):
+        dt.reset_time_statistics()
+        step = TrainStep(dt, precision="f16x2")
+        if calib is not None:
+            step.calib_log2 = calib
+        loss, grads = step.loss_and_grads(x0, cond, t, pt, u)
+        check_grads(g, meta, loss, grads, "train L19 B20 %s (largest |dY| calibrated to 2^%d, loss scale 2^%d)"
+                    % (profile, step.calib_log2, step.loss_scale_exp))
+        if calib is None:
+            assert torch.allclose(dt.Lt_history.cpu(), g["Lt_history"], rtol=5e-4, atol=1e-6)
+            assert torch.equal(dt.Lt_count.cpu(), g["Lt_count"])
+            # the saturation monitor saw this backward: its reading sits where the calibration aimed
+            assert step.check_loss_scale(force=True) is False
+            assert step.calib_log2 <= step.monitor_log[-1] < step.calib_log2 + 1, step.monitor_log
+        del step, grads
+    if profile != "init":
+        del m
+    torch.cuda.empty_cache()
+
+
+def test_solver_step_from_the_reference_batch(model_init):
+    """`Solver(model=dalle).step({'image', 'text'})` = the reference's `self.model(batch, return_loss=True)` entry
+    (engine/solver_spec.py:308-331): BPE -> CLIP -> VQ encode -> sample_time -> q_sample noise -> loss + backward -> clip ->
+    AdamW, against the golden with the product's OWN prologue (its CLIP embedding is 4e-4 from the reference's and a few VQ
+    codes sit on the other side of a tie: the loss agrees to that, not to 1e-5), and bit-for-bit against the same step fed
+    with the tensors `training_inputs` returns for the same generator state."""
+    from text_to_sound_synthesis_amd.modeling.solver import GradClipWindow, Solver
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep, training_inputs
+    tag, meta = names("init")
+    g = golden(tag)
+    m = model_init
+    dt = m.transformer
+    dt.reset_time_statistics()
+    t_g, pt_g, u_g = injected(g)
+    # (1) the product's own prologue + the golden's timesteps / noise: loss within what the prologue's tolerance allows
+    x0, cond, _, _, _ = training_inputs(m, batch_of(meta))
+    step = TrainStep(dt, precision="f16x2")
+    loss, grads = step.loss_and_grads(x0, cond, t_g, pt_g, u_g)
+    total = math.sqrt(sum(float(v.double().pow(2).sum()) for v in grads.values()))
+    e_loss = abs(float(loss) - float(g["loss"])) / float(g["loss"])
+    e_tot = abs(total - float(g["grad_total"])) / float(g["grad_total"])
+    parity_line("train L19 B20 from mel + captions (own CLIP + VQ encode): loss rel %.1e, global grad norm rel %.1e" % (e_loss, e_tot))
+    assert e_loss < 5e-3 and e_tot < 2e-2
+    # (2) Solver.step(batch dict) == Solver.step(*training_inputs(batch)) for the same generator state, weights and statistics
+    keep = {k: v.detach().clone() for k, v in dt.state_dict().items()}
+
+    def run(as_dict):
+        dt.load_state_dict(keep)
+        dt.transformer.invalidate()
+        gen = torch.Generator(device="cuda").manual_seed(99)
+        solver = Solver(TrainStep(dt, precision="f16x2"), lr=1e-4, clip_grad_norm=GradClipWindow(0, 5000, 0.5), model=m, generator=gen)
+        if as_dict:
+            out = solver.step(batch_of(meta))
+        else:
+            out = solver.step(*training_inputs(m, batch_of(meta), generator=gen))
+        w = dict(dt.named_parameters())["transformer.blocks.7.mlp.0.weight"].detach().clone()
+        return float(out["loss"]), float(out["grad_norm"]), w
+    a, b = run(True), run(False)
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2])
+    assert not torch.equal(a[2], keep["transformer.blocks.7.mlp.0.weight"])         # the update happened
+    dt.load_state_dict(keep)
+    dt.transformer.invalidate()
+    with pytest.raises(ValueError):
+        Solver(TrainStep(dt, precision="f16x2")).step(batch_of(meta))                # a batch dict needs the model
+
+
+def test_graph_solver_from_the_reference_batch_three_iterations(model_init):
+    """GraphSolver.step(batch dict): the prologue runs eagerly on the stream, the captured iteration replays on its output --
+    three iterations with new mel + captions each equal the eager Solver's (same generator, same weights) to rounding."""
+    from text_to_sound_synthesis_amd.modeling.solver import GradClipWindow, GraphSolver, Solver
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    m = model_init
+    dt = m.transformer
+    dt.reset_time_statistics()
+    keep = {k: v.detach().clone() for k, v in dt.state_dict().items()}
+
+    def run(cls):
+        dt.load_state_dict(keep)
+        dt.transformer.invalidate()
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        solver = cls(TrainStep(dt, precision="f16x2"), lr=1e-4, clip_grad_norm=GradClipWindow(0, 5000, 0.5), model=m, generator=gen)
+        outs = []
+        for it in range(3):
+            mel = torch.rand((B, 1, 80, 848), device="cuda", generator=gen) * 2 - 1
+            out = solver.step({"image": mel, "text": synth.synth_captions(B, seed=40 + it)})
+            outs.append((float(out["loss"]), float(out["grad_norm"])))
+        return outs, getattr(getattr(solver, "iteration_graph", None), "recaptures", 0)
+    eager, _ = run(Solver)
+    graphed, rec = run(GraphSolver)
+    print("eager %s\ngraph %s" % (eager, graphed))
+    for (le, ne), (lg, ng) in zip(eager, graphed):
+        assert abs(le - lg) < 1e-5 * abs(le) and abs(ne - ng) < 1e-4 * abs(ne)
+    assert rec == 0
+    dt.load_state_dict(keep)
+    dt.transformer.invalidate()

@@ -174,6 +174,59 @@ def test_attention_backward_recompute(L, B, H, Lq, Lk, fusedkv, split):
         assert err < 2e-5, (name, err)
     for gt in grads.values():
         assert not torch.isnan(gt).any()        # every column range of the fused gradient buffers was written
+    if split:
+        # ds_attention_bwd_f16x2_mon (round 6): the same kernels fold max(|dO|, |dS|) -- everything they split to
+        # fp16 -- into the step's saturation monitor; dS = scale P (dP - delta) exists only in registers.  Same gradients bit
+        # for bit, and the scalar equals the float64 value of that maximum (|dO| through its fp16 hi plane: 2^-11 relative).
+        P = torch.softmax(0.125 * (Q.detach() @ K.detach().transpose(-1, -2)), dim=-1)
+        dOh = heads(dO.double(), 0, Lq)
+        dP = dOh @ V.detach().transpose(-1, -2)
+        dS = 0.125 * P * (dP - (dOh * out.detach()).sum(-1, keepdim=True))
+        want_m = max(float(dO.abs().max()), float(dS.abs().max()))
+        grads2 = {id(t): torch.full(t.shape, float("nan"), device="cuda") for t, _, _ in srcs}
+        gops2 = [(grads2[id(t)], col, ld) for t, col, ld in srcs]
+        for start in (0.0, 2.0 * want_m):       # an empty monitor takes the maximum; one that already holds more is left alone
+            amax = torch.full((1,), start, device="cuda")
+            L.check(L.lib().ds_attention_bwd_f16x2_mon(
+                L.ptr_off(*ops[0][:2]), ops[0][2], L.ptr_off(*ops[1][:2]), ops[1][2], L.ptr_off(*ops[2][:2]), ops[2][2], L.ptr(o), D,
+                L.ptr(dOc), D, L.ptr_off(*gops2[0][:2]), gops2[0][2], L.ptr_off(*gops2[1][:2]), gops2[1][2], L.ptr_off(*gops2[2][:2]),
+                gops2[2][2], L.ptr(stats), B, H, Lq, Lk, 0.125, L.ptr(amax), L.stream()))
+            got_m = float(amax.item())
+            print("monitor: %.6g (float64 max(|dO|, |dS|) %.6g; |dO| %.6g, |dS| %.6g)"
+                  % (got_m, want_m, float(dO.abs().max()), float(dS.abs().max())))
+            assert abs(got_m - max(start, want_m)) <= 1e-3 * max(start, want_m)
+        for key in grads:
+            assert torch.equal(grads[key], grads2[key])
+
+
+def test_attention_backward_monitor_sees_dS_above_dO(L):
+    """The case the monitor was missing until round 6: values with |V| ~ 40 make |dS| = scale P |dP - delta| several times
+    |dO| -- the scalar must report dS, not dO."""
+    B, H, Lq, Lk = 1, 2, 40, 33
+    D = H * 64
+    q, kv = rnd((B * Lq, D), "abm.q", 1.5), rnd((B * Lk, 2 * D), "abm.kv", 1.5)
+    kv[:, D:] *= 40.0
+    dO = rnd((B * Lq, D), "abm.do", 64.0)
+
+    def heads(t, col, Lx):
+        return t[:, col:col + D].reshape(B, Lx, H, 64).permute(0, 2, 1, 3).double()
+    Q, K, V, dOh = heads(q, 0, Lq), heads(kv, 0, Lk), heads(kv, D, Lk), heads(dO, 0, Lq)
+    P = torch.softmax(0.125 * (Q @ K.transpose(-1, -2)), dim=-1)
+    O = P @ V
+    dS = 0.125 * P * (dOh @ V.transpose(-1, -2) - (dOh * O).sum(-1, keepdim=True))
+    assert float(dS.abs().max()) > 3.0 * float(dO.abs().max())
+    qc, kvc, dOc = q.cuda(), kv.cuda(), dO.cuda()
+    o = torch.empty(B * Lq, D, device="cuda")
+    L.check(L.lib().ds_attention(L.ptr(qc), D, L.ptr(kvc), 2 * D, L.ptr_off(kvc, D), 2 * D, L.ptr(o), D, B, H, Lq, Lk, 0.125, L.stream()))
+    dq, dkv = torch.empty_like(qc), torch.empty_like(kvc)
+    stats = torch.empty(2 * B * H * 64, device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    L.check(L.lib().ds_attention_bwd_f16x2_mon(L.ptr(qc), D, L.ptr(kvc), 2 * D, L.ptr_off(kvc, D), 2 * D, L.ptr(o), D, L.ptr(dOc), D,
+                                               L.ptr(dq), D, L.ptr(dkv), 2 * D, L.ptr_off(dkv, D), 2 * D, L.ptr(stats), B, H, Lq, Lk,
+                                               0.125, L.ptr(amax), L.stream()))
+    got, want = float(amax.item()), float(dS.abs().max())
+    print("monitor %.6g, float64 max |dS| %.6g, max |dO| %.6g" % (got, want, float(dO.abs().max())))
+    assert abs(got - want) < 1e-4 * want
 
 
 def test_embedding_backward_and_colsum_strided(L):

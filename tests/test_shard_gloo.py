@@ -60,6 +60,43 @@ def test_scatter_compute_gather(world, n_items):
     assert torch.equal(out, want)
 
 
+def _caption_worker(rank, world, port, n_items, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from text_to_sound_synthesis_amd import synth, tokenizer as tz
+        caps = synth.synth_captions(n_items + 3, seed=7)          # every rank holds the list (the dataset)
+        bpe = tz.SimpleTokenizer(bpe_path=tz.CLOSED_VOCAB_PATH)
+        tok = lambda strings: tz.tokenize(strings, context_length=77, add_start_and_end=True, tokenizer=bpe)["token"]
+        order = list(range(n_items + 2, 2, -1)) if rank == 0 else None     # rank 0 alone knows which captions run, and in which order
+        ids, mine = shard.scatter_captions(caps, n_items, torch.device("cpu"), tok, order=order)
+        lo, hi = shard.shard_bounds(n_items, world, rank)
+        assert ids.shape == (hi - lo, 77) and ids.dtype == torch.long and len(mine) == hi - lo
+        out = shard.gather_outputs(ids, n_items)
+        if rank == 0:
+            q.put((out, tok([caps[i] for i in order])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 8), (3, 7)])
+def test_per_rank_tokenisation_equals_rank0_tokenise_then_scatter(world, n_items):
+    """each rank tokenises its OWN captions (rank 0 scatters caption indices, 8 B each); gathered back in
+    caption order the ids are exactly what rank 0 would have produced by tokenising everything and scattering the ids."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_caption_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, want = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(got, want)
+
+
 def test_shard_bounds_cover_everything():
     for n in (1, 7, 64, 512, 513):
         for w in (1, 2, 3, 8):

@@ -47,18 +47,19 @@ def build_model(config, args=None):
     return instantiate_from_config(config["model"])
 
 
-def default_config(n_layer=19, diffusion_step=100, n_embed=256, with_clip=False):
+def default_config(n_layer=19, diffusion_step=100, n_embed=256, with_clip=False, bpe_path=None):
     """The shapes of Diffsound/evaluation/caps_text.yaml (values cited in SURVEY.md section 8),
     expressed with this package's own class paths.  with_clip attaches the text stage (BPE tokenizer +
     CLIP ViT-B/32 text tower, caps_text.yaml:30-41,67-76); without it the caption conditioning is
-    passed in as `condition_embed_token`."""
+    passed in as `condition_embed_token`.  bpe_path: the tokenizer's merge table (default: DIFFSOUND_BPE_PATH /
+    CLIP's full table; tokenizer.CLOSED_VOCAB_PATH = the closed vocabulary of the synthetic captions)."""
     m = _PKG + ".modeling."
     cfg = _default_config(m, n_layer, diffusion_step, n_embed)
     if with_clip:
         p = cfg["model"]["params"]
         p["condition_codec_config"] = {"target": _PKG + ".tokenizer.Tokenize", "params": {
             "context_length": 77, "add_start_and_end": True, "with_mask": True, "pad_value": 0,
-            "clip_embedding": False, "tokenizer_config": {"params": {"end_idx": 49152}}}}
+            "clip_embedding": False, "tokenizer_config": {"params": {"end_idx": 49152}}, "bpe_path": bpe_path}}
         p["diffusion_config"]["params"]["condition_emb_config"] = {
             "target": m + "clip_text.CLIPTextEmbedding", "params": {
                 "clip_name": "ViT-B/32", "num_embed": 49408, "normalize": True, "pick_last_embedding": False,

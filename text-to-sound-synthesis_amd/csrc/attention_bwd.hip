@@ -23,9 +23,13 @@
 // matrix-pipe time.  The LDS operand is split ONCE when it is staged (two swizzled fp16 planes, ab_stage_split), register
 // fragments when they are loaded, the score / dS tiles right at the MFMA.  Only the k-index mapping of the fragments changes (a lane holds 8 consecutive d / 8 of its own
 // accumulator rows per MFMA instead of 1).  P in [0, 1] is multiplied by 2^10 before it is split (its lo plane would sit in
-// fp16's subnormal range otherwise) and dV by 2^-10 when it is stored; dO / dS carry the step's loss scale: |dO| is folded into
-// the step's saturation monitor (modeling/train.py), |dS| = scale P |dP - delta| is not monitored itself -- it is bounded by the
-// monitored |dQ|, |dK| it sums into in practice, and the split SATURATES at 65504 instead of overflowing.
+// fp16's subnormal range otherwise) and dV by 2^-10 when it is stored; dO / dS carry the step's loss scale.  BOTH are split to
+// fp16 inside these kernels, so both are folded into the step's saturation monitor (modeling/train.py) by the q kernel itself
+// (ds_attention_bwd_f16x2_mon, round 6): max |dO| over the fragment every lane holds anyway and max |dS| over the 9 x 16
+// accumulator values of its dS^T tiles, one wave reduction, and an atomicMax that is skipped when the monitor already holds
+// more (it nearly always does: the packs of the surrounding linears feed the same scalar).  |dS| = scale P |dP - delta| can
+// exceed |dO| by |V| x 64 / 8: until round 5 only |dO| was monitored (a separate ds_amax launch) and a saturated dS --
+// the split SATURATES at 65504 instead of overflowing -- would have gone unseen.
 #include "common.h"
 
 typedef _Float16 ab_h8 __attribute__((ext_vector_type(8)));
@@ -116,6 +120,15 @@ __device__ __forceinline__ void ab_load_frag(AbFragH& f, const float* __restrict
         const f32x4 a = *(const f32x4*)(rowp + 8 * hh + 16 * c), b = *(const f32x4*)(rowp + 8 * hh + 16 * c + 4);
         ab_split8(a, b, f.hi[c], f.lo[c]);
     }
+}
+// max |x| over the fragment a lane holds (monitor: the hi plane is x to 2^-11 relative)
+__device__ __forceinline__ float ab_frag_absmax(const AbFragH& f) {
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)f.hi[c][e]));
+    return m;
 }
 // delta_q = sum_d dO[q][d] O[q][d] needs the fp32 dO values of this lane's k-slots next to the split fragment
 __device__ __forceinline__ float ab_frag_dot(const float* __restrict__ ap, const float* __restrict__ bp, int hh, bool split) {
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
                                                                 int ldk, const float* __restrict__ Vp, int ldv,
                                                                 const float* __restrict__ O, int ldo, const float* __restrict__ dO,
                                                                 int lddo, float* __restrict__ dQ, int lddq, float* __restrict__ stats,
-                                                                int Lq, int Lk, int heads, float scale) {
+                                                                int Lq, int Lk, int heads, float scale, unsigned* __restrict__ amax) {
     extern __shared__ __attribute__((aligned(16))) float kv[];  // [NKT*32][AB_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -356,6 +369,19 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = scale * s[kt][r] * (dp[r] - delta);   // dS^T (0 for masked keys: P = 0)
             AB_FENCE();                       // one dP tile live at a time
+        }
+        if constexpr (SPLIT) {
+            if (amax != nullptr) {            // saturation monitor: everything this wave is about to split to fp16
+                float m = ab_frag_absmax(dof);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(s[kt][r]));          // (fmaxf drops a NaN: it never wins)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                // non-negative floats order like their bit patterns; the plain load may be stale, but only ever too SMALL
+                if (lane == 0 && __float_as_uint(m) > *(volatile unsigned*)amax) atomicMax(amax, __float_as_uint(m));
+            }
         }
     }
     __syncthreads();
@@ -477,7 +503,7 @@ static int ab_set_lds(KernelT kernel, size_t lds, DsOnce& done) {
 template <bool SPLIT>
 static int ab_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                      const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, float* stats, int B,
-                     int heads, int Lq, int Lk, float scale, hipStream_t stream) {
+                     int heads, int Lq, int Lk, float scale, hipStream_t stream, float* amax = nullptr) {
     DS_CHECK_ARG(q && k && v && o && d_o && dq && dk && dv && stats, "null pointer");
     DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lq <= 288 && Lk <= 288, "at most 288 queries / keys are supported");
     DS_CHECK_ARG(((ldq | ldk | ldv | ldo | lddo) & 3) == 0, "leading dims of the inputs must be multiples of 4");
@@ -488,12 +514,12 @@ static int ab_launch(const float* q, int ldq, const float* k, int ldk, const flo
         const size_t lds = ab_buf_floats<SPLIT>(3) * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_q_kernel<3, SPLIT>, lds, a3)) return -2;
         hipLaunchKernelGGL((ds_attn_bwd_q_kernel<3, SPLIT>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o,
-                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
+                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale, (unsigned*)amax);
     } else {
         const size_t lds = ab_buf_floats<SPLIT>(9) * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_q_kernel<9, SPLIT>, lds, a9)) return -2;
         hipLaunchKernelGGL((ds_attn_bwd_q_kernel<9, SPLIT>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o,
-                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale);
+                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale, (unsigned*)amax);
     }
     DS_CHECK_LAUNCH();
     {
@@ -520,4 +546,15 @@ extern "C" int ds_attention_bwd_f16x2(const float* q, int ldq, const float* k, i
                                       int lddv, float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream_) {
     return ab_launch<true>(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, dq, lddq, dk, lddk, dv, lddv, stats, B, heads, Lq, Lk, scale,
                            (hipStream_t)stream_);
+}
+
+// ... and with the saturation monitor of the training step folded in: *amax (a float the caller zeroed at some point; it is
+// only ever raised) takes max(|dO|, |dS|) over everything the kernels split to fp16 -- no separate ds_amax pass over dO.
+extern "C" int ds_attention_bwd_f16x2_mon(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                          int ldo, const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv,
+                                          int lddv, float* stats, int B, int heads, int Lq, int Lk, float scale, float* amax,
+                                          ds_stream_t stream_) {
+    DS_CHECK_ARG(amax, "null monitor pointer");
+    return ab_launch<true>(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, dq, lddq, dk, lddk, dv, lddv, stats, B, heads, Lq, Lk, scale,
+                           (hipStream_t)stream_, amax);
 }

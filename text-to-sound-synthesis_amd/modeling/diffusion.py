@@ -199,15 +199,19 @@ class DiffusionTransformer(nn.Module):
         if ids.shape != (B,):
             raise ValueError("caption_ids must have one entry per caption: got %s for a batch of %d" % (tuple(ids.shape), B))
         # The range is checked on host lists / CPU tensors every time (it costs nothing there), and on a DEVICE tensor the
-        # first time that very tensor is seen (one host synchronisation; keyed by storage address and version counter, so an
-        # id tensor re-used across sample() calls -- bench.py's timed loop -- is checked once and a modified one again).  An
-        # id outside [0, 2^32) would be truncated into the Philox counter and could share a noise stream with another caption.
-        key = (ids.data_ptr(), ids._version, B) if on_device else None
-        if B > 0 and (not on_device or key != getattr(self, "_gids_checked", None)):
+        # first time that very tensor OBJECT is seen at its current version (one host synchronisation; remembered through a
+        # weak reference to the object, so an id tensor re-used across sample() calls -- bench.py's timed loop -- is checked
+        # once, a modified one again, and a NEW tensor that the caching allocator happens to put at the same address is not
+        # mistaken for the checked one).  An id outside [0, 2^32) would be truncated into the Philox counter and could share
+        # a noise stream with another caption.
+        seen = getattr(self, "_gids_checked", None)
+        known = on_device and seen is not None and seen[0]() is caption_ids and seen[1] == caption_ids._version
+        if B > 0 and not known:
             if int(ids.min()) < 0 or int(ids.max()) >= 2 ** 32:
                 raise ValueError("caption ids must be in [0, 2^32)")
             if on_device:
-                self._gids_checked = key
+                import weakref
+                self._gids_checked = (weakref.ref(caption_ids), caption_ids._version)
         return ids.to(device).contiguous()
 
     def _cond(self, condition_token, condition_embed):
@@ -218,21 +222,37 @@ class DiffusionTransformer(nn.Module):
         return condition_embed.float()
 
     # ---- training loss: the forward value (the step with gradients is modeling/train.py) ----
-    def sample_time(self, b, device, method="uniform"):
+    def sample_time(self, b, device, method="uniform", generator=None):
         """Timesteps for a batch and their sampling probabilities (:379-406): importance sampling by sqrt(Lt_history)
-        once every timestep has been seen more than 10 times, uniform before."""
+        once every timestep has been seen more than 10 times, uniform before.  generator: optional torch.Generator of
+        `device` (the reference draws from the global one)."""
         if method == "importance":
-            if not (self.Lt_count > 10).all():
-                return self.sample_time(b, device, method="uniform")
+            # (Lt_count only grows -- scatter_add of ones --, so once every timestep has been seen 11 times the test stays
+            # true: it is read from the device until then, one host synchronisation per call, and never again.  A state-dict
+            # load or a manual reset of the statistics clears the memo: _load_from_state_dict / reset_time_statistics.)
+            if not getattr(self, "_lt_all_seen", False):
+                if not (self.Lt_count > 10).all():
+                    return self.sample_time(b, device, method="uniform", generator=generator)
+                self._lt_all_seen = True
             lt_sqrt = torch.sqrt(self.Lt_history + 1e-10) + 0.0001
             lt_sqrt[0] = lt_sqrt[1]
             pt_all = lt_sqrt / lt_sqrt.sum()
-            t = torch.multinomial(pt_all, num_samples=b, replacement=True)
+            t = torch.multinomial(pt_all, num_samples=b, replacement=True, generator=generator)
             return t, pt_all.gather(dim=0, index=t)
         if method == "uniform":
-            t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+            t = torch.randint(0, self.num_timesteps, (b,), device=device, generator=generator).long()
             return t, torch.ones_like(t).float() / self.num_timesteps
         raise ValueError(method)
+
+    def reset_time_statistics(self):
+        """Zero the importance-sampling statistics (:88-89) and forget that every timestep had been seen."""
+        self.Lt_history.zero_()
+        self.Lt_count.zero_()
+        self._lt_all_seen = False
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._lt_all_seen = False
+        return super()._load_from_state_dict(*args, **kwargs)
 
     @torch.no_grad()
     def _train_loss(self, x, cond_emb, is_train=True, noise=None):

@@ -51,14 +51,17 @@ class PlateauWarmupLR:
         return a > best * (1.0 + self.threshold) if self.threshold_mode == "rel" else a > best + self.threshold
 
     def step(self, metric):
-        """One scheduler step with this iteration's loss; returns the lr for the next iteration."""
-        current = float(metric)
+        """One scheduler step with this iteration's loss; returns the lr for the next iteration.  The metric is read
+        (`float(metric)`: a host synchronisation when it is a device scalar) only once the warm-up is over -- the reference
+        converts it first and then ignores it for `warmup` steps (lr_scheduler.py:124-131), same schedule, one stall per
+        iteration more."""
         self.last_epoch += 1
         if self.last_epoch <= self.warmup:
             if self.warmup_lr_step is None:
                 raise RuntimeError("warmup > 0 needs warmup_lr")      # the reference fails here too (None in a sum)
             self.lr = max(self.lr + self.warmup_lr_step, self.min_lr)
             return self.lr
+        current = float(metric)
         if self.is_better(current, self.best):
             self.best = current
             self.num_bad_epochs = 0
@@ -190,6 +193,17 @@ def _window_always_clips(clip):
     return clip.start_iteration <= 0 or (clip.end_iteration > 0 and clip.end_iteration >= clip.start_iteration)
 
 
+def _batch_tensors(solver, batch):
+    """step()'s arguments -> (x0, cond_emb, t, pt, noise): a single dict is the reference's batch and goes through the
+    prologue (needs Solver(model=...)); five tensors pass through."""
+    if len(batch) == 1 and isinstance(batch[0], dict):
+        if solver.model is None:
+            raise ValueError("step(batch dict) needs the DALLE model: Solver(..., model=dalle)")
+        from .train import training_inputs
+        return training_inputs(solver.model, batch[0], generator=solver.generator)
+    return batch
+
+
 class Solver:
     """One training iteration in the reference's order (engine/solver_spec.py:308-331).  `train_step` supplies
     `loss_and_grads(*batch) -> (loss, {name: grad})` and `adamw_step(grads, state, step, lr, betas, eps, weight_decay)`
@@ -197,11 +211,15 @@ class Solver:
     all-reduce, shard.allreduce_gradients) before clipping, which is where DDP's reduction lands too."""
 
     def __init__(self, train_step, lr=3.0e-6, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, scheduler=None,
-                 clip_grad_norm=None, ema=None, allreduce=None, reducer=None):
+                 clip_grad_norm=None, ema=None, allreduce=None, reducer=None, model=None, generator=None):
         """allreduce: callable(grads) run after the backward (shard.allreduce_gradients); reducer: a shard.GradientReducer --
         the same reduction overlapped with the backward (buckets are all-reduced while earlier blocks are still being
-        differentiated).  Give one or neither."""
+        differentiated).  Give one or neither.
+        model: the DALLE drop-in whose `transformer` the train_step differentiates -- with it `step(batch)` takes the
+        reference's batch dict {'image': mel, 'text': captions} (modeling.train.training_inputs: BPE -> CLIP -> VQ encode ->
+        sample_time -> noise); generator: torch.Generator for the timesteps and the q_sample noise."""
         assert allreduce is None or reducer is None
+        self.model, self.generator = model, generator
         self.train_step, self.lr = train_step, float(lr)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.scheduler, self.clip_grad_norm, self.ema, self.allreduce = scheduler, clip_grad_norm, ema, allreduce
@@ -210,6 +228,9 @@ class Solver:
         self.last_iter = -1
 
     def step(self, *batch):
+        """step(batch_dict) -- the reference's `self.model(batch, return_loss=True)` entry -- or step(x0, cond_emb, t, pt,
+        noise) with the five tensors of TrainStep.loss_and_grads."""
+        batch = _batch_tensors(self, batch)
         if self.reducer is not None:
             loss, grads = self.train_step.loss_and_grads(*batch, on_grads=self.reducer.ready)
             self.reducer.finish(grads)
@@ -265,7 +286,10 @@ class GraphSolver:
     captured on the first batch (shapes are fixed from then on)."""
 
     def __init__(self, train_step, lr=3.0e-6, betas=(0.9, 0.96), eps=1e-8, weight_decay=4.5e-2, scheduler=None,
-                 clip_grad_norm=None, ema=None, reduce=None):
+                 clip_grad_norm=None, ema=None, reduce=None, model=None, generator=None):
+        """model / generator: as in Solver -- `step(batch_dict)` then runs the caption / mel prologue eagerly on the current
+        stream (it is enqueued while the previous replay is still executing) and replays the captured iteration on its output."""
+        self.model, self.generator = model, generator
         self.train_step, self.lr = train_step, float(lr)
         self.reduce = reduce
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
@@ -281,6 +305,7 @@ class GraphSolver:
         self.last_iter = -1
 
     def step(self, *batch):
+        batch = _batch_tensors(self, batch)
         if self.iteration_graph is None:
             max_norm = self.clip_grad_norm.max_norm if self.clip_grad_norm is not None else None
             self.iteration_graph = self.train_step.capture(*batch, betas=self.betas, eps=self.eps,

@@ -377,17 +377,49 @@ class _FusedAttn:
                     L_.ptr(self.out), H * 64, B, H, Lq, Lk, 0.125, L_.stream()))
 
     def backward(self, dO, dq, dk, dv, amax=None):
-        """split: the tile products of the recomputation on the fp16 matrix cores too (ds_attention_bwd_f16x2); dO enters
-        them as an fp16-split operand, so its magnitude is folded into the step's saturation monitor (`amax`)."""
+        """split: the tile products of the recomputation on the fp16 matrix cores too (ds_attention_bwd_f16x2_mon); dO and the
+        in-register dS enter them as fp16-split operands, so the kernel folds max(|dO|, |dS|) into the step's saturation
+        monitor (`amax`) itself."""
         q, k, v, B, Lq, Lk, H = self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H
         stats = torch.empty(2 * B * H * _ceil(Lq, 32), device=dO.device)
+        args = (L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2], L_.ptr(self.out), H * 64,
+                L_.ptr(dO), H * 64, L_.ptr_off(dq[0], dq[1]), dq[2], L_.ptr_off(dk[0], dk[1]), dk[2], L_.ptr_off(dv[0], dv[1]), dv[2],
+                L_.ptr(stats), B, H, Lq, Lk, 0.125)
         if self.split and amax is not None:
-            L_.check(L_.lib().ds_amax(L_.ptr(dO), dO.numel(), L_.ptr(amax), L_.stream()))
-        bwd = L_.lib().ds_attention_bwd_f16x2 if self.split else L_.lib().ds_attention_bwd
-        L_.check(bwd(
-            L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2], L_.ptr(self.out), H * 64,
-            L_.ptr(dO), H * 64, L_.ptr_off(dq[0], dq[1]), dq[2], L_.ptr_off(dk[0], dk[1]), dk[2], L_.ptr_off(dv[0], dv[1]), dv[2],
-            L_.ptr(stats), B, H, Lq, Lk, 0.125, L_.stream()))
+            L_.check(L_.lib().ds_attention_bwd_f16x2_mon(*args, L_.ptr(amax), L_.stream()))
+        else:
+            L_.check((L_.lib().ds_attention_bwd_f16x2 if self.split else L_.lib().ds_attention_bwd)(*args, L_.stream()))
+
+
+@torch.no_grad()
+def training_inputs(model, batch, generator=None):
+    """The reference's training batch -> the five tensors of `TrainStep.loss_and_grads`: what happens between
+    `self.model(batch, return_loss=True)` (engine/solver_spec.py:308-331) and the loss arithmetic.
+
+        batch {'image': mel f32[B,1,80,848], 'text': list of B captions}
+          -> DALLE.prepare_input (dalle_spec.py:93-133): Tokenize (BPE ids i64[B,77], host) and VQModel.encode + argmin +
+             ColumnMajor of the mel -> content_token i64[B,265]                       (HIP: vqgan.py, ds_vq_argmin)
+          -> DiffusionTransformer.forward (diffusion_transformer.py:552-566): CLIPTextEmbedding of the ids -> f32[B,77,512]
+          -> _train_loss (:408-421): sample_time(b, device, 'importance') -> (t, pt); the uniforms q_sample's
+             log_sample_categorical draws as torch.rand_like(logits [B, K+1, L]) (:359-368)
+
+    `model` is the DALLE drop-in (`condition_codec` + `transformer.condition_emb` built: config.default_config(with_clip=True)).
+    A batch that already carries 'condition_embed_token' / 'condition_token' (DALLE.prepare_condition's other forms) or
+    'content_token' skips the respective stage.  generator: torch.Generator of the model's device for t and the noise.
+    Everything is enqueued on the current stream; the only host synchronisation is sample_time's Lt_count test while it
+    is still false."""
+    dt = model.transformer
+    dev = dt.device
+    cond = model.prepare_condition(batch)
+    if batch.get("content_token") is not None:
+        x0 = batch["content_token"].to(dev)
+    else:
+        x0 = model.prepare_content(batch)["content_token"]
+    cond_emb = dt._cond(cond.get("condition_token"), cond.get("condition_embed_token")).to(dev)
+    B = x0.shape[0]
+    t, pt = dt.sample_time(B, dev, "importance", generator=generator)
+    noise = torch.rand((B, dt.num_classes, dt.content_seq_len), device=dev, generator=generator)
+    return x0.contiguous(), cond_emb.contiguous(), t.to(dev), pt.to(dev), noise
 
 
 class TrainStep:
@@ -412,22 +444,36 @@ class TrainStep:
         # scalar (ds_amax, the calibration's own probe; captured into the graph like any other launch), and
         # check_loss_scale() reads it on the host every `monitor_interval` steps -- whether or not clipping is configured.
         self.monitor_interval = 16
-        self.monitor_window = (6, 15)           # log2 bounds of max |scaled dY| outside which the calibration is dropped
+        # Where a calibration puts the largest |dY| of ITS batch: 2^calib_log2 .. 2^(calib_log2 + 1).  Rounds 3-5 used 12, three
+        # bits under the window's upper bound -- and the measured batch-to-batch spread of that maximum IS three bits (most
+        # batches 2^-8.7, every fifth 2^-5.73 = (1 / pt) / (B L): one position whose d logit is ~1), so a run re-captured as soon
+        # as its first large batch came by (profiles/r05last_monitor_ab.txt).  10 leaves five bits (32x) above and costs nothing
+        # below: a split value keeps 22 bits down to 2^-3 and 2^-25 absolutely under that, i.e. every element within 2^13 of
+        # the largest one is fp32-class and the rest err by < 2^-35 of it (gradient parity at 19 layers / B = 20 on both weight
+        # profiles, tests/test_hip_train_batch.py, holds at 8 as well as at 12).
+        self.calib_log2 = 10
+        self.monitor_window = (4, 15)           # log2 bounds of max |scaled dY| outside which the calibration is dropped
         self.monitor_log = []                   # log2 of the last readings (host floats; tools/bench_train.py prints them)
         # what a HIGH reading teaches: the largest exponent that keeps the batches seen so far inside fp16 (None: no bound).
         # A calibration looks at ONE batch; batches differ (B = 20, random init: every fifth or so has a largest |dY| 5-10x the
         # usual one -- 4 re-captures in 100 iterations, profiles/r05last_monitor_ab.txt), so without this memory the next
         # calibration picks the scale that has just saturated.  Dropped again when a reading falls under the window.
         self._scale_cap = None
+        self._clean_readings = 0                # consecutive readings at least 4 bits under the calibration target (cap decay)
+        self.cap_decay_readings = 32            # ... after that many (512 iterations) the bound is forgotten
         self._amax_live = None
         self._since_check = 0
         # weight swaps outside this class (checkpoint / EMA loads: solver._invalidate) must drop the cached pre-scales
         import weakref
         diffusion_transformer.__dict__.setdefault("_scale_clients", []).append(weakref.ref(self))
 
-    def reset_scales(self):
+    def reset_scales(self, weights_replaced=True):
         """Forget the per-matrix weight pre-scales 2^s and the loss scale: the next step re-derives both (one calibration
-        backward).  Called after the weights were replaced behind this object's back (solver._invalidate)."""
+        backward).  Called after the weights were replaced behind this object's back (solver._invalidate) -- then what the
+        saturation monitor had learnt about the OLD weights' gradients (`_scale_cap`) goes too -- and, with
+        weights_replaced=False, by a re-capture of the same run (the bound is exactly what that re-calibration needs)."""
+        if weights_replaced:
+            self._scale_cap, self._clean_readings = None, 0
         if hasattr(self.gemm, "wexp"):
             self.gemm.wexp.clear()
         if self.precision == "f16x2":
@@ -459,26 +505,39 @@ class TrainStep:
             # same step tells them apart at this very host sync.
             last = getattr(self, "_last_loss", None)
             if last is not None and not math.isfinite(float(last)):
-                self.loss_scale_exp, self._calib_norm = None, None
-                return True
+                # a diverged run: no loss scale repairs it, and answering True here would re-calibrate (and re-capture a graphed
+                # iteration) at every monitor interval for the rest of the run
+                raise FloatingPointError("training diverged: the loss is %r (every scaled gradient is NaN)" % float(last))
             return False
         lo, hi = self.monitor_window
         if math.isfinite(m) and 2.0 ** lo <= m < 2.0 ** hi:
+            # inside the window.  A bound learnt from one excursion must not hold the scale down for ever: once the readings
+            # have stayed >= 4 bits under the calibration target for `cap_decay_readings` checks in a row it is forgotten (the
+            # scale itself is left alone -- the next re-calibration, whenever something asks for one, is free again)
+            if self._scale_cap is not None:
+                self._clean_readings = self._clean_readings + 1 if m < 2.0 ** (self.calib_log2 - 3) else 0
+                if self._clean_readings >= self.cap_decay_readings:
+                    self._scale_cap, self._clean_readings = None, 0
             return False
         if math.isfinite(m) and m >= 2.0 ** hi and self.loss_scale_exp is not None:
-            cap = self.loss_scale_exp - (math.floor(math.log2(m)) - 12)        # this window's largest value -> 2^12..2^13
+            cap = self.loss_scale_exp - (math.floor(math.log2(m)) - self.calib_log2)     # this window's largest value -> the target
             self._scale_cap = cap if self._scale_cap is None else min(self._scale_cap, cap)
+            self._clean_readings = 0
+            self.last_trip = "monitor high: max |scaled dY| = 2^%.2f" % math.log2(m)
         elif math.isfinite(m):
             self._scale_cap = None                                             # gradients have shrunk: calibrate freely again
+            self.last_trip = "monitor low: max |scaled dY| = 2^%.2f" % math.log2(m)
+        else:
+            self.last_trip = "monitor: max |scaled dY| = %r" % m
         self.loss_scale_exp, self._calib_norm = None, None
         return True
 
     def _exp_from_amax(self, m):
-        """loss-scale exponent k for a calibration batch whose largest unscaled |dY| is m: m 2^k in [2^12, 2^13), no larger than
-        what the saturation monitor has learnt (`_scale_cap`)"""
+        """loss-scale exponent k for a calibration batch whose largest unscaled |dY| is m: m 2^k in [2^calib_log2, 2 * that), no
+        larger than what the saturation monitor has learnt (`_scale_cap`)"""
         if m == 0.0 or not math.isfinite(m):
             return 0
-        k = 12 - math.floor(math.log2(m))
+        k = self.calib_log2 - math.floor(math.log2(m))
         return k if self._scale_cap is None else min(k, self._scale_cap)
 
     @torch.no_grad()
@@ -539,9 +598,10 @@ class TrainStep:
         f32[B, K+1, L] uniforms for q_sample.  Returns (loss scalar as forward() reports it, {parameter name relative to
         the DiffusionTransformer: gradient}).  Gradients are those of that loss.
         on_grads(named, streams): called during the backward -- after the logits layer and after every transformer block,
-        last block first -- with the WEIGHT-matrix gradients that are final at that point (98 % of the bytes; biases and
-        norm gains are un-scaled in one multiply at the very end) and the streams that wrote them: the hook of the
-        overlapped data-parallel reduction (shard.GradientReducer.ready)."""
+        last block first -- with the WEIGHT-matrix gradients that are final at that point (76 % of the bytes), then once
+        after the block loop with the AdaLN tables' parameter gradients (22 %: they come out of two grouped GEMMs over all
+        modules); biases and norm gains are un-scaled in one multiply at the very end and stay with finish().  `streams`:
+        the streams that wrote them.  The hook of the overlapped data-parallel reduction (shard.GradientReducer.ready)."""
         if self.loss_scale_exp is None:
             self.calibrate(x0, cond_emb, t, pt, noise)
         return self._run(x0, cond_emb, t, pt, noise, calibrating=False, on_grads=on_grads)
@@ -768,6 +828,9 @@ class TrainStep:
                                        "attn2.key.weight", "attn2.value.weight", "attn1.proj.weight", "attn1.query.weight",
                                        "attn1.key.weight", "attn1.value.weight")])
         adaln_param_grads_all()
+        # the AdaLN parameter gradients (17 MB per block, 22 % of the gradient bytes) are final here: hand them to the
+        # overlapped reduction before the embedding backward and the closing un-scale instead of leaving them to finish()
+        hand_over([pfx + sfx for _, _, _, pfx in ada for sfx in (".linear.weight", ".emb.weight")])
         # ---- embedding
         demb = torch.zeros_like(emb.emb.weight)
         L_.check(L_.lib().ds_embed_bwd(L_.ptr(dx), L_.ptr(xt), L_.ptr(demb), M, D, demb.shape[0], L_.stream()))
@@ -907,14 +970,15 @@ class GraphedIteration:
                       hyper=self.hyper)
         self.loss, self.grad_norm, self.grads = loss, total, grads
 
-    def recapture(self, static=None):
+    def recapture(self, static=None, reason="requested"):
         """New calibration of the loss scale / weight pre-scales on the current static batch (or `static`, the batch about
-        to run), then a new graph."""
+        to run), then a new graph.  `reason` is kept (recapture_reasons: what a long run's log shows next to its rate)."""
         if static is not None:
             for dst, src in zip(self.static, static):
                 dst.copy_(src)
         self.recaptures = getattr(self, "recaptures", 0) + 1
-        self.step.reset_scales()
+        self.recapture_reasons = getattr(self, "recapture_reasons", []) + ["iteration %d: %s" % (self.iteration, reason)]
+        self.step.reset_scales(weights_replaced=False)
         keep_state = {k: (m.clone(), v.clone()) for k, (m, v) in self.opt_state.items()}
         self._capture()
         for k, (m, v) in keep_state.items():
@@ -944,7 +1008,7 @@ class GraphedIteration:
         if getattr(self.step, "_scales_epoch", 0) != self._scales_epoch:
             # the weights were replaced behind the graph (checkpoint / EMA load -> TrainStep.reset_scales): its frozen
             # pre-scales belong to the old weights.  Re-capture on THIS batch before anything is replayed.
-            self.recapture(static=(x0, cond_emb, t, pt, noise))
+            self.recapture(static=(x0, cond_emb, t, pt, noise), reason="weights replaced (reset_scales)")
         for dst, src in zip(self.static, (x0, cond_emb, t, pt, noise)):
             dst.copy_(src)
         self.iteration += 1
@@ -973,9 +1037,9 @@ class GraphedIteration:
         if getattr(self, "_replays", 0) >= max(1, st.rescale_interval):
             self._replays = 0
             if st.prescales_drifted():
-                self.recapture()
+                self.recapture(reason="a weight pre-scale 2^s left its place")
                 return True
         if st.check_loss_scale():
-            self.recapture()
+            self.recapture(reason=getattr(st, "last_trip", "saturation monitor"))
             return True
         return False
