@@ -280,8 +280,9 @@ int ds_amax(const float* x, long long n, float* out, ds_stream_t stream);
  *                (t_col0, t_cols % 32 == 0; 0, 0 = the matrix is the whole destination) -- row ranges of the ROW form are
  *                reached by offsetting dst_row by whole 16-row groups: the parts of a fused projection weight need no
  *                concatenated copy;
- *   colsum_part  [ds_pack_operand_tile_rows(rows, rows_pad)][cols] per-64-row column sums of scale * X, the first
- *                ceil(rows / 64) rows of which ds_colsum adds up in a fixed order (bias gradients; no atomics);
+ *   colsum_part  [ds_pack_operand_tile_rows(rows, rows_pad)][cols] per-64-row column sums of X (after the prologue, BEFORE
+ *                `scale`: a gradient's scale is its site's own power of two, which the bias gradient does not carry), the
+ *                first ceil(rows / 64) rows of which ds_colsum adds up in a fixed order (bias gradients; no atomics);
  *   amax         *amax = max(*amax, max |scale * X|) (atomicMax on the bit pattern; the caller zeroes it);
  * with an elementwise prologue: DS_PACK_GELU2 (X := gelu2(X): GELU2 of transformer_utils.py:111-115 between the MLP's
  * linears) or DS_PACK_GELU2_BWD (X := X * gelu2'(aux), aux fp32 [rows][ld_aux]: its backward).  scale: a power of two. */

@@ -321,8 +321,9 @@ def test_pack_operand_all_outputs(L, rows, cols, S):
     fullt[:cols, :rows] = want.t()
     assert torch.equal(got_t, _split_planes(fullt)), "transposed form (zero-padded contraction)"
     nr = (rows + 63) // 64
-    sums = part[:nr].cpu().double().sum(0)
-    assert (sums - want.double().sum(0)).abs().max().item() < 1e-5 * want.abs().sum(0).max().item()
+    sums = part[:nr].cpu().double().sum(0)            # (round 6: the column sums are those of X itself, BEFORE `scale`)
+    unscaled = src[:, :cols].double()
+    assert (sums - unscaled.sum(0)).abs().max().item() < 1e-5 * unscaled.abs().sum(0).max().item()
     want_amax = want.abs().max().item()
     assert amax.item() == want_amax
 

@@ -41,29 +41,13 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define AH_WAVES 3
-// Probe switches (tools/build_variant.sh; the defaults are the adopted configuration, DESIGN.md section 3 "Attention"):
-#ifndef AH_TPC
+// The adopted configuration (DESIGN.md section 3 "Attention"; the alternatives -- other chunk sizes and read-ahead depths,
+// separate K / V^T buffers, a persistent grid that walks several items per workgroup: all measured, profiles/r04g_*, r04r_* --
+// and the in-kernel timing stamps are in tools/probe/attn_probe.patch, applied by the probe builds only).
 #define AH_TPC 3                       // 32-key tiles per chunk, many-chunk kernel (self-attention: 288 key slots = 3 chunks of 96)
-#endif
-#ifndef AH_TPC1
 #define AH_TPC1 3                      // ... of the kernel for <= 96 keys (cross-attention): 3 = one chunk
-#endif
-#ifndef AH_KAHEAD
-#define AH_KAHEAD 2                    // k-steps a K fragment is read ahead of its MFMAs
-#endif
-#ifndef AH_VAHEAD
-#define AH_VAHEAD 1                    // V^T fragments read one k-step ahead
-#endif
-#ifndef AH_XSHARE
+#define AH_KAHEAD 2                    // k-steps a K fragment is read ahead of its MFMAs; V^T fragments are read one k-step ahead
 #define AH_XSHARE 1                    // READY: K and V^T chunks share ONE LDS buffer (4 / 5 workgroups per CU; every next K chunk is waited for)
-#endif
-#ifndef AH_PERSIST
-#define AH_PERSIST 0                   // READY, separate buffers (AH_XSHARE 0): a workgroup walks several (sample, head, query group) items
-#endif                                 // and fetches the next item's first K chunk + Q rows under the last chunk of the current one.
-                                       // Measured SLOWER than one item per workgroup (profiles/r04g_*): kept as a probe switch.
-#ifndef AH_WGS_PER_CU
-#define AH_WGS_PER_CU 0                // persistent grid = CUs x this (0: what the occupancy query says)
-#endif
 #define AH_TS 72                       // halves per staged output row (64 + 8: 16-byte aligned, 2-way banks at most)
 
 __device__ __forceinline__ _Float16 ah_hi(float a) { return ds_split_hi(a); }
@@ -114,7 +98,6 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
     constexpr int NKEY = NKT * 32;
     constexpr int KPL = NKEY * 64;   // halves per K plane of the image ([key][64 d]) = per V^T plane ([d][NKEY])
     constexpr bool XS = READY && AH_XSHARE;
-    constexpr bool PERSIST = READY && !XS && AH_PERSIST;
     _Float16* Kb = (_Float16*)smem_raw;            // [2][CK][64]
     _Float16* Vb = Kb + (XS ? 0 : 2 * PL);         // [2][4 d-blocks][TPC][16][32]
     constexpr int VB_BYTES = XS ? 0 : 4 * PL;      // byte offset of the V^T chunk buffer
@@ -124,12 +107,6 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
     const int l31 = lane & 31, hh = lane >> 5;
     const int nch = (Lk + CK - 1) / CK;          // chunks that hold keys (<= NCH by the launch rule)
     const int per_b = groups * heads;
-#ifdef AH_TIMING   // probe build only (tools/attn_timing.py): per-wave s_memrealtime accounting through the unused V pointer
-    unsigned long long ah_t0 = __builtin_amdgcn_s_memrealtime(), ah_tl = ah_t0, ah_acc[6] = {0, 0, 0, 0, 0, 0};
-#define AH_STAMP(i_) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ah_acc[i_] += n_ - ah_tl; ah_tl = n_; } while (0)
-#else
-#define AH_STAMP(i_) do { } while (0)
-#endif
 
     // READY: a (sample, head)'s image  K hi | K lo | V^T hi | V^T lo  (bytes), NKEY/4 KB per operand
     const unsigned vlane = (lane >> 2) * (NKEY * 2) + (lane & 3) * 16;   // V^T gather: lane -> (d row, 16-byte piece) of a tile
@@ -378,7 +355,6 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr int NS = 2 * TPC;
         if constexpr (FULL) {
-#if AH_VAHEAD
             h8 vf[2][4];
             vfrag(0, vf[0]);
 #pragma unroll
@@ -387,15 +363,6 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
                 pv_step(step, vf[step & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#else
-#pragma unroll
-            for (int step = 0; step < NS; ++step) {
-                h8 v[4];
-                vfrag(step, v);
-                pv_step(step, v);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
         } else {
 #pragma unroll
             for (int step = 0; step < NS; ++step) {
@@ -411,9 +378,9 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
     const std::true_type yes{};
     const std::false_type no{};
 
-    // (one pass unless the launch is persistent: the launcher gives every item its own workgroup otherwise)
-    int item = blockIdx.x;
-    if (item < n_items) while (true) {
+    // (one (sample, head, query group) item per workgroup)
+    const int item = blockIdx.x;
+    if (item < n_items) {
         const int b = item / per_b, rem = item - b * per_b;
         const int grp = rem / heads, head = rem - grp * heads;
         const int q0 = (grp * AH_WAVES + wave) * 32;
@@ -421,10 +388,8 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
         const unsigned long long img_s = image_of(b, head);
         const float* kb = Kp + (size_t)b * Lk * ldk + head * 64;
         const float* vb = Vp + (size_t)b * Lk * ldv + head * 64;
-        const int next = item + (int)gridDim.x;
-        const bool has_next = PERSIST && next < n_items;   // workgroup-uniform
 
-        if (!PERSIST || item == (int)blockIdx.x) {
+        {
             // ---- first chunk of K (and V^T), the wave's Q rows ----
             if constexpr (READY) {
                 issue_k(img_s, 0);
@@ -440,19 +405,10 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
             }
             __syncthreads();   // chunk 0 of K (and V^T) is in LDS
         }
-        AH_STAMP(0);
         m_run = -INFINITY;
         l_run = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-        if constexpr (PERSIST) {
-            // the score registers are written under `if (active)`: without a definition here they would count as live
-            // across the item loop's back edge (through the whole output staging) -- 30 registers of pressure, spills
-#pragma unroll
-            for (int kt = 0; kt < TPC; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-        }
 
         // chunks 0 .. nch-2 hold CK keys < Lk each (FULL); ONE copy of that code in a rolled loop, then the last chunk
         int c = 0;
@@ -460,7 +416,6 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
 #pragma nounroll
         for (; c + 1 < nch; ++c) {
             if (active) scores(yes, c);
-            AH_STAMP(1);
             if constexpr (XS) {
                 __syncthreads();            // every wave is done with the K chunk: V^T replaces it, landing under the softmax
                 issue_v(img_s, c);
@@ -469,15 +424,12 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
                 __syncthreads();            // every wave is done with the K chunk; the V^T chunk is visible
                 issue_k(img_s, c + 1);
             }
-            AH_STAMP(2);
             if (active) softmax();
-            AH_STAMP(3);
             if constexpr (XS) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();            // V^T is in LDS
             }
             if (active) pv(yes, c);
-            AH_STAMP(4);
             if constexpr (XS) {
                 __syncthreads();            // every wave is done with the V^T chunk: the next K chunk replaces it
                 issue_k(img_s, c + 1);
@@ -493,33 +445,22 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
                 stage_v(vb, c + 1);
                 __syncthreads();
             }
-            AH_STAMP(0);
         }
         {   // last chunk: keys c * CK .. Lk - 1
             if (active) scores(no, c);
-            AH_STAMP(1);
             if constexpr (XS) {
                 __syncthreads();
                 issue_v(img_s, c);
             } else if constexpr (READY) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();            // every wave is done with the K chunk (and with its Q rows); V^T is visible
-                if (has_next) {
-                    // PERSIST: the next item's first K chunk and Q rows, under this item's last softmax + P V
-                    const int nb = next / per_b, nrem = next - nb * per_b, ngrp = nrem / heads, nhead = nrem - ngrp * heads;
-                    issue_k(image_of(nb, nhead), 0);
-                    load_q(nb, nhead, (ngrp * AH_WAVES + wave) * 32);
-                }
             }
-            AH_STAMP(2);
             if (active) softmax();
-            AH_STAMP(3);
             if constexpr (XS) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
             if (active) pv(no, c);
-            AH_STAMP(4);
         }
         // ---- normalise (in-lane: the row sum of query l31 is this lane's + the other half's) ----
         if (active) {
@@ -530,9 +471,8 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
         if (o_plane > 0) {
             // packed split planes for the f16x2 projection GEMM (K = ldo): each wave stages its 32 x 64 tile, one plane after
             // the other, in the now free V^T buffer (8-byte writes: 4 consecutive d of a query) and stores 16-byte chunks (8 d
-            // of one row).  PERSIST: the next item's K chunk may be landing in the K buffer meanwhile.
-            if (has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (before this item's stores join the queue)
-            __syncthreads();                                   // every wave is done reading K / V^T; the next K chunk is visible
+            // of one row).
+            __syncthreads();                                   // every wave is done reading K / V^T
             if (active) {
                 _Float16* T = (_Float16*)(smem_raw + VB_BYTES) + wave * (32 * AH_TS);      // [32 rows][AH_TS]
 #pragma unroll
@@ -561,10 +501,6 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
                     }
                 }
             }
-            if (has_next) {
-                __syncthreads();                               // the staged tiles are read: the buffers belong to the next item
-                issue_v(image_of(next / per_b, (next % per_b) % heads), 0);
-            }
         } else {
             if (active) {
                 const int qr = q0 + l31;
@@ -577,27 +513,8 @@ __global__ __launch_bounds__(AH_WAVES * 64, READY ? 3 : 2) void ds_attn_f16x2_ke
                             *(f32x4*)(orow + dh * 32 + 8 * g) = f32x4{o[dh][4 * g], o[dh][4 * g + 1], o[dh][4 * g + 2], o[dh][4 * g + 3]};
                 }
             }
-            if (has_next) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                issue_v(image_of(next / per_b, (next % per_b) % heads), 0);
-            }
         }
-        AH_STAMP(5);
-        if constexpr (!PERSIST) break;      // compile-time single pass: nothing is live around a back edge
-        item += (int)gridDim.x;
-        if (item >= n_items) break;
     }
-#ifdef AH_TIMING
-    if (READY && Vp && lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* ot = (unsigned long long*)Vp + ((size_t)blockIdx.x * AH_WAVES + wave) * 8;
-        ot[0] = ah_t0;                                   // entry
-        for (int i = 0; i < 5; ++i) ot[1 + i] = ah_acc[i];   // operands landed | scores | barrier + DMA issue | softmax | P V
-        ot[6] = __builtin_amdgcn_s_memrealtime();        // end (output staged and stored)
-        ot[7] = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // items this workgroup worked
-    }
-#endif
 }
 
 template <int NKT, bool READY>
@@ -606,7 +523,6 @@ static int attn_f16x2_launch_n(const float* q, int ldq, const float* k, int ldk,
                                hipStream_t stream) {
     constexpr int TPC = ah_tpc(NKT);
     constexpr bool XS = READY && AH_XSHARE;
-    constexpr bool PERSIST = READY && !XS && AH_PERSIST;
     const int qtiles = (Lq + 31) / 32;
     const int groups = (qtiles + AH_WAVES - 1) / AH_WAVES;
     const long long items = (long long)groups * heads * B;
@@ -616,9 +532,7 @@ static int attn_f16x2_launch_n(const float* q, int ldq, const float* k, int ldk,
     constexpr size_t pl_bytes = (size_t)2 * TPC * 32 * 64 * sizeof(unsigned short);       // one operand chunk, both planes
     constexpr size_t lds = XS ? (pl_bytes > stage_bytes ? pl_bytes : stage_bytes) : 2 * pl_bytes;
     static_assert(pl_bytes >= stage_bytes, "the staged output plane fits in the V^T chunk buffer");
-    static int grid_cap_dev[64];   // persistent launches: workgroups that are resident at once, per device
     static DsOnce cap_once;
-    const int devi = DsOnce::dev();
     if (cap_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)ds_attn_f16x2_kernel<NKT, READY>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -626,17 +540,9 @@ static int attn_f16x2_launch_n(const float* q, int ldq, const float* k, int ldk,
             ds_set_error("attention_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -2;
         }
-        int per_cu = AH_WGS_PER_CU, dev = 0, cus = 0;
-        if (per_cu <= 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ds_attn_f16x2_kernel<NKT, READY>,
-                                                                        AH_WAVES * 64, lds) != hipSuccess)
-            per_cu = 1;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 256;
-        grid_cap_dev[devi] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
         cap_once.done();
     }
-    const int grid_cap = grid_cap_dev[devi];
-    const int grid = PERSIST && items > grid_cap ? grid_cap : (int)items;
+    const int grid = (int)items;
     hipLaunchKernelGGL((ds_attn_f16x2_kernel<NKT, READY>), dim3(grid), dim3(AH_WAVES * 64), lds, stream, q, ldq, k, ldk, v, ldv,
                        o, ldo, Lq, Lk, heads, scale, o_plane, q_plane, groups, (int)items);
     DS_CHECK_LAUNCH();
@@ -678,19 +584,12 @@ extern "C" int ds_attn_nkey(int Lk) { return Lk <= 96 ? 96 : (Lk <= 288 ? 288 : 
 // Attention on attention-ready operands (common.h): qh = Q planes [2][B][heads][Lq][64] (q_plane halves apart),
 // kv_img = [B][heads][4][nkey*64] halves (K hi | K lo | V^T hi | V^T lo, rows of keys >= Lk zero), output as in
 // ds_attention_f16x2_split.  Bit-identical to ds_attention_f16x2_split on the same values.
-#ifdef AH_TIMING
-static const float* g_ah_timing_buf = nullptr;       // probe build: 8 x u64 per wave (ds_attn_timing_buffer)
-extern "C" void ds_attn_timing_buffer(void* p) { g_ah_timing_buf = (const float*)p; }
-#define AH_TIMING_V g_ah_timing_buf
-#else
-#define AH_TIMING_V nullptr
-#endif
 extern "C" int ds_attention_f16x2_ready(const void* qh, long long q_plane, const void* kv_img, void* oh, int ldo, int B,
                                         int heads, int Lq, int Lk, float scale, ds_stream_t stream) {
     DS_CHECK_ARG(ldo % 32 == 0 && ldo >= heads * 64, "packed output needs ldo % 32 == 0");
     DS_CHECK_ARG(q_plane >= (long long)B * heads * Lq * 64 && q_plane % 8 == 0, "Q plane stride");
     DS_CHECK_ARG(((uintptr_t)qh & 15) == 0 && ((uintptr_t)kv_img & 15) == 0, "operands must be 16-byte aligned");
-    return attn_f16x2_launch<true>((const float*)qh, 0, (const float*)kv_img, 0, AH_TIMING_V, 0, (float*)oh, ldo, B, heads,
+    return attn_f16x2_launch<true>((const float*)qh, 0, (const float*)kv_img, 0, nullptr, 0, (float*)oh, ldo, B, heads,
                                    Lq, Lk, scale, (long long)((B * Lq + 15) & ~15) * ldo, q_plane, (hipStream_t)stream);
 }
 

@@ -32,7 +32,7 @@
 //     WAR  quarter g + 6 lands on the region of quarter g - 2, last read two or more phases before phase g.
 //   Waves 4..7 repeat the ninth-block loads of waves 0..3 (same bytes to the same LDS address) so that every wave
 //   counts the same number of instructions.
-// * Measured (tools/probe/probe_gemm_f16x2.hip ps_kernel, M = 16960): 343 / 374 / 385 / 412 TF-eq at
+// * Measured (round 2, a standalone probe of this loop that has since been removed; M = 16960): 343 / 374 / 385 / 412 TF-eq at
 //   (N, K) = (1024, 1024) / (3072, 1024) / (4096, 1024) / (1024, 4096) against 253 / 286 / 290 / 283 for the
 //   128 x 128 two-workgroups-per-CU program on the same shapes (profiles/r02_probe_per_sample.txt).
 // Epilogue: the three store families of gemm_f16x2.hip (row-major fp32 + residual; packed split planes; attention-ready
@@ -42,14 +42,9 @@
 
 #include "common.h"
 
-// Probe builds only (tools/probe/probe_ceiling.hip includes this file with -DPS_ABLATE=bits): take one ingredient out of the
-// main loop so that the launch time and the shader clock show what it costs.  1 = no LDS-DMA inside the loop, 2 = no
-// fragment reads inside the loop (the registers keep k-tile 0's fragments), 4 = no MFMAs, 8 = no epilogue, 16 = no
-// barriers inside the loop, 32 = epilogue without its global loads / stores (LDS staging only), 64 = epilogue without the
-// LDS staging (global loads / stores only).  The product is built with PS_ABLATE = 0: none of this changes its code.
-#ifndef PS_ABLATE
-#define PS_ABLATE 0
-#endif
+// (The ablation switches and in-kernel time stamps this file carried through rounds 3-5 -- PS_ABLATE / PS_TIMING -- live in
+// tools/probe/ps_probe.patch: the probe builds apply it to a scratch copy of this file, tools/probe/README.md.  Nothing of
+// them is left in the product source.)
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -104,14 +99,6 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
         tm_ = first + in % gsz;
         tn_ = in / gsz;
     }
-#ifdef PS_TIMING   // probe build only (tools/ps_timing.py): per-workgroup time stamps through the unused pro_scale pointer
-    unsigned long long ps_ts[8];
-#define PS_STAMP(i_) do { ps_ts[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    const unsigned long long ps_c0 = __builtin_amdgcn_s_memtime();
-    PS_STAMP(0);
-#else
-#define PS_STAMP(i_) do { } while (0)
-#endif
     const int row_lo = tm_ * L;                     // the sample's rows [row_lo, row_lo + L) are what this tile stores
     const int m0 = (row_lo >> 4) << 4, n0 = tn_ * BN;
     const int nk = p.K / 32;                        // even (K % 64 == 0)
@@ -176,19 +163,15 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     // tq_: the k-tile (run time, used by the builtin form)
 #define PS_ISSUE_LOOP(tq_, ty_, buf_)                                                                \
     do {                                                                                             \
-        if (PS_ABLATE & 128) { PS_ISSUE(tq_, ty_, buf_); }                                           \
-        else {                                                                                       \
-            PS_DMA_ASM(cur[ty_][0], ldsabs[ty_][0], (buf_) * (STAGE * 2));                           \
-            PS_DMA_ASM(cur[ty_][1], ldsabs[ty_][1], (buf_) * (STAGE * 2));                           \
-            if ((ty_) == 3) PS_DMA_ASM(cur8, ldsabs8, (buf_) * (STAGE * 2));                         \
-        }                                                                                            \
+        PS_DMA_ASM(cur[ty_][0], ldsabs[ty_][0], (buf_) * (STAGE * 2));                               \
+        PS_DMA_ASM(cur[ty_][1], ldsabs[ty_][1], (buf_) * (STAGE * 2));                               \
+        if ((ty_) == 3) PS_DMA_ASM(cur8, ldsabs8, (buf_) * (STAGE * 2));                             \
     } while (0)
 #define PS_FENCE()                                                                                   \
     do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PS_BAR()                                                                                     \
     do { PS_FENCE(); __builtin_amdgcn_s_barrier(); PS_FENCE(); } while (0)
-#define PS_LBAR()                                                                                    \
-    do { if (!(PS_ABLATE & 16)) PS_BAR(); else PS_FENCE(); } while (0)
+#define PS_LBAR() PS_BAR()
     const int swz[2] = {((0 + hh) ^ ((l31 >> 2) & 3)) * 8, ((2 + hh) ^ ((l31 >> 2) & 3)) * 8};
     f32x16 acc[4][2], acc8;
     f32x4 acc9[2];                  // NB16: the two 16 x 16 tiles of the ninth block row
@@ -278,17 +261,15 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     // one phase: P = phase within the k-tile (compile time), BUF = parity of the k-tile t (compile time)
 #define PS_PHASE(P, BUF)                                                                             \
     do {                                                                                             \
-        if (!(PS_ABLATE & 2)) {                                                                      \
-            if (P == 0) { PS_READ_A(BUF, 0); PS_READ_B(BUF, 0); }                                    \
-            if (P == 1) { PS_READ_B(BUF, 1); if (NB16) PS_READ_EB16(BUF); }                          \
-            if (P == 2) { PS_READ_A(BUF, 1); if (NB16) PS_READ_EA16(BUF); }                          \
-            if (P == 3 && !NB16) PS_READ_E(BUF);                                                     \
-        }                                                                                            \
+        if (P == 0) { PS_READ_A(BUF, 0); PS_READ_B(BUF, 0); }                                        \
+        if (P == 1) { PS_READ_B(BUF, 1); if (NB16) PS_READ_EB16(BUF); }                              \
+        if (P == 2) { PS_READ_A(BUF, 1); if (NB16) PS_READ_EA16(BUF); }                              \
+        if (P == 3 && !NB16) PS_READ_E(BUF);                                                         \
         PS_FENCE();                                                                                  \
         {                                                                                            \
             constexpr int dq = (P) + LEAD;                     /* quarter 4 t + dq */                \
             const int tq = t + (dq >> 2);                                                            \
-            if (tq < nk && !(PS_ABLATE & 1)) {                                                       \
+            if (tq < nk) {                                                                           \
                 PS_ISSUE_LOOP(tq, dq & 3, ((BUF) + (dq >> 2)) & 1);                                  \
                 asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   /* the 4 youngest quarters: 2+2+2+3 */ \
             } else {                                                                                 \
@@ -297,34 +278,21 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
         }                                                                                            \
         PS_LBAR();                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                               \
-        if (!(PS_ABLATE & 4)) {                                                                      \
-            if (P == 0) PS_QUAD(0, 0);                                                               \
-            if (P == 1) PS_QUAD(0, 1);                                                               \
-            if (P == 2) { PS_QUAD(1, 1); if (NB16) PS_EXTRA16(); }                                   \
-            if (P == 3) { PS_QUAD(1, 0); if (!NB16) { if (wr == 0) PS_EXTRA(0); else PS_EXTRA(1); } } \
-        } else {                                               /* probe: the fragment reads stay live */ \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                            \
-                _Pragma("unroll") for (int y = 0; y < 2; ++y)                                        \
-                    asm volatile("" :: "v"(a0[x][y]), "v"(a1[x][y]), "v"(b0[x][y]), "v"(b1[x][y]));  \
-            asm volatile("" :: "v"(ea0), "v"(ea1), "v"(eb0[0]), "v"(eb1[0]), "v"(eb0[1]), "v"(eb1[1])); \
-        }                                                                                            \
+        if (P == 0) PS_QUAD(0, 0);                                                                   \
+        if (P == 1) PS_QUAD(0, 1);                                                                   \
+        if (P == 2) { PS_QUAD(1, 1); if (NB16) PS_EXTRA16(); }                                       \
+        if (P == 3) { PS_QUAD(1, 0); if (!NB16) { if (wr == 0) PS_EXTRA(0); else PS_EXTRA(1); } }    \
         __builtin_amdgcn_s_setprio(0);                                                               \
         PS_LBAR();                                                                                   \
     } while (0)
     // prologue: quarters 0 .. 5 (k-tile 0 and types 0, 1 of k-tile 1) = 13 instructions per wave; quarters 0 and 1 have
     // landed once only the 4 youngest (2 + 3 + 2 + 2 = 9) are outstanding
 #pragma unroll
-    for (int q = 0; q < ((PS_ABLATE & 1) ? 8 : LEAD); ++q)        // (probe without DMA in the loop: both stages filled here)
+    for (int q = 0; q < LEAD; ++q)
         if ((q >> 2) < nk) PS_ISSUE(q >> 2, q & 3, (q >> 2) & 1);
-    if (4 * nk >= LEAD && !(PS_ABLATE & 3)) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    if (4 * nk >= LEAD) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PS_BAR();
-    PS_STAMP(1);
-    if (PS_ABLATE & 2) {            // probe: the only fragment reads of the launch
-        PS_READ_A(0, 0); PS_READ_B(0, 0); PS_READ_B(0, 1); PS_READ_E(0);
-        if (NB16) { PS_READ_EB16(0); PS_READ_EA16(0); }
-        PS_BAR();
-    }
     if (wr == 1) PS_LBAR();         // the second wave row runs one barrier behind the first
     // running tile bases of the written-out transfers: the first k-tile each quarter type is issued for inside the loop is
     // 1 (types 2, 3: phases 0, 1 of k-tile 0 issue quarters 6, 7) or 2 (types 0, 1: quarters 8, 9)
@@ -346,41 +314,12 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ps_kernel(const GemmPara
     }
     if (wr == 0) PS_LBAR();         // ... and the first row waits for it at the end
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PS_STAMP(2);
-    if (PS_ABLATE & 8) {            // probe: no epilogue (the accumulators stay live through a store that never runs)
-        if (p.M == -12345) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) p.C[(i * 2 + j) * 16 + r + tid * 256] = acc[i][j][r];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p.C[r + tid * 256 + 128] = acc8[r];
-            p.C[tid * 256 + 150] = acc9[0][0] + acc9[1][1];
-        }
-        return;
-    }
-#ifdef PS_TIMING
-    const unsigned long long ps_c1 = __builtin_amdgcn_s_memtime();
-#endif
 
     constexpr int WROW = 128, EROW0 = 256;         // tile geometry of the full tile (gemm_f16x2_ps_epilogue.inc)
     constexpr bool HALF_TILE = false;
     const bool hasE = true;
     const int pos0 = 0, tile_rows = L;
 #include "gemm_f16x2_ps_epilogue.inc"
-#ifdef PS_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tile's stores have left the wave's queue
-    PS_STAMP(6);
-    if (p.pro_scale && (tid_e == 0 || tid_e == 256)) {
-        unsigned long long* o = (unsigned long long*)p.pro_scale + ((size_t)blockIdx.x * 2 + (tid_e >> 8)) * 10;
-        for (int i = 0; i < 7; ++i) o[i] = ps_ts[i];
-        o[7] = ps_c1 - ps_c0;                               // shader cycles from entry to the end of the main loop
-        o[8] = (unsigned long long)(tm_ * 65536 + tn_);
-        o[9] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_ID: CU / XCC fields
-    }
-#endif
 }
 
 // ---- half tiles: the same program for grids that full tiles cannot fill ------------------------------------------------
@@ -603,12 +542,9 @@ __global__ __launch_bounds__(512, 1) void ds_gemm_f16x2_ph_kernel(const GemmPara
     }
     if (wr == 0) PS_BAR();          // ... and the first row waits for it at the end
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef PS_STAMP
-#define PS_STAMP(i_) do { } while (0)
     constexpr int WROW = 64, EROW0 = 128;          // tile geometry of a half tile (gemm_f16x2_ps_epilogue.inc)
     constexpr bool HALF_TILE = true;
 #include "gemm_f16x2_ps_epilogue.inc"
-#undef PS_STAMP
 }
 
 // Whether the per-sample program serves this problem: packed operands, sample-structured rows with 256 < L + 15 <= 288, N

@@ -10,8 +10,9 @@
 //                         fused projection are packed straight into their row / k ranges of the fused operand -- no
 //                         concatenated fp32 copy of the weights per step
 //                       * per-tile-row column sums (bias gradients: db = column sums of dY), summed by ds_colsum afterwards
-//                         in a fixed order -- no atomics, the gradients stay bit-reproducible
-//                       * max |x| (the loss-scale calibration / saturation monitor of the step)
+//                         in a fixed order -- no atomics, the gradients stay bit-reproducible; taken BEFORE `scale` is applied
+//                         (round 6: `scale` of a gradient is its site's own power of two, which the bias gradient must not carry)
+//                       * max |x * scale| (the loss-scale calibration / saturation monitor of the step)
 //                     with an optional elementwise prologue, so that the MLP's activation never exists in fp32:
 //                       DS_PACK_GELU2      x := gelu2(x)                  (forward: fc2's input from fc1's output)
 //                       DS_PACK_GELU2_BWD  x := x * gelu2'(aux)           (backward: d fc1-output from d gelu-output)
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * pk_gelu2_grad(u[e]);
                 }
+                sum += v;                                   // column sums: of the values BEFORE `scale` (see ds_pack_operand)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] *= scale;
@@ -73,7 +75,6 @@ __global__ __launch_bounds__(256) void ds_pack_operand_kernel(const float* __res
                     m = a > m ? a : m;                      // NaN never wins (a calibration quantity, not a validity check)
                 }
             }
-            sum += v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[r][c4 + e] = ds_split_pack(v[e]);
         }

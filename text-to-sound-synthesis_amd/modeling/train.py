@@ -107,7 +107,7 @@ class _Fp32Gemm:
     def prep_x(self, lin, x, pro=PACK_PLAIN):
         return _gelu2(x) if pro == PACK_GELU2 else x
 
-    def prep_dy(self, lin, dy, pro=PACK_PLAIN, aux=None, amax=None, need_row=True):
+    def prep_dy(self, lin, dy, pro=PACK_PLAIN, aux=None, amax=None, need_row=True, scale=1.0):
         return _gelu2(aux, dy) if pro == PACK_GELU2_BWD else dy
 
     def fwd(self, lin, x, R=None):
@@ -115,7 +115,7 @@ class _Fp32Gemm:
         y = torch.empty(M, lin.N, device=x.device)
         return L_.gemm(x, lin.W, y, M, lin.N, lin.K, bias=lin.b, R=R)
 
-    def dx(self, lin, dy):
+    def dx(self, lin, dy, unscale=1.0):
         M, N, K = dy.shape[0], lin.N, lin.K
         Np = _ceil(N, 32)
         Wt = lin.extra.get("Wt")
@@ -238,9 +238,12 @@ class _SplitGemm:
         M = x.shape[0]
         return _pack(x, M, lin.K, pro=pro, rows_pad=self.rows_pad(lin, M))
 
-    def prep_dy(self, lin, dy, pro=PACK_PLAIN, aux=None, amax=None, need_row=True):
+    def prep_dy(self, lin, dy, pro=PACK_PLAIN, aux=None, amax=None, need_row=True, scale=1.0):
+        """scale: the site's own power of two (TrainStep._site_exp): the planes hold dY * scale, the column sums (bias
+        gradient) are those of dY itself, `amax` takes max |dY * scale|"""
         M = dy.shape[0]
-        return _pack(dy, M, lin.N, pro=pro, aux=aux, want_row=need_row, rows_pad=self.rows_pad(lin, M), colsum=True, amax=amax)
+        return _pack(dy, M, lin.N, scale=scale, pro=pro, aux=aux, want_row=need_row, rows_pad=self.rows_pad(lin, M), colsum=True,
+                     amax=amax)
 
     def fwd(self, lin, xp, R=None):
         M = xp.rows
@@ -249,13 +252,15 @@ class _SplitGemm:
         return L_.gemm(xp.row, Wp.row, y, M, lin.N, lin.K, bias=lin.b, R=R, split2=lin.extra["osc"], a_plane=xp.row_plane,
                        w_plane=Wp.row_plane)
 
-    def dx(self, lin, dyp):
+    def dx(self, lin, dyp, unscale=1.0):
+        """unscale: 2^-e of the site's own scale, folded into the epilogue's output scale (exact: powers of two)"""
         M = dyp.rows
         Wp = lin.extra["Wp"]
         out = torch.empty(M, lin.K, device=dyp.row.device)
         Np = Wp.rows_pad                                       # contraction length of dX = dY W (N, a multiple of 32 here)
         assert Np == lin.N, "dX needs N % 32 == 0 (true for every linear of this network)"
-        return L_.gemm(dyp.row, Wp.t, out, M, lin.K, Np, split2=lin.extra["osc"], a_plane=dyp.row_plane, w_plane=Wp.t_plane)
+        return L_.gemm(dyp.row, Wp.t, out, M, lin.K, Np, split2=lin.extra["osc"] * unscale, a_plane=dyp.row_plane,
+                       w_plane=Wp.t_plane)
 
     def dw(self, lin, xp, dyp, inv_scale):
         N, K, Mp = lin.N, lin.K, dyp.rows_pad
@@ -459,6 +464,8 @@ class TrainStep:
         # usual one -- 4 re-captures in 100 iterations, profiles/r05last_monitor_ab.txt), so without this memory the next
         # calibration picks the scale that has just saturated.  Dropped again when a reading falls under the window.
         self._scale_cap = None
+        self._site_exp = None                   # {linear key: e}: the site's own 2^e on top of the loss scale (calibrate)
+        self._site_order = []
         self._clean_readings = 0                # consecutive readings at least 4 bits under the calibration target (cap decay)
         self.cap_decay_readings = 32            # ... after that many (512 iterations) the bound is forgotten
         self._amax_live = None
@@ -478,6 +485,7 @@ class TrainStep:
             self.gemm.wexp.clear()
         if self.precision == "f16x2":
             self.loss_scale_exp = None
+            self._site_exp = None
         self._calib_norm = None
         if self._amax_live is not None:
             self._amax_live.zero_()
@@ -613,16 +621,33 @@ class TrainStep:
         importance-sampling statistics (Lt_history / Lt_count) are not touched."""
         if self.precision != "f16x2":
             return 0
-        self.loss_scale_exp = 0
+        self.loss_scale_exp, self._site_exp = 0, None
         amax = torch.zeros(1, device=x0.device)
         self._run(x0, cond_emb, t, pt, noise, calibrating=True, amax=amax)
         m = float(amax.item())
         self.calibrated_amax = m
         self.loss_scale_exp = self._exp_from_amax(m)
+        # Second pass, under that loss scale: max |dY| of EVERY linear's output gradient (one more host sync).  One scale for
+        # the whole backward leaves the small gradients behind: against the reference at 19 layers / B = 20
+        # (tests/test_hip_train_batch.py) the cross-attention query projections -- whose dY is a softmax gradient of
+        # near-uniform probabilities, 2^-14 of the largest dY -- came out with 1e-2 relative error, their fp16 lo plane
+        # below the subnormal range (the reference's own fp32 has 6e-7 there).  So every site gets its own power of two on top:
+        # dY 2^e is what is split, 2^-e goes into the dX / dW epilogues -- exact, and every site's largest |dY| sits where
+        # the calibration aims.  (Under the loss scale, not in the first pass: unscaled, the deep sites' operands flush to 0.)
+        sites = torch.zeros(8 * len(self.tr.blocks) + 8, device=x0.device)
+        self._run(x0, cond_emb, t, pt, noise, calibrating=True, amax=torch.zeros(1, device=x0.device), site_amax=sites)
+        per_site = sites[:len(self._site_order)].tolist()
+        self._site_exp = {k: (0 if (v == 0.0 or not math.isfinite(v)) else
+                              max(0, min(40, self.calib_log2 - math.floor(math.log2(v)))))
+                          for k, v in zip(self._site_order, per_site)}
         return self.loss_scale_exp
 
-    def _run(self, x0, cond_emb, t, pt, noise, calibrating, amax=None, on_grads=None):
+    def _run(self, x0, cond_emb, t, pt, noise, calibrating, amax=None, on_grads=None, site_amax=None):
+        """site_amax: second calibration pass -- a zeroed f32[>= number of linears] whose slot i takes max |dY| of the i-th
+        linear's output gradient IN THE ORDER THE BACKWARD VISITS THEM (self._site_order receives the keys)"""
         dt, tr, G_ = self.dt, self.tr, self.gemm
+        site_exp = {} if (calibrating or self._site_exp is None) else self._site_exp
+        site_index = {}
         dev = x0.device
         B, Lx = x0.shape
         D, H, K = tr.n_embd, tr.n_head, tr.num_codes
@@ -733,9 +758,13 @@ class TrainStep:
             bias column sums, max |dY|), then dX, dW and db.  (Rounds 2-4 could put dW / db on a second HIP stream; measured
             slower in both rounds it was tried -- 15.6 vs 15.9 and 16.2 vs 16.6 it/s, the GEMMs fill the power-capped chip -- and
             removed in round 5.)"""
-            dyh = G_.prep_dy(lin, dy, pro=pro, aux=aux, amax=amax, need_row=need_dx)
-            dxo = G_.dx(lin, dyh) if need_dx else None
-            dW = G_.dw(lin, xh, dyh, inv)
+            # the site's own power of two on top of the loss scale (module docstring; 1 while calibrating)
+            e = site_exp.get(lin.key, 0)
+            up, down = 2.0 ** e, 2.0 ** -e
+            site_slot = amax if site_amax is None else site_amax[site_index.setdefault(lin.key, len(site_index))]
+            dyh = G_.prep_dy(lin, dy, pro=pro, aux=aux, amax=site_slot, need_row=need_dx, scale=up)
+            dxo = G_.dx(lin, dyh, unscale=down) if need_dx else None
+            dW = G_.dw(lin, xh, dyh, inv * down)
             db = G_.db(lin, dyh)
             small.append(db)
             return dxo, dW, db
@@ -847,6 +876,8 @@ class TrainStep:
         small += [demb, dhh, dw]
         if inv != 1.0:
             torch._foreach_mul_(small, inv)
+        if site_amax is not None:
+            self._site_order = list(site_index)
         if not calibrating:
             self._steps += 1
             self._last_loss = loss          # (device scalar; a captured iteration keeps updating this very tensor)

@@ -3,8 +3,8 @@
 // through rocm_smi while every variant runs back to back for a fixed time.  Answers two questions the round-2 review left
 // open: (1) what the MFMA stream of THIS 8-wave program sustains when nothing else is in the loop (the ceiling a schedule
 // change can approach), and (2) whether the launch time is set by the schedule or by the power budget (clock x busy).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I text-to-sound-synthesis_amd/csrc tools/probe/probe_ceiling.hip \
-//         -lrocm_smi64 -o tools/probe/probe_ceiling
+//   bash tools/probe/build_probe_ceiling.sh      (applies tools/probe/ps_probe.patch -- the PS_ABLATE switches -- to a scratch copy
+//                                                 of csrc/ and compiles this file against it; -> tools/probe/probe_ceiling)
 // Not part of the product library.
 #include <hip/hip_runtime.h>
 #include <rocm_smi/rocm_smi.h>
