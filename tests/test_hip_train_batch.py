@@ -99,8 +99,8 @@ def check_grads(g, meta, loss, grads, what):
     assert not missing, missing[:4]
     worst, ref_worst = [], 0.0
     for n, n32, n64, amax in zip(ref_names, g["grad_norms"].tolist(), g["grad_norms64"].tolist(), g["grad_amax"].tolist()):
-        if amax < 1e-7:      # analytically zero (the attention key biases: softmax is invariant to them): rounding noise on both sides
-            assert got_norm[n] < 1e-5, n
+        if amax < 1e-7:      # analytically zero (the attention key biases: softmax is invariant to them): rounding noise on both
+            assert got_norm[n] < 1e-7 * float(g["grad_total64"]), (n, got_norm[n])      # sides -- 1e-7 of the global norm at most
             continue
         worst.append((abs(got_norm[n] - n64) / n64, n, n64))
         ref_worst = max(ref_worst, abs(n32 - n64) / n64)
@@ -130,7 +130,7 @@ def check_grads(g, meta, loss, grads, what):
 def test_loss_and_gradients_L19_b20_vs_reference(model_init, profile):
     """The loss and every parameter gradient of the benchmarked training shape against the reference's own loss.backward(),
     entered at what the reference's prologue produced (its VQ token ids and its CLIP embedding, so that the comparison is
-    the denoiser's alone) -- at the default loss-scale calibration and at 2^8 / 2^13 (the policy constant `calib_log2`
+    the denoiser's alone) -- at the default calibration target (2^6) and at 2^2 / 2^10 (the policy constant `calib_log2`
     must not be what the precision hangs on)."""
     from text_to_sound_synthesis_amd.modeling.train import TrainStep
     tag, meta = names(profile)
@@ -139,14 +139,14 @@ def test_loss_and_gradients_L19_b20_vs_reference(model_init, profile):
     dt = m.transformer
     t, pt, u = injected(g)
     x0, cond = g["tokens"].long().cuda(), g["cond_emb"].float().cuda()
-    for calib in (None, 8, 13):
+    for calib in (None, 2, 10):
         dt.reset_time_statistics()
         step = TrainStep(dt, precision="f16x2")
         if calib is not None:
             step.calib_log2 = calib
         loss, grads = step.loss_and_grads(x0, cond, t, pt, u)
-        check_grads(g, meta, loss, grads, "train L19 B20 %s (largest |dY| calibrated to 2^%d, loss scale 2^%d)"
-                    % (profile, step.calib_log2, step.loss_scale_exp))
+        check_grads(g, meta, loss, grads, "train L19 B20 %s (operand maxima calibrated to 2^%d, loss scale 2^%d, site exponents %d..%d)"
+                    % (profile, step.calib_log2, step.loss_scale_exp, min(step._site_exp.values()), max(step._site_exp.values())))
         if calib is None:
             # what ONE scale for the whole backward (rounds 2-5) does to the small gradients, for the record: the same step
             # with the per-site exponents dropped
@@ -167,9 +167,9 @@ def test_loss_and_gradients_L19_b20_vs_reference(model_init, profile):
             # the saturation monitor saw this backward: its reading sits where the calibration aimed, and every linear's dY
             # carries its own power of two on top of the loss scale (the small ones many bits)
             assert step.check_loss_scale(force=True) is False
-            assert step.calib_log2 <= step.monitor_log[-1] < step.calib_log2 + 2, step.monitor_log
+            assert step.calib_log2 - 1 <= step.monitor_log[-1] < step.calib_log2 + 2, step.monitor_log
             ex = step._site_exp
-            assert len(ex) == 19 * 7 + 1 and min(ex.values()) == 0
+            assert len(ex) == 19 * 7 + 1 and min(ex.values()) == ex["logits"]
             print("site exponents: logits %d, block 18 %s, block 0 %s" % (ex["logits"], {k[4:]: v for k, v in ex.items() if k.startswith("b18.")},
                                                                         {k[3:]: v for k, v in ex.items() if k.startswith("b0.")}))
         del step, grads

@@ -449,25 +449,25 @@ class TrainStep:
         # scalar (ds_amax, the calibration's own probe; captured into the graph like any other launch), and
         # check_loss_scale() reads it on the host every `monitor_interval` steps -- whether or not clipping is configured.
         self.monitor_interval = 16
-        # Where a calibration puts the largest |dY| of ITS batch: 2^calib_log2 .. 2^(calib_log2 + 1).  Rounds 3-5 used 12, three
-        # bits under the window's upper bound -- and the measured batch-to-batch spread of that maximum IS three bits (most
-        # batches 2^-8.7, every fifth 2^-5.73 = (1 / pt) / (B L): one position whose d logit is ~1), so a run re-captured as soon
-        # as its first large batch came by (profiles/r05last_monitor_ab.txt).  10 leaves five bits (32x) above and costs nothing
-        # below: a split value keeps 22 bits down to 2^-3 and 2^-25 absolutely under that, i.e. every element within 2^13 of
-        # the largest one is fp32-class and the rest err by < 2^-35 of it (gradient parity at 19 layers / B = 20 on both weight
-        # profiles, tests/test_hip_train_batch.py, holds at 8 as well as at 12).
-        self.calib_log2 = 10
-        self.monitor_window = (4, 15)           # log2 bounds of max |scaled dY| outside which the calibration is dropped
+        # Where a calibration puts the largest value of every fp16-split gradient operand of ITS batch: 2^calib_log2 .. 2x that.
+        # What matters for precision is only that a tensor's largest element is >= 2^0 (a split value keeps 22 bits down to
+        # 2^-3 and 2^-25 absolutely under that: with the maximum at 2^T every element errs by <= 2^-(25+T) of it -- fp32's own
+        # 2^-24 at T = 0), and since round 6 EVERY site has its own power of two (calibrate: `_site_exp`), so the target can sit
+        # low and leave the room above to the batches: rounds 3-5 put ONE global maximum at 2^12, three bits under the window's
+        # upper bound, and the measured batch-to-batch spread of that maximum is three bits (most batches 2^-8.7, every fifth
+        # 2^-5.73 = (1 / pt) / (B L): one position whose d logit is ~1) -- a run re-captured as soon as its first large batch
+        # came by (profiles/r05last_monitor_ab.txt); per site the spread is another 2.5 bits (profiles/r06b_*).  6 leaves nine.
+        self.calib_log2 = 6
+        self.monitor_window = (0, 15)           # log2 bounds of max |scaled operand| outside which the calibration is dropped
         self.monitor_log = []                   # log2 of the last readings (host floats; tools/bench_train.py prints them)
-        # what a HIGH reading teaches: the largest exponent that keeps the batches seen so far inside fp16 (None: no bound).
-        # A calibration looks at ONE batch; batches differ (B = 20, random init: every fifth or so has a largest |dY| 5-10x the
-        # usual one -- 4 re-captures in 100 iterations, profiles/r05last_monitor_ab.txt), so without this memory the next
-        # calibration picks the scale that has just saturated.  Dropped again when a reading falls under the window.
-        self._scale_cap = None
+        # what a HIGH reading teaches: by how many bits later calibrations aim lower (a calibration looks at ONE batch; the
+        # excursion that tripped the monitor is then put at 2^12).  Forgotten after `cap_decay_readings` quiet readings in a
+        # row, when a reading falls under the window, and when the weights are replaced.
+        self._target_drop = 0
         self._site_exp = None                   # {linear key: e}: the site's own 2^e on top of the loss scale (calibrate)
         self._site_order = []
-        self._clean_readings = 0                # consecutive readings at least 4 bits under the calibration target (cap decay)
-        self.cap_decay_readings = 32            # ... after that many (512 iterations) the bound is forgotten
+        self._clean_readings = 0                # consecutive readings under 2^11 while a drop is in force
+        self.cap_decay_readings = 32            # ... after that many (512 iterations) the drop is forgotten
         self._amax_live = None
         self._since_check = 0
         # weight swaps outside this class (checkpoint / EMA loads: solver._invalidate) must drop the cached pre-scales
@@ -477,10 +477,10 @@ class TrainStep:
     def reset_scales(self, weights_replaced=True):
         """Forget the per-matrix weight pre-scales 2^s and the loss scale: the next step re-derives both (one calibration
         backward).  Called after the weights were replaced behind this object's back (solver._invalidate) -- then what the
-        saturation monitor had learnt about the OLD weights' gradients (`_scale_cap`) goes too -- and, with
+        saturation monitor had learnt about the OLD weights' gradients (`_target_drop`) goes too -- and, with
         weights_replaced=False, by a re-capture of the same run (the bound is exactly what that re-calibration needs)."""
         if weights_replaced:
-            self._scale_cap, self._clean_readings = None, 0
+            self._target_drop, self._clean_readings = 0, 0
         if hasattr(self.gemm, "wexp"):
             self.gemm.wexp.clear()
         if self.precision == "f16x2":
@@ -519,34 +519,36 @@ class TrainStep:
             return False
         lo, hi = self.monitor_window
         if math.isfinite(m) and 2.0 ** lo <= m < 2.0 ** hi:
-            # inside the window.  A bound learnt from one excursion must not hold the scale down for ever: once the readings
-            # have stayed >= 4 bits under the calibration target for `cap_decay_readings` checks in a row it is forgotten (the
-            # scale itself is left alone -- the next re-calibration, whenever something asks for one, is free again)
-            if self._scale_cap is not None:
-                self._clean_readings = self._clean_readings + 1 if m < 2.0 ** (self.calib_log2 - 3) else 0
+            # inside the window.  What one excursion taught must not hold the target down for ever: once the readings have
+            # stayed under 2^11 for `cap_decay_readings` checks in a row it is forgotten (the scales themselves are left
+            # alone -- the next re-calibration, whenever something asks for one, aims at the full target again)
+            if self._target_drop:
+                self._clean_readings = self._clean_readings + 1 if m < 2.0 ** 11 else 0
                 if self._clean_readings >= self.cap_decay_readings:
-                    self._scale_cap, self._clean_readings = None, 0
+                    self._target_drop, self._clean_readings = 0, 0
             return False
-        if math.isfinite(m) and m >= 2.0 ** hi and self.loss_scale_exp is not None:
-            cap = self.loss_scale_exp - (math.floor(math.log2(m)) - self.calib_log2)     # this window's largest value -> the target
-            self._scale_cap = cap if self._scale_cap is None else min(self._scale_cap, cap)
+        if math.isfinite(m) and m >= 2.0 ** hi:
+            # put THIS excursion at 2^12 from now on: aim that many bits lower (never under 2^1)
+            self._target_drop = min(self.calib_log2 - 1, self._target_drop + math.floor(math.log2(m)) - 12)
             self._clean_readings = 0
-            self.last_trip = "monitor high: max |scaled dY| = 2^%.2f" % math.log2(m)
+            self.last_trip = "monitor high: max |scaled operand| = 2^%.2f" % math.log2(m)
         elif math.isfinite(m):
-            self._scale_cap = None                                             # gradients have shrunk: calibrate freely again
-            self.last_trip = "monitor low: max |scaled dY| = 2^%.2f" % math.log2(m)
+            self._target_drop = 0                                              # gradients have shrunk: aim at the full target again
+            self.last_trip = "monitor low: max |scaled operand| = 2^%.2f" % math.log2(m)
         else:
-            self.last_trip = "monitor: max |scaled dY| = %r" % m
+            self.last_trip = "monitor: max |scaled operand| = %r" % m
         self.loss_scale_exp, self._calib_norm = None, None
         return True
 
+    def _target(self):
+        """log2 of where calibrations put a site's largest operand value right now (calib_log2 minus what excursions taught)"""
+        return max(1, self.calib_log2 - self._target_drop)
+
     def _exp_from_amax(self, m):
-        """loss-scale exponent k for a calibration batch whose largest unscaled |dY| is m: m 2^k in [2^calib_log2, 2 * that), no
-        larger than what the saturation monitor has learnt (`_scale_cap`)"""
+        """exponent k that puts a largest value m at 2^target .. 2^(target + 1)"""
         if m == 0.0 or not math.isfinite(m):
             return 0
-        k = self.calib_log2 - math.floor(math.log2(m))
-        return k if self._scale_cap is None else min(k, self._scale_cap)
+        return self._target() - math.floor(math.log2(m))
 
     @torch.no_grad()
     def prescales_drifted(self):
@@ -564,17 +566,17 @@ class TrainStep:
         return any(k not in old or s < old[k] or s > old[k] + 2 for k, s in new.items())
 
     def observe_grad_norm(self, norm):
-        """Guard of the calibrated loss scale ("f16x2" backend): the calibration leaves 8x of headroom below fp16's range
-        (largest |dY| at 2^12..2^13, saturation at 2^16) and ~2^9 below it before the smallest interesting values lose
-        fp32-class precision.  Gradients grow and shrink together, so the global gradient norm the solver computes anyway
-        is the monitor: once it has moved by more than 4x up or 64x down from its value at calibration time, the next
-        step re-calibrates (returns True then).  Call it with a HOST float (the solvers do, next to float(loss))."""
+        """Second guard of the calibrated scales ("f16x2" backend, eager solver): the calibration leaves 2^9 of headroom below
+        fp16's range and 2^6 above the point where the largest element of an operand would fall under 2^0.  Gradients grow and
+        shrink together, so the global gradient norm the solver computes anyway is a monitor too: once it has moved by more
+        than 32x up or 64x down from its value at calibration time, the next step re-calibrates (returns True then).  Call
+        it with a HOST float (the solvers do, next to float(loss))."""
         if self.precision != "f16x2" or not math.isfinite(norm) or norm <= 0.0:
             return False
         if self._calib_norm is None:
             self._calib_norm = norm
             return False
-        if norm > 4.0 * self._calib_norm or norm < self._calib_norm / 64.0:
+        if norm > 32.0 * self._calib_norm or norm < self._calib_norm / 64.0:
             self.loss_scale_exp, self._calib_norm = None, None
             return True
         return False
@@ -626,20 +628,30 @@ class TrainStep:
         self._run(x0, cond_emb, t, pt, noise, calibrating=True, amax=amax)
         m = float(amax.item())
         self.calibrated_amax = m
-        self.loss_scale_exp = self._exp_from_amax(m)
-        # Second pass, under that loss scale: max |dY| of EVERY linear's output gradient (one more host sync).  One scale for
-        # the whole backward leaves the small gradients behind: against the reference at 19 layers / B = 20
-        # (tests/test_hip_train_batch.py) the cross-attention query projections -- whose dY is a softmax gradient of
-        # near-uniform probabilities, 2^-14 of the largest dY -- came out with 1e-2 relative error, their fp16 lo plane
-        # below the subnormal range (the reference's own fp32 has 6e-7 there).  So every site gets its own power of two on top:
-        # dY 2^e is what is split, 2^-e goes into the dX / dW epilogues -- exact, and every site's largest |dY| sits where
-        # the calibration aims.  (Under the loss scale, not in the first pass: unscaled, the deep sites' operands flush to 0.)
-        sites = torch.zeros(8 * len(self.tr.blocks) + 8, device=x0.device)
+        k0 = self._exp_from_amax(m)
+        # Second pass, under that provisional scale (unscaled, the deep sites' operands flush to 0): the largest value of EVERY
+        # operand the backward splits to fp16 -- max |dY| per linear (its dY feeds the dX and dW GEMMs) and max(|dO|, |dS|)
+        # over the attention backwards -- in one more host sync.  One scale for the whole backward leaves the small gradients
+        # behind: against the reference at 19 layers / B = 20 (tests/test_hip_train_batch.py) the cross-attention query
+        # projections -- whose dY is a softmax gradient of near-uniform probabilities, 2^-14 of the largest dY -- came out with
+        # 1e-2 relative error, their fp16 lo plane under the subnormal range (the reference's own fp32: 6e-7).  So
+        #   * the loss scale 2^k itself is set by what has NO scale of its own: the attention backward's in-kernel splits
+        #     (its dO arrives in loss-scale units; 6.5e-5 on the same tensors while k was set by d logits) -- fp32 tensors in
+        #     between carry it without harm, whatever it is;
+        #   * every linear gets its own power of two on top: dY 2^e is what is split (ds_pack_operand `scale`), 2^-e goes into
+        #     the dX / dW epilogues -- exact; e < 0 where the loss scale alone would overflow (d logits).
+        self.loss_scale_exp = k0
+        n_lin = 7 * len(self.tr.blocks) + 1
+        sites = torch.zeros(n_lin + 1, device=x0.device)                     # [linears in backward order ..., attention]
         self._run(x0, cond_emb, t, pt, noise, calibrating=True, amax=torch.zeros(1, device=x0.device), site_amax=sites)
-        per_site = sites[:len(self._site_order)].tolist()
+        per_site = sites.tolist()
+        assert len(self._site_order) == n_lin
+        att = per_site[-1]
+        shift = 0 if (att == 0.0 or not math.isfinite(att)) else max(-24, min(24, self._target() - math.floor(math.log2(att))))
+        self.loss_scale_exp = k0 + shift
         self._site_exp = {k: (0 if (v == 0.0 or not math.isfinite(v)) else
-                              max(0, min(40, self.calib_log2 - math.floor(math.log2(v)))))
-                          for k, v in zip(self._site_order, per_site)}
+                              max(-40, min(40, self._target() - math.floor(math.log2(v)) - shift)))
+                          for k, v in zip(self._site_order, per_site[:n_lin])}
         return self.loss_scale_exp
 
     def _run(self, x0, cond_emb, t, pt, noise, calibrating, amax=None, on_grads=None, site_amax=None):
@@ -648,6 +660,7 @@ class TrainStep:
         dt, tr, G_ = self.dt, self.tr, self.gemm
         site_exp = {} if (calibrating or self._site_exp is None) else self._site_exp
         site_index = {}
+        att_slot = None                         # where the attention backwards fold max(|dO|, |dS|): set below
         dev = x0.device
         B, Lx = x0.shape
         D, H, K = tr.n_embd, tr.n_head, tr.num_codes
@@ -669,7 +682,8 @@ class TrainStep:
                 self._amax_live = torch.zeros(1, device=dev)
             amax = self._amax_live
 
-        # (every gradient that enters a GEMM passes G_.prep_dy, whose pack folds max |dY| into `amax`: calibration / monitor)
+        # (every gradient that enters a GEMM passes G_.prep_dy, whose pack folds max |dY 2^e| into `amax`: calibration / monitor)
+        att_slot = amax if site_amax is None else site_amax[-1]
 
         sched = dt._schedule_table()
         xt = dt.q_sample_tokens(x0.contiguous(), t, noise)
@@ -832,7 +846,7 @@ class TrainStep:
             dq = torch.empty(M, D, device=dev)
             dkv = torch.empty(B * Lc, 2 * D, device=dev)
             if fused:
-                s["att2"].backward(dao, (dq, 0, D), (dkv, 0, 2 * D), (dkv, D, 2 * D), amax=amax)
+                s["att2"].backward(dao, (dq, 0, D), (dkv, 0, 2 * D), (dkv, D, 2 * D), amax=att_slot)
             else:
                 s["att2"].backward(dao, dq, dkv[:, :D], dkv[:, D:])
             dh, g[p + "attn2.query.weight"], g[p + "attn2.query.bias"] = lin_bwd(ls["q2"], s["h2"], dq)
@@ -845,7 +859,7 @@ class TrainStep:
             dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["o1"], dx)
             dqkv = torch.empty(M, 3 * D, device=dev)
             if fused:
-                s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D), amax=amax)
+                s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D), amax=att_slot)
             else:
                 s["att1"].backward(dao, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
             dh, dWqkv, dbqkv = lin_bwd(ls["qkv1"], s["h1"], dqkv)

@@ -2,7 +2,7 @@
 # Round 6, second GPU call: gradient parity at 19 layers / B = 20 with the per-site gradient scales, the pack kernel's new
 # column-sum semantics, the sustained training rate again, and a per-kernel profile of the captured iteration (60 replays, so
 # that capture-time kernels do not pollute the per-replay counts).
-O=gpurun_out/r06b
+O=gpurun_out/${1:-r06b}
 mkdir -p $O
 export PYTHONUNBUFFERED=1
 timeout 1200 python -m pytest tests/test_hip_train_batch.py -m gpu -q -s > $O/train_batch_tests.log 2>&1; echo "train_batch rc=$?" | tee -a $O/rc.txt
@@ -12,5 +12,5 @@ tail -5 $O/train_kernel_tests.log
 timeout 300 python tools/bench_train.py --graph --steps 200 --warmup 5 > $O/bench_train_200.json 2> $O/bench_train_200.err
 echo "bench_train rc=$?" | tee -a $O/rc.txt
 cut -c1-1300 $O/bench_train_200.json; tail -3 $O/bench_train_200.err
-bash tools/train_profile.sh $O --graph --steps 60 2>&1 | tail -48 > $O/train_graph_kernel_top.txt
-cat $O/train_graph_kernel_top.txt | cut -c1-190
+true
+true
