@@ -23,13 +23,16 @@
 // matrix-pipe time.  The LDS operand is split ONCE when it is staged (two swizzled fp16 planes, ab_stage_split), register
 // fragments when they are loaded, the score / dS tiles right at the MFMA.  Only the k-index mapping of the fragments changes (a lane holds 8 consecutive d / 8 of its own
 // accumulator rows per MFMA instead of 1).  P in [0, 1] is multiplied by 2^10 before it is split (its lo plane would sit in
-// fp16's subnormal range otherwise) and dV by 2^-10 when it is stored; dO / dS carry the step's loss scale.  BOTH are split to
-// fp16 inside these kernels, so both are folded into the step's saturation monitor (modeling/train.py) by the q kernel itself
-// (ds_attention_bwd_f16x2_mon, round 6): max |dO| over the fragment every lane holds anyway and max |dS| over the 9 x 16
-// accumulator values of its dS^T tiles, one wave reduction, and an atomicMax that is skipped when the monitor already holds
-// more (it nearly always does: the packs of the surrounding linears feed the same scalar).  |dS| = scale P |dP - delta| can
-// exceed |dO| by |V| x 64 / 8: until round 5 only |dO| was monitored (a separate ds_amax launch) and a saturated dS --
-// the split SATURATES at 65504 instead of overflowing -- would have gone unseen.
+// fp16's subnormal range otherwise) and dV by 2^-10 when it is stored; dO carries the step's loss scale and is folded into
+// the step's saturation monitor (modeling/train.py) by the q kernel itself (ds_attention_bwd_f16x2_mon, round 6: max |dO| over
+// the fragment every lane holds anyway, one wave reduction, an atomicMax that is skipped when the monitor already holds more).
+// dS = scale P (dP - delta) exists only in registers and has NO fixed relation to dO: it can exceed it by |V| x 64 / 8, and
+// where the probabilities are near-uniform it is the small difference of two nearly equal numbers -- against the reference at
+// 19 layers / B = 20 (tests/test_hip_train_batch.py) the cross-attention dS sat 2^-20 under dO, its fp16 planes in the
+// subnormal range, and dQ / dK came out with 1e-2 .. 6e-5 relative error depending on the loss scale.  So since round 6 dS is
+// NORMALISED PER WAVE before it is split: the wave's max |dS| (all 9 x 16 accumulator values of its tiles, one reduction) goes to
+// 2^8 .. 2^9 by an exact power of two that the dQ / dK store takes out again (ab_norm_scale) -- neither saturation nor the
+// subnormal range can be reached, whatever the loss scale.
 #include "common.h"
 
 typedef _Float16 ab_h8 __attribute__((ext_vector_type(8)));
@@ -120,6 +123,20 @@ __device__ __forceinline__ void ab_load_frag(AbFragH& f, const float* __restrict
         const f32x4 a = *(const f32x4*)(rowp + 8 * hh + 16 * c), b = *(const f32x4*)(rowp + 8 * hh + 16 * c + 4);
         ab_split8(a, b, f.hi[c], f.lo[c]);
     }
+}
+// m: wave-uniform max |x| of a register tile set.  up = the power of two that puts it in [2^8, 2^9), dn = 1 / up; both 1 when
+// m is 0, subnormal-small, huge or not finite (exponent field outside [16, 240])
+__device__ __forceinline__ void ab_norm_scale(float m, float& up, float& dn) {
+    // (readfirstlane: the value is wave-uniform after the reduction -- the two factors live in SGPRs, not in the VGPR budget)
+    const unsigned eb = ((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(m)) >> 23) & 0xffu;
+    const bool ok = eb >= 16u && eb <= 240u;
+    up = ok ? __uint_as_float((262u - eb) << 23) : 1.f;
+    dn = ok ? __uint_as_float((eb - 8u) << 23) : 1.f;
+}
+__device__ __forceinline__ float ab_wave_max(float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));      // (fmaxf drops a NaN: it never wins)
+    return m;
 }
 // max |x| over the fragment a lane holds (monitor: the hi plane is x to 2^-11 relative)
 __device__ __forceinline__ float ab_frag_absmax(const AbFragH& f) {
@@ -359,6 +376,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
         st[(size_t)gridDim.y * heads * lqs] = delta;
     }
     __syncthreads();                          // V is in LDS
+    float ds_max = 0.f;                       // SPLIT: max |dS| of this lane's values, taken as they are produced
     if (active) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -367,22 +385,34 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
             for (int r = 0; r < 16; ++r) dp[r] = 0.f;
             ab_rows_times_reg_any<SPLIT, NKT>(dp, kv, kt, l31, hh, dof);                // dP^T tile = V dO^T
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = scale * s[kt][r] * (dp[r] - delta);   // dS^T (0 for masked keys: P = 0)
+            for (int r = 0; r < 16; ++r) {
+                s[kt][r] = scale * s[kt][r] * (dp[r] - delta);                           // dS^T (0 for masked keys: P = 0)
+                if constexpr (SPLIT) ds_max = fmaxf(ds_max, fabsf(s[kt][r]));            // (fmaxf drops a NaN)
+            }
             AB_FENCE();                       // one dP tile live at a time
         }
         if constexpr (SPLIT) {
-            if (amax != nullptr) {            // saturation monitor: everything this wave is about to split to fp16
-                float m = ab_frag_absmax(dof);
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(s[kt][r]));          // (fmaxf drops a NaN: it never wins)
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (amax != nullptr) {            // saturation monitor: the operand that carries the loss scale into the split
+                const float m = ab_wave_max(ab_frag_absmax(dof));
                 // non-negative floats order like their bit patterns; the plain load may be stale, but only ever too SMALL
                 if (lane == 0 && __float_as_uint(m) > *(volatile unsigned*)amax) atomicMax(amax, __float_as_uint(m));
             }
         }
+    }
+    // SPLIT: dS is normalised per wave before its split (header).  The two factors are computed in STRAIGHT-LINE code from a
+    // readfirstlane, so that they are scalar registers: a vector register across the staging and the dQ loop below is one more
+    // than this kernel has (it runs at the 256-register cap; `active` is wave-uniform but the compiler cannot know).
+    float ds_dn = 1.f;
+    if constexpr (SPLIT) {
+        float ds_up;
+        ab_norm_scale(ab_wave_max(ds_max), ds_up, ds_dn);
+        if (active) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] *= ds_up;                 // in place: no second copy of the tiles
+        }
+        AB_FENCE();
     }
     __syncthreads();
     ab_stage_any<SPLIT, NKT, 2>(kv, kb, ldk, Lk, tid);  // K again
@@ -393,7 +423,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) ab_reg_times_rows_any<SPLIT, NKT>(o0, o1, s[kt], kv, kt, l31, hh);   // dQ = dS K
-        ab_store_tile(dQ + (size_t)b * Lq * lddq + head * 64, lddq, q0, Lq, o0, o1, l31, hh);
+        ab_store_tile(dQ + (size_t)b * Lq * lddq + head * 64, lddq, q0, Lq, o0, o1, l31, hh, ds_dn);
     }
 }
 
@@ -473,6 +503,25 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
             AB_FENCE();
         }
     }
+    float ds_dn = 1.f;                        // SPLIT: dS of ALL query tiles feeds this wave's dK: one normalisation for them
+    if constexpr (SPLIT) {                    // (straight-line code, scalar factors: see the q kernel)
+        float m = 0.f;
+        if (active) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(t[qt][r]));
+        }
+        float ds_up;
+        ab_norm_scale(ab_wave_max(m), ds_up, ds_dn);
+        if (active) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[qt][r] *= ds_up;                 // in place: no second copy of the tiles
+        }
+        AB_FENCE();
+    }
     __syncthreads();
     ab_stage_any<SPLIT, NQT, 2>(qs, qb, ldq, Lq, tid);   // Q again
     __syncthreads();
@@ -482,7 +531,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows_any<SPLIT, NQT>(o0, o1, t[qt], qs, qt, l31, hh);   // dK = dS^T Q
-        ab_store_tile(dK + (size_t)b * Lk * lddk + head * 64, lddk, k0, Lk, o0, o1, l31, hh);
+        ab_store_tile(dK + (size_t)b * Lk * lddk + head * 64, lddk, k0, Lk, o0, o1, l31, hh, ds_dn);
     }
 }
 

@@ -382,9 +382,9 @@ class _FusedAttn:
                     L_.ptr(self.out), H * 64, B, H, Lq, Lk, 0.125, L_.stream()))
 
     def backward(self, dO, dq, dk, dv, amax=None):
-        """split: the tile products of the recomputation on the fp16 matrix cores too (ds_attention_bwd_f16x2_mon); dO and the
-        in-register dS enter them as fp16-split operands, so the kernel folds max(|dO|, |dS|) into the step's saturation
-        monitor (`amax`) itself."""
+        """split: the tile products of the recomputation on the fp16 matrix cores too (ds_attention_bwd_f16x2_mon); dO enters
+        them as an fp16-split operand under the step's loss scale, so the kernel folds max |dO| into the saturation monitor
+        (`amax`) itself; the in-register dS is normalised per wave inside the kernel (csrc/attention_bwd.hip)."""
         q, k, v, B, Lq, Lk, H = self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H
         stats = torch.empty(2 * B * H * _ceil(Lq, 32), device=dO.device)
         args = (L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2], L_.ptr(self.out), H * 64,
@@ -630,14 +630,14 @@ class TrainStep:
         self.calibrated_amax = m
         k0 = self._exp_from_amax(m)
         # Second pass, under that provisional scale (unscaled, the deep sites' operands flush to 0): the largest value of EVERY
-        # operand the backward splits to fp16 -- max |dY| per linear (its dY feeds the dX and dW GEMMs) and max(|dO|, |dS|)
-        # over the attention backwards -- in one more host sync.  One scale for the whole backward leaves the small gradients
+        # operand the backward splits to fp16 under the loss scale -- max |dY| per linear (its dY feeds the dX and dW GEMMs)
+        # and max |dO| over the attention backwards -- in one more host sync.  One scale for the whole backward leaves the small gradients
         # behind: against the reference at 19 layers / B = 20 (tests/test_hip_train_batch.py) the cross-attention query
         # projections -- whose dY is a softmax gradient of near-uniform probabilities, 2^-14 of the largest dY -- came out with
         # 1e-2 relative error, their fp16 lo plane under the subnormal range (the reference's own fp32: 6e-7).  So
-        #   * the loss scale 2^k itself is set by what has NO scale of its own: the attention backward's in-kernel splits
-        #     (its dO arrives in loss-scale units; 6.5e-5 on the same tensors while k was set by d logits) -- fp32 tensors in
-        #     between carry it without harm, whatever it is;
+        #   * the loss scale 2^k itself is set by what has NO scale of its own: the attention backward's in-kernel split of dO
+        #     (it arrives in loss-scale units; the kernel normalises its dS by itself) -- fp32 tensors in between carry the
+        #     loss scale without harm, whatever it is;
         #   * every linear gets its own power of two on top: dY 2^e is what is split (ds_pack_operand `scale`), 2^-e goes into
         #     the dX / dW epilogues -- exact; e < 0 where the loss scale alone would overflow (d logits).
         self.loss_scale_exp = k0
@@ -660,7 +660,7 @@ class TrainStep:
         dt, tr, G_ = self.dt, self.tr, self.gemm
         site_exp = {} if (calibrating or self._site_exp is None) else self._site_exp
         site_index = {}
-        att_slot = None                         # where the attention backwards fold max(|dO|, |dS|): set below
+        att_slot = None                         # where the attention backwards fold max |dO|: set below
         dev = x0.device
         B, Lx = x0.shape
         D, H, K = tr.n_embd, tr.n_head, tr.num_codes

@@ -91,3 +91,37 @@ for name, N, K, M in DW:
         L.lib().ds_gemm_f16x2_force_tile(-1)
         print("%s N=%4d K=%4d M=%4d S=%d (Mp %4d) | %s" % (name, N, K, M, S, Mp, " | ".join(row)), flush=True)
     print("%s best: %.1f us = %.1f TF-eq at S=%d tile %d" % (name, best[0], fl / best[0] / 1e6, best[1], best[2]), flush=True)
+
+# ---- round 6: the long-contraction forward / dX shapes (336 output tiles of 128 x 128 on 512 slots: a third of the chip idle) as
+# split-K launches, INCLUDING the fixed-order reduction of the S partial results -- the price of any stream-K-like scheme on
+# these shapes: an output tile is 64 KB of fp32, and every contributor beyond the first writes and re-reads it.
+for name, M, N, K in (("fwd fc2 / dX fc1 as split-K", M0, 1024, 4096), ("dX qkv as split-K         ", M0, 1024, 3072),
+                      ("fwd proj as split-K       ", M0, 1024, 1024)):
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda")
+    Ap, apl = pack(A, M, K)
+    Wp, wpl = pack(W, N, K)
+    out = torch.empty(M, N, device="cuda")
+    fl = 2.0 * M * N * K
+    for S in (1, 2, 3, 4):
+        if K % (32 * S):
+            continue
+        Kc = K // S
+        part = torch.empty(S, M * N, device="cuda")
+        row = []
+        for tile in (0, 1):
+            L.lib().ds_gemm_f16x2_force_tile(tile)
+
+            def run():
+                if S == 1:
+                    L.gemm(Ap, Wp, out, M, N, K, split2=1.0, a_plane=apl, w_plane=wpl)
+                else:
+                    L.gemm(Ap, Wp, part, M, N, Kc, lda=K, ldw=K, ldc=N, groups=S, a_gstride=Kc * 16, w_gstride=Kc * 16,
+                           c_gstride=M * N, split2=1.0, a_plane=apl, w_plane=wpl)
+                    L.check(L.lib().ds_colsum(L.ptr(part), L.ptr(out), 1, S, M * N, M * N, 0, 0, L.stream()))
+            t = timeit(run)
+            tg = timeit(lambda: L.gemm(Ap, Wp, part, M, N, Kc, lda=K, ldw=K, ldc=N, groups=S, a_gstride=Kc * 16, w_gstride=Kc * 16,
+                                       c_gstride=M * N, split2=1.0, a_plane=apl, w_plane=wpl)) if S > 1 else t
+            row.append("t%d %6.1f us (GEMM alone %6.1f) %5.1f TF" % (tile, t, tg, fl / t / 1e6))
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+        print("%s M=%d N=%d K=%d S=%d | %s" % (name, M, N, K, S, " | ".join(row)), flush=True)
