@@ -252,14 +252,16 @@ int ds_attention_bwd_f16x2(const float* q, int ldq, const float* k, int ldk, con
                            const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                            float* stats, int B, int heads, int Lq, int Lk, float scale, ds_stream_t stream);
 /* ... with the training step's saturation monitor folded in (round 6): *amax -- a device float the caller zeroes when it
- * reads it; the kernels only ever raise it -- takes max |dO|, the operand that carries the step's loss scale into these
- * kernels' fp16 splits (replaces the separate ds_amax over dO of rounds 3-5).  dS = scale P (dP - delta), which exists only
+ * reads it; the kernels only ever raise it -- takes max |dO * do_scale|, the operand that carries the step's loss scale into
+ * these kernels' fp16 splits (replaces the separate ds_amax over dO of rounds 3-5).  do_scale: a positive power of two, this
+ * call's own scale on top of the loss scale: dO * do_scale is what is split, the dQ / dK / dV stores take it out again (exact).  dS = scale P (dP - delta), which exists only
  * in registers and has no fixed relation to dO (it can exceed it by |V| x 8, or sit 2^-20 under it where the probabilities
  * are near-uniform), is normalised per wave by an exact power of two before ITS split in all three entry points of the f16x2
  * form -- it can neither saturate nor fall into fp16's subnormal range.  Reference: the same loss.backward() lines as above. */
 int ds_attention_bwd_f16x2_mon(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                                const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
-                               float* stats, int B, int heads, int Lq, int Lk, float scale, float* amax, ds_stream_t stream);
+                               float* stats, int B, int heads, int Lq, int Lk, float scale, float do_scale, float* amax,
+                               ds_stream_t stream);
 /* d emb[tokens[m]] += dx[m] (atomic) */
 int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
 /* fused AdamW update (torch.optim.AdamW semantics), step >= 1 */

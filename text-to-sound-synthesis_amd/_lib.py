@@ -98,7 +98,7 @@ _PROTOS = {
     "ds_attention_bwd_f16x2": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                    _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp]),
     "ds_attention_bwd_f16x2_mon": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
-                                   _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _vp, _vp]),
+                                   _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _vp, _vp]),
     "ds_embed_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, C.c_int, _vp]),
     "ds_adamw_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),

@@ -99,7 +99,7 @@ __device__ __forceinline__ void ab_reg_times_rows(f32x16& o0, f32x16& o1, const 
 struct AbFragF {
     f32x4 v[8];
 };
-__device__ __forceinline__ void ab_load_frag(AbFragF& f, const float* __restrict__ rowp, int hh) {
+__device__ __forceinline__ void ab_load_frag(AbFragF& f, const float* __restrict__ rowp, int hh, float pre = 1.f) {   // (pre: SPLIT only)
 #pragma unroll
     for (int c = 0; c < 8; ++c) f.v[c] = *(const f32x4*)(rowp + 4 * hh + 8 * c);
 }
@@ -117,10 +117,10 @@ __device__ __forceinline__ void ab_split8(const f32x4& a, const f32x4& b, ab_h8&
         lo[4 + e] = ds_split_lo(b[e], hi[4 + e]);
     }
 }
-__device__ __forceinline__ void ab_load_frag(AbFragH& f, const float* __restrict__ rowp, int hh) {
+__device__ __forceinline__ void ab_load_frag(AbFragH& f, const float* __restrict__ rowp, int hh, float pre = 1.f) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const f32x4 a = *(const f32x4*)(rowp + 8 * hh + 16 * c), b = *(const f32x4*)(rowp + 8 * hh + 16 * c + 4);
+        const f32x4 a = *(const f32x4*)(rowp + 8 * hh + 16 * c) * pre, b = *(const f32x4*)(rowp + 8 * hh + 16 * c + 4) * pre;
         ab_split8(a, b, f.hi[c], f.lo[c]);
     }
 }
@@ -178,7 +178,8 @@ __device__ __forceinline__ float ab_frag_dot(const float* __restrict__ ap, const
 __device__ __forceinline__ int ab_hoff(int row, int d) { return row * 64 + ((((d >> 3) ^ (row & 7))) << 3) + (d & 7); }
 typedef _Float16 ab_h4 __attribute__((ext_vector_type(4)));
 template <int NT, int INFLIGHT>
-__device__ __forceinline__ void ab_stage_split(_Float16* __restrict__ lds, const float* __restrict__ src, int ld, int valid, int tid) {
+__device__ __forceinline__ void ab_stage_split(_Float16* __restrict__ lds, const float* __restrict__ src, int ld, int valid, int tid,
+                                               float pre = 1.f) {
     static_assert((NT * 32 * 16) % (AB_NT * INFLIGHT) == 0, "staging trip count");
     asm volatile("" : "+v"(tid));
     for (int it0 = 0; it0 < NT * 32 * 16 / AB_NT; it0 += INFLIGHT) {
@@ -197,8 +198,9 @@ __device__ __forceinline__ void ab_stage_split(_Float16* __restrict__ lds, const
             ab_h4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hi[e] = ds_split_hi(t8[u][e]);
-                lo[e] = ds_split_lo(t8[u][e], hi[e]);
+                const float v = t8[u][e] * pre;                // (a power of two: exact)
+                hi[e] = ds_split_hi(v);
+                lo[e] = ds_split_lo(v, hi[e]);
             }
             _Float16* d = lds + ab_hoff(row, c4);          // 4 consecutive d stay inside one 8-half chunk
             *(ab_h4*)d = hi;
@@ -287,9 +289,10 @@ __device__ __forceinline__ void ab_rows_times_reg_any(f32x16& acc, const float* 
     else ab_rows_times_reg(acc, lds, tile, l31, hh, y);
 }
 template <bool SPLIT, int NT, int INFLIGHT>
-__device__ __forceinline__ void ab_stage_any(float* __restrict__ lds, const float* __restrict__ src, int ld, int valid, int tid) {
-    if constexpr (SPLIT) ab_stage_split<NT, INFLIGHT>((_Float16*)lds, src, ld, valid, tid);
-    else ab_stage<NT, INFLIGHT>(lds, src, ld, valid, tid);
+__device__ __forceinline__ void ab_stage_any(float* __restrict__ lds, const float* __restrict__ src, int ld, int valid, int tid,
+                                             float pre = 1.f) {
+    if constexpr (SPLIT) ab_stage_split<NT, INFLIGHT>((_Float16*)lds, src, ld, valid, tid, pre);
+    else ab_stage<NT, INFLIGHT>(lds, src, ld, valid, tid);       // (pre is 1 in the exact-fp32 form)
 }
 // floats of the operand buffer for NT row tiles
 template <bool SPLIT> __host__ __device__ constexpr int ab_buf_floats(int nt) { return SPLIT ? nt * 32 * 64 : nt * 32 * AB_LD; }
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
                                                                 int ldk, const float* __restrict__ Vp, int ldv,
                                                                 const float* __restrict__ O, int ldo, const float* __restrict__ dO,
                                                                 int lddo, float* __restrict__ dQ, int lddq, float* __restrict__ stats,
-                                                                int Lq, int Lk, int heads, float scale, unsigned* __restrict__ amax) {
+                                                                int Lq, int Lk, int heads, float scale, unsigned* __restrict__ amax,
+                                                                float do_scale, float do_inv) {
     extern __shared__ __attribute__((aligned(16))) float kv[];  // [NKT*32][AB_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -366,15 +370,16 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
     // its 256 registers; the fence keeps the scheduler from hoisting the loads over the softmax)
     AB_FENCE();
     typename AbSel<SPLIT>::Frag dof;
-    ab_load_frag(dof, dO + qrow * lddo + head * 64, hh);
+    ab_load_frag(dof, dO + qrow * lddo + head * 64, hh, do_scale);      // SPLIT: dO 2^e is what is split (the call's own scale)
     float delta = ab_frag_dot(dO + qrow * lddo + head * 64, O + qrow * ldo + head * 64, hh, SPLIT);   // (fp32 values, L1-hot)
     delta += __shfl_xor(delta, 32);
     if (active && hh == 0 && q0 + l31 < Lq) {
         const int lqs = ((Lq + 31) >> 5) << 5;
         float* st = stats + ((size_t)b * heads + head) * lqs + q0 + l31;
         st[0] = Lrow;
-        st[(size_t)gridDim.y * heads * lqs] = delta;
+        st[(size_t)gridDim.y * heads * lqs] = delta;      // (in dO's own units: the kv kernel applies do_scale itself)
     }
+    if constexpr (SPLIT) delta *= do_scale;
     __syncthreads();                          // V is in LDS
     float ds_max = 0.f;                       // SPLIT: max |dS| of this lane's values, taken as they are produced
     if (active) {
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) ab_reg_times_rows_any<SPLIT, NKT>(o0, o1, s[kt], kv, kt, l31, hh);   // dQ = dS K
-        ab_store_tile(dQ + (size_t)b * Lq * lddq + head * 64, lddq, q0, Lq, o0, o1, l31, hh, ds_dn);
+        ab_store_tile(dQ + (size_t)b * Lq * lddq + head * 64, lddq, q0, Lq, o0, o1, l31, hh, ds_dn * do_inv);
     }
 }
 
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
                                                                  int ldk, const float* __restrict__ Vp, int ldv,
                                                                  const float* __restrict__ dO, int lddo, float* __restrict__ dK, int lddk,
                                                                  float* __restrict__ dV, int lddv, const float* __restrict__ stats, int Lq,
-                                                                 int Lk, int heads, float scale) {
+                                                                 int Lk, int heads, float scale, float do_scale, float do_inv) {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQT*32][AB_LD] operand rows, then L[NQT*32], delta[NQT*32]
     float* Ls = qs + ab_buf_floats<SPLIT>(NQT);
     float* Ds = Ls + NQT * 32;
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
         const float* st = stats + ((size_t)b * heads + head) * lqs;
         for (int i = tid; i < NQT * 32; i += AB_NT) {
             Ls[i] = i < Lq ? st[i] : 0.f;
-            Ds[i] = i < Lq ? st[(size_t)gridDim.y * heads * lqs + i] : 0.f;
+            Ds[i] = i < Lq ? st[(size_t)gridDim.y * heads * lqs + i] * do_scale : 0.f;       // delta in the scaled dO's units
         }
     }
     f32x16 t[NQT];
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
         }
     }
     __syncthreads();                          // everyone is done reading Q
-    ab_stage_any<SPLIT, NQT, 2>(qs, dob, lddo, Lq, tid);
+    ab_stage_any<SPLIT, NQT, 2>(qs, dob, lddo, Lq, tid, do_scale);       // SPLIT: dO 2^e is what is split
     __syncthreads();
     if (active) {
         f32x16 o0, o1;
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt)
             ab_reg_times_rows_any<SPLIT, NQT>(o0, o1, t[qt], qs, qt, l31, hh, SPLIT ? AB_PSCALE : 1.f);   // dV = P^T dO
-        ab_store_tile(dV + (size_t)b * Lk * lddv + head * 64, lddv, k0, Lk, o0, o1, l31, hh, SPLIT ? 1.f / AB_PSCALE : 1.f);
+        ab_store_tile(dV + (size_t)b * Lk * lddv + head * 64, lddv, k0, Lk, o0, o1, l31, hh, (SPLIT ? 1.f / AB_PSCALE : 1.f) * do_inv);
         typename AbSel<SPLIT>::Frag vf;
         ab_load_frag(vf, Vp + krow * ldv + head * 64, hh);
 #pragma unroll
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) ab_reg_times_rows_any<SPLIT, NQT>(o0, o1, t[qt], qs, qt, l31, hh);   // dK = dS^T Q
-        ab_store_tile(dK + (size_t)b * Lk * lddk + head * 64, lddk, k0, Lk, o0, o1, l31, hh, ds_dn);
+        ab_store_tile(dK + (size_t)b * Lk * lddk + head * 64, lddk, k0, Lk, o0, o1, l31, hh, ds_dn * do_inv);
     }
 }
 
@@ -552,7 +557,9 @@ static int ab_set_lds(KernelT kernel, size_t lds, DsOnce& done) {
 template <bool SPLIT>
 static int ab_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                      const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, float* stats, int B,
-                     int heads, int Lq, int Lk, float scale, hipStream_t stream, float* amax = nullptr) {
+                     int heads, int Lq, int Lk, float scale, hipStream_t stream, float* amax = nullptr, float do_scale = 1.f) {
+    DS_CHECK_ARG(do_scale > 0.f && (SPLIT || do_scale == 1.f), "do_scale: a positive power of two (f16x2 form only)");
+    const float do_inv = 1.f / do_scale;
     DS_CHECK_ARG(q && k && v && o && d_o && dq && dk && dv && stats, "null pointer");
     DS_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lq <= 288 && Lk <= 288, "at most 288 queries / keys are supported");
     DS_CHECK_ARG(((ldq | ldk | ldv | ldo | lddo) & 3) == 0, "leading dims of the inputs must be multiples of 4");
@@ -563,19 +570,19 @@ static int ab_launch(const float* q, int ldq, const float* k, int ldk, const flo
         const size_t lds = ab_buf_floats<SPLIT>(3) * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_q_kernel<3, SPLIT>, lds, a3)) return -2;
         hipLaunchKernelGGL((ds_attn_bwd_q_kernel<3, SPLIT>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o,
-                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale, (unsigned*)amax);
+                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale, (unsigned*)amax, do_scale, do_inv);
     } else {
         const size_t lds = ab_buf_floats<SPLIT>(9) * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_q_kernel<9, SPLIT>, lds, a9)) return -2;
         hipLaunchKernelGGL((ds_attn_bwd_q_kernel<9, SPLIT>), dim3(qgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv, o,
-                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale, (unsigned*)amax);
+                           ldo, d_o, lddo, dq, lddq, stats, Lq, Lk, heads, scale, (unsigned*)amax, do_scale, do_inv);
     }
     DS_CHECK_LAUNCH();
     {
         const size_t lds = (ab_buf_floats<SPLIT>(9) + 2 * 9 * 32) * sizeof(float);
         if (ab_set_lds(ds_attn_bwd_kv_kernel<9, SPLIT>, lds, akv)) return -2;
         hipLaunchKernelGGL((ds_attn_bwd_kv_kernel<9, SPLIT>), dim3(kgroups * heads, B), dim3(AB_NT), lds, stream, q, ldq, k, ldk, v, ldv,
-                           d_o, lddo, dk, lddk, dv, lddv, stats, Lq, Lk, heads, scale);
+                           d_o, lddo, dk, lddk, dv, lddv, stats, Lq, Lk, heads, scale, do_scale, do_inv);
     }
     DS_CHECK_LAUNCH();
     return 0;
@@ -598,12 +605,14 @@ extern "C" int ds_attention_bwd_f16x2(const float* q, int ldq, const float* k, i
 }
 
 // ... and with the saturation monitor of the training step folded in: *amax (a float the caller zeroed at some point; it is
-// only ever raised) takes max(|dO|, |dS|) over everything the kernels split to fp16 -- no separate ds_amax pass over dO.
+// only ever raised) takes max |dO * do_scale|: the operand that carries the step's loss scale into the kernels' fp16 splits --
+// no separate ds_amax pass over dO.  do_scale: a power of two, this CALL's own scale on top of the loss scale (the training
+// step calibrates one per attention, like one per linear): dO * do_scale is what is split, 1 / do_scale goes into the stores.
 extern "C" int ds_attention_bwd_f16x2_mon(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                                           int ldo, const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv,
-                                          int lddv, float* stats, int B, int heads, int Lq, int Lk, float scale, float* amax,
-                                          ds_stream_t stream_) {
+                                          int lddv, float* stats, int B, int heads, int Lq, int Lk, float scale, float do_scale,
+                                          float* amax, ds_stream_t stream_) {
     DS_CHECK_ARG(amax, "null monitor pointer");
     return ab_launch<true>(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, dq, lddq, dk, lddk, dv, lddv, stats, B, heads, Lq, Lk, scale,
-                           (hipStream_t)stream_, amax);
+                           (hipStream_t)stream_, amax, do_scale);
 }

@@ -381,17 +381,18 @@ class _FusedAttn:
         L_.check(fn(L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2],
                     L_.ptr(self.out), H * 64, B, H, Lq, Lk, 0.125, L_.stream()))
 
-    def backward(self, dO, dq, dk, dv, amax=None):
+    def backward(self, dO, dq, dk, dv, amax=None, do_scale=1.0):
         """split: the tile products of the recomputation on the fp16 matrix cores too (ds_attention_bwd_f16x2_mon); dO enters
-        them as an fp16-split operand under the step's loss scale, so the kernel folds max |dO| into the saturation monitor
-        (`amax`) itself; the in-register dS is normalised per wave inside the kernel (csrc/attention_bwd.hip)."""
+        them as an fp16-split operand under the step's loss scale AND this call's own power of two `do_scale` (the kernel
+        splits dO * do_scale and takes it out again at its stores), and the kernel folds max |dO * do_scale| into the saturation
+        monitor (`amax`) itself; the in-register dS is normalised per wave inside the kernel (csrc/attention_bwd.hip)."""
         q, k, v, B, Lq, Lk, H = self.q, self.k, self.v, self.B, self.Lq, self.Lk, self.H
         stats = torch.empty(2 * B * H * _ceil(Lq, 32), device=dO.device)
         args = (L_.ptr_off(q[0], q[1]), q[2], L_.ptr_off(k[0], k[1]), k[2], L_.ptr_off(v[0], v[1]), v[2], L_.ptr(self.out), H * 64,
                 L_.ptr(dO), H * 64, L_.ptr_off(dq[0], dq[1]), dq[2], L_.ptr_off(dk[0], dk[1]), dk[2], L_.ptr_off(dv[0], dv[1]), dv[2],
                 L_.ptr(stats), B, H, Lq, Lk, 0.125)
         if self.split and amax is not None:
-            L_.check(L_.lib().ds_attention_bwd_f16x2_mon(*args, L_.ptr(amax), L_.stream()))
+            L_.check(L_.lib().ds_attention_bwd_f16x2_mon(*args, float(do_scale), L_.ptr(amax), L_.stream()))
         else:
             L_.check((L_.lib().ds_attention_bwd_f16x2 if self.split else L_.lib().ds_attention_bwd)(*args, L_.stream()))
 
@@ -635,23 +636,19 @@ class TrainStep:
         # behind: against the reference at 19 layers / B = 20 (tests/test_hip_train_batch.py) the cross-attention query
         # projections -- whose dY is a softmax gradient of near-uniform probabilities, 2^-14 of the largest dY -- came out with
         # 1e-2 relative error, their fp16 lo plane under the subnormal range (the reference's own fp32: 6e-7).  So
-        #   * the loss scale 2^k itself is set by what has NO scale of its own: the attention backward's in-kernel split of dO
-        #     (it arrives in loss-scale units; the kernel normalises its dS by itself) -- fp32 tensors in between carry the
-        #     loss scale without harm, whatever it is;
-        #   * every linear gets its own power of two on top: dY 2^e is what is split (ds_pack_operand `scale`), 2^-e goes into
-        #     the dX / dW epilogues -- exact; e < 0 where the loss scale alone would overflow (d logits).
+        # every SITE gets its own power of two on top of the loss scale (the fp32 tensors in between carry the loss scale without
+        # harm, whatever it is): a linear's dY 2^e is what is split (ds_pack_operand `scale`) and 2^-e goes into its dX / dW
+        # epilogues; an attention backward's dO 2^e is what its kernels split and their stores take 2^-e out again (they
+        # normalise their in-register dS by themselves) -- all exact.
         self.loss_scale_exp = k0
-        n_lin = 7 * len(self.tr.blocks) + 1
-        sites = torch.zeros(n_lin + 1, device=x0.device)                     # [linears in backward order ..., attention]
+        n_sites = 9 * len(self.tr.blocks) + 1                                # 7 linears + 2 attentions per block, + the logits layer
+        sites = torch.zeros(n_sites, device=x0.device)                       # in the order the backward visits them
         self._run(x0, cond_emb, t, pt, noise, calibrating=True, amax=torch.zeros(1, device=x0.device), site_amax=sites)
         per_site = sites.tolist()
-        assert len(self._site_order) == n_lin
-        att = per_site[-1]
-        shift = 0 if (att == 0.0 or not math.isfinite(att)) else max(-24, min(24, self._target() - math.floor(math.log2(att))))
-        self.loss_scale_exp = k0 + shift
+        assert len(self._site_order) == n_sites or self.attention != "fused", (len(self._site_order), n_sites)
         self._site_exp = {k: (0 if (v == 0.0 or not math.isfinite(v)) else
-                              max(-40, min(40, self._target() - math.floor(math.log2(v)) - shift)))
-                          for k, v in zip(self._site_order, per_site[:n_lin])}
+                              max(-40, min(40, self._target() - math.floor(math.log2(v)))))
+                          for k, v in zip(self._site_order, per_site)}
         return self.loss_scale_exp
 
     def _run(self, x0, cond_emb, t, pt, noise, calibrating, amax=None, on_grads=None, site_amax=None):
@@ -660,7 +657,6 @@ class TrainStep:
         dt, tr, G_ = self.dt, self.tr, self.gemm
         site_exp = {} if (calibrating or self._site_exp is None) else self._site_exp
         site_index = {}
-        att_slot = None                         # where the attention backwards fold max |dO|: set below
         dev = x0.device
         B, Lx = x0.shape
         D, H, K = tr.n_embd, tr.n_head, tr.num_codes
@@ -683,7 +679,10 @@ class TrainStep:
             amax = self._amax_live
 
         # (every gradient that enters a GEMM passes G_.prep_dy, whose pack folds max |dY 2^e| into `amax`: calibration / monitor)
-        att_slot = amax if site_amax is None else site_amax[-1]
+        def att_site(key):      # (monitor slot, this attention backward's own power of two)
+            if site_amax is not None:
+                return site_amax[site_index.setdefault(key, len(site_index))], 1.0
+            return amax, 2.0 ** site_exp.get(key, 0)
 
         sched = dt._schedule_table()
         xt = dt.q_sample_tokens(x0.contiguous(), t, noise)
@@ -846,7 +845,8 @@ class TrainStep:
             dq = torch.empty(M, D, device=dev)
             dkv = torch.empty(B * Lc, 2 * D, device=dev)
             if fused:
-                s["att2"].backward(dao, (dq, 0, D), (dkv, 0, 2 * D), (dkv, D, 2 * D), amax=att_slot)
+                slot, dsc = att_site("b%d.att2" % li)
+                s["att2"].backward(dao, (dq, 0, D), (dkv, 0, 2 * D), (dkv, D, 2 * D), amax=slot, do_scale=dsc)
             else:
                 s["att2"].backward(dao, dq, dkv[:, :D], dkv[:, D:])
             dh, g[p + "attn2.query.weight"], g[p + "attn2.query.bias"] = lin_bwd(ls["q2"], s["h2"], dq)
@@ -859,7 +859,8 @@ class TrainStep:
             dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["o1"], dx)
             dqkv = torch.empty(M, 3 * D, device=dev)
             if fused:
-                s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D), amax=att_slot)
+                slot, dsc = att_site("b%d.att1" % li)
+                s["att1"].backward(dao, (dqkv, 0, 3 * D), (dqkv, D, 3 * D), (dqkv, 2 * D, 3 * D), amax=slot, do_scale=dsc)
             else:
                 s["att1"].backward(dao, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
             dh, dWqkv, dbqkv = lin_bwd(ls["qkv1"], s["h1"], dqkv)
