@@ -68,8 +68,11 @@ def scatter_captions(captions, n_items, device, tokenize, order=None, group=None
     if not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0:
         idx_all = torch.arange(n_items, dtype=torch.long) if order is None else torch.as_tensor(order, dtype=torch.long)
         assert idx_all.shape == (n_items,)
-    mine = scatter_conditions(idx_all, n_items, (), device, group=group, dtype=torch.long,
-                              always_collective=always_collective).tolist()
+    if _single(group, always_collective):
+        mine = idx_all.tolist()            # one process: the indices never leave the host (no device round trip, no sync)
+    else:
+        mine = scatter_conditions(idx_all, n_items, (), device, group=group, dtype=torch.long,
+                                  always_collective=always_collective).tolist()
     toks = tokenize([captions[i] for i in mine])
     return toks.to(device=device, dtype=torch.long), mine
 

@@ -22,6 +22,7 @@ done
 python "$ROOT/tools/pmc_summarize.py" "$OUT/pmc_step" "$OUT/${TAG}_pmc_denoiser_step_b64.csv" \
     "$OUT/${TAG}_pmc_denoiser_step_b64.json" > "$OUT/pmc_summarize.log" 2>&1 || true
 cp "$OUT/${TAG}_pmc_denoiser_step_b64.json" "$ROOT/profiles/" 2>/dev/null || true
+rm -rf "$OUT/pmc_step"        # the per-pass rocprofv3 directories are hundreds of MB: gpurun merges at most 64 MiB back
 
 timeout 900 python "$ROOT/bench.py" > "$OUT/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"
 
@@ -30,4 +31,5 @@ timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench --output-fo
 cp "$OUT/prof/bench_kernel_stats.csv" "$OUT/${TAG}_bench_default_kernel_stats.csv" 2>/dev/null || \
     find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/${TAG}_bench_default_kernel_stats.csv" \;
 
+rm -rf "$OUT/prof"
 ls -la "$OUT"
