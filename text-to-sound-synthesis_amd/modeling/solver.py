@@ -195,13 +195,53 @@ def _window_always_clips(clip):
 
 def _batch_tensors(solver, batch):
     """step()'s arguments -> (x0, cond_emb, t, pt, noise): a single dict is the reference's batch and goes through the
-    prologue (needs Solver(model=...)); five tensors pass through."""
+    prologue (needs Solver(model=...)); five tensors pass through.  A batch whose prologue was started by `prefetch` (same
+    dict object) only waits for it."""
     if len(batch) == 1 and isinstance(batch[0], dict):
         if solver.model is None:
             raise ValueError("step(batch dict) needs the DALLE model: Solver(..., model=dalle)")
-        from .train import training_inputs
-        return training_inputs(solver.model, batch[0], generator=solver.generator)
+        from .train import training_draws, training_prologue
+        pre = getattr(solver, "_prefetched", None)
+        if pre is not None and pre[0] is batch[0]:
+            solver._prefetched = None
+            _, x0, cond_emb, side = pre
+            cur = torch.cuda.current_stream(x0.device)
+            cur.wait_stream(side)
+            x0.record_stream(cur)
+            cond_emb.record_stream(cur)
+        else:
+            x0, cond_emb = training_prologue(solver.model, batch[0])
+        return training_draws(solver.model, x0, cond_emb, generator=solver.generator)
     return batch
+
+
+def _prefetch(solver, batch, ready=None):
+    """Enqueue the mel / caption prologue of a LATER batch on a side stream now (modeling.train.training_prologue: BPE, CLIP, VQ
+    encoder -- frozen weights only, nothing of the training state), so that it runs beside the iteration in flight; step(batch)
+    with the same dict then only waits for it.  The reference's DataLoader workers do the host half of this; the device half
+    exists because the reference encodes inside the iteration (dalle_spec.py:93-133)."""
+    if solver.model is None:
+        raise ValueError("prefetch(batch dict) needs the DALLE model: Solver(..., model=dalle)")
+    from .train import training_prologue
+    dev = solver.model.transformer.device
+    if getattr(solver, "_side_stream", None) is None:
+        solver._side_stream = torch.cuda.Stream(dev)
+    side = solver._side_stream
+    # `ready`: the stream (or event) after which the batch's device tensors are valid -- a data-loading stream; default: the
+    # caller's current stream, which is correct but waits for everything enqueued on it (the replay in flight included)
+    if ready is None:
+        if any(torch.is_tensor(v) and v.is_cuda for v in batch.values()):
+            side.wait_stream(torch.cuda.current_stream(dev))
+    elif isinstance(ready, torch.cuda.Event):
+        side.wait_event(ready)
+    else:
+        side.wait_stream(ready)
+    for v in batch.values():                      # the batch's tensors are read on the side stream: the caching allocator must know
+        if torch.is_tensor(v) and v.is_cuda:
+            v.record_stream(side)
+    with torch.cuda.stream(side):
+        x0, cond_emb = training_prologue(solver.model, batch)
+    solver._prefetched = (batch, x0, cond_emb, side)
 
 
 class Solver:
@@ -226,6 +266,9 @@ class Solver:
         self.reducer = reducer
         self.opt_state = {}
         self.last_iter = -1
+
+    def prefetch(self, batch, ready=None):
+        _prefetch(self, batch, ready)
 
     def step(self, *batch):
         """step(batch_dict) -- the reference's `self.model(batch, return_loss=True)` entry -- or step(x0, cond_emb, t, pt,
@@ -303,6 +346,10 @@ class GraphSolver:
         self.iteration_graph = None
         self._pending_state = None          # load_state_dict before the first batch: applied right after the capture
         self.last_iter = -1
+
+    def prefetch(self, batch, ready=None):
+        """the next batch's BPE / CLIP / VQ-encode prologue on a side stream, beside the replay in flight (solver._prefetch)"""
+        _prefetch(self, batch, ready)
 
     def step(self, *batch):
         batch = _batch_tensors(self, batch)

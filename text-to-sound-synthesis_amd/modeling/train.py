@@ -414,6 +414,15 @@ def training_inputs(model, batch, generator=None):
     'content_token' skips the respective stage.  generator: torch.Generator of the model's device for t and the noise.
     Everything is enqueued on the current stream; the only host synchronisation is sample_time's Lt_count test while it
     is still false."""
+    x0, cond_emb = training_prologue(model, batch)
+    return training_draws(model, x0, cond_emb, generator=generator)
+
+
+@torch.no_grad()
+def training_prologue(model, batch):
+    """The part of `training_inputs` that depends on the batch and on FROZEN weights only (BPE, the CLIP text tower, the VQ
+    encoder): (x0 i64[B,265], cond_emb f32[B,77,512]).  Nothing the optimiser touches is read, so it may run ahead of the
+    previous iteration -- GraphSolver.prefetch enqueues it on a side stream."""
     dt = model.transformer
     dev = dt.device
     cond = model.prepare_condition(batch)
@@ -422,10 +431,19 @@ def training_inputs(model, batch, generator=None):
     else:
         x0 = model.prepare_content(batch)["content_token"]
     cond_emb = dt._cond(cond.get("condition_token"), cond.get("condition_embed_token")).to(dev)
+    return x0.contiguous(), cond_emb.contiguous()
+
+
+@torch.no_grad()
+def training_draws(model, x0, cond_emb, generator=None):
+    """... and the part that depends on the training state: sample_time reads the importance-sampling statistics the previous
+    iteration updated.  -> (x0, cond_emb, t, pt, noise)"""
+    dt = model.transformer
+    dev = dt.device
     B = x0.shape[0]
     t, pt = dt.sample_time(B, dev, "importance", generator=generator)
     noise = torch.rand((B, dt.num_classes, dt.content_seq_len), device=dev, generator=generator)
-    return x0.contiguous(), cond_emb.contiguous(), t.to(dev), pt.to(dev), noise
+    return x0, cond_emb, t.to(dev), pt.to(dev), noise
 
 
 class TrainStep:

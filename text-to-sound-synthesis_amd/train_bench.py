@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 
 def run(batch=20, steps=200, warmup=5, n_layer=19, codes=256, precision="f16x2", ema_device="cuda", attention="fused",
-        graph=True, world=1, rank=0, dev=None, monitor_hi=None, from_batch=True, calib_target=None):
+        graph=True, world=1, rank=0, dev=None, monitor_hi=None, from_batch=True, calib_target=None, prefetch=False):
     """Time `steps` training iterations (after `warmup`) and return the result dict (module docstring).
     from_batch=False: the round-5 form -- pre-made tokens and a stand-in caption embedding, no mel / caption prologue
     (kept as the A/B leg that prices the prologue).  (Per-kernel rates: tools/train_profile.sh.)"""
@@ -92,13 +92,35 @@ def run(batch=20, steps=200, warmup=5, n_layer=19, codes=256, precision="f16x2",
         solver = Solver(step, allreduce=timed_allreduce if world > 1 else None, **common)
 
     it_no = [0]
+    ahead = []
+
+    data_stream = torch.cuda.Stream(dev) if (prefetch and from_batch) else None      # where the synthetic mel is drawn
+    gen_data = torch.Generator(device=dev).manual_seed(4321 + rank)
+
+    def make_batch():
+        it_no[0] += 1
+        if data_stream is not None:
+            with torch.cuda.stream(data_stream):
+                mel = torch.rand((B, 1, 80, 848), device=dev, generator=gen_data) * 2.0 - 1.0
+        else:
+            mel = torch.rand((B, 1, 80, 848), device=dev, generator=gen) * 2.0 - 1.0
+        return {"image": mel, "text": synth.synth_captions(B, seed=100003 * rank + it_no[0])}
 
     def one():
-        it_no[0] += 1
+        if from_batch and prefetch:
+            # software pipeline: the NEXT batch's prologue is enqueued on a side stream right after this iteration's replay
+            if ahead:
+                cur = ahead.pop()
+            else:
+                cur = make_batch()
+                torch.cuda.current_stream(dev).wait_stream(data_stream)
+            out_ = solver.step(cur)
+            nxt = make_batch()
+            solver.prefetch(nxt, ready=data_stream)
+            ahead.append(nxt)
+            return out_
         if from_batch:
-            mel = torch.rand((B, 1, 80, 848), device=dev, generator=gen) * 2.0 - 1.0
-            caps = synth.synth_captions(B, seed=100003 * rank + it_no[0])
-            return solver.step({"image": mel, "text": caps})
+            return solver.step(make_batch())
         t, pt = dt.sample_time(B, dev, "importance", generator=gen)
         u = torch.rand((B, K1, L), device=dev, generator=gen)
         return solver.step(x0, cond, t, pt, u)
@@ -140,7 +162,7 @@ def run(batch=20, steps=200, warmup=5, n_layer=19, codes=256, precision="f16x2",
         "data": "synthetic", "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
         "ms": {k: 1e3 * v / steps for k, v in times.items()},
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-        "graph": use_graph, "attention": attention,
+        "graph": use_graph, "attention": attention, "prefetch": bool(prefetch and from_batch),
         "loss_scale_exp": solver.train_step.loss_scale_exp,
         # the saturation monitor over the run: log2 of max |scaled dY| at each check, and how often the iteration was re-captured
         "monitor_log2": list(step.monitor_log), "recaptures": getattr(g, "recaptures", 0) - rec0,
