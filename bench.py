@@ -67,6 +67,9 @@ def parse():
                          "layers: mel + captions -> BPE + CLIP + VQ encode -> loss + hand-written backward + all-reduce + clip + "
                          "AdamW + EMA; 5 + --train-steps iterations AFTER the sampling measurement, outside its timed region), "
                          "reported as the \"train\" object of the JSON line (text_to_sound_synthesis_amd/train_bench.py)")
+    ap.add_argument("--no-train-prefetch", action="store_true",
+                    help="training leg: run every batch's BPE / CLIP / VQ-encode prologue in line instead of prefetching the next "
+                         "batch's on a side stream beside the replay in flight (GraphSolver.prefetch; +2.7 % measured)")
     ap.add_argument("--train-steps", type=int, default=200, help="timed iterations of the training leg (sustained rate; ~15 s)")
     ap.add_argument("--train-leg", action="store_true", help=argparse.SUPPRESS)   # (round-4 spelling; the leg is on by default)
     ap.add_argument("--collectives-selftest", action="store_true",
@@ -764,7 +767,7 @@ def main():
         from text_to_sound_synthesis_amd import train_bench
         torch.set_grad_enabled(False)
         r = train_bench.run(batch=20, steps=args.train_steps, warmup=5, n_layer=args.n_layer, codes=args.codes,
-                            precision="f16x2", graph=True, world=world, rank=rank, dev=dev)
+                            precision="f16x2", graph=True, world=world, rank=rank, dev=dev, prefetch=not args.no_train_prefetch)
         if rank == 0:
             line["train"] = {"it_per_s_sustained": round(r["it_per_s_sustained"], 3), "it_per_s_replay": round(r["it_per_s_replay"], 3),
                              "iterations": r["steps"], "recaptures": r["recaptures"], "recapture_reasons": r["recapture_reasons"],
@@ -772,8 +775,8 @@ def main():
                              "samples_per_s": round(r["samples_per_s"], 2), "ms_per_it": round(r["ms_per_step"], 2),
                              "ms_per_replay_median": round(r["ms_per_replay_median"], 2),
                              "ms_per_iteration_max": round(r["ms_per_iteration_max"], 2),
-                             "batch_per_gpu": 20, "graph": r["graph"], "dtype": r["dtype"], "loss": r["loss"],
-                             "grad_norm": r["grad_norm"], "workload": r["config"]["workload"],
+                             "batch_per_gpu": 20, "graph": r["graph"], "prefetch": r["prefetch"], "dtype": r["dtype"],
+                             "loss": r["loss"], "grad_norm": r["grad_norm"], "workload": r["config"]["workload"],
                              "parallelism": r["config"]["parallelism"]}
 
     def leg_cpu_baseline():
