@@ -246,7 +246,8 @@ def test_solver_step_from_the_reference_batch(model_init):
 def test_graph_solver_from_the_reference_batch_three_iterations(model_init):
     """GraphSolver.step(batch dict): the prologue runs eagerly on the stream, the captured iteration replays on its output --
     three iterations with new mel + captions each equal the eager Solver's (same generator, same weights) to rounding; with the
-    next batch's prologue PREFETCHED on a side stream (GraphSolver.prefetch) the numbers are the graphed ones bit for bit."""
+    next batch's prologue PREFETCHED on a side stream (GraphSolver.prefetch) the numbers are the graphed ones (to the last bit
+    but for the atomically summed token-embedding gradient)."""
     from text_to_sound_synthesis_amd.modeling.solver import GradClipWindow, GraphSolver, Solver
     from text_to_sound_synthesis_amd.modeling.train import TrainStep
     m = model_init
@@ -276,7 +277,8 @@ def test_graph_solver_from_the_reference_batch_three_iterations(model_init):
     print("eager %s\ngraph %s\ngraph + prefetch %s" % (eager, graphed, ahead))
     for (le, ne), (lg, ng) in zip(eager, graphed):
         assert abs(le - lg) < 1e-5 * abs(le) and abs(ne - ng) < 1e-4 * abs(ne)
-    assert ahead == graphed                    # the same kernels on the same inputs, only enqueued earlier: bit for bit
+    for (lg, ng), (la, na) in zip(graphed, ahead):      # the same kernels on the same inputs, only enqueued earlier (the token
+        assert abs(lg - la) <= 1e-6 * abs(lg) and abs(ng - na) <= 1e-6 * abs(ng)     # embedding's gradient is summed with atomics)
     assert rec == 0 and rec2 == 0
     dt.load_state_dict(keep)
     dt.transformer.invalidate()

@@ -28,7 +28,8 @@ import torch.distributed as dist
 
 
 def run(batch=20, steps=200, warmup=5, n_layer=19, codes=256, precision="f16x2", ema_device="cuda", attention="fused",
-        graph=True, world=1, rank=0, dev=None, monitor_hi=None, from_batch=True, calib_target=None, prefetch=False):
+        graph=True, world=1, rank=0, dev=None, monitor_hi=None, from_batch=True, calib_target=None, prefetch=False,
+        profile="init"):
     """Time `steps` training iterations (after `warmup`) and return the result dict (module docstring).
     from_batch=False: the round-5 form -- pre-made tokens and a stand-in caption embedding, no mel / caption prologue
     (kept as the A/B leg that prices the prologue).  (Per-kernel rates: tools/train_profile.sh.)"""
@@ -42,6 +43,8 @@ def run(batch=20, steps=200, warmup=5, n_layer=19, codes=256, precision="f16x2",
     m = build_model(default_config(n_layer=n_layer, diffusion_step=100, n_embed=codes, with_clip=from_batch,
                                    bpe_path=tokenizer.CLOSED_VOCAB_PATH))
     synth.synth_init_(m, seed=0)
+    if profile != "init":            # the denoiser off the N(0, 0.02) manifold (synth.py profile="trained": heavy-tailed gradients)
+        synth.synth_init_(m, seed=0, skip=("content_codec.", "transformer.condition_emb."), profile=profile)
     m = m.to(dev).eval()
     dt = m.transformer
     dt.auxiliary_loss_weight, dt.adaptive_auxiliary_loss, dt.mask_weight = 5.0e-4, True, [1, 1]   # configs/caps.yaml
@@ -162,7 +165,7 @@ def run(batch=20, steps=200, warmup=5, n_layer=19, codes=256, precision="f16x2",
         "data": "synthetic", "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"]),
         "ms": {k: 1e3 * v / steps for k, v in times.items()},
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-        "graph": use_graph, "attention": attention, "prefetch": bool(prefetch and from_batch),
+        "graph": use_graph, "attention": attention, "prefetch": bool(prefetch and from_batch), "weights": profile,
         "loss_scale_exp": solver.train_step.loss_scale_exp,
         # the saturation monitor over the run: log2 of max |scaled dY| at each check, and how often the iteration was re-captured
         "monitor_log2": list(step.monitor_log), "recaptures": getattr(g, "recaptures", 0) - rec0,

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--monitor-hi", type=int, default=None, help="experiment: log2 upper bound of the saturation monitor's window")
     ap.add_argument("--calib-log2", type=int, default=None, help="experiment: log2 of where a calibration puts the largest |dY|")
     ap.add_argument("--from-tokens", action="store_true", help="pre-made tokens + stand-in caption embedding (no prologue)")
+    ap.add_argument("--weights", default="init", choices=("init", "trained"), help="synth.py weight profile of the denoiser")
     ap.add_argument("--prefetch", action="store_true", help="the next batch's BPE / CLIP / VQ-encode prologue on a side stream")
     ap.add_argument("--graph", action="store_true", help="gradients -> clip -> AdamW captured in one hipGraph (one GPU)")
     args = ap.parse_args()
@@ -48,7 +49,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     out = train_bench.run(args.batch, args.steps, args.warmup, args.n_layer, args.codes, args.precision, args.ema_device,
                           args.attention, args.graph, world, rank, dev, args.monitor_hi, from_batch=not args.from_tokens,
-                          calib_target=args.calib_log2, prefetch=args.prefetch)
+                          calib_target=args.calib_log2, prefetch=args.prefetch, profile=args.weights)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
