@@ -489,6 +489,10 @@ class TrainStep:
         self.cap_decay_readings = 32            # ... after that many (512 iterations) the drop is forgotten
         self._amax_live = None
         self._since_check = 0
+        # A calibration has seen ONE batch: the monitor is read after 1, 2, 4, 8 iterations before it settles at every
+        # `monitor_interval`-th -- on trained-like weights a batch 2^11 above the calibration batch came by within the first 16
+        # iterations (profiles/r06k_bench_train_long_runs.txt: reading 2^17.65, i.e. saturated planes until the check)
+        self._next_check = 1
         # weight swaps outside this class (checkpoint / EMA loads: solver._invalidate) must drop the cached pre-scales
         import weakref
         diffusion_transformer.__dict__.setdefault("_scale_clients", []).append(weakref.ref(self))
@@ -520,9 +524,10 @@ class TrainStep:
         if self.precision != "f16x2" or self._amax_live is None:
             return False
         self._since_check += 1
-        if not force and self._since_check < self.monitor_interval:
+        if not force and self._since_check < min(self._next_check, self.monitor_interval):
             return False
         self._since_check = 0
+        self._next_check = min(self.monitor_interval, 2 * self._next_check)
         m = float(self._amax_live.item())
         self._amax_live.zero_()
         self.monitor_log = self.monitor_log[-63:] + [round(math.log2(m), 2) if m > 0.0 and math.isfinite(m) else m]
@@ -643,6 +648,7 @@ class TrainStep:
         if self.precision != "f16x2":
             return 0
         self.loss_scale_exp, self._site_exp = 0, None
+        self._next_check, self._since_check = 1, 0
         amax = torch.zeros(1, device=x0.device)
         self._run(x0, cond_emb, t, pt, noise, calibrating=True, amax=amax)
         m = float(amax.item())
