@@ -479,6 +479,8 @@ class HeadlineGuard:
                 return
             self.closed = True
             try:
+                print("bench.py: side legs unfinished after %d s -- printing the measured line with \"incomplete\" and ending the "
+                      "process (the timed region had completed)" % self.limit_s, file=sys.stderr)
                 self.emit("side legs unfinished after %d s" % self.limit_s)
             finally:
                 sys.stdout.flush()

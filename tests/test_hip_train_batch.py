@@ -197,6 +197,21 @@ def test_loss_and_gradients_L19_b20_vs_reference(model_init, profile):
     torch.cuda.empty_cache()
 
 
+def test_exact_fp32_backend_L19_b20_vs_reference(model_init):
+    """The strict backend (every GEMM and both attention passes on the exact-fp32 MFMA, no fp16 anywhere, no scales) on the same
+    golden: the yardstick for what the split backend's numbers above are worth."""
+    from text_to_sound_synthesis_amd.modeling.train import TrainStep
+    tag, meta = names("init")
+    g = golden(tag)
+    dt = model_init.transformer
+    dt.reset_time_statistics()
+    t, pt, u = injected(g)
+    step = TrainStep(dt, precision="fp32")
+    loss, grads = step.loss_and_grads(g["tokens"].long().cuda(), g["cond_emb"].float().cuda(), t, pt, u)
+    check_grads(g, meta, loss, grads, "train L19 B20 init, exact-fp32 backend")
+    dt.reset_time_statistics()
+
+
 def test_solver_step_from_the_reference_batch(model_init):
     """`Solver(model=dalle).step({'image', 'text'})` = the reference's `self.model(batch, return_loss=True)` entry
     (engine/solver_spec.py:308-331): BPE -> CLIP -> VQ encode -> sample_time -> q_sample noise -> loss + backward -> clip ->

@@ -23,13 +23,16 @@ Two GEMM backends (`TrainStep(precision=...)`), both behind the same step:
              * GELU2 rides in the pack's prologue in both directions (fc2's input from fc1's output; d fc1-output from
                d gelu-output), so the MLP's activation and its gradient never exist in fp32.
            dW runs as a split-K launch on the packed planes (`groups` K-ranges fill the chip: a 1024 x 1024 dW is only 64
-           tiles) whose partial sums `ds_colsum` adds in a fixed order.  The gradients' magnitude (|dY| ~ 1e-8 .. 1e-2, far
-           below fp16's range) is handled by ONE loss scale 2^k for the whole backward -- d logits is multiplied by it, every
-           dX carries it, the dW GEMMs' epilogue and one multiply over the small gradients take it out again; k comes from a
-           calibration pass (max |dY| over every GEMM input of one backward, one host sync).  A split value keeps an absolute
-           precision of 2^-25, so anything above 2^-3 after scaling is fp32-class; the calibration puts the largest |dY| at
-           2^12..2^13.  The step has no host synchronisation at all and is captured in a hipGraph (`capture`): one graph
-           launch per iteration instead of ~2000 kernel launches from Python.
+           tiles) whose partial sums `ds_colsum` adds in a fixed order.  The gradients' magnitude (|dY| ~ 1e-12 .. 1e-2, far
+           below fp16's range, and spread over 2^25 between the sites of one backward) is handled by a loss scale 2^k -- d
+           logits is multiplied by it, every dX carries it, the dW GEMMs' epilogue and one multiply over the small gradients
+           take it out again -- PLUS one power of two per site (every linear's dY, every attention backward's dO; round 6): the
+           operand times 2^e is what is split to fp16 and 2^-e goes into the consuming epilogues / stores, exact.  k and the e
+           come from a two-pass calibration (`calibrate`: max |operand| per site, two host syncs).  A split value keeps an
+           absolute precision of 2^-25, so anything above 2^-3 after scaling is fp32-class; the calibration puts every site's
+           largest value at 2^6..2^7 under a saturation monitor whose window ends at 2^15.  The step has no host
+           synchronisation at all and is captured in a hipGraph (`capture`): one graph launch per iteration instead of ~2000
+           kernel launches from Python.
 
 Attention: `attention="fused"` (default) = a fused forward + a backward by tile-wise recomputation that reads Q | K | V and
 writes dQ | dK | dV in place in the fused projection buffers and never stores the probabilities -- `ds_attention` +
@@ -517,10 +520,11 @@ class TrainStep:
         self._scales_epoch = getattr(self, "_scales_epoch", 0) + 1
 
     def check_loss_scale(self, force=False):
-        """Host side of the saturation monitor: every `monitor_interval` calls (or when forced) read max |scaled dY| since
-        the last check (one sync) and drop the calibration when it has left [2^6, 2^15) -- fp16 saturates at 2^16, and below
-        2^6 the smallest interesting gradients fall under the split's absolute resolution.  Returns True when the next step
-        must re-calibrate (a captured iteration must then be re-captured)."""
+        """Host side of the saturation monitor: every `monitor_interval` calls (after 1, 2, 4, 8 calls right behind a
+        calibration; or when forced) read max |scaled operand| over all sites since the last check (one sync) and drop the
+        calibration when it has left `monitor_window` = [2^0, 2^15) -- fp16 saturates at 2^16, and a site whose largest element
+        is under 2^0 no longer has fp32-class planes.  Returns True when the next step must re-calibrate (a captured iteration
+        must then be re-captured)."""
         if self.precision != "f16x2" or self._amax_live is None:
             return False
         self._since_check += 1
