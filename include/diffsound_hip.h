@@ -301,6 +301,11 @@ int ds_pack_operand_tile_rows(int rows, int rows_pad);
  * arithmetic as for ds_adamw_dev. */
 int ds_adamw_multi(const void* tensors, int n_tensors, const float* hyper, float beta1, float beta2, float eps,
                    float weight_decay, ds_stream_t stream);
+/* engine/ema.py:40-56 (EMA.update: ema = ema * decay + current * (1 - decay) for every entry of the state dict) as one pass:
+ * `tensors` = HOST array of n_tensors records { ema, current (device pointers, fp32), n (int64 element count) } = 3 x 8 bytes
+ * each; 96 tensors per launch, descriptors by value (graph-capturable).  The reference's expression term for term: two
+ * products and a sum, each rounded to fp32; one_minus_decay = the host's (1 - decay), which is what the reference multiplies by. */
+int ds_ema_multi(const void* tensors, int n_tensors, float decay, float one_minus_decay, ds_stream_t stream);
 
 /* ---- the whole denoiser (Text2ImageTransformer.forward, transformer_utils.py:421-443) ---------- */
 enum {  /* per-layer device pointers, layer-major: ptrs[layer * DS_LP_COUNT + slot] */

@@ -289,3 +289,70 @@ extern "C" int ds_adamw_multi(const void* tensors, int n_tensors, const float* h
     }
     return 0;
 }
+
+// ---- multi-tensor EMA (engine/ema.py:40-56: ema = ema * decay + current * (1 - decay) over the whole state dict) ------------------
+// The reference's loop is three elementwise launches per tensor, 767 tensors: ~25 ms every `update_interval` iterations when the
+// average lives on the GPU.  Same by-value descriptor batches as ds_adamw_multi: 12 launches, one pass over the bytes.
+struct DsEmaTensor {
+    float* e;
+    const float* c;
+    long long n, first_chunk;
+};
+#define EMA_BATCH 96
+struct DsEmaBatch {
+    DsEmaTensor t[EMA_BATCH];
+    int n;
+};
+__global__ __launch_bounds__(256) void ds_ema_multi_kernel(const DsEmaBatch batch, float decay, float w) {
+    const long long chunk = blockIdx.x;
+    int lo = 0, hi = batch.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (batch.t[mid].first_chunk <= chunk) lo = mid;
+        else hi = mid - 1;
+    }
+    const DsEmaTensor T = batch.t[lo];
+    const long long base = (chunk - T.first_chunk) * AW_CHUNK;
+    const bool al = ((((uintptr_t)T.e | (uintptr_t)T.c) & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < AW_CHUNK / 1024; ++it) {
+        const long long i = base + (long long)(it * 256 + threadIdx.x) * 4;
+        if (i >= T.n) break;
+        if (al && i + 4 <= T.n) {
+            const f32x4 e = *(const f32x4*)(T.e + i), c = *(const f32x4*)(T.c + i);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(__fmul_rn(e[k], decay), __fmul_rn(c[k], w));   // two products, one sum:
+                                                                      // each rounded, as torch's three elementwise ops do (no FMA)
+            *(f32x4*)(T.e + i) = o;
+        } else {
+            for (int k = 0; k < 4 && i + k < T.n; ++k) T.e[i + k] = __fadd_rn(__fmul_rn(T.e[i + k], decay), __fmul_rn(T.c[i + k], w));
+        }
+    }
+}
+
+// tensors: HOST array of n_tensors records { ema, current (device pointers, fp32), n (int64 elements) } = 3 x 8 bytes each.
+// one_minus_decay: the host's (1 - decay) rounded to fp32 -- what the reference's `cur * (1 - self.decay)` multiplies by (1.f - decay
+// evaluated in fp32 is a different number)
+extern "C" int ds_ema_multi(const void* tensors, int n_tensors, float decay, float one_minus_decay, ds_stream_t stream) {
+    DS_CHECK_ARG(tensors && n_tensors > 0, "bad arguments");
+    const long long* rec = (const long long*)tensors;
+    for (int i0 = 0; i0 < n_tensors; i0 += EMA_BATCH) {
+        DsEmaBatch b;
+        b.n = n_tensors - i0 < EMA_BATCH ? n_tensors - i0 : EMA_BATCH;
+        long long chunks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const long long* r = rec + (size_t)(i0 + j) * 3;
+            DS_CHECK_ARG(r[0] && r[1] && r[2] > 0, "null pointer / empty tensor in the table");
+            b.t[j].e = (float*)(uintptr_t)r[0];
+            b.t[j].c = (const float*)(uintptr_t)r[1];
+            b.t[j].n = r[2];
+            b.t[j].first_chunk = chunks;
+            chunks += (r[2] + AW_CHUNK - 1) / AW_CHUNK;
+        }
+        DS_CHECK_ARG(chunks < (1ll << 31), "too many chunks in one batch");
+        hipLaunchKernelGGL(ds_ema_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, b, decay, one_minus_decay);
+        DS_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -10,8 +10,8 @@ the reference's names for their knobs (configs/caps.yaml:88-131) and its quirks:
   * GradClipWindow    = engine/clip_grad_norm.py:8-29   ClipGradNorm (+ torch.nn.utils.clip_grad_norm_)
   * EMA               = engine/ema.py:8-72
 
-Nothing here needs the GPU library, so the CPU test suite drives the whole iteration order against a golden run of the
-reference's own classes (tests/golden/solver_schedule.npz).
+Nothing here needs the GPU library on the CPU (an EMA that lives on the GPU updates through ds_ema_multi), so the CPU test suite
+drives the whole iteration order against a golden run of the reference's own classes (tests/golden/solver_schedule.npz).
 """
 import math
 
@@ -136,7 +136,22 @@ class EMA:
         if (iteration + 1) % self.update_interval != 0:
             return
         cur = self._target().state_dict()
-        for k, e in self.ema.items():
+        rest = self.ema
+        if self.device.type == "cuda":
+            # the average lives on the GPU: every fp32 entry in ONE pass (ds_ema_multi: the reference's expression term for
+            # term; 12 launches instead of three elementwise launches per tensor, ~25 ms per update at 19 layers)
+            import ctypes
+            from .. import _lib
+            fast = [k for k, e in self.ema.items() if e.dtype == torch.float32 and cur[k].dtype == torch.float32 and
+                    cur[k].device == e.device and e.is_contiguous() and cur[k].is_contiguous() and e.numel() > 0]
+            if fast:
+                rec = (ctypes.c_int64 * (3 * len(fast)))()
+                for i, k in enumerate(fast):
+                    rec[3 * i:3 * i + 3] = [self.ema[k].data_ptr(), cur[k].data_ptr(), self.ema[k].numel()]
+                _lib.check(_lib.lib().ds_ema_multi(ctypes.cast(rec, ctypes.c_void_p), len(fast), float(self.decay), float(1 - self.decay), _lib.stream()))
+                done = set(fast)
+                rest = {k: e for k, e in self.ema.items() if k not in done}
+        for k, e in rest.items():
             e.copy_(e * self.decay + cur[k].detach().to(self.device) * (1 - self.decay))
 
     def state_dict(self):
