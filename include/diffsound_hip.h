@@ -301,6 +301,12 @@ int ds_pack_operand_tile_rows(int rows, int rows_pad);
  * arithmetic as for ds_adamw_dev. */
 int ds_adamw_multi(const void* tensors, int n_tensors, const float* hyper, float beta1, float beta2, float eps,
                    float weight_decay, ds_stream_t stream);
+/* engine/clip_grad_norm.py:8-29 -> torch.nn.utils.clip_grad_norm_: total = the L2 norm over ALL gradient tensors and coef =
+ * min(1, max_norm / (total + 1e-6)) in device memory (ds_adamw_multi reads it as hyper[3]; nothing comes back to the host):
+ * `tensors` = HOST array of n_tensors records { g (device pointer, fp32), n (int64 element count) }; part = workspace of at
+ * least sum ceil(n_i / 4096) doubles; partial sums per 4096-element chunk, added in a fixed order in double. */
+int ds_grad_norm_multi(const void* tensors, int n_tensors, double* part, long long part_len, float max_norm, float* total,
+                       float* coef, ds_stream_t stream);
 /* engine/ema.py:40-56 (EMA.update: ema = ema * decay + current * (1 - decay) for every entry of the state dict) as one pass:
  * `tensors` = HOST array of n_tensors records { ema, current (device pointers, fp32), n (int64 element count) } = 3 x 8 bytes
  * each; 96 tensors per launch, descriptors by value (graph-capturable).  The reference's expression term for term: two

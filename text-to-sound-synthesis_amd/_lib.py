@@ -108,6 +108,7 @@ _PROTOS = {
     "ds_pack_operand_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "ds_adamw_multi": (C.c_int, [_vp, C.c_int, _vp, _f, _f, _f, _f, _vp]),
     "ds_ema_multi": (C.c_int, [_vp, C.c_int, _f, _f, _vp]),
+    "ds_grad_norm_multi": (C.c_int, [_vp, C.c_int, _vp, _i64, _f, _vp, _vp, _vp]),
     "ds_denoiser_create": (C.c_int, [C.POINTER(DenoiserDesc), C.POINTER(_vp), C.POINTER(_vp)]),
     "ds_denoiser_destroy": (None, [_vp]),
     "ds_denoiser_set_row_padding": (C.c_int, [_vp, C.c_int]),

@@ -356,3 +356,98 @@ extern "C" int ds_ema_multi(const void* tensors, int n_tensors, float decay, flo
     }
     return 0;
 }
+
+// ---- global gradient norm + clip coefficient (engine/clip_grad_norm.py:8-29 -> torch.nn.utils.clip_grad_norm_) ---------------------
+// total = || all gradients ||_2 and coef = min(1, max_norm / (total + 1e-6)), written to device memory for ds_adamw_multi's
+// hyper[3]: one pass over the gradient bytes in the same by-value descriptor batches (4096-element chunks, one double per chunk)
+// + one small fixed-order reduction -- instead of torch._foreach_norm + stack + vector_norm + clamp + copy (a dozen launches).
+struct DsNormTensor {
+    const float* g;
+    long long n, first_chunk;
+};
+#define GN_BATCH 128
+struct DsNormBatch {
+    DsNormTensor t[GN_BATCH];
+    int n;
+};
+__global__ __launch_bounds__(256) void ds_sqnorm_multi_kernel(const DsNormBatch batch, double* __restrict__ part) {
+    __shared__ double ws[4];
+    const long long chunk = blockIdx.x;
+    int lo = 0, hi = batch.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (batch.t[mid].first_chunk <= chunk) lo = mid;
+        else hi = mid - 1;
+    }
+    const DsNormTensor T = batch.t[lo];
+    const long long base = (chunk - T.first_chunk) * AW_CHUNK;
+    const bool al = (((uintptr_t)T.g & 15) == 0);
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < AW_CHUNK / 1024; ++it) {
+        const long long i = base + (long long)(it * 256 + threadIdx.x) * 4;
+        if (i >= T.n) break;
+        if (al && i + 4 <= T.n) {
+            const f32x4 g = *(const f32x4*)(T.g + i);
+            acc += (g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]);
+        } else {
+            for (int k = 0; k < 4 && i + k < T.n; ++k) acc += T.g[i + k] * T.g[i + k];
+        }
+    }
+    double d = (double)acc;                       // 16 values per thread in fp32, everything above in double
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) part[chunk] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+__global__ __launch_bounds__(1024) void ds_norm_finish_kernel(const double* __restrict__ part, long long n, float max_norm,
+                                                              float* __restrict__ total, float* __restrict__ coef) {
+    __shared__ double ws[16];
+    double d = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) d += part[i];       // fixed order: bit-reproducible
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += ws[w];
+        const float t = (float)sqrt(s);
+        *total = t;
+        if (coef) {
+            const float c = max_norm / (t + 1e-6f);                       // torch: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+            *coef = max_norm > 0.f ? (c < 1.f ? c : 1.f) : 1.f;
+        }
+    }
+}
+
+// tensors: HOST array of n_tensors records { g (device pointer, fp32), n (int64 elements) } = 2 x 8 bytes each.  part: >= sum of
+// ceil(n_i / 4096) doubles of workspace.  total: float[1]; coef (may be null): float[1] = min(1, max_norm / (total + 1e-6)), 1 if
+// max_norm <= 0.
+extern "C" int ds_grad_norm_multi(const void* tensors, int n_tensors, double* part, long long part_len, float max_norm, float* total,
+                                  float* coef, ds_stream_t stream) {
+    DS_CHECK_ARG(tensors && n_tensors > 0 && part && total, "bad arguments");
+    const long long* rec = (const long long*)tensors;
+    long long done = 0;
+    for (int i0 = 0; i0 < n_tensors; i0 += GN_BATCH) {
+        DsNormBatch b;
+        b.n = n_tensors - i0 < GN_BATCH ? n_tensors - i0 : GN_BATCH;
+        long long chunks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const long long* r = rec + (size_t)(i0 + j) * 2;
+            DS_CHECK_ARG(r[0] && r[1] > 0, "null pointer / empty tensor in the table");
+            b.t[j].g = (const float*)(uintptr_t)r[0];
+            b.t[j].n = r[1];
+            b.t[j].first_chunk = chunks;
+            chunks += (r[1] + AW_CHUNK - 1) / AW_CHUNK;
+        }
+        DS_CHECK_ARG(chunks < (1ll << 31) && done + chunks <= part_len, "workspace too small for the gradients' chunks");
+        hipLaunchKernelGGL(ds_sqnorm_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, b, part + done);
+        DS_CHECK_LAUNCH();
+        done += chunks;
+    }
+    hipLaunchKernelGGL(ds_norm_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, done, max_norm, total, coef);
+    DS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1036,10 +1036,23 @@ class GraphedIteration:
 
     def _body_update(self):
         st, loss, grads = self.step, self.loss, self.grads
-        tensors = list(grads.values())
-        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)))
-        if self.max_norm is not None:                  # torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), <= 1
-            self.hyper[3:4].copy_(torch.clamp(self.max_norm / (total + 1e-6), max=1.0).reshape(1))
+        # global gradient norm + clip coefficient (torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), <= 1) in two
+        # launches, the coefficient written straight into the AdamW kernel's hyper[3] (ds_grad_norm_multi)
+        import ctypes
+        tensors = [g_.contiguous() for g_ in grads.values()]
+        assert all(g_.dtype == torch.float32 for g_ in tensors)
+        rec = (ctypes.c_int64 * (2 * len(tensors)))()
+        chunks = 0
+        for i, g_ in enumerate(tensors):
+            rec[2 * i:2 * i + 2] = [g_.data_ptr(), g_.numel()]
+            chunks += (g_.numel() + 4095) // 4096
+        part = torch.empty(chunks, dtype=torch.float64, device=self.hyper.device)
+        total1 = torch.empty(1, device=self.hyper.device)
+        L_.check(L_.lib().ds_grad_norm_multi(ctypes.cast(rec, ctypes.c_void_p), len(tensors), L_.ptr(part), chunks,
+                                             float(self.max_norm) if self.max_norm is not None else 0.0, L_.ptr(total1),
+                                             L_.ptr_off(self.hyper, 3) if self.max_norm is not None else None, L_.stream()))
+        self._norm_keep = (tensors, part)              # alive until the launches are enqueued / for the life of the captured graph
+        total = total1.reshape(())
         st.adamw_step(grads, self.opt_state, 0, 0.0, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay,
                       hyper=self.hyper)
         self.loss, self.grad_norm, self.grads = loss, total, grads
