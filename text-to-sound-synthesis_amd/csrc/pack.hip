@@ -304,6 +304,7 @@ struct DsEmaBatch {
     int n;
 };
 __global__ __launch_bounds__(256) void ds_ema_multi_kernel(const DsEmaBatch batch, float decay, float w) {
+#pragma clang fp contract(off)      // two products and one sum, each rounded: never a fused multiply-add (hipcc contracts by default)
     const long long chunk = blockIdx.x;
     int lo = 0, hi = batch.n - 1;
     while (lo < hi) {
@@ -322,11 +323,16 @@ __global__ __launch_bounds__(256) void ds_ema_multi_kernel(const DsEmaBatch batc
             const f32x4 e = *(const f32x4*)(T.e + i), c = *(const f32x4*)(T.c + i);
             f32x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(__fmul_rn(e[k], decay), __fmul_rn(c[k], w));   // two products, one sum:
-                                                                      // each rounded, as torch's three elementwise ops do (no FMA)
+            for (int k = 0; k < 4; ++k) {                 // two products, one sum, each rounded -- as torch's three elementwise ops
+                const float a = e[k] * decay, b = c[k] * w;  // do (the pragma above: no FMA; __fmul_rn / __fadd_rn are plain
+                o[k] = a + b;                                // operators in HIP's headers and DO get contracted)
+            }
             *(f32x4*)(T.e + i) = o;
         } else {
-            for (int k = 0; k < 4 && i + k < T.n; ++k) T.e[i + k] = __fadd_rn(__fmul_rn(T.e[i + k], decay), __fmul_rn(T.c[i + k], w));
+            for (int k = 0; k < 4 && i + k < T.n; ++k) {
+                const float a = T.e[i + k] * decay, b = T.c[i + k] * w;
+                T.e[i + k] = a + b;
+            }
         }
     }
 }
