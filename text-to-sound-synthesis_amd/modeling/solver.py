@@ -217,8 +217,8 @@ def _batch_tensors(solver, batch):
             raise ValueError("step(batch dict) needs the DALLE model: Solver(..., model=dalle)")
         from .train import training_draws, training_prologue
         pre = getattr(solver, "_prefetched", None)
+        solver._prefetched = None                  # (a prefetch for ANOTHER batch than the one that arrives is dropped)
         if pre is not None and pre[0] is batch[0]:
-            solver._prefetched = None
             _, x0, cond_emb, side = pre
             cur = torch.cuda.current_stream(x0.device)
             cur.wait_stream(side)
