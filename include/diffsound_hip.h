@@ -476,6 +476,11 @@ int ds_melgan_convt2_ok(int Cin, int Cout);
 int ds_melgan_final(const float* x, const float* w, float bias, float* out, int B, int T, int C, ds_stream_t stream);
 /* AttnBlock softmax (model.py:214-216): x[row][0..n) <- softmax(scale*x), x[row][n..ld) <- 0 */
 int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t stream);
+/* Encoder.conv_in (specvqgan/modules/diffusionmodules/model.py:423-427, :480): Conv2d(1, Cout, 3, stride 1, padding 1) on a
+ * ONE-channel image x f32[B][H][W], w [Cout][9] (= weight [Cout][1][3][3]), bias [Cout] -> out f32[B][H][W][Cout]
+ * (channels-last).  Direct fp32 multiply-adds, taps in the conv's order; store-bound.  Cout % 4 == 0, divides 1024. */
+int ds_conv3x3_c1(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
+                  ds_stream_t stream);
 /* tap-sum for single-output-channel convs fed by a GEMM with N = taps */
 int ds_stencil9(const float* taps, int ldt, float bias, float* out, int B, int H, int W, ds_stream_t stream);
 int ds_stencil7_tanh(const float* taps, int ldt, float bias, float* out, int B, int N, ds_stream_t stream);

@@ -404,3 +404,19 @@ def test_training_loss_and_gradients_other_settings(aux, adaptive, mask_w, ts):
         worst = max(worst, (got - v.grad.double()).abs().max().item() / mag)
     print("worst gradient error %.2e" % worst)
     assert worst < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 80, 848, 128), (1, 7, 5, 64), (3, 16, 33, 256)])
+def test_conv3x3_one_input_channel_direct(B, H, W, Cout):
+    """ds_conv3x3_c1 = Encoder.conv_in (diffusionmodules/model.py:423-427, :480): Conv2d(1, Cout, 3, padding 1) on the one-channel mel,
+    channels-last output -- against torch's conv2d in float64, borders (zero padding) included."""
+    from text_to_sound_synthesis_amd import _lib as L
+    x = synth.synth_uniform((B, 1, H, W), key="c1.x%d" % H) * 2 - 1
+    w = (synth.synth_uniform((Cout, 1, 3, 3), key="c1.w%d" % Cout) * 2 - 1) * 0.3
+    b = (synth.synth_uniform((Cout,), key="c1.b%d" % Cout) * 2 - 1) * 0.1
+    want = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    xc, wc, bc = x[:, 0].contiguous().cuda(), w.reshape(Cout, 9).contiguous().cuda(), b.cuda()
+    out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    L.check(L.lib().ds_conv3x3_c1(L.ptr(xc), L.ptr(wc), L.ptr(bc), L.ptr(out), B, H, W, Cout, L.stream()))
+    err = float((out.cpu().double() - want).abs().max())
+    assert err < 2e-6, err

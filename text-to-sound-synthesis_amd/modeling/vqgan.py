@@ -305,11 +305,11 @@ class VQModel(nn.Module):
             return {"n": gb(a.norm), "qk": (torch.cat((qw, kw), 0).contiguous(), torch.cat((qb, kb), 0).contiguous()),
                     "v": _pack_conv1(a.v), "proj": _pack_conv1(a.proj_out), "c": a.in_channels}
         e = self.encoder
-        # conv_in has one input channel: its 9-tap K axis is zero-padded to the GEMM's 32-wide channel granule
+        # conv_in has ONE input channel: a direct 9-tap kernel (ds_conv3x3_c1), not an implicit GEMM with a contraction of 9
+        # zero-padded to the conv kernel's 32-wide channel granule (rounds 2-5: 1.15 ms per 20 mels + a 174 MB zero fill)
         w = e.conv_in.weight.detach().float()                                   # [ch, 1, 3, 3]
-        w_in = torch.zeros(w.shape[0], 9, 32, device=w.device)
-        w_in[:, :, 0] = w[:, 0].reshape(w.shape[0], 9)
-        pk = {"conv_in": _with_split(w_in.reshape(w.shape[0], -1).contiguous(), e.conv_in.bias.detach().float().contiguous()),
+        assert w.shape[1] == 1, "the SpecVQGAN encoder reads a one-channel mel"
+        pk = {"conv_in": (w.reshape(w.shape[0], 9).contiguous(), e.conv_in.bias.detach().float().contiguous()),
               "down": [], "mid": (res(e.mid.block_1), att(e.mid.attn_1), res(e.mid.block_2)),
               "norm_out": gb(e.norm_out), "conv_out": _pack_conv3(e.conv_out), "quant": _pack_conv1(self.quant_conv)}
         for lvl in range(e.num_resolutions):
@@ -428,10 +428,13 @@ class VQModel(nn.Module):
 
     @torch.no_grad()
     def _encode_cl(self, x, B, H, W):
-        """x: [B, H, W, 32] channels-last image with channel 0 = the mel, the rest zero -> latent [B, H/16, W/16, C]
+        """x: f32 [B, H, W], the one-channel mel -> latent [B, H/16, W/16, C]
         (Encoder.forward, diffusionmodules/model.py:467-500, + quant_conv)."""
         pk, e = self._packed_encoder(), self.encoder
-        h = self._conv3(x, B, H, W, 32, pk["conv_in"])
+        w_in, b_in = pk["conv_in"]
+        h = torch.empty(B, H, W, w_in.shape[0], device=x.device)
+        _lib.check(_lib.lib().ds_conv3x3_c1(_lib.ptr(x), _lib.ptr(w_in), _lib.ptr(b_in), _lib.ptr(h), B, H, W, w_in.shape[0],
+                                            _lib.stream()))
         for lvl in range(e.num_resolutions):
             dn = pk["down"][lvl]
             for i, r in enumerate(dn["block"]):
@@ -458,11 +461,8 @@ class VQModel(nn.Module):
         assert Cin == 1 and H % 16 == 0 and W % 16 == 0
         hs = []
         for s in range(0, B, self.decode_chunk):
-            xc = x[s:s + self.decode_chunk].float()
-            b = xc.shape[0]
-            xin = torch.zeros(b, H, W, 32, device=x.device)
-            xin[..., 0] = xc[:, 0]
-            hs.append(self._encode_cl(xin, b, H, W))
+            xc = x[s:s + self.decode_chunk, 0].float().contiguous()                # [b, H, W]: the one channel
+            hs.append(self._encode_cl(xc, xc.shape[0], H, W))
         h = (torch.cat(hs, 0) if len(hs) > 1 else hs[0]).permute(0, 3, 1, 2).contiguous()
         return self.quantize(h)
 
@@ -470,9 +470,7 @@ class VQModel(nn.Module):
     def encode_latent(self, x):
         """quant_conv(encoder(x)) -> [B, 256, 5, 53] (the pre-quantisation latent; tests / partial pipelines)"""
         B, _, H, W = x.shape
-        xin = torch.zeros(B, H, W, 32, device=x.device)
-        xin[..., 0] = x[:, 0].float()
-        return self._encode_cl(xin, B, H, W).permute(0, 3, 1, 2).contiguous()
+        return self._encode_cl(x[:, 0].float().contiguous(), B, H, W).permute(0, 3, 1, 2).contiguous()
 
     @torch.no_grad()
     def decode(self, quant):
