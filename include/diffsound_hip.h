@@ -478,9 +478,12 @@ int ds_melgan_final(const float* x, const float* w, float bias, float* out, int 
 int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t stream);
 /* Encoder.conv_in (specvqgan/modules/diffusionmodules/model.py:423-427, :480): Conv2d(1, Cout, 3, stride 1, padding 1) on a
  * ONE-channel image x f32[B][H][W], w [Cout][9] (= weight [Cout][1][3][3]), bias [Cout] -> out f32[B][H][W][Cout]
- * (channels-last).  Direct fp32 multiply-adds, taps in the conv's order; store-bound.  Cout % 4 == 0, divides 1024. */
+ * (channels-last).  Direct fp32 multiply-adds, taps in the conv's order; store-bound.  Cout % 4 == 0, divides 1024.  gn_part
+ * (may be null): [B][ds_conv3x3_c1_chunks(H, W)][2][Cout] doubles = per-channel sum / sum of squares of the output per row
+ * segment, what ds_groupnorm_finish reads (the GroupNorm that follows needs no pass of its own over the output). */
 int ds_conv3x3_c1(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
-                  ds_stream_t stream);
+                  double* gn_part, ds_stream_t stream);
+int ds_conv3x3_c1_chunks(int H, int W);
 /* tap-sum for single-output-channel convs fed by a GEMM with N = taps */
 int ds_stencil9(const float* taps, int ldt, float bias, float* out, int B, int H, int W, ds_stream_t stream);
 int ds_stencil7_tanh(const float* taps, int ldt, float bias, float* out, int B, int N, ds_stream_t stream);

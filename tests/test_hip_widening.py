@@ -417,6 +417,15 @@ def test_conv3x3_one_input_channel_direct(B, H, W, Cout):
     want = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
     xc, wc, bc = x[:, 0].contiguous().cuda(), w.reshape(Cout, 9).contiguous().cuda(), b.cuda()
     out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
-    L.check(L.lib().ds_conv3x3_c1(L.ptr(xc), L.ptr(wc), L.ptr(bc), L.ptr(out), B, H, W, Cout, L.stream()))
+    nch = L.lib().ds_conv3x3_c1_chunks(H, W)
+    part = torch.full((B, nch, 2, Cout), float("nan"), device="cuda", dtype=torch.float64)
+    L.check(L.lib().ds_conv3x3_c1(L.ptr(xc), L.ptr(wc), L.ptr(bc), L.ptr(out), B, H, W, Cout, L.ptr(part), L.stream()))
     err = float((out.cpu().double() - want).abs().max())
     assert err < 2e-6, err
+    # the GroupNorm partial sums of the output (per row segment): summed over the chunks they are the per-channel sums
+    sums = part.sum(1).cpu()
+    assert float((sums[:, 0] - want.sum((1, 2))).abs().max()) < 1e-4 * float(want.abs().sum((1, 2)).max())
+    assert float((sums[:, 1] - want.pow(2).sum((1, 2))).abs().max()) < 1e-5 * float(want.pow(2).sum((1, 2)).max())
+    out2 = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    L.check(L.lib().ds_conv3x3_c1(L.ptr(xc), L.ptr(wc), L.ptr(bc), L.ptr(out2), B, H, W, Cout, None, L.stream()))
+    assert torch.equal(out, out2)

@@ -155,24 +155,27 @@ extern "C" int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, d
 // ---- Encoder.conv_in (diffusionmodules/model.py:423-427, :480): 3x3, zero padding 1, ONE input channel -> Cout channels, written
 // channels-last.  9 multiply-adds per output value: as an implicit GEMM the contraction is 9 long (it ran zero-padded to the 32-wide
 // channel granule of the conv kernel: 1.15 ms per 20 mels at 87 TF-eq, plus a 174 MB zero fill and a strided copy to build the padded
-// input); here it is a store-bound pass over the output.  A thread keeps the 4 x 9 weights of its four output channels in
-// registers and walks pixels; the 32 threads of a pixel write its 512 contiguous bytes (Cout = 128).
+// input); here it is a store-bound pass over the output.  A workgroup takes 64 pixels of one image row; a thread keeps the 4 x 9
+// weights of its four output channels in registers and walks pixels; the 32 threads of a pixel write its 512 contiguous bytes
+// (Cout = 128).  The GroupNorm that follows gets its statistics from this pass (per-segment partial sums), like from the 3x3 kernel.
+#define C1_XS 64       // output pixels of one image row per workgroup
 __global__ __launch_bounds__(256) void ds_conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W,
-                                                            int Cout) {
+                                                            const float* __restrict__ bias, float* __restrict__ out, int H, int W,
+                                                            int Cout, double* __restrict__ gn_part) {
+    __shared__ float red[2][256][4];
     const int tpp = Cout >> 2;                        // threads per pixel (4 output channels each)
     const int cg = threadIdx.x % tpp, slot = threadIdx.x / tpp, slots = 256 / tpp;
+    const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * C1_XS;      // one row segment of one sample: no index divisions
     float wr[4][9];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int k = 0; k < 9; ++k) wr[c][k] = w[(size_t)(cg * 4 + c) * 9 + k];
     const f32x4 bv = *(const f32x4*)(bias + cg * 4);
-    const long long P = (long long)B * H * W;
-    for (long long p = (long long)blockIdx.x * slots + slot; p < P; p += (long long)gridDim.x * slots) {
-        const int b = (int)(p / ((long long)H * W)), rem = (int)(p - (long long)b * H * W);
-        const int y = rem / W, xx = rem - y * W;
-        const float* xb = x + (size_t)b * H * W;
+    const float* xb = x + (size_t)b * H * W;
+    float* ob = out + ((size_t)b * H + y) * W * Cout;
+    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    for (int xx = x0 + slot; xx < x0 + C1_XS && xx < W; xx += slots) {
         float t[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -183,24 +186,46 @@ __global__ __launch_bounds__(256) void ds_conv3x3_c1_kernel(const float* __restr
             }
         f32x4 o = bv;
 #pragma unroll
-        for (int k = 0; k < 9; ++k)                   // taps in the conv's own order (ky major), fp32 FMA chain like torch's direct conv
+        for (int k = 0; k < 9; ++k)                   // taps in the conv's own order (ky major): an fp32 multiply-add chain
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] += wr[c][k] * t[k];
-        *(f32x4*)(out + (size_t)p * Cout + cg * 4) = o;
+        *(f32x4*)(ob + (size_t)xx * Cout + cg * 4) = o;
+        s1 += o;
+        s2 += o * o;
+    }
+    if (gn_part) {
+        // GroupNorm statistics of the OUTPUT (the next op is a GroupNorm): per-channel sum and sum of squares of this row
+        // segment, slots added in a fixed order -> part[b][chunk][2][Cout] doubles (the format ds_groupnorm_finish reads)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { red[0][threadIdx.x][c] = s1[c]; red[1][threadIdx.x][c] = s2[c]; }
+        __syncthreads();
+        if (slot == 0) {
+            const int chunk = y * gridDim.x + blockIdx.x, nchunk = gridDim.y * gridDim.x;
+            double* pp = gn_part + (((size_t)b * nchunk + chunk) * 2) * Cout + cg * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double a1 = 0.0, a2 = 0.0;
+                for (int sl = 0; sl < slots; ++sl) { a1 += (double)red[0][sl * tpp + cg][c]; a2 += (double)red[1][sl * tpp + cg][c]; }
+                pp[c] = a1;
+                pp[Cout + c] = a2;
+            }
+        }
     }
 }
 
-// x: f32 [B][H][W] (the one input channel), w: [Cout][9] (= Conv2d.weight [Cout][1][3][3]), bias [Cout], out: f32 [B][H][W][Cout]
+// chunks of GroupNorm partial sums per sample that ds_conv3x3_c1 writes for an H x W image
+extern "C" int ds_conv3x3_c1_chunks(int H, int W) { return H * ((W + C1_XS - 1) / C1_XS); }
+
+// x: f32 [B][H][W] (the one input channel), w: [Cout][9] (= Conv2d.weight [Cout][1][3][3]), bias [Cout], out: f32 [B][H][W][Cout];
+// gn_part (may be null): [B][ds_conv3x3_c1_chunks(H, W)][2][Cout] doubles
 extern "C" int ds_conv3x3_c1(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
-                             ds_stream_t stream_) {
+                             double* gn_part, ds_stream_t stream_) {
     DS_CHECK_ARG(x && w && bias && out && B > 0 && H > 0 && W > 0, "bad arguments");
     DS_CHECK_ARG(Cout % 4 == 0 && Cout >= 4 && Cout <= 1024 && 1024 % Cout == 0, "Cout: a multiple of 4 that divides 1024");
     DS_CHECK_ARG((((uintptr_t)bias | (uintptr_t)out) & 15) == 0, "bias / out must be 16-byte aligned");
-    const long long P = (long long)B * H * W;
-    const int slots = 256 / (Cout / 4);
-    long long blocks = (P + slots - 1) / slots;
-    if (blocks > 8192) blocks = 8192;                 // grid-stride: ~32 workgroups per CU, the weights are loaded once per thread
-    hipLaunchKernelGGL(ds_conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, x, w, bias, out, B, H, W, Cout);
+    DS_CHECK_ARG(H <= 65535 && B <= 65535, "grid limits");
+    hipLaunchKernelGGL(ds_conv3x3_c1_kernel, dim3((W + C1_XS - 1) / C1_XS, H, B), dim3(256), 0, (hipStream_t)stream_, x, w, bias, out,
+                       H, W, Cout, gn_part);
     DS_CHECK_LAUNCH();
     return 0;
 }

@@ -433,8 +433,10 @@ class VQModel(nn.Module):
         pk, e = self._packed_encoder(), self.encoder
         w_in, b_in = pk["conv_in"]
         h = torch.empty(B, H, W, w_in.shape[0], device=x.device)
+        part = torch.empty(B, _lib.lib().ds_conv3x3_c1_chunks(H, W), 2, w_in.shape[0], device=x.device, dtype=torch.float64)
         _lib.check(_lib.lib().ds_conv3x3_c1(_lib.ptr(x), _lib.ptr(w_in), _lib.ptr(b_in), _lib.ptr(h), B, H, W, w_in.shape[0],
-                                            _lib.stream()))
+                                            _lib.ptr(part), _lib.stream()))
+        h._gn_part = part         # picked up by _gn(): the first ResnetBlock's GroupNorm needs no statistics pass
         for lvl in range(e.num_resolutions):
             dn = pk["down"][lvl]
             for i, r in enumerate(dn["block"]):
