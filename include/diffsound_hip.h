@@ -480,7 +480,8 @@ int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, ds_stream_t 
  * ONE-channel image x f32[B][H][W], w [Cout][9] (= weight [Cout][1][3][3]), bias [Cout] -> out f32[B][H][W][Cout]
  * (channels-last).  Direct fp32 multiply-adds, taps in the conv's order; store-bound.  Cout % 4 == 0, divides 1024.  gn_part
  * (may be null): [B][ds_conv3x3_c1_chunks(H, W)][2][Cout] doubles = per-channel sum / sum of squares of the output per row
- * segment, what ds_groupnorm_finish reads (the GroupNorm that follows needs no pass of its own over the output). */
+ * (one chunk per image row), what ds_groupnorm_finish reads (the GroupNorm that follows needs no pass of its own over the
+ * output).  W <= 2046. */
 int ds_conv3x3_c1(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
                   double* gn_part, ds_stream_t stream);
 int ds_conv3x3_c1_chunks(int H, int W);

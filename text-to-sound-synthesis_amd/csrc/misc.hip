@@ -155,53 +155,54 @@ extern "C" int ds_softmax_rows(float* x, int rows, int n, int ld, float scale, d
 // ---- Encoder.conv_in (diffusionmodules/model.py:423-427, :480): 3x3, zero padding 1, ONE input channel -> Cout channels, written
 // channels-last.  9 multiply-adds per output value: as an implicit GEMM the contraction is 9 long (it ran zero-padded to the 32-wide
 // channel granule of the conv kernel: 1.15 ms per 20 mels at 87 TF-eq, plus a 174 MB zero fill and a strided copy to build the padded
-// input); here it is a store-bound pass over the output.  A workgroup takes 64 pixels of one image row; a thread keeps the 4 x 9
-// weights of its four output channels in registers and walks pixels; the 32 threads of a pixel write its 512 contiguous bytes
-// (Cout = 128).  The GroupNorm that follows gets its statistics from this pass (per-segment partial sums), like from the 3x3 kernel.
-#define C1_XS 64       // output pixels of one image row per workgroup
+// input); here it is a store-bound pass over the output.  A workgroup takes one image row (its three input rows staged in LDS); a
+// thread keeps the 4 x 9 weights of its four output channels in registers and walks the row's pixels; the 32 threads of a pixel
+// write its 512 contiguous bytes (Cout = 128).  The GroupNorm that follows gets its statistics from this pass (per-segment partial sums), like from the 3x3 kernel.
+#define C1_WMAX 2046   // widest image row (three zero-padded input rows of it live in LDS: 24 KB)
 __global__ __launch_bounds__(256) void ds_conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                             int Cout, double* __restrict__ gn_part) {
+    __shared__ float xs[3][C1_WMAX + 2];              // input rows y-1, y, y+1 with the zero padding in place
     __shared__ float red[2][256][4];
     const int tpp = Cout >> 2;                        // threads per pixel (4 output channels each)
     const int cg = threadIdx.x % tpp, slot = threadIdx.x / tpp, slots = 256 / tpp;
-    const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * C1_XS;      // one row segment of one sample: no index divisions
+    const int b = blockIdx.y, y = blockIdx.x;         // one image row of one sample per workgroup: no index divisions
+    const float* xb = x + (size_t)b * H * W;
+    for (int i = threadIdx.x; i < 3 * (W + 2); i += 256) {
+        const int r = i / (W + 2), c = i - r * (W + 2), sy = y + r - 1, sx = c - 1;
+        xs[r][c] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? xb[(size_t)sy * W + sx] : 0.f;
+    }
     float wr[4][9];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int k = 0; k < 9; ++k) wr[c][k] = w[(size_t)(cg * 4 + c) * 9 + k];
     const f32x4 bv = *(const f32x4*)(bias + cg * 4);
-    const float* xb = x + (size_t)b * H * W;
     float* ob = out + ((size_t)b * H + y) * W * Cout;
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
-    for (int xx = x0 + slot; xx < x0 + C1_XS && xx < W; xx += slots) {
-        float t[9];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int sy = y + ky - 1, sx = xx + kx - 1;
-                t[ky * 3 + kx] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? xb[(size_t)sy * W + sx] : 0.f;
-            }
+    __syncthreads();
+    for (int xx = slot; xx < W; xx += slots) {
         f32x4 o = bv;
 #pragma unroll
-        for (int k = 0; k < 9; ++k)                   // taps in the conv's own order (ky major): an fp32 multiply-add chain
+        for (int ky = 0; ky < 3; ++ky)                // taps in the conv's own order (ky major): an fp32 multiply-add chain
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] += wr[c][k] * t[k];
+            for (int kx = 0; kx < 3; ++kx) {
+                const float t = xs[ky][xx + kx];      // (the threads of a pixel read the same word: an LDS broadcast)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] += wr[c][ky * 3 + kx] * t;
+            }
         *(f32x4*)(ob + (size_t)xx * Cout + cg * 4) = o;
         s1 += o;
         s2 += o * o;
     }
     if (gn_part) {
-        // GroupNorm statistics of the OUTPUT (the next op is a GroupNorm): per-channel sum and sum of squares of this row
-        // segment, slots added in a fixed order -> part[b][chunk][2][Cout] doubles (the format ds_groupnorm_finish reads)
+        // GroupNorm statistics of the OUTPUT (the next op is a GroupNorm): per-channel sum and sum of squares of this row,
+        // slots added in a fixed order -> part[b][row][2][Cout] doubles (the format ds_groupnorm_finish reads)
 #pragma unroll
         for (int c = 0; c < 4; ++c) { red[0][threadIdx.x][c] = s1[c]; red[1][threadIdx.x][c] = s2[c]; }
         __syncthreads();
         if (slot == 0) {
-            const int chunk = y * gridDim.x + blockIdx.x, nchunk = gridDim.y * gridDim.x;
-            double* pp = gn_part + (((size_t)b * nchunk + chunk) * 2) * Cout + cg * 4;
+            double* pp = gn_part + (((size_t)b * H + y) * 2) * Cout + cg * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 double a1 = 0.0, a2 = 0.0;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void ds_conv3x3_c1_kernel(const float* __restr
 }
 
 // chunks of GroupNorm partial sums per sample that ds_conv3x3_c1 writes for an H x W image
-extern "C" int ds_conv3x3_c1_chunks(int H, int W) { return H * ((W + C1_XS - 1) / C1_XS); }
+extern "C" int ds_conv3x3_c1_chunks(int H, int W) { (void)W; return H; }      // one chunk per image row
 
 // x: f32 [B][H][W] (the one input channel), w: [Cout][9] (= Conv2d.weight [Cout][1][3][3]), bias [Cout], out: f32 [B][H][W][Cout];
 // gn_part (may be null): [B][ds_conv3x3_c1_chunks(H, W)][2][Cout] doubles
@@ -223,9 +224,8 @@ extern "C" int ds_conv3x3_c1(const float* x, const float* w, const float* bias, 
     DS_CHECK_ARG(x && w && bias && out && B > 0 && H > 0 && W > 0, "bad arguments");
     DS_CHECK_ARG(Cout % 4 == 0 && Cout >= 4 && Cout <= 1024 && 1024 % Cout == 0, "Cout: a multiple of 4 that divides 1024");
     DS_CHECK_ARG((((uintptr_t)bias | (uintptr_t)out) & 15) == 0, "bias / out must be 16-byte aligned");
-    DS_CHECK_ARG(H <= 65535 && B <= 65535, "grid limits");
-    hipLaunchKernelGGL(ds_conv3x3_c1_kernel, dim3((W + C1_XS - 1) / C1_XS, H, B), dim3(256), 0, (hipStream_t)stream_, x, w, bias, out,
-                       H, W, Cout, gn_part);
+    DS_CHECK_ARG(W <= C1_WMAX && B <= 65535, "rows of at most 2046 pixels, at most 65535 samples");
+    hipLaunchKernelGGL(ds_conv3x3_c1_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream_, x, w, bias, out, H, W, Cout, gn_part);
     DS_CHECK_LAUNCH();
     return 0;
 }
