@@ -35,7 +35,7 @@ def _worker(rank, world, port, n_items, q):
         local = mine.sum((1, 2))[:, None] + noise
         out = shard.gather_outputs(local, n_items)
         if rank == 0:
-            q.put(out)
+            q.put(out.numpy().copy())            # numpy: pickled by value (a tensor travels as a shared fd the exiting worker may close)
         else:
             assert out is None
     finally:
@@ -57,7 +57,7 @@ def test_scatter_compute_gather(world, n_items):
     cond_all = torch.arange(n_items * 6, dtype=torch.float32).view(n_items, 2, 3)
     noise = shard.per_caption_noise(range(n_items), step=7, shape_tail=(5, 3), device=torch.device("cpu")).flatten(1)
     want = cond_all.sum((1, 2))[:, None] + noise          # what a single process would produce
-    assert torch.equal(out, want)
+    assert torch.equal(torch.from_numpy(out), want)
 
 
 def _caption_worker(rank, world, port, n_items, q):
@@ -75,7 +75,7 @@ def _caption_worker(rank, world, port, n_items, q):
         assert ids.shape == (hi - lo, 77) and ids.dtype == torch.long and len(mine) == hi - lo
         out = shard.gather_outputs(ids, n_items)
         if rank == 0:
-            q.put((out, tok([caps[i] for i in order])))
+            q.put((out.numpy().copy(), tok([caps[i] for i in order]).numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -94,7 +94,7 @@ def test_per_rank_tokenisation_equals_rank0_tokenise_then_scatter(world, n_items
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert torch.equal(got, want)
+    assert got.dtype == want.dtype and (got == want).all()
 
 
 def test_shard_bounds_cover_everything():
