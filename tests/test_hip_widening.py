@@ -429,3 +429,6 @@ def test_conv3x3_one_input_channel_direct(B, H, W, Cout):
     out2 = torch.full((B, H, W, Cout), float("nan"), device="cuda")
     L.check(L.lib().ds_conv3x3_c1(L.ptr(xc), L.ptr(wc), L.ptr(bc), L.ptr(out2), B, H, W, Cout, None, L.stream()))
     assert torch.equal(out, out2)
+    # a row wider than the kernel's LDS image, or a channel count it cannot split over a workgroup, is refused (not mis-computed)
+    assert L.lib().ds_conv3x3_c1(L.ptr(xc), L.ptr(wc), L.ptr(bc), L.ptr(out2), B, H, 2047, Cout, None, L.stream()) != 0
+    assert L.lib().ds_conv3x3_c1(L.ptr(xc), L.ptr(wc), L.ptr(bc), L.ptr(out2), B, H, W, 12, None, L.stream()) != 0
