@@ -227,7 +227,7 @@ def torch_split(a):
 
 @pytest.mark.parametrize("M,N,K", [(530, 1024, 1024), (300, 256, 1024), (530, 1024, 4096), (64, 96, 32), (1, 32, 64),
                                    (2100, 1024, 1024)])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
 def test_f16x2_packed_operands_bit_identical(M, N, K, tile):
     """A and W handed over as packed split planes (LDS-DMA staging) give the same bits as the loader-split GEMM on
     row-major operands; C written packed is the packed split of C."""
@@ -301,7 +301,7 @@ def test_f16x2_large_grids_all_launch_variants(M, N, K):
     L.gemm(A, W2, ref, M, N, K, bias=b, split2=sc)
     assert relerr(ref.cpu(), (A.double() @ W.double().t() + b.double()).float().cpu()) < 2e-6
     try:
-        for tile, slots in ((1, 512), (2, 512), (0, 1 << 30), (0, 512), (0, 64), (0, 1)):
+        for tile, slots in ((1, 512), (2, 512), (3, 512), (0, 1 << 30), (0, 512), (0, 64), (0, 1)):
             L.lib().ds_gemm_f16x2_force_tile(tile)
             L.lib().ds_gemm_f16x2_set_balance_slots(slots)
             for rep in range(2):
@@ -383,7 +383,7 @@ def test_gemm_attention_store_bit_identical():
     Wq2p, scq = L.split_f16x2(W[:D].contiguous(), packed=True)        # the cross-attention query projection alone
     refq = torch.empty(M, D, device="cuda")
     L.gemm(A2p, Wq2p, refq, M, D, K, bias=b, split2=scq, a_plane=M16 * K)
-    for slots, tile in ((512, -1), (8, 0), (512, 1), (512, 2)):     # (8, 0): these shapes take the hybrid path
+    for slots, tile in ((512, -1), (8, 0), (512, 1), (512, 2), (512, 3)):     # (8, 0): these shapes take the hybrid path
         L.lib().ds_gemm_f16x2_set_balance_slots(slots)
         L.lib().ds_gemm_f16x2_force_tile(tile)
         try:

@@ -430,7 +430,7 @@ def test_gemm_f16x2_packed_split_k_groups(L):
     scale = ref.abs().max().item()
     assert (one.cpu().double() - 0.5 * ref).abs().max().item() < 2e-6 * scale
     Kc = Mp // S
-    for tile in (-1, 0, 1, 2):
+    for tile in (-1, 0, 1, 2, 3):
         L.lib().ds_gemm_f16x2_force_tile(tile)
         try:
             part = torch.full((S, N * K), float("nan"), device="cuda")

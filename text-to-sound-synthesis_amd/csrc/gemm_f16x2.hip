@@ -47,14 +47,19 @@ typedef __attribute__((address_space(3))) void* ds_lptr;
 // removed them: none beat this loop by more than a few per cent on the shapes it still serves.)
 // (Round 5 measured a 2-wave form of the 128 x 64 tile -- wave tile 64 x 64, a third fewer LDS fragment bytes per MFMA -- on the
 // training step's packed shapes: 15-25 % SLOWER than this 4-wave form everywhere, profiles/r05n_*; removed.)
-template <int BM, int BN, int AMODE>
+// (Round 6: WGM x WGN = the wave grid.  2 x 2 everywhere but the 96 x 128 tile, whose four waves sit side by side (1 x 4: wave
+// tile 96 x 32) -- M = 5 300 training rows x N = 1024 columns are 448 such tiles = ONE round of the 512 resident slots, where
+// 128 x 128 leaves a third of the slots empty and 128 x 64 needs two rounds.)
+template <int BM, int BN, int AMODE, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid, const int nblk,
                                                    unsigned char* smem_raw) {
-    constexpr int WGM = 2, WGN = 2, NS = 2;
+    constexpr int NS = 2;
     constexpr int NW = WGM * WGN, NT = NW * 64;
+    static_assert(NW == 4, "256 threads");
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0, "wave tiles are made of 32x32 blocks");
     static_assert(AMODE == 0 || AMODE == 2, "0: fp32 A split by the loader, 2: packed split planes by LDS-DMA");
+    static_assert(AMODE == 2 || BM % 64 == 0, "register staging covers 64 rows per pass");
     constexpr int SA = BM / 64;   // 8-element (2 x float4) staging chunks per thread (A)
     constexpr int SB = BN / 64;   // 16-byte staging chunks per thread per plane (B)
     constexpr int APL = BM * HLD, BPL = BN * HLD;       // plane strides (halves)
@@ -444,7 +449,7 @@ __device__ __forceinline__ void ds_gemm_f16x2_body(const GemmParams& p, int bid,
 // blockIdx.y = group: A / W / C advance by the group strides -- the training step's split-K dW GEMMs are `groups` K-ranges
 // of one product (a_gstride = w_gstride = K per group for row-major operands; 16 K halves = K / 32 k-tiles for packed
 // operands, whose row groups stay lda / 32 k-tiles apart; partial results c_gstride apart)
-template <int BM, int BN, int AMODE>
+template <int BM, int BN, int AMODE, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     if (blockIdx.y != 0) {                // (0 in an ungrouped launch)
@@ -453,10 +458,10 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_kernel(const GemmParams 
         q.A = AMODE == 0 ? p.A + g * (size_t)p.a_gstride : (const float*)((const _Float16*)p.A + g * (size_t)p.a_gstride);
         q.W = (const float*)((const _Float16*)p.W + g * (size_t)p.w_gstride);
         q.C = p.C + g * (size_t)p.c_gstride;
-        ds_gemm_f16x2_body<BM, BN, AMODE>(q, blockIdx.x, gridDim.x, smem_dyn);
+        ds_gemm_f16x2_body<BM, BN, AMODE, WGM, WGN>(q, blockIdx.x, gridDim.x, smem_dyn);
         return;
     }
-    ds_gemm_f16x2_body<BM, BN, AMODE>(p, blockIdx.x, gridDim.x, smem_dyn);
+    ds_gemm_f16x2_body<BM, BN, AMODE, WGM, WGN>(p, blockIdx.x, gridDim.x, smem_dyn);
 }
 
 // Balanced launch for packed operands: the first `nbig` workgroups compute 128x128 tiles of the leading rows
@@ -493,12 +498,12 @@ static BalancePlan ds_balance_plan(int M, int N, int BM, int BN, int slots, int 
     return pl;
 }
 
-template <int BM, int BN, int AMODE>
+template <int BM, int BN, int AMODE, int WGM = 2, int WGN = 2>
 static int launch_h2(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * sizeof(unsigned short);
     static DsOnce attr_set;
     if (attr_set.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_kernel<BM, BN, AMODE>,
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_kernel<BM, BN, AMODE, WGM, WGN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("gemm_f16x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -507,7 +512,7 @@ static int launch_h2(const GemmParams& p, hipStream_t s) {
         attr_set.done();
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE>), dim3(tiles, p.groups > 1 ? p.groups : 1),
+    hipLaunchKernelGGL((ds_gemm_f16x2_kernel<BM, BN, AMODE, WGM, WGN>), dim3(tiles, p.groups > 1 ? p.groups : 1),
                        dim3(256), lds, s, p);
     DS_CHECK_LAUNCH();
     return 0;
@@ -632,19 +637,30 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     // ~235-250 TF-eq once the grid has >= 3 rounds of 512 resident blocks; below that 128x64 (3 blocks/CU,
     // ~205-230 TF-eq) quantises better; 64x64 (~190) only wins for tiny grids.
     int best;
-    if (g_force_tile_h >= 0 && g_force_tile_h <= 2) {
-        best = g_force_tile_h;
+    if (g_force_tile_h >= 0 && g_force_tile_h <= 3) {
+        best = g_force_tile_h == 3 && !p.a_split ? 1 : g_force_tile_h;     // (the 96-row tile exists for packed operands only)
     } else {
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.groups > 1 ? p.groups : 1);
         // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups; a packed split-K
         // launch (the training step's dW) from 1.5 rounds on (3072 x 1024 in 4 K-ranges: 118 vs 128 us,
         // profiles/r05g_train_gemm_packed_sweep.txt)
         best = t128 >= (p.a_split ? (p.groups > 1 ? 700 : 1000) : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
+        // Packed operands, one product (round 6, profiles/r06x_gemm_tile_batch_sweep.txt: M = 265 B rows, B = 4 .. 48, on the
+        // four layer shapes).  One workgroup alone on a CU runs a tile in ~0.6 of the time two co-resident ones take, so what
+        // counts is the most loaded CU: up to 256 tiles -> one each, up to 512 -> some CUs carry two.  The 96 x 128 tile turns
+        // 257 .. 341 tiles of 128 x 128 (two per CU somewhere, a third of the slots empty) into <= 512 tiles of 3/4 the work
+        // (-9 .. -18 %: every N = 1024 layer of the training step), and 129 .. 192 into <= 256 (-11 .. -19 %); between 342
+        // and 999 tiles the plain / balanced 128 x 128 launch beats 128 x 64 (0 .. -23 %: the old rule took 128 x 64 there).
+        if (p.a_split && p.groups <= 1 && t128 >= 128) {
+            const long t96 = (long)((p.M + 95) / 96) * ((p.N + 127) / 128);
+            best = t96 <= 256 ? 3 : t128 <= 256 ? 1 : t96 <= 512 ? 3 : 0;
+        }
     }
-    g_last_tile = best;
+    g_last_tile = best == 3 ? 5 : best;          // (3 and 4 name the per-sample programs above)
     switch (best) {
         case 0: return p.a_split && p.groups <= 1 ? launch_hybrid(p, stream) : launch_h<128, 128>(p, stream);
         case 1: return launch_h<128, 64>(p, stream);
+        case 3: return launch_h2<96, 128, 2, 1, 4>(p, stream);
         default: return launch_h<64, 64>(p, stream);
     }
 }

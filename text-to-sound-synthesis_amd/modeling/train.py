@@ -217,10 +217,11 @@ class _SplitGemm:
         """K-ranges of a dW = dY^T X launch over M rows, from the measured sweep of the packed kernel INCLUDING the fixed-order
         reduction of the partial results (tools/train_gemm_ab.py -> profiles/r05g_train_gemm_packed_sweep.txt, M = 5300 / 1540):
         >= 256 tiles of 128 x 128 (fc1 / fc2: half a round of the chip) run unsplit -- the partials' write + re-read costs more
-        than the idle slots (133 vs 148 us); smaller products take 4 ranges (1024 x 1024: 48 us against 52 at 8, 83 unsplit;
-        3072 x 1024: 118 against 124 unsplit), 2 when the contraction itself is short (the caption rows: 22 us against 31 at 8)."""
+        than the idle slots (133 vs 148 us); so does 3072 x 1024 since round 6 (256 tiles of 96 x 128, one per CU: 111 us against
+        118 in 4 ranges, profiles/r06x_train_gemm_tile_sweep.txt); smaller products take 4 ranges (1024 x 1024: 48 us against 52
+        at 8, 83 unsplit), 2 when the contraction itself is short (the caption rows: 22 us against 31 at 8)."""
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        if tiles >= 256:
+        if tiles >= 192:
             return 1
         return 4 if M >= 4096 else 2
 

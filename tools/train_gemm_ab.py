@@ -50,7 +50,7 @@ for name, M, N, K in FWD:
     Wp, wpl = pack(W, N, K)
     out = torch.empty(M, N, device="cuda")
     fl, row, ref = 2.0 * M * N * K, [], None
-    for tile in (-1, 0, 1, 2):
+    for tile in (-1, 0, 1, 2, 3):
         L.lib().ds_gemm_f16x2_force_tile(tile)
         out.fill_(float("nan"))
         t = timeit(lambda: L.gemm(Ap, Wp, out, M, N, K, split2=1.0, a_plane=apl, w_plane=wpl))
@@ -67,14 +67,14 @@ for name, N, K, M in DW:
     fl = 2.0 * M * N * K
     dW = torch.empty(N, K, device="cuda")
     best = None
-    for S in (1, 2, 4):
+    for S in (1, 2, 3, 4, 5, 6):
         Mp = (M + 32 * S - 1) // (32 * S) * (32 * S)
         a, apl = pack(dY, M, N, Mp)
         w, wpl = pack(X, M, K, Mp)
         part = torch.empty(S, N * K, device="cuda")
         Kc = Mp // S
         row = []
-        for tile in (0, 1, 2):
+        for tile in (0, 1, 2, 3):
             L.lib().ds_gemm_f16x2_force_tile(tile)
 
             def run():
@@ -125,3 +125,25 @@ for name, M, N, K in (("fwd fc2 / dX fc1 as split-K", M0, 1024, 4096), ("dX qkv 
             row.append("t%d %6.1f us (GEMM alone %6.1f) %5.1f TF" % (tile, t, tg, fl / t / 1e6))
         L.lib().ds_gemm_f16x2_force_tile(-1)
         print("%s M=%d N=%d K=%d S=%d | %s" % (name, M, N, K, S, " | ".join(row)), flush=True)
+
+# ---- round 6: which tile wins where -- rows M = 265 B for B = 4 .. 48 on the four forward shapes, tiles 0 (128 x 128 / hybrid),
+# 1 (128 x 64), 2 (64 x 64), 3 (96 x 128, four waves side by side); '*' marks what the dispatcher takes on its own
+if "--batch-sweep" in sys.argv:
+    for B in (4, 8, 12, 16, 20, 24, 28, 32, 40, 48):
+        M = 265 * B
+        for N, K in ((1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096)):
+            A = torch.randn(M, K, device="cuda")
+            W = torch.randn(N, K, device="cuda")
+            Ap, apl = pack(A, M, K)
+            Wp, wpl = pack(W, N, K)
+            out = torch.empty(M, N, device="cuda")
+            row = []
+            ts = {}
+            for tile in (-1, 0, 1, 2, 3):
+                L.lib().ds_gemm_f16x2_force_tile(tile)
+                ts[tile] = timeit(lambda: L.gemm(Ap, Wp, out, M, N, K, split2=1.0, a_plane=apl, w_plane=wpl), n=20)
+            L.lib().ds_gemm_f16x2_force_tile(-1)
+            best = min((t for t in ts if t >= 0), key=lambda t: ts[t])
+            print("B=%2d M=%5d N=%4d K=%4d | auto %6.1f | %s | best t%d %+.0f%% vs auto | t128 %4d t96 %4d" % (
+                B, M, N, K, ts[-1], " ".join("t%d %6.1f" % (t, ts[t]) for t in (0, 1, 2, 3)), best,
+                100.0 * (ts[best] / ts[-1] - 1.0), -(-M // 128) * -(-N // 128), -(-M // 96) * -(-N // 128)), flush=True)
