@@ -104,6 +104,29 @@ def test_colsum_chunked(L, G, R, C):
     assert (acc.cpu().double() - 1.0 - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("G,R,C", [(1, 83, 1024), (1, 83, 4096), (2, 18, 100), (1, 16, 64), (3, 37, 1000)])
+def test_colsum_small_launch_keeps_the_chain_order(L, G, R, C):
+    """ds_colsum on few, long columns (the bias gradients: 83 row-tile partials) runs the four interleaved chains of a column on four
+    threads: the result is bit-for-bit the one-thread order  (s0 + s1) + (s2 + s3),  s_j = rows j, j + 4, ... in turn, the R % 4
+    tail rows joining s0 -- reproduced here in fp32 on the host."""
+    x = rnd((G * R, C), "cs4.%d.%d" % (R, C), 2.0)
+    xs = x.view(G, R, C)
+    R4 = R - R % 4
+    ch = [torch.zeros(G, C) for _ in range(4)]
+    for r in range(R4):
+        ch[r % 4] = ch[r % 4] + xs[:, r]
+    for r in range(R4, R):
+        ch[0] = ch[0] + xs[:, r]
+    want = (ch[0] + ch[1]) + (ch[2] + ch[3])
+    xc = x.cuda()
+    out = torch.full((G, C), float("nan"), device="cuda")
+    L.check(L.lib().ds_colsum(L.ptr(xc), L.ptr(out), G, R, C, C, R * C, 0, L.stream()))
+    assert torch.equal(out.cpu(), want)
+    acc = torch.ones(G, C, device="cuda")
+    L.check(L.lib().ds_colsum(L.ptr(xc), L.ptr(acc), G, R, C, C, R * C, 1, L.stream()))
+    assert torch.equal(acc.cpu(), 1.0 + want)
+
+
 def test_gelu2_forward_backward(L):
     x = rnd((300, 4096), "g2.x", 6.0).double().requires_grad_(True)
     dy = rnd((300, 4096), "g2.dy")

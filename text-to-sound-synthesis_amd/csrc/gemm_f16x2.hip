@@ -653,7 +653,8 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
         // and 999 tiles the plain / balanced 128 x 128 launch beats 128 x 64 (0 .. -23 %: the old rule took 128 x 64 there).
         if (p.a_split && p.groups <= 1 && t128 >= 128) {
             const long t96 = (long)((p.M + 95) / 96) * ((p.N + 127) / 128);
-            best = t96 <= 256 ? 3 : t128 <= 256 ? 1 : t96 <= 512 ? 3 : 0;
+            // (193 .. 256 tiles of 128 x 128 -- one per CU, most CUs busy -- beat 128 x 64 by 0 .. 6 %: the fc1 / fc2 dW)
+            best = t96 <= 256 ? 3 : t128 <= 256 ? (t128 > 192 ? 0 : 1) : t96 <= 512 ? 3 : 0;
         }
     }
     g_last_tile = best == 3 ? 5 : best;          // (3 and 4 name the per-sample programs above)

@@ -214,9 +214,53 @@ __global__ __launch_bounds__(256) void ds_colsum_kernel(const float* __restrict_
     *o = accumulate ? *o + s : s;
 }
 
+// The same sums, same order, for launches too small to hide a chain of R dependent row visits (the bias gradients: 83 row-tile
+// partials x 1024 .. 4096 columns were 4 .. 16 workgroups walking 83 rows each, ~8 us a call, 133 calls per training
+// iteration): the four interleaved chains s0 .. s3 of a column go to four threads (one per wave: a wave still reads 64
+// consecutive floats), combined through LDS as (s0 + s1) + (s2 + s3); the R % 4 tail rows join chain 0 as above.
+__global__ __launch_bounds__(256) void ds_colsum4_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C,
+                                                         long long ld, long long gstride, int accumulate) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float s = 0.f;
+    if (c < C) {
+        const float* p = x + (size_t)blockIdx.y * gstride + c;
+        const int R4 = R & ~3;
+        int r = ch;
+        // a chain's loads go out in batches (16, then 4, then single rows) and are added in row order: with one load per loop
+        // trip every row cost a full memory latency (~0.45 us: 83 rows = 10 us a call)
+#define CS4_BATCH(NB)                                                      \
+        for (; r + 4 * (NB - 1) < R4; r += 4 * NB) {                       \
+            float v[NB];                                                   \
+            _Pragma("unroll") for (int k = 0; k < NB; ++k) v[k] = p[(size_t)(r + 4 * k) * ld]; \
+            _Pragma("unroll") for (int k = 0; k < NB; ++k) s += v[k];      \
+        }
+        CS4_BATCH(16)
+        CS4_BATCH(4)
+        CS4_BATCH(1)
+#undef CS4_BATCH
+        if (ch == 0)
+            for (int r2 = R4; r2 < R; ++r2) s += p[(size_t)r2 * ld];
+    }
+    part[ch][cx] = s;
+    __syncthreads();
+    if (ch == 0 && c < C) {
+        const float t = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+        float* o = out + (size_t)blockIdx.y * C + c;
+        *o = accumulate ? *o + t : t;
+    }
+}
+
 extern "C" int ds_colsum(const float* x, float* out, int G, int R, int C, long long ld, long long gstride, int accumulate,
                          ds_stream_t stream) {
     DS_CHECK_ARG(x && out && G > 0 && R > 0 && C > 0 && ld >= C, "bad arguments");
+    if (R >= 16 && (long long)((C + 255) / 256) * G < 256) {      // few workgroups, long chains: one thread per chain
+        hipLaunchKernelGGL(ds_colsum4_kernel, dim3((C + 63) / 64, G), dim3(256), 0, (hipStream_t)stream, x, out, R, C, ld, gstride,
+                           accumulate);
+        DS_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(ds_colsum_kernel, dim3((C + 255) / 256, G), dim3(256), 0, (hipStream_t)stream, x, out, R, C, ld, gstride,
                        accumulate);
     DS_CHECK_LAUNCH();

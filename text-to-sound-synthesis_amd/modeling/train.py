@@ -202,6 +202,7 @@ class _SplitGemm:
 
     def __init__(self):
         self.wexp = {}              # key -> s: the weight is split as W * 2^s (max |W| 2^s in [2^13, 2^14))
+        self.rows_per_sample = 0    # token rows per sample of the activations (set by the step; 0: unknown)
 
     @staticmethod
     def scales_of(lins):
@@ -253,8 +254,10 @@ class _SplitGemm:
         M = xp.rows
         y = torch.empty(M, lin.N, device=xp.row.device)
         Wp = lin.extra["Wp"]
+        # (rows_per_sample: lets the dispatcher take the sampling loop's per-sample 272 x 256 program where its grid pays --
+        #  the 20 x 12 tiles of the QKV projection, 91 us against 101; same bits, tests/test_hip_widening.py)
         return L_.gemm(xp.row, Wp.row, y, M, lin.N, lin.K, bias=lin.b, R=R, split2=lin.extra["osc"], a_plane=xp.row_plane,
-                       w_plane=Wp.row_plane)
+                       w_plane=Wp.row_plane, rows_per_sample=self.rows_per_sample if M % max(1, self.rows_per_sample) == 0 else 0)
 
     def dx(self, lin, dyp, unscale=1.0):
         """unscale: 2^-e of the site's own scale, folded into the epilogue's output scale (exact: powers of two)"""
@@ -691,6 +694,7 @@ class TrainStep:
         D, H, K = tr.n_embd, tr.n_head, tr.num_codes
         M = B * Lx
         T = dt.num_timesteps
+        G_.rows_per_sample = Lx
         blocks, lin_logits = self._linears()
         all_lins = [l for b in blocks for l in b.values()] + [lin_logits]
         if self.precision == "f16x2" and (not G_.wexp or (self._steps % self.rescale_interval == 0 and not calibrating

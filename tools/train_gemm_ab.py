@@ -147,3 +147,23 @@ if "--batch-sweep" in sys.argv:
             print("B=%2d M=%5d N=%4d K=%4d | auto %6.1f | %s | best t%d %+.0f%% vs auto | t128 %4d t96 %4d" % (
                 B, M, N, K, ts[-1], " ".join("t%d %6.1f" % (t, ts[t]) for t in (0, 1, 2, 3)), best,
                 100.0 * (ts[best] / ts[-1] - 1.0), -(-M // 128) * -(-N // 128), -(-M // 96) * -(-N // 128)), flush=True)
+
+# ---- round 6: the per-sample programs of the sampling loop (gemm_f16x2_ps.hip: 272 x 256 tiles, 8 waves, one workgroup per CU;
+# force_tile 9 = whole-sample tiles, 10 = half tiles) on the training step's 20 samples of 265 rows
+if "--per-sample" in sys.argv:
+    for name, M, N, K in FWD[:5]:
+        A = torch.randn(M, K, device="cuda")
+        W = torch.randn(N, K, device="cuda")
+        Ap, apl = pack(A, M, K)
+        Wp, wpl = pack(W, N, K)
+        out = torch.empty(M, N, device="cuda")
+        ref = torch.empty(M, N, device="cuda")
+        L.gemm(Ap, Wp, ref, M, N, K, split2=1.0, a_plane=apl, w_plane=wpl)
+        fl, row = 2.0 * M * N * K, []
+        for tile in (-1, 9, 10):
+            L.lib().ds_gemm_f16x2_force_tile(tile)
+            out.fill_(float("nan"))
+            t = timeit(lambda: L.gemm(Ap, Wp, out, M, N, K, split2=1.0, a_plane=apl, w_plane=wpl, rows_per_sample=265), n=20)
+            row.append("%s %6.1f us %5.1f TF%s" % ("auto" if tile < 0 else "t%d" % tile, t, fl / t / 1e6, "" if torch.equal(out, ref) else " DIFF"))
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+        print("%s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
