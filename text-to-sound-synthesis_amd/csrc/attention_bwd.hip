@@ -225,27 +225,38 @@ __device__ __forceinline__ void ab_rows_times_reg_h(f32x16& acc, const _Float16*
 }
 // out[i = lane's own index][d] += sum over the 32 register rows of `tile`: (wscale W[i][row]) * Z_lds[row][d].  MFMA m (0, 1)
 // contracts the 16 rows held in accumulator registers 8m .. 8m+7 of the two lane halves: k-slot (hh, e) <-> row
-// (e & 3) + 8 (2m + (e >> 2)) + 4 hh -- the A operand is the lane's own registers, the B operand 8 scalar LDS reads.
+// (e & 3) + 8 (2m + (e >> 2)) + 4 hh -- the A operand is the lane's own registers; the B operand is one COLUMN d of 4 + 4
+// consecutive LDS rows per lane: two transposing reads (ds_read_b64_tr_b16: the 16 lanes of a group address a [4 rows][16 d]
+// block, lane 4 j + r the four halves at (row0 + j, d0 + 4 r), and lane l receives column d0 + l of the four rows; lane map
+// measured in tools/probe/tr/).  Rounds 5-6 read it with 8 ds_read_u16 + byte permutes per fragment: 1152 two-byte LDS reads
+// and ~600 v_perm of the kv kernel's 11 000 instructions.
+typedef short ab_v4s __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ ab_h8 ab_tr8(const _Float16* p0, const _Float16* p1) {
+    union { struct { ab_v4s a, b; } q; ab_h8 v; } u;
+    u.q.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ab_v4s*)p0);
+    u.q.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ab_v4s*)p1);
+    return u.v;
+}
 template <int NT>
 __device__ __forceinline__ void ab_reg_times_rows_split(f32x16& o0, f32x16& o1, const f32x16& w, const _Float16* __restrict__ lds,
                                                         int tile, int l31, int hh, float wscale) {
-    const int c0 = l31 >> 3, d7 = l31 & 7;                 // d = l31 (o0) and 32 + l31 (o1): chunks c0 and 4 + c0
+    // this lane's read address inside a [4 rows][16 d] block: row 4 hh + (l >> 2), d = 16 (l31 >> 4) + 4 (l & 3) (+ 32 for o1)
+    const int rl = 4 * hh + ((l31 >> 2) & 3), cq = l31 & 3, ch = 2 * (l31 >> 4) + (cq >> 1);       // (rl < 8 = its swizzle key)
+    const _Float16* zb = lds + (tile * 32 + rl) * 64 + (cq & 1) * 4;
+    const _Float16* z0 = zb + ((ch ^ rl) << 3);
+    const _Float16* z1 = zb + (((4 + ch) ^ rl) << 3);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        ab_h8 wh, wl, z0h, z0l, z1h, z1l;
+        ab_h8 wh, wl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float wv = w[8 * m + e] * wscale;
             wh[e] = ds_split_hi(wv);
             wl[e] = ds_split_lo(wv, wh[e]);
-            const int row = tile * 32 + (e & 3) + 8 * (2 * m + (e >> 2)) + 4 * hh;
-            const _Float16* zr = lds + row * 64 + d7;
-            const int o0f = (c0 ^ (row & 7)) << 3, o1f = ((4 + c0) ^ (row & 7)) << 3;
-            z0h[e] = zr[o0f];
-            z0l[e] = zr[AB_HPLANE(NT) + o0f];
-            z1h[e] = zr[o1f];
-            z1l[e] = zr[AB_HPLANE(NT) + o1f];
         }
+        // rows 16 m + 4 hh + 0..3 (k-slots e = 0..3) and + 8 (e = 4..7): 1024 and 512 halves apart
+        const ab_h8 z0h = ab_tr8(z0 + m * 1024, z0 + m * 1024 + 512), z0l = ab_tr8(z0 + AB_HPLANE(NT) + m * 1024, z0 + AB_HPLANE(NT) + m * 1024 + 512);
+        const ab_h8 z1h = ab_tr8(z1 + m * 1024, z1 + m * 1024 + 512), z1l = ab_tr8(z1 + AB_HPLANE(NT) + m * 1024, z1 + AB_HPLANE(NT) + m * 1024 + 512);
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, z0h, o0, 0, 0, 0);
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, z0l, o0, 0, 0, 0);
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, z0h, o0, 0, 0, 0);
