@@ -117,6 +117,31 @@ def test_f16x2_per_sample_program_bit_identical(B, N, K):
         L.lib().ds_gemm_f16x2_force_tile(-1)
 
 
+@pytest.mark.parametrize("B,N,K", [(20, 4096, 128), (35, 4096, 64), (17, 4096, 256), (70, 1024, 64)])
+def test_f16x2_leading_samples_on_the_per_sample_program(B, N, K):
+    """With rows_per_sample given, a batch whose per-sample tiles do not fill whole rounds of the chip (20 samples x 16 column
+    tiles = 1.25 rounds) runs its leading whole rounds (16 samples) on the per-sample program and the rest as a second, smaller
+    launch: the same bits as one launch of a 4-wave tile, with bias and an in-place residual, nothing written past row M."""
+    from test_hip_split_gemm import rnd, torch_split
+    from text_to_sound_synthesis_amd import _lib as L
+    Lq = 265
+    M = B * Lq
+    A, W, b, R = rnd((M, K), "ls.A", 2.0).cuda(), rnd((N, K), "ls.W", 0.05).cuda(), rnd((N,), "ls.b").cuda(), rnd((M, N), "ls.R").cuda()
+    W2p, sc = L.split_f16x2(W, packed=True)
+    A2p = L.pack_planes(torch_split(A))
+    M16 = (M + 15) // 16 * 16
+    L.lib().ds_gemm_f16x2_force_tile(1)
+    try:
+        ref = R.clone()
+        L.gemm(A2p, W2p, ref, M, N, K, bias=b, R=ref, split2=sc, a_plane=M16 * K)
+    finally:
+        L.lib().ds_gemm_f16x2_force_tile(-1)
+    out = torch.full((M + 40, N), float("nan"), device="cuda")
+    out[:M] = R
+    L.gemm(A2p, W2p, out, M, N, K, bias=b, R=out, split2=sc, a_plane=M16 * K, rows_per_sample=Lq)
+    assert torch.equal(out[:M], ref) and torch.isnan(out[M:]).all()
+
+
 @pytest.mark.parametrize("B", [1, 3, 8])
 def test_f16x2_per_sample_program_attention_store_bit_identical(B):
     """The attention-ready stores (QKV: Q planes, K image, V^T image; cross-attention Q alone) through the per-sample

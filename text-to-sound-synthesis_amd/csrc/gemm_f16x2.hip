@@ -632,6 +632,29 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
             g_last_tile = 4;
             return ds_launch_gemm_f16x2_ph(p, stream);
         }
+        // Round 6: the grid rule said no because the samples do not fill whole rounds of the chip -- but a LEADING run of
+        // samples may: B = 20 samples x N = 4096 columns are 320 per-sample tiles = 1.25 rounds (0.62), while the first 16
+        // samples are exactly one round.  Those go to the per-sample program, the rest (its own, smaller problem: the rules
+        // below) follows in a second launch: the training step's fc1 forward / fc2 dX 148 -> ~130 us.  Row-major stores only
+        // (the second launch's operand / output offsets are whole 16-row groups: 16 samples x 265 rows).
+        if (pick == 0 && g_force_tile_h < 0 && p.groups <= 1 && p.a_split && p.rows_per_sample > 0 && p.store == DS_STORE_ROW &&
+            !p.c_split && p.M % p.rows_per_sample == 0 && p.N % 256 == 0 && 256 % (p.N / 256) == 0) {
+            const int L = p.rows_per_sample, B = p.M / L, per_round = 256 / (p.N / 256);
+            const int nfull = B / per_round * per_round;
+            GemmParams pa = p;
+            pa.M = nfull * L;
+            if (nfull > 0 && nfull < B && pa.M % 16 == 0 && ds_gemm_f16x2_ps_pick(pa) == 1) {
+                g_last_tile = 3;
+                const int rc = ds_launch_gemm_f16x2_ps(pa, stream);
+                if (rc != 0) return rc;
+                GemmParams pb = p;
+                pb.M = p.M - pa.M;
+                pb.A = (const float*)((const _Float16*)p.A + (size_t)(pa.M / 16) * (p.lda / HBK) * 512);
+                pb.C = p.C + (size_t)pa.M * p.ldc;
+                if (p.R) pb.R = p.R + (size_t)pa.M * p.ldr;
+                return ds_launch_gemm_f16x2(pb, stream);
+            }
+        }
     }
     // Tile choice from the measured sweep (profiles/r01_gemm_tile_sweep_f16x2.txt, B=64): 128x128 reaches
     // ~235-250 TF-eq once the grid has >= 3 rounds of 512 resident blocks; below that 128x64 (3 blocks/CU,

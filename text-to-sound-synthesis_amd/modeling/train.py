@@ -267,7 +267,7 @@ class _SplitGemm:
         Np = Wp.rows_pad                                       # contraction length of dX = dY W (N, a multiple of 32 here)
         assert Np == lin.N, "dX needs N % 32 == 0 (true for every linear of this network)"
         return L_.gemm(dyp.row, Wp.t, out, M, lin.K, Np, split2=lin.extra["osc"] * unscale, a_plane=dyp.row_plane,
-                       w_plane=Wp.t_plane)
+                       w_plane=Wp.t_plane, rows_per_sample=self.rows_per_sample if M % max(1, self.rows_per_sample) == 0 else 0)
 
     def dw(self, lin, xp, dyp, inv_scale):
         N, K, Mp = lin.N, lin.K, dyp.rows_pad
