@@ -728,20 +728,23 @@ class TrainStep:
         # operand handles (G_.prep_x): the forward's GEMM input AND the X^T of the same layer's dW, made in one pass; the
         # caption embedding feeds every block's cross K | V projection (same K, same padded contraction: one handle)
         cond_h = G_.prep_x(blocks[0]["kv2"], cond)
-        # the 2 n_layer AdaLN tables  Linear(SiLU(Emb))  (transformer_utils.py:145-147) as ONE grouped exact-fp32 GEMM (the
-        # per-module AdaLayerNorm.table() is the same kernel with the bias in its epilogue: identical values)
+        # the 2 n_layer AdaLN modulations  Linear(SiLU(Emb(t_b)))  (transformer_utils.py:145-147) as ONE grouped exact-fp32 GEMM over
+        # the batch's OWN timesteps -- B rows per module, as the reference computes them (the sampling loop tabulates all T rows
+        # once; here the weights change every iteration and a table of 100 rows was 5x the work: 416 -> 90 us, and as much again
+        # in the backward).  The AdaLN kernels index the [B][2D] rows with sample_rows = 0 .. B-1.
         lns = [ln for blk in tr.blocks for ln in (blk.ln1, blk.ln1_1)]
-        ada_E = torch.stack([ln.emb.weight.detach() for ln in lns])                    # [G][T][D]
+        ada_E = torch.stack([ln.emb.weight.detach() for ln in lns]).index_select(1, t)   # [G][B][D] = Emb(t_b)
         ada_W = torch.stack([ln.linear.weight.detach() for ln in lns])                 # [G][2D][D]
-        tabs = torch.empty(len(lns), T, 2 * D, device=dev)
-        L_.gemm(torch.nn.functional.silu(ada_E), ada_W, tabs, T, 2 * D, D, groups=len(lns), a_gstride=T * D,
-                w_gstride=2 * D * D, c_gstride=T * 2 * D)
+        sample_rows = torch.arange(B, device=dev)
+        tabs = torch.empty(len(lns), B, 2 * D, device=dev)
+        L_.gemm(torch.nn.functional.silu(ada_E), ada_W, tabs, B, 2 * D, D, groups=len(lns), a_gstride=B * D,
+                w_gstride=2 * D * D, c_gstride=B * 2 * D)
         tabs += torch.stack([ln.linear.bias.detach() for ln in lns])[:, None, :]
         saved = []
         for li, (blk, ls) in enumerate(zip(tr.blocks, blocks)):
             s = {"x0": x}
             s["tab1"] = tabs[2 * li]
-            s["h1"] = h = G_.prep_x(ls["qkv1"], _norm_fwd(x, 0, Lx, table=s["tab1"], t=t))
+            s["h1"] = h = G_.prep_x(ls["qkv1"], _norm_fwd(x, 0, Lx, table=s["tab1"], t=sample_rows))
             qkv = G_.fwd(ls["qkv1"], h)                                             # [M][3D]: q | k | v
             if fused:
                 s["att1"] = _FusedAttn((qkv, 0, 3 * D), (qkv, D, 3 * D), (qkv, 2 * D, 3 * D), B, Lx, Lx, H, split=self.split_attention)
@@ -751,7 +754,7 @@ class TrainStep:
             x = G_.fwd(ls["proj1"], s["o1"], R=x)
             s["x1"] = x
             s["tab2"] = tabs[2 * li + 1]
-            s["h2"] = h = G_.prep_x(ls["q2"], _norm_fwd(x, 0, Lx, table=s["tab2"], t=t))
+            s["h2"] = h = G_.prep_x(ls["q2"], _norm_fwd(x, 0, Lx, table=s["tab2"], t=sample_rows))
             q = G_.fwd(ls["q2"], h)
             kv = G_.fwd(ls["kv2"], cond_h)                                          # [B*Lc][2D]: k | v
             if fused:
@@ -825,7 +828,7 @@ class TrainStep:
         g["transformer.to_logits.0.weight"], g["transformer.to_logits.0.bias"] = dgam[0], dbet[0]
         small += [dgam, dbet]
 
-        Tp = _ceil(T, 32)
+        Bp = _ceil(B, 32)
 
         ada = []                    # (AdaLayerNorm module, d scale [B][D], d shift [B][D], parameter prefix): batched below
 
@@ -835,31 +838,30 @@ class TrainStep:
             ada.append((ln, both, None, pfx))
 
         def adaln_param_grads_all():
-            """d table[t_b] rows -> emb.weight / linear.{weight, bias} through  table = Linear(SiLU(emb))  (AdaLayerNorm,
-            transformer_utils.py:134-149) for ALL 2 n_layer AdaLN modules at once: dW = dtab^T silu(e), db = column sums of
-            dtab, de = (dtab W) silu'(e) as two GROUPED exact-fp32 GEMMs (one group per module) instead of two small GEMMs,
-            three transposing copies and a dozen elementwise launches per module (4 ms of an 82 ms iteration in round 4)."""
+            """d modulation rows [B][2D] -> emb.weight / linear.{weight, bias} through  mod_b = Linear(SiLU(emb[t_b]))  (AdaLayerNorm,
+            transformer_utils.py:134-149) for ALL 2 n_layer AdaLN modules at once: dW = dmod^T silu(e_b), db = column sums of
+            dmod, de[t_b] += (dmod_b W) silu'(e_b) as two GROUPED exact-fp32 GEMMs over the B samples (one group per module)
+            instead of two small GEMMs, three transposing copies and a dozen elementwise launches per module (4 ms of an 82 ms
+            iteration in round 4; over all T table rows until round 6)."""
             G = len(ada)
             if G == 0:
                 return
-            dmod = torch.stack([both for _, both, _, _ in ada])                                     # [G][B][2D]
-            dtab = torch.zeros(G, T, 2 * D, device=dev)
-            dtab.index_add_(1, t, dmod)
-            dtab.mul_(inv)
+            dmod = torch.stack([both for _, both, _, _ in ada]) * inv                               # [G][B][2D]
             order = [lns.index(ln) for ln, _, _, _ in ada]                                         # (the backward visits the blocks last first)
-            E = torch.stack([ada_E[i] for i in order])         # [G][T][D]  (views + stack: no host index tensor, capturable)
+            E = torch.stack([ada_E[i] for i in order])         # [G][B][D]  (views + stack: no host index tensor, capturable)
             sg = torch.sigmoid(E)
-            dtabT = torch.zeros(G, 2 * D, Tp, device=dev)                                          # K = T padded to 32
-            dtabT[:, :, :T] = dtab.transpose(1, 2)
-            sT = torch.zeros(G, D, Tp, device=dev)
-            sT[:, :, :T] = (E * sg).transpose(1, 2)
-            dw = torch.empty(G, 2 * D, D, device=dev)                                              # dW[g] = dtab[g]^T silu(e[g])
-            L_.gemm(dtabT, sT, dw, 2 * D, D, Tp, groups=G, a_gstride=2 * D * Tp, w_gstride=D * Tp, c_gstride=2 * D * D)
+            dmodT = torch.zeros(G, 2 * D, Bp, device=dev)                                          # K = B padded to 32
+            dmodT[:, :, :B] = dmod.transpose(1, 2)
+            sT = torch.zeros(G, D, Bp, device=dev)
+            sT[:, :, :B] = (E * sg).transpose(1, 2)
+            dw = torch.empty(G, 2 * D, D, device=dev)                                              # dW[g] = dmod[g]^T silu(e_b[g])
+            L_.gemm(dmodT, sT, dw, 2 * D, D, Bp, groups=G, a_gstride=2 * D * Bp, w_gstride=D * Bp, c_gstride=2 * D * D)
             wT = torch.stack([ada_W[i].t() for i in order])    # [G][D][2D] (stack of transposed views = one transposing copy)
-            ds_ = torch.empty(G, T, D, device=dev)                                                 # dtab[g] W[g]
-            L_.gemm(dtab, wT, ds_, T, D, 2 * D, groups=G, a_gstride=T * 2 * D, w_gstride=D * 2 * D, c_gstride=T * D)
-            de = ds_ * (sg * (1.0 + E * (1.0 - sg)))
-            dbias = dtab.sum(1)                                                                    # [G][2D]
+            ds_ = torch.empty(G, B, D, device=dev)                                                 # dmod[g] W[g]
+            L_.gemm(dmod, wT, ds_, B, D, 2 * D, groups=G, a_gstride=B * 2 * D, w_gstride=D * 2 * D, c_gstride=B * D)
+            de = torch.zeros(G, T, D, device=dev)
+            de.index_add_(1, t, ds_ * (sg * (1.0 + E * (1.0 - sg))))                               # samples that share a timestep add up
+            dbias = dmod.sum(1)                                                                    # [G][2D]
             for i, (_, _, _, pfx) in enumerate(ada):
                 g[pfx + ".emb.weight"], g[pfx + ".linear.weight"], g[pfx + ".linear.bias"] = de[i], dw[i], dbias[i]
 
@@ -886,7 +888,7 @@ class TrainStep:
             _, dWkv, dbkv = lin_bwd(ls["kv2"], cond_h, dkv, need_dx=False)
             g[p + "attn2.key.weight"], g[p + "attn2.value.weight"] = dWkv[:D], dWkv[D:]
             g[p + "attn2.key.bias"], g[p + "attn2.value.bias"] = dbkv[:D], dbkv[D:]
-            _, dsc, dsh = _norm_bwd(s["x1"], dh, 0, Lx, table=s["tab2"], t=t, add_to=dx)
+            _, dsc, dsh = _norm_bwd(s["x1"], dh, 0, Lx, table=s["tab2"], t=sample_rows, add_to=dx)
             adaln_param_grads(blk.ln1_1, dsc, dsh, p + "ln1_1")
             # x1 = x0 + proj1(attn1(qkv(ln1(x0))))
             dao, g[p + "attn1.proj.weight"], g[p + "attn1.proj.bias"] = lin_bwd(ls["proj1"], s["o1"], dx)
@@ -899,7 +901,7 @@ class TrainStep:
             dh, dWqkv, dbqkv = lin_bwd(ls["qkv1"], s["h1"], dqkv)
             for j, nm in enumerate(("query", "key", "value")):
                 g[p + "attn1.%s.weight" % nm], g[p + "attn1.%s.bias" % nm] = dWqkv[j * D:(j + 1) * D], dbqkv[j * D:(j + 1) * D]
-            _, dsc, dsh = _norm_bwd(s["x0"], dh, 0, Lx, table=s["tab1"], t=t, add_to=dx)
+            _, dsc, dsh = _norm_bwd(s["x0"], dh, 0, Lx, table=s["tab1"], t=sample_rows, add_to=dx)
             adaln_param_grads(blk.ln1, dsc, dsh, p + "ln1")
             hand_over([p + n for n in ("mlp.2.weight", "mlp.0.weight", "attn2.proj.weight", "attn2.query.weight",
                                        "attn2.key.weight", "attn2.value.weight", "attn1.proj.weight", "attn1.query.weight",
