@@ -250,9 +250,12 @@ __device__ __forceinline__ void ab_reg_times_rows_split(f32x16& o0, f32x16& o1, 
         ab_h8 wh, wl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+#pragma clang fp contract(off)
+            // (no saturation clamps here, unlike ds_split_hi / _lo: w * wscale is a probability x 2^10 or a dS tile the wave has
+            //  just normalised to [2^8, 2^9) -- two v_med3 per value, 768 of the kv kernel's instructions, guarded nothing)
             const float wv = w[8 * m + e] * wscale;
-            wh[e] = ds_split_hi(wv);
-            wl[e] = ds_split_lo(wv, wh[e]);
+            wh[e] = (_Float16)wv;
+            wl[e] = (_Float16)(wv - (float)wh[e]);
         }
         // rows 16 m + 4 hh + 0..3 (k-slots e = 0..3) and + 8 (e = 4..7): 1024 and 512 halves apart
         const ab_h8 z0h = ab_tr8(z0 + m * 1024, z0 + m * 1024 + 512), z0l = ab_tr8(z0 + AB_HPLANE(NT) + m * 1024, z0 + AB_HPLANE(NT) + m * 1024 + 512);
@@ -365,7 +368,9 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_q_kernel(const float* __
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(s[kt][r] - mx);
+                // SPLIT: the forward's own exponential (attention_f16x2.hip: one v_exp_f32 on a fused multiply-add); expf's
+                // range reduction and overflow guards were 9 instructions per score, 1 300 of the kernel's 8 400
+                const float e = SPLIT ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], 1.44269504f, -mx * 1.44269504f)) : expf(s[kt][r] - mx);
                 s[kt][r] = e;
                 sum += e;
             }
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
         const int lqs = ((Lq + 31) >> 5) << 5;
         const float* st = stats + ((size_t)b * heads + head) * lqs;
         for (int i = tid; i < NQT * 32; i += AB_NT) {
-            Ls[i] = i < Lq ? st[i] : 0.f;
+            Ls[i] = i < Lq ? (SPLIT ? st[i] * 1.44269504f : st[i]) : 0.f;
             Ds[i] = i < Lq ? st[(size_t)gridDim.y * heads * lqs + i] * do_scale : 0.f;       // delta in the scaled dO's units
         }
     }
@@ -487,8 +492,12 @@ __global__ __launch_bounds__(AB_NT, 2) void ds_attn_bwd_kv_kernel(const float* _
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int q = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    t[qt][r] = (q < Lq && key_ok) ? expf(t[qt][r] * scale - Ls[q]) : 0.f;      // P[q][key]
+                    // P[q][key]  (SPLIT: Ls holds L_q log2(e), see its load above)
+                    const float pe = SPLIT ? __builtin_amdgcn_exp2f(__builtin_fmaf(t[qt][r], scale * 1.44269504f, -Ls[q]))
+                                           : expf(t[qt][r] * scale - Ls[q]);
+                    t[qt][r] = (q < Lq && key_ok) ? pe : 0.f;
                 }
+                AB_FENCE();      // (one query tile at a time: without expf's branches the scheduler overlaps tiles and spills)
             }
         }
     }
