@@ -49,7 +49,8 @@ typedef struct ds_gemm_desc {
     int32_t loader, pro, act, store;
     const float* pro_scale; /* [samples][Cin] for DS_PRO_AFFINE* (GroupNorm folded to a*s + o) */
     const float* pro_shift;
-    int32_t rows_per_sample; /* dense prologue / DS_STORE_BATCH_T: rows of one sample */
+    int32_t rows_per_sample; /* dense prologue / DS_STORE_BATCH_T: rows of one sample; ds_gemm_f16x2 with packed operands: lets
+                                the dispatcher take the per-sample programs (see ds_gemm_f16x2_force_tile), 0 = never */
     int32_t Cin;             /* channels per tap (conv loaders; dense prologue: = K) */
     int32_t H, Wd;           /* conv2d: output H, W; conv1d / convT1d: Wd = output length / phase rows */
     int32_t up;              /* conv2d: 1 = source is (H/2, W/2), nearest-upsampled on the fly; 2 = stride-2 conv over a
@@ -96,9 +97,11 @@ int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
 /* cfg: -1 automatic (default): the per-sample ping-pong program (gemm_f16x2_ps.hip: one 288 x 256 tile of an 8-wave
    workgroup per (sample, 256 columns)) when the problem has packed operands, rows_per_sample in (240, 273] with
    M % rows_per_sample == 0, N % 256 == 0, K % 64 == 0, a row / packed / attention store and a grid that fills whole
-   rounds of the 256 CUs (the denoiser's GEMMs at batch 64); else 128x128 (balanced launch for packed operands) /
-   128x64 / 64x64 tiles of a 4-wave workgroup by grid size.  0 / 1 / 2 pin those three; 9 pins the per-sample program
-   for every problem it can compute, whatever the grid (tests).  Every cfg produces the same bits.
+   rounds of the 256 CUs (the denoiser's GEMMs at batch 64) -- or, for a row-major store, its LEADING samples that do, the
+   rest following as a second launch (20 samples x 4096 columns: 16 + 4); else 128x128 (balanced launch for packed
+   operands) / 128x64 / 64x64 / 96x128 (packed operands only: four waves side by side) tiles of a 4-wave workgroup by grid
+   size (the rule for packed operands: gemm_f16x2.hip).  0 / 1 / 2 / 3 pin those four; 9 pins the per-sample program, 10 its
+   half-tile form, for every problem they can compute, whatever the grid (tests).  Every cfg produces the same bits.
    PROCESS-GLOBAL test / measurement switch, like every *_force_tile, *_set_balance_slots and ds_profile_* entry:
    not for use while another thread or stream of the process is launching GEMMs. */
 void ds_gemm_f16x2_force_tile(int cfg);
