@@ -265,6 +265,11 @@ int ds_attention_bwd_f16x2_mon(const float* q, int ldq, const float* k, int ldk,
                                const float* d_o, int lddo, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                                float* stats, int B, int heads, int Lq, int Lk, float scale, float do_scale, float* amax,
                                ds_stream_t stream);
+/* part[ks][g][b][d] = sum over k in [256 ks, 256 ks + 256) of x[g][b][k] * W[g][k][d]:  B <= 32 rows times G ROW-MAJOR matrices
+ * [K][D] (K % 256 == 0), read once from where they lie -- the AdaLN backward's (d modulation) x linear.weight for all modules
+ * (what autograd computes for AdaLayerNorm.linear's input, transformer_utils.py:145-147).  The caller adds the K / 256 partial
+ * results in a fixed order (ds_colsum over part as [K / 256][G * B * D]). */
+int ds_rows_times_matrix(const float* x, const float* W, float* part, int G, int B, int K, int D, ds_stream_t stream);
 /* d emb[tokens[m]] += dx[m] (atomic) */
 int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
 /* fused AdamW update (torch.optim.AdamW semantics), step >= 1 */

@@ -127,6 +127,27 @@ def test_colsum_small_launch_keeps_the_chain_order(L, G, R, C):
     assert torch.equal(acc.cpu(), 1.0 + want)
 
 
+@pytest.mark.parametrize("G,B,K,D", [(3, 20, 2048, 1024), (1, 32, 256, 300), (2, 1, 512, 64)])
+def test_rows_times_row_major_matrix(L, G, B, K, D):
+    """ds_rows_times_matrix: B <= 32 rows times G row-major [K][D] matrices (the AdaLN backward's (d modulation) x linear.weight),
+    K / 256 partial results added by ds_colsum -- against float64, twice (deterministic), columns past D untouched."""
+    x, W = rnd((G, B, K), "rtm.x%d" % K, 2.0), rnd((G, K, D), "rtm.w%d" % D, 0.5)
+    ref = torch.einsum("gbk,gkd->gbd", x.double(), W.double())
+    xc, Wc = x.cuda(), W.cuda()
+    KS = K // 256
+    outs = []
+    for _ in range(2):
+        part = torch.full((KS, G, B, D), float("nan"), device="cuda")
+        L.check(L.lib().ds_rows_times_matrix(L.ptr(xc), L.ptr(Wc), L.ptr(part), G, B, K, D, L.stream()))
+        out = torch.empty(G, B, D, device="cuda")
+        L.check(L.lib().ds_colsum(L.ptr(part), L.ptr(out), 1, KS, G * B * D, G * B * D, 0, 0, L.stream()))
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    assert L.lib().ds_rows_times_matrix(L.ptr(xc), L.ptr(Wc), L.ptr(part), G, 33, K, D, L.stream()) != 0      # more than 32 rows
+    assert L.lib().ds_rows_times_matrix(L.ptr(xc), L.ptr(Wc), L.ptr(part), G, B, K + 32, D, L.stream()) != 0  # K % 256
+
+
 def test_gelu2_forward_backward(L):
     x = rnd((300, 4096), "g2.x", 6.0).double().requires_grad_(True)
     dy = rnd((300, 4096), "g2.dy")

@@ -291,6 +291,64 @@ __global__ __launch_bounds__(256) void ds_colsum_chunk_kernel(const float* __res
     work[((size_t)blockIdx.y * gridDim.z + blockIdx.z) * C + c] = (s0 + s1) + (s2 + s3);
 }
 
+// ---- few rows times a row-major matrix:  part[ks][g][b][d] = sum_{k in range ks} x[g][b][k] * W[g][k][d]  (b < B <= 32) -------
+// The AdaLN backward's  d silu-input = (d modulation) W  for all 2 n_layer modules (W = linear.weight [2D][D],
+// transformer_utils.py:145-147): B = 20 rows against 38 matrices of 8 MB.  As a GEMM it needs W^T as its K-contiguous operand -- a
+// 319 MB transposing copy per iteration plus a tile program that is 84 % padding rows.  Here a thread owns one output column
+// d and walks its k-range: W is read once, coalesced along d, straight from the parameters; the B rows of x sit in LDS and
+// are read as broadcasts (16 bytes = 4 k per read).  The KS k-ranges are separate workgroups (parallelism: 4 KS G of them);
+// their partial results are added by ds_colsum in a fixed order.  Bound by the 2 D D 4 bytes of each matrix.
+#define RM_KC 256                       // k per workgroup
+__global__ __launch_bounds__(256) void ds_rows_times_matrix_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                   float* __restrict__ part, int B, int K, int D) {
+    __shared__ __attribute__((aligned(16))) float xs[32][RM_KC];
+    const int g = blockIdx.z, ks = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = ks * RM_KC;
+    const float* xg = x + ((size_t)g * B) * K + k0;
+    for (int i = threadIdx.x; i < B * (RM_KC / 4); i += 256) {
+        const int b = i / (RM_KC / 4), c4 = (i - b * (RM_KC / 4)) * 4;
+        *(f32x4*)&xs[b][c4] = *(const f32x4*)(xg + (size_t)b * K + c4);
+    }
+    __syncthreads();
+    if (d >= D) return;
+    float acc[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) acc[b] = 0.f;
+    const float* wp = W + ((size_t)g * K + k0) * D + d;
+    for (int k = 0; k < RM_KC; k += 8) {                     // eight rows of W in flight per thread (a load per trip would
+        float w[8];                                          //  cost a memory latency per row: see ds_colsum4_kernel)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = wp[(size_t)(k + u) * D];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            if (b < B) {                                     // (uniform; B is small and fixed per launch)
+                const f32x4 xa = *(const f32x4*)&xs[b][k], xb = *(const f32x4*)&xs[b][k + 4];
+                float a = acc[b];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a = fmaf(xa[u], w[u], a);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a = fmaf(xb[u], w[4 + u], a);
+                acc[b] = a;
+            }
+        }
+    }
+    float* o = part + (((size_t)ks * gridDim.z + g) * B) * D + d;
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+        if (b < B) o[(size_t)b * D] = acc[b];
+}
+
+// x [G][B][K], W [G][K][D] (row-major), part [K / 256][G][B][D]: the caller adds the K / 256 partial results (ds_colsum).
+extern "C" int ds_rows_times_matrix(const float* x, const float* W, float* part, int G, int B, int K, int D, ds_stream_t stream) {
+    DS_CHECK_ARG(x && W && part && G > 0 && B > 0 && B <= 32 && K > 0 && K % RM_KC == 0 && D > 0, "B <= 32 rows, K a multiple of 256");
+    DS_CHECK_ARG((((uintptr_t)x) & 15) == 0 && K % 4 == 0, "x must be 16-byte aligned");
+    DS_CHECK_ARG(G <= 65535 && K / RM_KC <= 65535, "grid limits");
+    hipLaunchKernelGGL(ds_rows_times_matrix_kernel, dim3((D + 255) / 256, K / RM_KC, G), dim3(256), 0, (hipStream_t)stream, x, W, part, B,
+                       K, D);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
 // number of row chunks ds_colsum_ws uses for (G, R, C): about 2048 workgroups in stage 1, >= 16 rows per chunk, <= 64
 static int ds_colsum_chunks(int G, int R, int C) {
     const long blocks1 = (long)((C + 255) / 256) * G;
