@@ -87,6 +87,11 @@ void ds_gemm_force_tile(int cfg); /* test hook: 0..2 pins the block tile, -1 = a
  * lda = ldw = the FULL contraction length the planes were packed with) this is a split-K launch whose partial results the
  * caller sums (ds_colsum). */
 int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
+/* n <= 4 INDEPENDENT packed-operand products (a_split = 1, row store, no bias / residual / activation, the same `groups` each)
+ * as ONE grid of tile configuration cfg (0: 128x128, 1: 128x64, 3: 96x128): the weight gradients dW = dY^T X of several
+ * nn.Linear layers of a block (transformer_utils.py:31-36,75-82,248-253 under loss.backward()), each sized to one workgroup per
+ * CU, side by side instead of back to back.  Every product gets the bits ds_gemm_f16x2 gives it with that tile forced. */
+int ds_gemm_f16x2_multi(const ds_gemm_desc* descs, int n, int cfg, ds_stream_t stream);
 /* the conv-family loaders in the same fp32-class 3-pass formulation: A fp32 (split while it is staged), W = the two fp16
    planes [groups][N][ldw] of W * 2^s from split_f16x2 (w3_plane halves apart, groups w_gstride apart), out_scale = 2^-s.
    d->loader: DS_LOAD_CONV2D (3x3 conv over a channels-last image: Cin, H, Wd, up; prologue none or GroupNorm affine +
@@ -105,6 +110,9 @@ int ds_conv2d_f16x2(const ds_gemm_desc* d, ds_stream_t stream);
    PROCESS-GLOBAL test / measurement switch, like every *_force_tile, *_set_balance_slots and ds_profile_* entry:
    not for use while another thread or stream of the process is launching GEMMs. */
 void ds_gemm_f16x2_force_tile(int cfg);
+/* the tile configuration (0 .. 3 as above) an M x N packed-operand product in `groups` K-ranges takes when nothing is forced
+   (pure arithmetic; the training step groups its weight gradients by it for ds_gemm_f16x2_multi) */
+int ds_gemm_f16x2_auto_tile(int M, int N, int groups);
 /* packed-operand launches that pick the 128x128 tile are balanced: 128x128 tiles over the leading rows that fill
    whole rounds of `slots` resident workgroups (default 512 = 256 CUs x 2), 64x64 tiles over the rest.  Test hook
    (process-global). */

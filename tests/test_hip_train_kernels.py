@@ -431,6 +431,55 @@ def test_pack_operand_parts_into_a_fused_operand(L):
     assert int((row_a == 0x7777).sum()) < 8 and int((t_a == 0x7777).sum()) < 8        # (everything was written)
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 3])
+@pytest.mark.parametrize("S", [1, 2])
+def test_gemm_f16x2_multi_equals_separate_launches(L, cfg, S):
+    """ds_gemm_f16x2_multi: up to four independent dW = dY^T X products (different shapes, the same number of K-ranges) as ONE
+    grid of a tile configuration == each product launched alone with that tile forced, bit for bit; five products, unequal
+    K-range counts and a residual are refused."""
+    M = 530
+    shapes = [(256, 128), (128, 384), (96, 96), (512, 64)]
+    Mp = (M + 32 * S - 1) // (32 * S) * (32 * S)
+    Kc = Mp // S
+
+    def tform(src, cols):
+        C16 = (cols + 15) // 16 * 16
+        d = torch.empty(2, C16 * Mp, dtype=torch.int16, device="cuda")
+        L.check(L.lib().ds_pack_operand(L.ptr(src), M, cols, cols, 1.0, 0, None, 0, None, 0, L.ptr(d), C16 * Mp, Mp, 0, 0, None, None,
+                                        L.stream()))
+        return d, C16 * Mp
+    keep, descs, outs, refs = [], [], [], []
+    for i, (N, K) in enumerate(shapes):
+        dy, x = rnd((M, N), "gm.dy%d" % i, 2.0).cuda(), rnd((M, K), "gm.x%d" % i, 1.5).cuda()
+        a, apl = tform(dy, N)
+        w, wpl = tform(x, K)
+        keep += [a, w]
+        kw = dict(lda=Mp, ldw=Mp, ldc=K, groups=S, a_gstride=Kc * 16, w_gstride=Kc * 16, c_gstride=N * K, split2=0.25, a_plane=apl, w_plane=wpl)
+        ref = torch.full((S, N * K), float("nan"), device="cuda")
+        L.lib().ds_gemm_f16x2_force_tile(cfg)
+        try:
+            L.gemm(a, w, ref, N, K, Kc, **kw)
+        finally:
+            L.lib().ds_gemm_f16x2_force_tile(-1)
+        out = torch.full((S, N * K), float("nan"), device="cuda")
+        descs.append(L.gemm(a, w, out, N, K, Kc, desc_only=True, **kw))
+        outs.append(out)
+        refs.append(ref)
+    L.gemm_multi(descs, cfg)
+    for out, ref in zip(outs, refs):
+        assert torch.equal(out, ref)
+    L.gemm_multi(descs[:1], cfg)                      # one product is fine too
+    with pytest.raises(RuntimeError):
+        L.gemm_multi(descs + descs[:1], cfg)          # five
+    with pytest.raises(RuntimeError):
+        L.gemm_multi(descs, 2)                        # no 64 x 64 form
+    bad = L.gemm(keep[0], keep[1], outs[0], shapes[0][0], shapes[0][1], Kc, desc_only=True, lda=Mp, ldw=Mp, ldc=shapes[0][1], groups=S + 1,
+                 a_gstride=Kc * 16, w_gstride=Kc * 16, c_gstride=shapes[0][0] * shapes[0][1], split2=0.25, a_plane=descs[0].a_plane,
+                 w_plane=descs[0].w3_plane)
+    with pytest.raises(RuntimeError):
+        L.gemm_multi([descs[1], bad], cfg)            # unequal K-range counts
+
+
 def test_pack_operand_gelu_prologues(L):
     """The MLP's activation rides in the pack: DS_PACK_GELU2 (x := gelu2(x), transformer_utils.py:111-115) and
     DS_PACK_GELU2_BWD (x := x * gelu2'(aux)) against float64; the packed value (hi + lo) is the fp32 result to 2^-22."""

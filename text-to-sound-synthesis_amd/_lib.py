@@ -50,6 +50,8 @@ _PROTOS = {
     "ds_gemm_force_tile": (None, [C.c_int]),
     "ds_gemm_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ds_conv2d_f16x2": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "ds_gemm_f16x2_multi": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_int, _vp]),
+    "ds_gemm_f16x2_auto_tile": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ds_gemm_f16x2_force_tile": (None, [C.c_int]),
     "ds_gemm_f16x2_set_balance_slots": (None, [C.c_int]),
     "ds_gemm_f16x2_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -203,11 +205,18 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def gemm_multi(descs, cfg):
+    """ds_gemm_f16x2_multi: the products described by `descs` (gemm(..., desc_only=True); packed operands, plain row store, equal
+    `groups`) as ONE grid of tile configuration cfg (0: 128x128, 1: 128x64, 3: 96x128)."""
+    arr = (GemmDesc * len(descs))(*descs)
+    check(lib().ds_gemm_f16x2_multi(arr, len(descs), cfg, stream()))
+
+
 def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=None, ldr=None,
          groups=1, a_gstride=0, w_gstride=0, c_gstride=0, loader=LOAD_DENSE, pro=PRO_NONE,
          act=ACT_NONE, store=STORE_ROW, pro_scale=None, pro_shift=None, rows_per_sample=0,
          Cin=0, H=0, Wd=0, up=0, taps=0, dil=1, ct_r=0, ct_p=0, ct_tin=0, f16_round=0, split2=None,
-         a_plane=0, c_plane=0, attn=None, w_plane=None, conv_split=False):
+         a_plane=0, c_plane=0, attn=None, w_plane=None, conv_split=False, desc_only=False):
     """split2: out_scale from split_f16x2(); W is its [2][N][K] fp16 split and the f16x2 kernel is used;
     a_plane / c_plane > 0 (f16x2 only): A and W are given / C is written as packed split planes (pack_planes())
     that many halves apart."""
@@ -239,6 +248,8 @@ def gemm(A, W, C_out, M, N, K, *, bias=None, R=None, lda=None, ldw=None, ldc=Non
             d.w3_plane = w_plane
         if attn is not None:        # (kv images tensor or None, heads, nkey, q plane stride): STORE_ATTN
             d.attn_kv, d.attn_heads, d.attn_nkey, d.attn_qplane = ptr(attn[0]), attn[1], attn[2], attn[3]
+        if desc_only:               # for gemm_multi(): the descriptor of this f16x2 product, not launched
+            return d
         check(lib().ds_gemm_f16x2(C.byref(d), stream()))
     else:
         check(lib().ds_gemm(C.byref(d), stream()))

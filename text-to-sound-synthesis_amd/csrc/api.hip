@@ -77,6 +77,21 @@ extern "C" int ds_gemm_f16x2(const ds_gemm_desc* d, ds_stream_t stream) {
     return ds_launch_gemm_f16x2(p, (hipStream_t)stream);
 }
 
+int ds_launch_gemm_f16x2_multi(const GemmParams* ps, int n, int cfg, hipStream_t stream);   // gemm_f16x2.hip
+extern "C" int ds_gemm_f16x2_multi(const ds_gemm_desc* descs, int n, int cfg, ds_stream_t stream) {
+    DS_CHECK_ARG(descs && n >= 1 && n <= 4, "1 .. 4 descriptors");
+    GemmParams ps[4];
+    memset(ps, 0, sizeof(ps));
+    for (int i = 0; i < n; ++i) {
+        const ds_gemm_desc* d = descs + i;
+        DS_CHECK_ARG(d->A && d->W && d->C, "null pointer");
+        DS_CHECK_ARG(d->loader == DS_LOAD_DENSE && d->pro == DS_PRO_NONE && !d->f16_round && d->w3_plane > 0,
+                     "f16x2 is the dense, no-prologue kernel; w3_plane is required");
+        fill(ps[i], d);
+    }
+    return ds_launch_gemm_f16x2_multi(ps, n, cfg, (hipStream_t)stream);
+}
+
 // ---- denoiser ---------------------------------------------------------------------------------------
 struct ds_denoiser {
     ds_denoiser_desc d;

@@ -477,6 +477,85 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_hybrid_kernel(const Gemm
     else ds_gemm_f16x2_body<64, 64, 2>(ps, bid - nbig, (int)gridDim.x - nbig, smem_dyn);
 }
 
+// Several INDEPENDENT products of one tile configuration in one grid (round 6: the training step's weight gradients).  Every dW
+// launch of the step is sized to <= 256 workgroups -- one per CU -- and a workgroup alone on a CU runs its tile in ~0.6 of the
+// time two co-resident ones take (profiles/r06x_gemm_tile_batch_sweep.txt): two such launches back to back cost 2.0 units,
+// their 512 workgroups side by side ~1.7.  The weight gradients are off the backward's critical path, so the step collects
+// them per block and launches the ones of equal tile / K-range count together.  blockIdx.x ranges [first[i], first[i + 1])
+// belong to problem i; blockIdx.y = the K-range (all problems of a launch have the same count).
+extern int g_last_tile;
+#define DS_GEMM_MULTI_MAX 4
+struct GemmMulti {
+    GemmParams p[DS_GEMM_MULTI_MAX];
+    int first[DS_GEMM_MULTI_MAX + 1];
+    int n;
+};
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void ds_gemm_f16x2_multi_kernel(const GemmMulti m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.first[i + 1]) ++i;        // (block-uniform: scalar loads of the argument block)
+    GemmParams q = m.p[i];
+    const size_t g = blockIdx.y;
+    q.A = (const float*)((const _Float16*)q.A + g * (size_t)q.a_gstride);
+    q.W = (const float*)((const _Float16*)q.W + g * (size_t)q.w_gstride);
+    q.C = q.C + g * (size_t)q.c_gstride;
+    ds_gemm_f16x2_body<BM, BN, 2, WGM, WGN>(q, (int)blockIdx.x - m.first[i], m.first[i + 1] - m.first[i], smem_dyn);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_multi(const GemmMulti& m, int groups, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * (BM + BN) * HLD * sizeof(unsigned short);
+    static DsOnce attr_set;
+    if (attr_set.need()) {
+        hipError_t e = hipFuncSetAttribute((const void*)ds_gemm_f16x2_multi_kernel<BM, BN, WGM, WGN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            ds_set_error("gemm_f16x2 multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -2;
+        }
+        attr_set.done();
+    }
+    hipLaunchKernelGGL((ds_gemm_f16x2_multi_kernel<BM, BN, WGM, WGN>), dim3(m.first[m.n], groups), dim3(256), lds, s, m);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
+// n <= 4 packed-operand products (row store, no bias / residual / activation, the same number of K-ranges each) as ONE grid of
+// tile configuration cfg (0: 128 x 128, 1: 128 x 64, 3: 96 x 128); each product is what ds_launch_gemm_f16x2 computes for it
+// with that tile forced -- the same bits.
+int ds_launch_gemm_f16x2_multi(const GemmParams* ps, int n, int cfg, hipStream_t stream) {
+    DS_CHECK_ARG(ps && n >= 1 && n <= DS_GEMM_MULTI_MAX, "1 .. 4 products per launch");
+    DS_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 3, "tile configuration: 0 (128 x 128), 1 (128 x 64) or 3 (96 x 128)");
+    const int bm = cfg == 3 ? 96 : 128, bn = cfg == 1 ? 64 : 128;
+    GemmMulti m = {};
+    m.n = n;
+    const int groups = ps[0].groups > 1 ? ps[0].groups : 1;
+    for (int i = 0; i < n; ++i) {
+        const GemmParams& p = ps[i];
+        DS_CHECK_ARG(p.A && p.W && p.C && p.M > 0 && p.N > 0 && p.K > 0 && p.K % HBK == 0, "K must be a positive multiple of 32");
+        DS_CHECK_ARG(p.a_split == 1 && !p.c_split && p.store == DS_STORE_ROW && !p.R && !p.bias && p.act == DS_ACT_NONE && p.out_scale > 0.f,
+                     "multi: packed operands, plain row store, no bias / residual / activation, out_scale set");
+        DS_CHECK_ARG((p.groups > 1 ? p.groups : 1) == groups, "multi: every product has the same number of K-ranges");
+        DS_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 && p.lda >= p.K && p.lda % HBK == 0 && p.ldw == p.lda &&
+                         p.a_plane >= (long long)((p.M + 15) / 16) * 16 * p.lda && p.a_plane % 8 == 0 &&
+                         p.w3_plane >= (long long)((p.N + 15) / 16) * 16 * p.lda && p.w3_plane % 8 == 0,
+                     "multi: lda = ldw = the packed contraction length (>= K), planes of ceil16(rows) * lda halves");
+        DS_CHECK_ARG(p.lda == p.K || groups > 1, "packed operands: lda > K only for the K-ranges of a split-K launch");
+        DS_CHECK_ARG(groups == 1 || (p.a_gstride % 512 == 0 && p.w_gstride % 512 == 0 && p.c_gstride % 4 == 0),
+                     "multi: K-range strides are whole k-tiles, 16-byte aligned partial results");
+        DS_CHECK_ARG(((p.N | p.ldc) & 3) == 0 && ((uintptr_t)p.C & 15) == 0, "multi: N, ldc multiples of 4, C 16-byte aligned");
+        m.p[i] = p;
+        m.first[i + 1] = m.first[i] + ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    }
+    g_last_tile = cfg == 3 ? 5 : cfg;
+    switch (cfg) {
+        case 0: return launch_multi<128, 128, 2, 2>(m, groups, stream);
+        case 1: return launch_multi<128, 64, 2, 2>(m, groups, stream);
+        default: return launch_multi<96, 128, 1, 4>(m, groups, stream);
+    }
+}
+
 // Row partition of a balanced launch: the first m_off rows go to BM x BN tiles (nbig of them = a whole number of rounds
 // of `slots` resident workgroups), the rows after them to tbm x tbn tail tiles (nsmall of them) in the same grid.
 // nsmall == 0: one program over all rows.  Pure arithmetic (ds_gemm_f16x2_plan exposes it to the CPU tests).
@@ -587,6 +666,24 @@ extern "C" int ds_gemm_f16x2_plan(int cfg, int M, int N, int store, int* m_off, 
     return 0;
 }
 
+// The tile a packed-operand launch of M x N (x groups K-ranges) takes when nothing is forced: 0 128x128 (balanced), 1 128x64,
+// 2 64x64, 3 96x128.  Written from the batch sweep of round 6 (profiles/r06x_gemm_tile_batch_sweep.txt: M = 265 B rows,
+// B = 4 .. 48, on the four layer shapes).  One workgroup alone on a CU runs a tile in ~0.6 of the time two co-resident ones
+// take, so what counts is the most loaded CU: up to 256 tiles -> one each, up to 512 -> some CUs carry two.  The 96 x 128 tile
+// turns 257 .. 341 tiles of 128 x 128 (two per CU somewhere, a third of the slots empty) into <= 512 tiles of 3/4 the work
+// (-9 .. -18 %: every N = 1024 layer of the training step), and 129 .. 192 into <= 256 (-11 .. -19 %); 193 .. 256 tiles of
+// 128 x 128 -- one per CU, most CUs busy -- beat 128 x 64 by 0 .. 6 % (the fc1 / fc2 dW); between 342 and 999 tiles the plain /
+// balanced 128 x 128 launch beats 128 x 64 (0 .. -23 %).  K-range launches (groups > 1: the dW products) keep the round-5
+// rule (profiles/r05g_train_gemm_packed_sweep.txt).  Exported: the training step asks it when it batches weight gradients.
+extern "C" int ds_gemm_f16x2_auto_tile(int M, int N, int groups) {
+    const int G = groups > 1 ? groups : 1;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * G;
+    if (G > 1) return t128 >= 700 ? 0 : (t128 >= 128 ? 1 : 2);
+    if (t128 < 128) return 2;
+    const long t96 = (long)((M + 95) / 96) * ((N + 127) / 128);
+    return t96 <= 256 ? 3 : t128 <= 256 ? (t128 > 192 ? 0 : 1) : t96 <= 512 ? 3 : 0;
+}
+
 // p.W: 2 fp16 planes holding W * 2^s, plane stride p.w3_plane (halves); p.out_scale = 2^-s.  Row-major planes
 // [N][ldw] with an fp32 A (a_split 0); packed split planes for both A and W when a_split is set.
 int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
@@ -662,23 +759,11 @@ int ds_launch_gemm_f16x2(const GemmParams& p, hipStream_t stream) {
     int best;
     if (g_force_tile_h >= 0 && g_force_tile_h <= 3) {
         best = g_force_tile_h == 3 && !p.a_split ? 1 : g_force_tile_h;     // (the 96-row tile exists for packed operands only)
+    } else if (p.a_split) {
+        best = ds_gemm_f16x2_auto_tile(p.M, p.N, p.groups);
     } else {
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.groups > 1 ? p.groups : 1);
-        // packed operands (DMA staging): 128x128 already wins at two rounds of 512 resident workgroups; a packed split-K
-        // launch (the training step's dW) from 1.5 rounds on (3072 x 1024 in 4 K-ranges: 118 vs 128 us,
-        // profiles/r05g_train_gemm_packed_sweep.txt)
-        best = t128 >= (p.a_split ? (p.groups > 1 ? 700 : 1000) : 1500) ? 0 : (t128 >= 128 ? 1 : 2);
-        // Packed operands, one product (round 6, profiles/r06x_gemm_tile_batch_sweep.txt: M = 265 B rows, B = 4 .. 48, on the
-        // four layer shapes).  One workgroup alone on a CU runs a tile in ~0.6 of the time two co-resident ones take, so what
-        // counts is the most loaded CU: up to 256 tiles -> one each, up to 512 -> some CUs carry two.  The 96 x 128 tile turns
-        // 257 .. 341 tiles of 128 x 128 (two per CU somewhere, a third of the slots empty) into <= 512 tiles of 3/4 the work
-        // (-9 .. -18 %: every N = 1024 layer of the training step), and 129 .. 192 into <= 256 (-11 .. -19 %); between 342
-        // and 999 tiles the plain / balanced 128 x 128 launch beats 128 x 64 (0 .. -23 %: the old rule took 128 x 64 there).
-        if (p.a_split && p.groups <= 1 && t128 >= 128) {
-            const long t96 = (long)((p.M + 95) / 96) * ((p.N + 127) / 128);
-            // (193 .. 256 tiles of 128 x 128 -- one per CU, most CUs busy -- beat 128 x 64 by 0 .. 6 %: the fc1 / fc2 dW)
-            best = t96 <= 256 ? 3 : t128 <= 256 ? (t128 > 192 ? 0 : 1) : t96 <= 512 ? 3 : 0;
-        }
+        best = t128 >= 1500 ? 0 : (t128 >= 128 ? 1 : 2);         // (fp32 A split by the loader: register staging)
     }
     g_last_tile = best == 3 ? 5 : best;          // (3 and 4 name the per-sample programs above)
     switch (best) {
