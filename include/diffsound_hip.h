@@ -278,6 +278,10 @@ int ds_attention_bwd_f16x2_mon(const float* q, int ldq, const float* k, int ldk,
  * (what autograd computes for AdaLayerNorm.linear's input, transformer_utils.py:145-147).  The caller adds the K / 256 partial
  * results in a fixed order (ds_colsum over part as [K / 256][G * B * D]). */
 int ds_rows_times_matrix(const float* x, const float* W, float* part, int G, int B, int K, int D, ds_stream_t stream);
+/* out[g][n][d] = sum over b < B of a[g][b][n] * s[g][b][d]  (a [G][B][N], s [G][B][D], out [G][N][D]; B <= 32, D % 4 == 0):
+ * the AdaLN backward's d linear.weight = (d modulation)^T silu(emb(t_b)) for all modules in one output-bound pass (what
+ * autograd computes for AdaLayerNorm.linear.weight, transformer_utils.py:145-147). */
+int ds_rows_outer(const float* a, const float* s, float* out, int G, int B, int N, int D, ds_stream_t stream);
 /* d emb[tokens[m]] += dx[m] (atomic) */
 int ds_embed_bwd(const float* dx, const int64_t* tokens, float* demb, int M, int D, int rows, ds_stream_t stream);
 /* fused AdamW update (torch.optim.AdamW semantics), step >= 1 */

@@ -148,6 +148,21 @@ def test_rows_times_row_major_matrix(L, G, B, K, D):
     assert L.lib().ds_rows_times_matrix(L.ptr(xc), L.ptr(Wc), L.ptr(part), G, B, K + 32, D, L.stream()) != 0  # K % 256
 
 
+@pytest.mark.parametrize("G,B,N,D", [(3, 20, 2048, 1024), (1, 32, 50, 2052), (2, 1, 33, 64)])
+def test_sum_of_outer_products(L, G, B, N, D):
+    """ds_rows_outer: out[g] = a[g]^T s[g] over B <= 32 rows (the AdaLN backward's d linear.weight) against float64; rows of the
+    output past N are not written."""
+    a, s_ = rnd((G, B, N), "ro.a%d" % N, 2.0), rnd((G, B, D), "ro.s%d" % D, 0.5)
+    ref = torch.einsum("gbn,gbd->gnd", a.double(), s_.double())
+    ac, sc = a.cuda(), s_.cuda()
+    out = torch.full((G * N + 3, D), float("nan"), device="cuda")
+    L.check(L.lib().ds_rows_outer(L.ptr(ac), L.ptr(sc), L.ptr(out), G, B, N, D, L.stream()))
+    got = out[:G * N].view(G, N, D).cpu().double()
+    assert (got - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    assert torch.isnan(out[G * N:]).all()
+    assert L.lib().ds_rows_outer(L.ptr(ac), L.ptr(sc), L.ptr(out), G, 33, N, D, L.stream()) != 0
+
+
 def test_gelu2_forward_backward(L):
     x = rnd((300, 4096), "g2.x", 6.0).double().requires_grad_(True)
     dy = rnd((300, 4096), "g2.dy")

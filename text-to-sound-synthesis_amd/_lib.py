@@ -141,6 +141,7 @@ _PROTOS = {
     "ds_conv3x3_c1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ds_conv3x3_c1_chunks": (C.c_int, [C.c_int, C.c_int]),
     "ds_rows_times_matrix": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ds_rows_outer": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_stencil9": (C.c_int, [_vp, C.c_int, _f, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ds_melgan_resblock_fused_ok": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ds_convt1d_f16x2": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

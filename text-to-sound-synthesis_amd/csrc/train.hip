@@ -349,6 +349,44 @@ extern "C" int ds_rows_times_matrix(const float* x, const float* W, float* part,
     return 0;
 }
 
+// ---- sum of B outer products:  out[g][n][d] = sum_{b < B} a[g][b][n] * s[g][b][d]   (B <= 32) --------------------------------
+// The AdaLN backward's weight gradient  d linear.weight = (d modulation)^T silu(emb(t_b))  for all modules: [2D][D] outputs from a
+// contraction over the B = 20 samples.  As a GEMM (K = 32 after padding) it was one k-tile of prologue + epilogue per 128 x 128
+// tile, 308 us for 319 MB of output; here a thread keeps its four columns of the B rows of s in registers and walks 32
+// output rows, whose B coefficients sit in LDS: one pass of 16-byte stores, bound by the output bytes.
+__global__ __launch_bounds__(256) void ds_rows_outer_kernel(const float* __restrict__ a, const float* __restrict__ s,
+                                                            float* __restrict__ out, int B, int N, int D) {
+    __shared__ float as[32][33];                      // [n - n0][b]
+    const int g = blockIdx.y, n0 = blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 32 * B; i += 256) {
+        const int b = i >> 5, nn = i & 31;            // (consecutive threads read consecutive n of one sample row)
+        as[nn][b] = n0 + nn < N ? a[((size_t)g * B + b) * N + n0 + nn] : 0.f;
+    }
+    __syncthreads();
+    for (int d4 = threadIdx.x * 4; d4 < D; d4 += 1024) {
+        f32x4 sv[32];
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            if (b < B) sv[b] = *(const f32x4*)(s + ((size_t)g * B + b) * D + d4);
+        for (int nn = 0; nn < 32 && n0 + nn < N; ++nn) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 32; ++b)
+                if (b < B) acc += as[nn][b] * sv[b];
+            *(f32x4*)(out + ((size_t)g * N + n0 + nn) * D + d4) = acc;
+        }
+    }
+}
+
+// a [G][B][N], s [G][B][D] -> out [G][N][D];  B <= 32, D % 4 == 0, 16-byte aligned s / out
+extern "C" int ds_rows_outer(const float* a, const float* s, float* out, int G, int B, int N, int D, ds_stream_t stream) {
+    DS_CHECK_ARG(a && s && out && G > 0 && G <= 65535 && B > 0 && B <= 32 && N > 0 && D > 0 && D % 4 == 0, "B <= 32 rows, D % 4 == 0");
+    DS_CHECK_ARG(((((uintptr_t)s) | ((uintptr_t)out)) & 15) == 0, "s / out must be 16-byte aligned");
+    hipLaunchKernelGGL(ds_rows_outer_kernel, dim3((N + 31) / 32, G), dim3(256), 0, (hipStream_t)stream, a, s, out, B, N, D);
+    DS_CHECK_LAUNCH();
+    return 0;
+}
+
 // number of row chunks ds_colsum_ws uses for (G, R, C): about 2048 workgroups in stage 1, >= 16 rows per chunk, <= 64
 static int ds_colsum_chunks(int G, int R, int C) {
     const long blocks1 = (long)((C + 255) / 256) * G;

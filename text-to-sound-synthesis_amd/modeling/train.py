@@ -882,8 +882,6 @@ class TrainStep:
         g["transformer.to_logits.0.weight"], g["transformer.to_logits.0.bias"] = dgam[0], dbet[0]
         small += [dgam, dbet]
 
-        Bp = _ceil(B, 32)
-
         ada = []                    # (AdaLayerNorm module, d scale [B][D], d shift [B][D], parameter prefix): batched below
 
         def adaln_param_grads(ln, d_scale, d_shift, pfx):
@@ -893,10 +891,10 @@ class TrainStep:
 
         def adaln_param_grads_all():
             """d modulation rows [B][2D] -> emb.weight / linear.{weight, bias} through  mod_b = Linear(SiLU(emb[t_b]))  (AdaLayerNorm,
-            transformer_utils.py:134-149) for ALL 2 n_layer AdaLN modules at once: dW = dmod^T silu(e_b), db = column sums of
-            dmod, de[t_b] += (dmod_b W) silu'(e_b) as two GROUPED exact-fp32 GEMMs over the B samples (one group per module)
+            transformer_utils.py:134-149) for ALL 2 n_layer AdaLN modules at once: dW = dmod^T silu(e_b) (ds_rows_outer), db = column
+            sums of dmod, de[t_b] += (dmod_b W) silu'(e_b) (ds_rows_times_matrix): two passes over the B samples for all modules
             instead of two small GEMMs, three transposing copies and a dozen elementwise launches per module (4 ms of an 82 ms
-            iteration in round 4; over all T table rows until round 6)."""
+            iteration in round 4; grouped GEMMs over all T table rows until round 6)."""
             G = len(ada)
             if G == 0:
                 return
@@ -905,12 +903,9 @@ class TrainStep:
             dmod = torch.stack([both for _, both, _, _ in ada]) * inv                               # [G][B][2D]
             E = ada_E if order == list(range(len(lns))) else torch.stack([ada_E[i] for i in order])   # [G][B][D]
             sg = torch.sigmoid(E)
-            dmodT = torch.zeros(G, 2 * D, Bp, device=dev)                                          # K = B padded to 32
-            dmodT[:, :, :B] = dmod.transpose(1, 2)
-            sT = torch.zeros(G, D, Bp, device=dev)
-            sT[:, :, :B] = (E * sg).transpose(1, 2)
-            dw = torch.empty(G, 2 * D, D, device=dev)                                              # dW[g] = dmod[g]^T silu(e_b[g])
-            L_.gemm(dmodT, sT, dw, 2 * D, D, Bp, groups=G, a_gstride=2 * D * Bp, w_gstride=D * Bp, c_gstride=2 * D * D)
+            dw = torch.empty(G, 2 * D, D, device=dev)                                              # dW[g] = dmod[g]^T silu(e_b[g]):
+            silu_e = (E * sg).contiguous()                                                         # B outer products per module
+            L_.check(L_.lib().ds_rows_outer(L_.ptr(dmod), L_.ptr(silu_e), L_.ptr(dw), G, B, 2 * D, D, L_.stream()))
             # dmod[g] W[g]: B rows against the row-major weights where they lie (ds_rows_times_matrix: no transposed copy of the
             # 38 matrices -- 0.38 ms per iteration -- and no tile program that is mostly padding rows); ada_W is in forward order
             Wg = ada_W if order == list(range(len(lns))) else torch.stack([ada_W[i] for i in order])
